@@ -1,0 +1,220 @@
+/*
+ * gpslam_oracle.h -- CPU oracle for the GP-SLAM Gauss-Newton / Levenberg-Marquardt hot path.
+ *
+ * >>> TEST INFRASTRUCTURE, NOT PRODUCT CODE. <<<
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import, call,
+ * link or execute anything under oracle/ -- and there only as the checker / the timed CPU
+ * baseline, never as the thing shipped.  The product path (gpslam_amd/, include/) must fail
+ * loudly when the HIP library is missing; it never falls back to this code.
+ *
+ * What it restates (paths relative to /root/reference, the gtrll/gpslam checkout):
+ *   gpslam/gp/GPutils.{h,cpp}, gpslam/gp/Pose3utils.{h,cpp},
+ *   gpslam/gp/GaussianProcessPrior{Linear,Pose2,Pose3,Rot3}.h,
+ *   gpslam/gp/GaussianProcessInterpolator{Linear,Pose2,Pose3,Rot3}.h,
+ *   gpslam/slam/GPInterpolatedRangeFactor{Pose2,Pose3,2DLinear}.h,
+ *   gpslam/slam/GPInterpolatedAttitudeFactorRot3.h, GPInterpolatedGPSFactorPose3.h,
+ *   gpslam/slam/{Range,RangeBearing,Odometry}Factor2DLinear.h
+ * plus the GTSAM pieces those call.  GTSAM (">= 4.0 alpha", unpinned: README.md:12,
+ * CMakeLists.txt:15) is a third-party dependency that is NOT in /root/reference and NOT in
+ * this image (no Eigen, no Boost either), so the reference itself is unbuildable here and
+ * GTSAM's published algorithms are restated from their documented semantics
+ * (SURVEY.md Appendix A).
+ *
+ * Parity pinning status:
+ *   PINNED  by the reference's own tests (tests/golden/ JSON files, transcribed from
+ *           the .cpp files under gpslam/gp/tests and gpslam/slam/tests): factor errors at the fixed inputs, analytic
+ *           Jacobians vs central differences of the same error function, the fixed points
+ *           of the 2-state Gauss-Newton problems, the Lie Jacobian utilities.
+ *   PARITY UNPINNED (no reference test or runnable reference exists for them):
+ *           whitening / error() scaling, iteration counts, the LM lambda schedule,
+ *           default retract charts, convergence thresholds, anything with N > 2 states,
+ *           GPInterpolatedAttitudeFactorRot3 (the reference has no test for it).
+ */
+#ifndef GPSLAM_ORACLE_H
+#define GPSLAM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* manifold kinds (same numbering as include/gpslam_hip.h) */
+enum { ORC_LINEAR2 = 0, ORC_LINEAR3 = 1, ORC_POSE2 = 2, ORC_POSE3 = 3, ORC_ROT3 = 4 };
+enum { ORC_CHART_EXPMAP = 0, ORC_CHART_FIRST_ORDER = 1 };
+
+/* ---- Lie groups (orc_lie.c) ---- */
+void orc_skew(const double w[3], double W[9]);
+void orc_rot3_ypr(double y, double p, double r, double R[9]);
+void orc_rot3_expmap_derivative(const double w[3], double J[9]);
+void orc_rot3_logmap_derivative(const double w[3], double J[9]);
+void orc_rot3_expmap(const double w[3], double R[9], double *H);
+void orc_rot3_logmap(const double R[9], double w[3], double *H);
+void orc_rot3_compose(const double R1[9], const double R2[9], double R[9], double *H1, double *H2);
+void orc_rot3_inverse(const double R[9], double Rinv[9], double *H);
+void orc_pose3_adjoint(const double T[12], double Ad[36]);
+void orc_pose3_inverse(const double T[12], double Tinv[12], double *H);
+void orc_pose3_compose(const double A[12], const double B[12], double C[12], double *H1, double *H2);
+void orc_pose3_Q(const double xi[6], double Q[9]);
+void orc_pose3_expmap_derivative(const double xi[6], double J[36]);
+void orc_pose3_logmap_derivative_xi(const double xi[6], double J[36]);
+void orc_pose3_expmap(const double xi[6], double T[12], double *H);
+void orc_pose3_logmap(const double T[12], double xi[6], double *H);
+void orc_pose3_transform_to(const double T[12], const double p[3], double q[3], double *Dpose, double *Dpoint);
+double orc_pose3_range(const double T[12], const double p[3], double *H1, double *H2);
+void orc_pose3_translation(const double T[12], double t[3], double *H);
+void orc_pose2_adjoint(const double p[3], double Ad[9]);
+void orc_pose2_inverse(const double p[3], double pinv[3], double *H);
+void orc_pose2_compose(const double a[3], const double b[3], double c[3], double *H1, double *H2);
+void orc_pose2_expmap_derivative(const double v[3], double J[9]);
+void orc_pose2_logmap_derivative_v(const double v[3], double J[9]);
+void orc_pose2_expmap(const double xi[3], double p[3], double *H);
+void orc_pose2_logmap(const double p[3], double xi[3], double *H);
+double orc_pose2_range(const double p[3], const double pt[2], double *H1, double *H2);
+void orc_pose2_transform_to(const double p[3], const double pt[2], double q[2]);
+void orc_unit3_basis(const double n[3], double B[6]);
+void orc_attitude_error(const double R[9], const double nZ[3], const double bRef[3], double e[2], double *H);
+
+/* ---- GP utilities, priors, interpolators (orc_gp.c) ---- */
+void orc_calcQ(int D, const double *Qc, double tau, double *Q);
+int orc_calcQ_inv(int D, const double *Qc, double tau, double *Qinv);
+void orc_calcPhi(int D, double tau, double *Phi);
+int orc_calcPsi(int D, const double *Qc, double dt, double tau, double *Psi);
+int orc_calcLambda(int D, const double *Qc, double dt, double tau, double *Lambda);
+int orc_getQc(int D, const double *R, double *Qc);
+int orc_gp_whitening(int D, const double *Qc, double dt, double *R);
+void orc_rightJacobianRot3(const double w[3], double J[9]);
+void orc_rightJacobianRot3inv(const double w[3], double J[9]);
+void orc_rightJacobianPose3Q(const double xi[6], double Q[9]);
+void orc_rightJacobianPose3(const double xi[6], double J[36]);
+void orc_rightJacobianPose3inv(const double xi[6], double J[36]);
+void orc_jacobianNumDiff_Pose3inv(const double xi[6], const double x[6], double dxi, double Diff[36]);
+void orc_getBodyCentricVb(const double p1[12], const double p2[12], double dt, double v[6]);
+void orc_getBodyCentricVs(const double p1[12], const double p2[12], double dt, double v[6]);
+
+void orc_gp_prior_linear(int D, const double *p1, const double *v1, const double *p2, const double *v2, double dt,
+                         double *e, double *H1, double *H2, double *H3, double *H4);
+void orc_gp_prior_pose2(const double *p1, const double *v1, const double *p2, const double *v2, double dt, double *e,
+                        double *H1, double *H2, double *H3, double *H4);
+void orc_gp_prior_rot3(const double *R1, const double *v1, const double *R2, const double *v2, double dt, double *e,
+                       double *H1, double *H2, double *H3, double *H4);
+void orc_gp_prior_pose3(const double *p1, const double *v1, const double *p2, const double *v2, double dt, double *e,
+                        double *H1, double *H2, double *H3, double *H4);
+
+void orc_interp_linear(int D, const double *Lambda, const double *Psi, const double *p1, const double *v1,
+                       const double *p2, const double *v2, double *pose, double *H1, double *H2, double *H3,
+                       double *H4);
+void orc_interp_linear_velocity(int D, const double *Lambda, const double *Psi, const double *p1, const double *v1,
+                                const double *p2, const double *v2, double *vel);
+void orc_interp_pose2(const double *Lambda, const double *Psi, const double *p1, const double *v1, const double *p2,
+                      const double *v2, double *pose, double *H1, double *H2, double *H3, double *H4);
+void orc_interp_rot3(const double *Lambda, const double *Psi, const double *R1, const double *v1, const double *R2,
+                     const double *v2, double *rot, double *H1, double *H2, double *H3, double *H4);
+void orc_interp_pose3(const double *Lambda, const double *Psi, const double *p1, const double *v1, const double *p2,
+                      const double *v2, double *pose, double *H1, double *H2, double *H3, double *H4);
+
+/* ---- measurement factors (orc_factors.c) ---- */
+double orc_interp_range_pose2(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                              const double *p1, const double *v1, const double *p2, const double *v2,
+                              const double *point, double *H1, double *H2, double *H3, double *H4, double *H5);
+double orc_interp_range_pose3(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                              const double *p1, const double *v1, const double *p2, const double *v2,
+                              const double *point, double *H1, double *H2, double *H3, double *H4, double *H5);
+double orc_interp_range_2dlinear(const double *Lambda, const double *Psi, double measured, const double *p1,
+                                 const double *v1, const double *p2, const double *v2, const double *point,
+                                 double *H1, double *H2, double *H3, double *H4, double *H5);
+void orc_interp_attitude_rot3(const double *Lambda, const double *Psi, const double *nZ, const double *bRef,
+                              const double *R1, const double *v1, const double *R2, const double *v2, double *e,
+                              double *H1, double *H2, double *H3, double *H4);
+void orc_interp_gps_pose3(const double *Lambda, const double *Psi, const double *measured, const double *sensor,
+                          const double *p1, const double *v1, const double *p2, const double *v2, double *e,
+                          double *H1, double *H2, double *H3, double *H4);
+double orc_range_2dlinear(double measured, const double *pose, const double *point, double *H1, double *H2);
+double orc_range_pose2(double measured, const double *pose, const double *point, double *H1, double *H2);
+void orc_range_bearing_2dlinear(double bearing, double range, const double *pose, const double *point, double *e,
+                                double *H1, double *H2);
+void orc_odometry_2dlinear(const double *measured, const double *pose1, const double *pose2, double *e, double *H1,
+                           double *H2);
+
+int orc_pose_dim(int kind);
+int orc_tangent_dim(int kind);
+void orc_retract(int kind, int chart, const double *x, const double *delta, double *out);
+void orc_local(int kind, int chart, const double *x, const double *y, double *v);
+void orc_prior_factor(int kind, int chart, const double *prior, const double *x, double *e, double *H);
+void orc_between_factor(int kind, int chart, const double *measured, const double *x1, const double *x2, double *e,
+                        double *H1, double *H2);
+
+/* ---- chain problem: GN / LM over a GP trajectory (orc_chain.c) ----
+ * Mirrors include/gpslam_hip.h one to one so a test can drive both with the same calls.
+ * Variable ordering is the explicit chain order [x0, v0, x1, v1, ..., l0, l1, ...]. */
+typedef struct orc_chain orc_chain;
+
+typedef struct {
+  double error_before;     /* 0.5 * sum |R e|^2 at the linearisation point */
+  double error_after;      /* the same after the accepted update */
+  double delta_inf_norm;   /* max |delta| over all variables */
+  double lambda;           /* LM damping after the step */
+  int32_t iterations;      /* iterations performed by this call */
+  int32_t status;          /* 0 ok, <0 failure (e.g. non-SPD block) */
+  int32_t accepted;        /* LM: 1 if the step was accepted */
+  int32_t pad;
+} orc_stats;
+
+typedef struct {
+  int32_t max_iterations;      /* GTSAM default 100 */
+  double relative_error_tol;   /* 1e-5 */
+  double absolute_error_tol;   /* 1e-5 */
+  double error_tol;            /* 0 */
+  double delta_tol;            /* if > 0: additionally stop when |delta|_inf < delta_tol (north-star rule) */
+  double lambda_initial;       /* 1e-5 */
+  double lambda_factor;        /* 10 */
+  double lambda_upper_bound;   /* 1e5 */
+  double lambda_lower_bound;   /* 0 */
+  double min_model_fidelity;   /* 1e-3 */
+  int32_t use_lm;              /* 0 = Gauss-Newton, 1 = Levenberg-Marquardt */
+  int32_t pad;
+} orc_params;
+
+void orc_default_params(orc_params *p);
+orc_chain *orc_chain_create(int kind, int chart, int landmark_dim);
+void orc_chain_destroy(orc_chain *c);
+int orc_chain_set_qc(orc_chain *c, const double *Qc);
+int orc_chain_set_states(orc_chain *c, int N, const double *pose, const double *vel);
+int orc_chain_get_states(const orc_chain *c, double *pose, double *vel);
+int orc_chain_set_landmarks(orc_chain *c, int L, const double *pts);
+int orc_chain_get_landmarks(const orc_chain *c, double *pts);
+int orc_chain_add_gp_priors(orc_chain *c, int count, const int32_t *left, const double *dt);
+int orc_chain_add_pose_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
+int orc_chain_add_vel_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
+int orc_chain_add_between(orc_chain *c, int count, const int32_t *left, const double *measured, const double *sigmas);
+int orc_chain_add_landmark_priors(orc_chain *c, int count, const int32_t *idx, const double *prior,
+                                  const double *sigmas);
+int orc_chain_add_interp_range(orc_chain *c, int count, const int32_t *left, const int32_t *landmark, const double *z,
+                               const double *sigma, const double *dt, const double *tau, const double *sensor);
+int orc_chain_add_range(orc_chain *c, int count, const int32_t *idx, const int32_t *landmark, const double *z,
+                        const double *sigma);
+int orc_chain_add_interp_attitude(orc_chain *c, int count, const int32_t *left, const double *nZ, const double *bRef,
+                                  const double *sigma, const double *dt, const double *tau);
+int orc_chain_add_interp_gps(orc_chain *c, int count, const int32_t *left, const double *measured,
+                             const double *sigmas, const double *dt, const double *tau, const double *sensor);
+int orc_chain_add_odometry2d(orc_chain *c, int count, const int32_t *left, const double *measured,
+                             const double *sigmas);
+int orc_chain_add_bearing_range(orc_chain *c, int count, const int32_t *idx, const int32_t *landmark,
+                                const double *bearing, const double *range, const double *sigmas);
+/* errors: count x rows (unwhitened); jac: count x 4 x rows x d row-major (H1..H4 for GP priors) */
+int orc_chain_linearize_gp(const orc_chain *c, double *errors, double *jac);
+int orc_chain_error(const orc_chain *c, double *err);
+int orc_chain_iterate_gn(orc_chain *c, orc_stats *st);
+int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_stats *st);
+int orc_chain_optimize(orc_chain *c, const orc_params *p, orc_stats *st);
+/* Normal equations of the current linearisation: D (N x b x b), O (N x b x b, O[i] couples i and i+1),
+ * g (N x b); with landmarks also B (N x b x nl), HLL (nl x nl), gL (nl).  Any pointer may be NULL. */
+int orc_chain_normal_equations(const orc_chain *c, double *D, double *O, double *g, double *B, double *HLL,
+                               double *gL);
+/* Solve the block-tridiagonal SPD system given as above (no landmarks); x: N x b. */
+int orc_block_tridiag_solve(int N, int b, const double *D, const double *O, const double *g, double *x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSLAM_ORACLE_H */

@@ -1,0 +1,332 @@
+/*
+ * orc_factors.c -- CPU restatement of gpslam/slam measurement factors plus the GTSAM
+ * PriorFactor / BetweenFactor the reference's graphs use beside them.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gpslam_oracle.h).  Paths relative to /root/reference.
+ */
+#include "gpslam_oracle.h"
+#include "orc_math.h"
+
+/* H_k (rows x d) = Hpose (rows x d) * Hint_k (d x d):
+ * GaussianProcessInterpolator*::updatePoseJacobians, e.g. GaussianProcessInterpolatorPose3.h:108-116 */
+static void update_pose_jacobians(int rows, int d, const double *Hpose, const double *Hint1, const double *Hint2,
+                                  const double *Hint3, const double *Hint4, double *H1, double *H2, double *H3,
+                                  double *H4) {
+  if (H1) orc_mm(rows, d, d, Hpose, Hint1, H1);
+  if (H2) orc_mm(rows, d, d, Hpose, Hint2, H2);
+  if (H3) orc_mm(rows, d, d, Hpose, Hint3, H3);
+  if (H4) orc_mm(rows, d, d, Hpose, Hint4, H4);
+}
+
+/* GPInterpolatedRangeFactorPose2::evaluateError -- GPInterpolatedRangeFactorPose2.h:64-98
+ * sensor: optional body_P_sensor (Pose2, 3 doubles) or NULL. */
+double orc_interp_range_pose2(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                              const double *p1, const double *v1, const double *p2, const double *v2,
+                              const double *point, double *H1, double *H2, double *H3, double *H4, double *H5) {
+  double Hi1[9], Hi2[9], Hi3[9], Hi4[9], pose[3], Hpose[3], hx;
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose2(Lambda, Psi, p1, v1, p2, v2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
+                   want ? Hi4 : NULL);
+  if (sensor) {
+    double H0[9], sp[3], Hr[3];
+    orc_pose2_compose(pose, sensor, sp, H0, NULL);
+    hx = orc_pose2_range(sp, point, Hr, H5);
+    orc_mm(1, 3, 3, Hr, H0, Hpose);
+  } else {
+    hx = orc_pose2_range(pose, point, Hpose, H5);
+  }
+  if (want) update_pose_jacobians(1, 3, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+  return hx - measured;
+}
+
+/* GPInterpolatedRangeFactorPose3::evaluateError -- GPInterpolatedRangeFactorPose3.h:64-98 */
+double orc_interp_range_pose3(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                              const double *p1, const double *v1, const double *p2, const double *v2,
+                              const double *point, double *H1, double *H2, double *H3, double *H4, double *H5) {
+  double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], Hpose[6], hx;
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose3(Lambda, Psi, p1, v1, p2, v2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
+                   want ? Hi4 : NULL);
+  if (sensor) {
+    double H0[36], sp[12], Hr[6];
+    orc_pose3_compose(pose, sensor, sp, H0, NULL);
+    hx = orc_pose3_range(sp, point, Hr, H5);
+    orc_mm(1, 6, 6, Hr, H0, Hpose);
+  } else {
+    hx = orc_pose3_range(pose, point, Hpose, H5);
+  }
+  if (want) update_pose_jacobians(1, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+  return hx - measured;
+}
+
+/* GPInterpolatedRangeFactor2DLinear::evaluateError -- GPInterpolatedRangeFactor2DLinear.h:60-88
+ * pose vectors are [x, y, theta]; Lambda/Psi are 6x6. */
+double orc_interp_range_2dlinear(const double *Lambda, const double *Psi, double measured, const double *p1,
+                                 const double *v1, const double *p2, const double *v2, const double *point,
+                                 double *H1, double *H2, double *H3, double *H4, double *H5) {
+  double Hi1[9], Hi2[9], Hi3[9], Hi4[9], pose[3];
+  orc_interp_linear(3, Lambda, Psi, p1, v1, p2, v2, pose, Hi1, Hi2, Hi3, Hi4);
+  double d[2] = {point[0] - pose[0], point[1] - pose[1]};
+  double r = sqrt(d[0] * d[0] + d[1] * d[1]);
+  double H[2] = {d[0] / r, d[1] / r};
+  if (H1 || H2 || H3 || H4) {
+    double Hpose[3] = {-H[0], -H[1], 0.0};                       /* :82 */
+    update_pose_jacobians(1, 3, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+  }
+  if (H5) { H5[0] = H[0]; H5[1] = H[1]; }                         /* :86 */
+  return r - measured;
+}
+
+/* GPInterpolatedAttitudeFactorRot3::evaluateError -- GPInterpolatedAttitudeFactorRot3.h:61-83 */
+void orc_interp_attitude_rot3(const double *Lambda, const double *Psi, const double *nZ, const double *bRef,
+                              const double *R1, const double *v1, const double *R2, const double *v2, double *e,
+                              double *H1, double *H2, double *H3, double *H4) {
+  double Hi1[9], Hi2[9], Hi3[9], Hi4[9], rot[9], Hrot[6];
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_rot3(Lambda, Psi, R1, v1, R2, v2, rot, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
+                  want ? Hi4 : NULL);
+  orc_attitude_error(rot, nZ, bRef, e, want ? Hrot : NULL);
+  if (want) update_pose_jacobians(2, 3, Hrot, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+}
+
+/* GPInterpolatedGPSFactorPose3::evaluateError -- GPInterpolatedGPSFactorPose3.h:66-95 */
+void orc_interp_gps_pose3(const double *Lambda, const double *Psi, const double *measured, const double *sensor,
+                          const double *p1, const double *v1, const double *p2, const double *v2, double *e,
+                          double *H1, double *H2, double *H3, double *H4) {
+  double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], Hpose[18], t[3];
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose3(Lambda, Psi, p1, v1, p2, v2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
+                   want ? Hi4 : NULL);
+  if (sensor) {
+    double H0[36], sp[12], Ht[18];
+    orc_pose3_compose(pose, sensor, sp, H0, NULL);
+    orc_pose3_translation(sp, t, Ht);
+    orc_mm(3, 6, 6, Ht, H0, Hpose);
+  } else {
+    orc_pose3_translation(pose, t, Hpose);
+  }
+  for (int i = 0; i < 3; i++) e[i] = t[i] - measured[i];
+  if (want) update_pose_jacobians(3, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+}
+
+/* RangeFactor2DLinear::evaluateError -- RangeFactor2DLinear.h:43-56 */
+double orc_range_2dlinear(double measured, const double *pose, const double *point, double *H1, double *H2) {
+  double d[2] = {point[0] - pose[0], point[1] - pose[1]};
+  double r = sqrt(d[0] * d[0] + d[1] * d[1]);
+  double H[2] = {d[0] / r, d[1] / r};
+  if (H1) { H1[0] = -H[0]; H1[1] = -H[1]; H1[2] = 0.0; }
+  if (H2) { H2[0] = H[0]; H2[1] = H[1]; }
+  return r - measured;
+}
+
+/* RangeFactorPose2 = gtsam::RangeFactor<Pose2,Point2> -- RangeFactorPose2.h:15 */
+double orc_range_pose2(double measured, const double *pose, const double *point, double *H1, double *H2) {
+  return orc_pose2_range(pose, point, H1, H2) - measured;
+}
+
+/* RangeBearingFactor2DLinear::evaluateError -- RangeBearingFactor2DLinear.h:47-84
+ * e = [Rot2::Logmap(bearing.between(atan2(rel))), |point - t| - range] */
+void orc_range_bearing_2dlinear(double bearing, double range, const double *pose, const double *point, double *e,
+                                double *H1, double *H2) {
+  double rel[2];
+  orc_pose2_transform_to(pose, point, rel);
+  double expect_theta = atan2(rel[1], rel[0]);
+  double d[2] = {point[0] - pose[0], point[1] - pose[1]};
+  double expect_d = sqrt(d[0] * d[0] + d[1] * d[1]);
+  double Hnorm[2] = {d[0] / expect_d, d[1] / expect_d};
+  if (H1 || H2) {
+    double tmp[2];
+    if (expect_d > 1e-5) {                                        /* :62 */
+      double d2 = expect_d * expect_d;
+      tmp[0] = -rel[1] / d2;
+      tmp[1] = rel[0] / d2;
+    } else {
+      tmp[0] = 0.0;
+      tmp[1] = 0.0;
+    }
+    double c = cos(pose[2]), s = sin(pose[2]);
+    double Rt[4] = {c, s, -s, c};                                 /* pose2.r().transpose() */
+    if (H1) {
+      double M[6] = {-Rt[0], -Rt[1], rel[1], -Rt[2], -Rt[3], -rel[0]};   /* [-R^T, t], t = (rel.y, -rel.x) */
+      orc_mm(1, 2, 3, tmp, M, H1);                                /* H11 */
+      H1[3] = -Hnorm[0]; H1[4] = -Hnorm[1]; H1[5] = 0.0;          /* H21 */
+    }
+    if (H2) {
+      orc_mm(1, 2, 2, tmp, Rt, H2);                               /* H12 */
+      H2[2] = Hnorm[0]; H2[3] = Hnorm[1];                         /* H22 */
+    }
+  }
+  double diff = expect_theta - bearing;
+  e[0] = atan2(sin(diff), cos(diff));
+  e[1] = expect_d - range;
+}
+
+/* OdometryFactor2DLinear::evaluateError -- OdometryFactor2DLinear.h:50-75 */
+void orc_odometry_2dlinear(const double *measured, const double *pose1, const double *pose2, double *e, double *H1,
+                           double *H2) {
+  double dv[3] = {pose2[0] - pose1[0], pose2[1] - pose1[1], pose2[2] - pose1[2]};
+  double c = cos(pose1[2]), s = sin(pose1[2]);
+  /* Rot2(theta).unrotate(p): q = R^T p; Hrot = (q.y, -q.x)^T; Hp = R^T */
+  double q[2] = {c * dv[0] + s * dv[1], -s * dv[0] + c * dv[1]};
+  if (H1) {
+    double A[9] = {-c, -s, q[1], s, -c, -q[0], 0.0, 0.0, -1.0};
+    orc_copy(9, A, H1);
+  }
+  if (H2) {
+    double A[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};
+    orc_copy(9, A, H2);
+  }
+  e[0] = q[0] - measured[0];
+  e[1] = q[1] - measured[1];
+  e[2] = dv[2] - measured[2];
+}
+
+/* ---------------------------------------------------------------- GTSAM PriorFactor / BetweenFactor
+ * used at gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:173-174, matlab/PlazaPose2.m:63,:80,:125.
+ * kind: one of ORC_LINEAR* / ORC_POSE2 / ORC_POSE3 / ORC_ROT3; chart: ORC_CHART_EXPMAP or
+ * ORC_CHART_FIRST_ORDER (Pose2 only: GTSAM's default Pose2 chart).
+ *   PriorFactor:   e = Local(prior, x),  H = dLocal/dx
+ *   BetweenFactor: hx = between(x1, x2), e = Local(measured, hx), H1 = Hlocal * (-Ad(hx^-1)), H2 = Hlocal */
+
+int orc_pose_dim(int kind) {
+  switch (kind) {
+    case ORC_LINEAR2: return 2;
+    case ORC_LINEAR3: return 3;
+    case ORC_POSE2: return 3;
+    case ORC_POSE3: return 12;
+    case ORC_ROT3: return 9;
+    default: return -1;
+  }
+}
+int orc_tangent_dim(int kind) {
+  switch (kind) {
+    case ORC_LINEAR2: return 2;
+    case ORC_LINEAR3: return 3;
+    case ORC_POSE2: return 3;
+    case ORC_POSE3: return 6;
+    case ORC_ROT3: return 3;
+    default: return -1;
+  }
+}
+
+/* v = Local_origin(h), H = dv/dh (d x d) */
+static void chart_local(int kind, int chart, const double *h, double *v, double *H) {
+  switch (kind) {
+    case ORC_POSE2:
+      if (chart == ORC_CHART_FIRST_ORDER) {
+        v[0] = h[0]; v[1] = h[1]; v[2] = atan2(sin(h[2]), cos(h[2]));
+        if (H) {
+          double c = cos(h[2]), s = sin(h[2]);
+          double A[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};   /* topLeft = R^T */
+          orc_copy(9, A, H);
+        }
+      } else {
+        orc_pose2_logmap(h, v, H);
+      }
+      break;
+    case ORC_POSE3: orc_pose3_logmap(h, v, H); break;
+    case ORC_ROT3: orc_rot3_logmap(h, v, H); break;
+    default: break;
+  }
+}
+
+void orc_retract(int kind, int chart, const double *x, const double *delta, double *out) {
+  switch (kind) {
+    case ORC_LINEAR2:
+    case ORC_LINEAR3: {
+      int d = orc_tangent_dim(kind);
+      for (int i = 0; i < d; i++) out[i] = x[i] + delta[i];
+    } break;
+    case ORC_POSE2: {
+      double ex[3];
+      if (chart == ORC_CHART_FIRST_ORDER) { ex[0] = delta[0]; ex[1] = delta[1]; ex[2] = delta[2]; }
+      else orc_pose2_expmap(delta, ex, NULL);
+      orc_pose2_compose(x, ex, out, NULL, NULL);
+    } break;
+    case ORC_POSE3: {
+      double ex[12];
+      orc_pose3_expmap(delta, ex, NULL);
+      orc_pose3_compose(x, ex, out, NULL, NULL);
+    } break;
+    case ORC_ROT3: {
+      double ex[9];
+      orc_rot3_expmap(delta, ex, NULL);
+      orc_rot3_compose(x, ex, out, NULL, NULL);
+    } break;
+    default: break;
+  }
+}
+
+/* local coordinates of y around x: Local_origin(x^-1 y) */
+void orc_local(int kind, int chart, const double *x, const double *y, double *v) {
+  switch (kind) {
+    case ORC_LINEAR2:
+    case ORC_LINEAR3: {
+      int d = orc_tangent_dim(kind);
+      for (int i = 0; i < d; i++) v[i] = y[i] - x[i];
+    } break;
+    case ORC_POSE2: { double inv[3], h[3]; orc_pose2_inverse(x, inv, NULL); orc_pose2_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
+    case ORC_POSE3: { double inv[12], h[12]; orc_pose3_inverse(x, inv, NULL); orc_pose3_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
+    case ORC_ROT3: { double inv[9], h[9]; orc_rot3_inverse(x, inv, NULL); orc_rot3_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
+    default: break;
+  }
+}
+
+void orc_prior_factor(int kind, int chart, const double *prior, const double *x, double *e, double *H) {
+  int d = orc_tangent_dim(kind);
+  switch (kind) {
+    case ORC_LINEAR2:
+    case ORC_LINEAR3:
+      for (int i = 0; i < d; i++) e[i] = x[i] - prior[i];
+      if (H) orc_eye(d, H);
+      break;
+    case ORC_POSE2: { double inv[3], h[3]; orc_pose2_inverse(prior, inv, NULL); orc_pose2_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
+    case ORC_POSE3: { double inv[12], h[12]; orc_pose3_inverse(prior, inv, NULL); orc_pose3_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
+    case ORC_ROT3: { double inv[9], h[9]; orc_rot3_inverse(prior, inv, NULL); orc_rot3_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
+    default: break;
+  }
+}
+
+void orc_between_factor(int kind, int chart, const double *measured, const double *x1, const double *x2, double *e,
+                        double *H1, double *H2) {
+  int d = orc_tangent_dim(kind);
+  switch (kind) {
+    case ORC_LINEAR2:
+    case ORC_LINEAR3:
+      for (int i = 0; i < d; i++) e[i] = (x2[i] - x1[i]) - measured[i];
+      if (H1) { orc_eye(d, H1); orc_scale(d * d, -1.0, H1); }
+      if (H2) orc_eye(d, H2);
+      break;
+    case ORC_POSE2: {
+      double inv[3], hx[3], minv[3], h[3], Hl[9];
+      orc_pose2_inverse(x1, inv, NULL);
+      orc_pose2_compose(inv, x2, hx, NULL, NULL);
+      orc_pose2_inverse(measured, minv, NULL);
+      orc_pose2_compose(minv, hx, h, NULL, NULL);
+      chart_local(kind, chart, h, e, Hl);
+      if (H1) { double hxinv[3], Ad[9]; orc_pose2_inverse(hx, hxinv, NULL); orc_pose2_adjoint(hxinv, Ad); orc_mm(3, 3, 3, Hl, Ad, H1); orc_scale(9, -1.0, H1); }
+      if (H2) orc_copy(9, Hl, H2);
+    } break;
+    case ORC_POSE3: {
+      double inv[12], hx[12], minv[12], h[12], Hl[36];
+      orc_pose3_inverse(x1, inv, NULL);
+      orc_pose3_compose(inv, x2, hx, NULL, NULL);
+      orc_pose3_inverse(measured, minv, NULL);
+      orc_pose3_compose(minv, hx, h, NULL, NULL);
+      chart_local(kind, chart, h, e, Hl);
+      if (H1) { double hxinv[12], Ad[36]; orc_pose3_inverse(hx, hxinv, NULL); orc_pose3_adjoint(hxinv, Ad); orc_mm(6, 6, 6, Hl, Ad, H1); orc_scale(36, -1.0, H1); }
+      if (H2) orc_copy(36, Hl, H2);
+    } break;
+    case ORC_ROT3: {
+      double inv[9], hx[9], minv[9], h[9], Hl[9];
+      orc_rot3_inverse(x1, inv, NULL);
+      orc_rot3_compose(inv, x2, hx, NULL, NULL);
+      orc_rot3_inverse(measured, minv, NULL);
+      orc_rot3_compose(minv, hx, h, NULL, NULL);
+      chart_local(kind, chart, h, e, Hl);
+      if (H1) { double hxT[9]; orc_tr(3, 3, hx, hxT); orc_mm(3, 3, 3, Hl, hxT, H1); orc_scale(9, -1.0, H1); }   /* Ad(R^-1) = R^T */
+      if (H2) orc_copy(9, Hl, H2);
+    } break;
+    default: break;
+  }
+}

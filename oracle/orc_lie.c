@@ -1,0 +1,496 @@
+/*
+ * orc_lie.c -- CPU restatement of the GTSAM Lie-group maths the reference calls.
+ *
+ * TEST INFRASTRUCTURE ONLY (see gpslam_oracle.h).
+ *
+ * The reference (gtrll/gpslam) does not contain this code: it calls GTSAM
+ * (">= 4.0 alpha", unpinned, README.md:12; find_package(GTSAM) CMakeLists.txt:15),
+ * which is absent from /root/reference and from this image.  What follows restates
+ * GTSAM 4.x's published algorithms for exactly the calls the hot path makes:
+ *   Pose3::inverse/compose/Logmap/Expmap (+Jacobians)  <- GaussianProcessPriorPose3.h:72,
+ *                                                         GaussianProcessInterpolatorPose3.h:68,:79
+ *   Pose2::inverse/compose/Logmap/Expmap               <- GaussianProcessPriorPose2.h:71,
+ *                                                         GaussianProcessInterpolatorPose2.h:70,:78
+ *   Rot3::inverse/compose/Logmap/Expmap                <- GaussianProcessPriorRot3.h:71,
+ *                                                         GaussianProcessInterpolatorRot3.h:67,:75
+ *   Pose2::range / Pose3::range / compose(body_P_sensor)<- GPInterpolatedRangeFactorPose{2,3}.h:86,:93
+ *   Unit3 / AttitudeFactor::attitudeError              <- GPInterpolatedAttitudeFactorRot3.h:74
+ * Conventions: Pose3 tangent = (omega, v) rotation first;
+ * Pose2 tangent = (vx, vy, omega); Jacobians are right (body-frame) Jacobians;
+ * all matrices row-major.  Pose3 is stored as 12 doubles: R (9, row-major) then t (3).
+ * The reference's own tests pin these through zero-error configurations and through
+ * analytic-vs-numerical Jacobian agreement (tests/test_oracle_*.py re-run those).
+ */
+#include "gpslam_oracle.h"
+#include "orc_math.h"
+
+#include <float.h>
+
+/* ---------------------------------------------------------------- so(3) / SO(3) */
+
+void orc_skew(const double w[3], double W[9]) {
+  W[0] = 0.0;   W[1] = -w[2]; W[2] = w[1];
+  W[3] = w[2];  W[4] = 0.0;   W[5] = -w[0];
+  W[6] = -w[1]; W[7] = w[0];  W[8] = 0.0;
+}
+
+/* Rot3::Ypr(y,p,r) = Rz(y) * Ry(p) * Rx(r) */
+void orc_rot3_ypr(double y, double p, double r, double R[9]) {
+  double cy = cos(y), sy = sin(y), cp = cos(p), sp = sin(p), cr = cos(r), sr = sin(r);
+  double Rz[9] = {cy, -sy, 0, sy, cy, 0, 0, 0, 1};
+  double Ry[9] = {cp, 0, sp, 0, 1, 0, -sp, 0, cp};
+  double Rx[9] = {1, 0, 0, 0, cr, -sr, 0, sr, cr};
+  double T[9];
+  orc_mm(3, 3, 3, Rz, Ry, T);
+  orc_mm(3, 3, 3, T, Rx, R);
+}
+
+/* SO3::ExpmapDerivative: right Jacobian of the exponential map.
+ * Same closed form the reference restates as rightJacobianRot3 (Pose3utils.cpp:203-212). */
+void orc_rot3_expmap_derivative(const double w[3], double J[9]) {
+  double theta2 = orc_dot(3, w, w);
+  if (theta2 <= DBL_EPSILON) { orc_eye(3, J); return; }
+  double theta = sqrt(theta2);
+  double Y[9], YY[9];
+  orc_skew(w, Y);
+  orc_scale(9, 1.0 / theta, Y);
+  orc_mm(3, 3, 3, Y, Y, YY);
+  double a = (1.0 - cos(theta)) / theta, b = 1.0 - sin(theta) / theta;
+  orc_eye(3, J);
+  for (int i = 0; i < 9; i++) J[i] += -a * Y[i] + b * YY[i];
+}
+
+/* SO3::LogmapDerivative: inverse right Jacobian.
+ * Same closed form as rightJacobianRot3inv (Pose3utils.cpp:215-224). */
+void orc_rot3_logmap_derivative(const double w[3], double J[9]) {
+  double theta2 = orc_dot(3, w, w);
+  if (theta2 <= DBL_EPSILON) { orc_eye(3, J); return; }
+  double theta = sqrt(theta2);
+  double X[9], XX[9];
+  orc_skew(w, X);
+  orc_mm(3, 3, 3, X, X, XX);
+  double c = 1.0 / (theta * theta) - (1.0 + cos(theta)) / (2.0 * theta * sin(theta));
+  orc_eye(3, J);
+  for (int i = 0; i < 9; i++) J[i] += 0.5 * X[i] + c * XX[i];
+}
+
+/* SO3::Expmap (Rodrigues), H = ExpmapDerivative(w) */
+void orc_rot3_expmap(const double w[3], double R[9], double *H) {
+  if (H) orc_rot3_expmap_derivative(w, H);
+  double theta2 = orc_dot(3, w, w);
+  double W[9];
+  orc_skew(w, W);
+  orc_eye(3, R);
+  if (theta2 > DBL_EPSILON) {
+    double theta = sqrt(theta2);
+    double K[9], KK[9];
+    orc_copy(9, W, K);
+    orc_scale(9, 1.0 / theta, K);
+    orc_mm(3, 3, 3, K, K, KK);
+    double s = sin(theta), one_minus_cos = 2.0 * sin(theta / 2.0) * sin(theta / 2.0);
+    for (int i = 0; i < 9; i++) R[i] += s * K[i] + one_minus_cos * KK[i];
+  } else {
+    for (int i = 0; i < 9; i++) R[i] += W[i];
+  }
+}
+
+/* SO3::Logmap with the near-pi and near-0 branches, H = LogmapDerivative(omega) */
+void orc_rot3_logmap(const double R[9], double w[3], double *H) {
+  const double R11 = R[0], R12 = R[1], R13 = R[2];
+  const double R21 = R[3], R22 = R[4], R23 = R[5];
+  const double R31 = R[6], R32 = R[7], R33 = R[8];
+  const double tr = R11 + R22 + R33;
+  if (fabs(tr + 1.0) < 1e-10) {
+    if (fabs(R33 + 1.0) > 1e-10) {
+      double k = M_PI / sqrt(2.0 + 2.0 * R33);
+      w[0] = k * R13; w[1] = k * R23; w[2] = k * (1.0 + R33);
+    } else if (fabs(R22 + 1.0) > 1e-10) {
+      double k = M_PI / sqrt(2.0 + 2.0 * R22);
+      w[0] = k * R12; w[1] = k * (1.0 + R22); w[2] = k * R32;
+    } else {
+      double k = M_PI / sqrt(2.0 + 2.0 * R11);
+      w[0] = k * (1.0 + R11); w[1] = k * R21; w[2] = k * R31;
+    }
+  } else {
+    double magnitude;
+    const double tr_3 = tr - 3.0;
+    if (tr_3 < -1e-7) {
+      double theta = acos((tr - 1.0) / 2.0);
+      magnitude = theta / (2.0 * sin(theta));
+    } else {
+      magnitude = 0.5 - tr_3 * tr_3 / 12.0;
+    }
+    w[0] = magnitude * (R32 - R23);
+    w[1] = magnitude * (R13 - R31);
+    w[2] = magnitude * (R21 - R12);
+  }
+  if (H) orc_rot3_logmap_derivative(w, H);
+}
+
+/* Rot3::compose: R = R1 R2, H1 = R2^T, H2 = I */
+void orc_rot3_compose(const double R1[9], const double R2[9], double R[9], double *H1, double *H2) {
+  double T[9];
+  orc_mm(3, 3, 3, R1, R2, T);
+  if (H1) orc_tr(3, 3, R2, H1);
+  if (H2) orc_eye(3, H2);
+  orc_copy(9, T, R);
+}
+
+/* Rot3::inverse: R^T, H = -R */
+void orc_rot3_inverse(const double R[9], double Rinv[9], double *H) {
+  double T[9];
+  orc_tr(3, 3, R, T);
+  if (H) for (int i = 0; i < 9; i++) H[i] = -R[i];
+  orc_copy(9, T, Rinv);
+}
+
+/* ---------------------------------------------------------------- SE(3) */
+
+/* Pose3::AdjointMap = [[R, 0], [skew(t) R, R]] (rotation-first tangent) */
+void orc_pose3_adjoint(const double T[12], double Ad[36]) {
+  const double *R = T, *t = T + 9;
+  double S[9], SR[9];
+  orc_skew(t, S);
+  orc_mm(3, 3, 3, S, R, SR);
+  orc_zero(36, Ad);
+  orc_blk(3, 3, R, 3, 0, 0, Ad, 6, 0, 0);
+  orc_blk(3, 3, SR, 3, 0, 0, Ad, 6, 3, 0);
+  orc_blk(3, 3, R, 3, 0, 0, Ad, 6, 3, 3);
+}
+
+/* Pose3::inverse: (R^T, -R^T t), H = -Ad(T) */
+void orc_pose3_inverse(const double T[12], double Tinv[12], double *H) {
+  double out[12];
+  orc_tr(3, 3, T, out);
+  for (int i = 0; i < 3; i++) out[9 + i] = -(out[3 * i] * T[9] + out[3 * i + 1] * T[10] + out[3 * i + 2] * T[11]);
+  if (H) {
+    orc_pose3_adjoint(T, H);
+    orc_scale(36, -1.0, H);
+  }
+  orc_copy(12, out, Tinv);
+}
+
+/* Pose3::compose: (R1 R2, t1 + R1 t2); H1 = Ad(T2^-1), H2 = I */
+void orc_pose3_compose(const double A[12], const double B[12], double C[12], double *H1, double *H2) {
+  double out[12];
+  orc_mm(3, 3, 3, A, B, out);
+  for (int i = 0; i < 3; i++)
+    out[9 + i] = A[9 + i] + A[3 * i] * B[9] + A[3 * i + 1] * B[10] + A[3 * i + 2] * B[11];
+  if (H1) {
+    double Binv[12];
+    orc_pose3_inverse(B, Binv, NULL);
+    orc_pose3_adjoint(Binv, H1);
+  }
+  if (H2) orc_eye(6, H2);
+  orc_copy(12, out, C);
+}
+
+/* Pose3::computeQforExpmapDerivative, Barfoot14tro eq. (102) with the odd-order signs
+ * flipped for the right Jacobian; identical to rightJacobianPose3Q (Pose3utils.cpp:92-113). */
+void orc_pose3_Q(const double xi[6], double Q[9]) {
+  const double *omega = xi, *rho = xi + 3;
+  const double theta = sqrt(orc_dot(3, omega, omega));
+  double X[9], Y[9], XY[9], YX[9], XYX[9], XXY[9], YXX[9], XYXX[9], XXYX[9];
+  orc_skew(omega, X);
+  orc_skew(rho, Y);
+  orc_mm(3, 3, 3, X, Y, XY);
+  orc_mm(3, 3, 3, Y, X, YX);
+  orc_mm(3, 3, 3, X, YX, XYX);
+  orc_mm(3, 3, 3, X, XY, XXY);
+  orc_mm(3, 3, 3, YX, X, YXX);
+  orc_mm(3, 3, 3, XYX, X, XYXX);
+  orc_mm(3, 3, 3, X, XYX, XXYX);
+  double a, b, c;
+  if (fabs(theta) > 1e-5) {
+    const double s = sin(theta), co = cos(theta);
+    const double t2 = theta * theta, t3 = t2 * theta, t4 = t3 * theta, t5 = t4 * theta;
+    a = (theta - s) / t3;
+    b = (1.0 - 0.5 * t2 - co) / t4;
+    c = -0.5 * ((1.0 - 0.5 * t2 - co) / t4 - 3.0 * (theta - s - t3 / 6.0) / t5);
+  } else {
+    a = 1.0 / 6.0;
+    b = 1.0 / 24.0;
+    c = -0.5 * (1.0 / 24.0 + 3.0 / 120.0);
+  }
+  for (int i = 0; i < 9; i++)
+    Q[i] = -0.5 * Y[i] + a * (XY[i] + YX[i] - XYX[i]) + b * (XXY[i] + YXX[i] - 3.0 * XYX[i]) +
+           c * (XYXX[i] + XXYX[i]);
+}
+
+/* Pose3::ExpmapDerivative = [[Jr(w), 0], [Q, Jr(w)]] */
+void orc_pose3_expmap_derivative(const double xi[6], double J[36]) {
+  double Jw[9], Q[9];
+  orc_rot3_expmap_derivative(xi, Jw);
+  orc_pose3_Q(xi, Q);
+  orc_zero(36, J);
+  orc_blk(3, 3, Jw, 3, 0, 0, J, 6, 0, 0);
+  orc_blk(3, 3, Q, 3, 0, 0, J, 6, 3, 0);
+  orc_blk(3, 3, Jw, 3, 0, 0, J, 6, 3, 3);
+}
+
+/* Pose3::LogmapDerivative in terms of xi = Logmap(T): [[Jw^-1, 0], [-Jw^-1 Q Jw^-1, Jw^-1]].
+ * Identical in structure to rightJacobianPose3inv (Pose3utils.cpp:192-200). */
+void orc_pose3_logmap_derivative_xi(const double xi[6], double J[36]) {
+  double Jw[9], Q[9], T1[9], Q2[9];
+  orc_rot3_logmap_derivative(xi, Jw);
+  orc_pose3_Q(xi, Q);
+  orc_mm(3, 3, 3, Jw, Q, T1);
+  orc_mm(3, 3, 3, T1, Jw, Q2);
+  orc_scale(9, -1.0, Q2);
+  orc_zero(36, J);
+  orc_blk(3, 3, Jw, 3, 0, 0, J, 6, 0, 0);
+  orc_blk(3, 3, Q2, 3, 0, 0, J, 6, 3, 0);
+  orc_blk(3, 3, Jw, 3, 0, 0, J, 6, 3, 3);
+}
+
+/* Pose3::Expmap */
+void orc_pose3_expmap(const double xi[6], double T[12], double *H) {
+  if (H) orc_pose3_expmap_derivative(xi, H);
+  const double *omega = xi, *v = xi + 3;
+  double R[9];
+  orc_rot3_expmap(omega, R, NULL);
+  double theta2 = orc_dot(3, omega, omega);
+  orc_copy(9, R, T);
+  if (theta2 > DBL_EPSILON) {
+    double wv = orc_dot(3, omega, v);
+    double t_par[3] = {omega[0] * wv, omega[1] * wv, omega[2] * wv};
+    double wxv[3], Rwxv[3];
+    orc_cross(omega, v, wxv);
+    orc_mm(3, 3, 1, R, wxv, Rwxv);
+    for (int i = 0; i < 3; i++) T[9 + i] = (wxv[i] - Rwxv[i] + t_par[i]) / theta2;
+  } else {
+    for (int i = 0; i < 3; i++) T[9 + i] = v[i];
+  }
+}
+
+/* Pose3::Logmap (Agrawal06iros eq. 14 form) */
+void orc_pose3_logmap(const double T[12], double xi[6], double *H) {
+  double w[3];
+  orc_rot3_logmap(T, w, NULL);
+  const double *tr = T + 9;
+  double t = sqrt(orc_dot(3, w, w));
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (t < 1e-10) {
+    xi[3] = tr[0]; xi[4] = tr[1]; xi[5] = tr[2];
+  } else {
+    double wn[3] = {w[0] / t, w[1] / t, w[2] / t};
+    double W[9], WT[3], WWT[3];
+    orc_skew(wn, W);
+    double Tan = tan(0.5 * t);
+    orc_mm(3, 3, 1, W, tr, WT);
+    orc_mm(3, 3, 1, W, WT, WWT);
+    for (int i = 0; i < 3; i++) xi[3 + i] = tr[i] - (0.5 * t) * WT[i] + (1.0 - t / (2.0 * Tan)) * WWT[i];
+  }
+  if (H) orc_pose3_logmap_derivative_xi(xi, H);
+}
+
+/* Pose3::transform_to: q = R^T (p - t); Dpose = [skew(q), -I]; Dpoint = R^T */
+void orc_pose3_transform_to(const double T[12], const double p[3], double q[3], double *Dpose, double *Dpoint) {
+  double d[3] = {p[0] - T[9], p[1] - T[10], p[2] - T[11]};
+  for (int i = 0; i < 3; i++) q[i] = T[i] * d[0] + T[3 + i] * d[1] + T[6 + i] * d[2];
+  if (Dpose) {
+    double wx = q[0], wy = q[1], wz = q[2];
+    double D[18] = {0.0, -wz, +wy, -1.0, 0.0, 0.0,
+                    +wz, 0.0, -wx, 0.0, -1.0, 0.0,
+                    -wy, +wx, 0.0, 0.0, 0.0, -1.0};
+    orc_copy(18, D, Dpose);
+  }
+  if (Dpoint) orc_tr(3, 3, T, Dpoint);
+}
+
+/* Pose3::range(point, H1 (1x6), H2 (1x3)) */
+double orc_pose3_range(const double T[12], const double p[3], double *H1, double *H2) {
+  double q[3], Dpose[18], Dpoint[9];
+  orc_pose3_transform_to(T, p, q, Dpose, Dpoint);
+  double r = sqrt(orc_dot(3, q, q));
+  double Drl[3] = {q[0] / r, q[1] / r, q[2] / r};
+  if (H1) orc_mm(1, 3, 6, Drl, Dpose, H1);
+  if (H2) orc_mm(1, 3, 3, Drl, Dpoint, H2);
+  return r;
+}
+
+/* Pose3::translation(H): H = [0, R] (3x6) */
+void orc_pose3_translation(const double T[12], double t[3], double *H) {
+  t[0] = T[9]; t[1] = T[10]; t[2] = T[11];
+  if (H) {
+    orc_zero(18, H);
+    orc_blk(3, 3, T, 3, 0, 0, H, 6, 0, 3);
+  }
+}
+
+/* ---------------------------------------------------------------- SE(2) */
+
+/* Pose2::AdjointMap = [[c, -s, y], [s, c, -x], [0, 0, 1]] */
+void orc_pose2_adjoint(const double p[3], double Ad[9]) {
+  double c = cos(p[2]), s = sin(p[2]);
+  double A[9] = {c, -s, p[1], s, c, -p[0], 0.0, 0.0, 1.0};
+  orc_copy(9, A, Ad);
+}
+
+void orc_pose2_inverse(const double p[3], double pinv[3], double *H) {
+  double c = cos(p[2]), s = sin(p[2]);
+  double out[3] = {-(c * p[0] + s * p[1]), -(-s * p[0] + c * p[1]), -p[2]};
+  if (H) {
+    orc_pose2_adjoint(p, H);
+    orc_scale(9, -1.0, H);
+  }
+  orc_copy(3, out, pinv);
+}
+
+void orc_pose2_compose(const double a[3], const double b[3], double c3[3], double *H1, double *H2) {
+  double c = cos(a[2]), s = sin(a[2]);
+  double out[3] = {a[0] + c * b[0] - s * b[1], a[1] + s * b[0] + c * b[1], a[2] + b[2]};
+  if (H1) {
+    double binv[3];
+    orc_pose2_inverse(b, binv, NULL);
+    orc_pose2_adjoint(binv, H1);
+  }
+  if (H2) orc_eye(3, H2);
+  orc_copy(3, out, c3);
+}
+
+/* wrap to (-pi, pi] the way Rot2::theta() = atan2(s, c) does */
+static double orc_wrap(double th) { return atan2(sin(th), cos(th)); }
+
+/* Pose2::adjointMap(v) = [[0,-w,vy],[w,0,-vx],[0,0,0]] */
+static void orc_pose2_ad(const double v[3], double ad[9]) {
+  double A[9] = {0.0, -v[2], v[1], v[2], 0.0, -v[0], 0.0, 0.0, 0.0};
+  orc_copy(9, A, ad);
+}
+
+/* Pose2::ExpmapDerivative (Chirikjian11book2 p.36) */
+void orc_pose2_expmap_derivative(const double v[3], double J[9]) {
+  double alpha = v[2];
+  if (fabs(alpha) > 1e-5) {
+    double sZ = sin(alpha) / alpha, c1Z = (cos(alpha) - 1.0) / alpha;
+    double v1Z = v[0] / alpha, v2Z = v[1] / alpha;
+    double A[9] = {sZ, -c1Z, v1Z + v2Z * c1Z - v1Z * sZ,
+                   c1Z, sZ, -v1Z * c1Z + v2Z - v2Z * sZ,
+                   0.0, 0.0, 1.0};
+    orc_copy(9, A, J);
+  } else {
+    double ad[9];
+    orc_pose2_ad(v, ad);
+    orc_eye(3, J);
+    orc_axpy(9, -0.5, ad, J);
+  }
+}
+
+/* Pose2::LogmapDerivative in terms of v = Logmap(p) */
+void orc_pose2_logmap_derivative_v(const double v[3], double J[9]) {
+  double alpha = v[2];
+  if (fabs(alpha) > 1e-5) {
+    double alphaInv = 1.0 / alpha;
+    double hc = 0.5 * sin(alpha) / (1.0 - cos(alpha));
+    double v1 = v[0], v2 = v[1];
+    double A[9] = {alpha * hc, -0.5 * alpha, v1 * alphaInv - v1 * hc + 0.5 * v2,
+                   0.5 * alpha, alpha * hc, v2 * alphaInv - 0.5 * v1 - v2 * hc,
+                   0.0, 0.0, 1.0};
+    orc_copy(9, A, J);
+  } else {
+    double ad[9];
+    orc_pose2_ad(v, ad);
+    orc_eye(3, J);
+    orc_axpy(9, 0.5, ad, J);
+  }
+}
+
+void orc_pose2_expmap(const double xi[3], double p[3], double *H) {
+  if (H) orc_pose2_expmap_derivative(xi, H);
+  double w = xi[2];
+  if (fabs(w) < 1e-10) {
+    p[0] = xi[0]; p[1] = xi[1]; p[2] = xi[2];
+  } else {
+    double c = cos(w), s = sin(w);
+    double vo[2] = {-xi[1], xi[0]};                 /* R_PI_2 * v */
+    double Rvo[2] = {c * vo[0] - s * vo[1], s * vo[0] + c * vo[1]};
+    p[0] = (vo[0] - Rvo[0]) / w;
+    p[1] = (vo[1] - Rvo[1]) / w;
+    p[2] = orc_wrap(w);
+  }
+}
+
+void orc_pose2_logmap(const double p[3], double xi[3], double *H) {
+  double w = orc_wrap(p[2]);
+  if (fabs(w) < 1e-10) {
+    xi[0] = p[0]; xi[1] = p[1]; xi[2] = w;
+  } else {
+    double c = cos(p[2]), s = sin(p[2]);
+    double c_1 = c - 1.0, det = c_1 * c_1 + s * s;
+    double ut[2] = {c * p[0] + s * p[1], -s * p[0] + c * p[1]};   /* R.unrotate(t) */
+    double d[2] = {ut[0] - p[0], ut[1] - p[1]};
+    double q[2] = {-d[1], d[0]};                                  /* R_PI_2 * d */
+    xi[0] = (w / det) * q[0];
+    xi[1] = (w / det) * q[1];
+    xi[2] = w;
+  }
+  if (H) orc_pose2_logmap_derivative_v(xi, H);
+}
+
+/* Pose2::range(point, H1 (1x3), H2 (1x2)) */
+double orc_pose2_range(const double p[3], const double pt[2], double *H1, double *H2) {
+  double d[2] = {pt[0] - p[0], pt[1] - p[1]};
+  double r = sqrt(d[0] * d[0] + d[1] * d[1]);
+  double Drd[2] = {d[0] / r, d[1] / r};
+  if (H1) {
+    double c = cos(p[2]), s = sin(p[2]);
+    double Ddp[6] = {-c, s, 0.0, -s, -c, 0.0};
+    orc_mm(1, 2, 3, Drd, Ddp, H1);
+  }
+  if (H2) { H2[0] = Drd[0]; H2[1] = Drd[1]; }
+  return r;
+}
+
+/* Pose2::transform_to(point) = R^T (p - t) */
+void orc_pose2_transform_to(const double p[3], const double pt[2], double q[2]) {
+  double c = cos(p[2]), s = sin(p[2]);
+  double d[2] = {pt[0] - p[0], pt[1] - p[1]};
+  q[0] = c * d[0] + s * d[1];
+  q[1] = -s * d[0] + c * d[1];
+}
+
+/* ---------------------------------------------------------------- Unit3 / attitude */
+
+/* Unit3::basis(): 3x2, columns b1 = n x axis (normalised), b2 = n x b1 (normalised), where
+ * axis is the coordinate axis with the smallest |component| of n. */
+void orc_unit3_basis(const double n[3], double B[6]) {
+  double mx = fabs(n[0]), my = fabs(n[1]), mz = fabs(n[2]);
+  double axis[3] = {0, 0, 0};
+  if (mx <= my && mx <= mz) axis[0] = 1.0;
+  else if (my <= mx && my <= mz) axis[1] = 1.0;
+  else axis[2] = 1.0;
+  double b1[3], b2[3];
+  orc_cross(n, axis, b1);
+  double n1 = sqrt(orc_dot(3, b1, b1));
+  for (int i = 0; i < 3; i++) b1[i] /= n1;
+  orc_cross(n, b1, b2);
+  double n2 = sqrt(orc_dot(3, b2, b2));
+  for (int i = 0; i < 3; i++) b2[i] /= n2;
+  for (int i = 0; i < 3; i++) { B[2 * i] = b1[i]; B[2 * i + 1] = b2[i]; }
+}
+
+/* AttitudeFactor::attitudeError(nRb, H (2x3)):
+ *   nRef = nRb.rotate(bRef, D_nRef_R);  e = nZ.error(nRef, D_e_nRef);  H = D_e_nRef * D_nRef_R
+ * with Rot3::rotate(Unit3 p, HR) : q = R p, HR = -q.basis()^T R skew(p)
+ *      Unit3::error(q, H)        : e = B_nZ^T q, H = B_nZ^T q.basis()                     */
+void orc_attitude_error(const double R[9], const double nZ[3], const double bRef[3], double e[2], double *H) {
+  double q[3];
+  orc_mm(3, 3, 1, R, bRef, q);
+  double nq = sqrt(orc_dot(3, q, q));
+  for (int i = 0; i < 3; i++) q[i] /= nq;
+  double Bz[6], BzT[6];
+  orc_unit3_basis(nZ, Bz);
+  orc_tr(3, 2, Bz, BzT);
+  orc_mm(2, 3, 1, BzT, q, e);
+  if (H) {
+    double Bq[6], BqT[6], S[9], RS[9], D_nRef_R[6], D_e_nRef[4];
+    orc_unit3_basis(q, Bq);
+    orc_tr(3, 2, Bq, BqT);
+    orc_skew(bRef, S);
+    orc_mm(3, 3, 3, R, S, RS);
+    orc_mm(2, 3, 3, BqT, RS, D_nRef_R);
+    orc_scale(6, -1.0, D_nRef_R);
+    orc_mm(2, 3, 2, BzT, Bq, D_e_nRef);
+    orc_mm(2, 2, 3, D_e_nRef, D_nRef_R, H);
+  }
+}

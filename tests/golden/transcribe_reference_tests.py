@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/reference_tests.json.
+
+The fixture is DATA: the inputs, expected outputs and tolerances of the reference's own unit
+tests (gtrll/gpslam, gpslam/gp/tests/*.cpp and gpslam/slam/tests/*.cpp), transcribed by hand
+with the file:line each case comes from.  Nothing here is reference source code and nothing is
+computed by the reference (it cannot be built in this image: GTSAM/Eigen/Boost are absent).
+Where the reference's expected Jacobian is `numericalDerivative11(evaluateError)`, the case
+records the finite-difference step and tolerance the reference used; the test recomputes that
+numerical derivative from the error function under test, exactly as the reference does.
+
+Pose encodings:  pose3 = {"ypr": [yaw, pitch, roll], "t": [x, y, z]}  (Rot3::Ypr, Point3)
+                 rot3  = {"ypr": [...]},  pose2 = [x, y, theta],  vectors = lists.
+Run:  python tests/golden/transcribe_reference_tests.py
+"""
+import json
+import math
+import os
+
+PI = math.pi
+GP = "gpslam/gp/tests/"
+SL = "gpslam/slam/tests/"
+
+
+def P3(y, p, r, x, yy, z):
+    return {"ypr": [y, p, r], "t": [x, yy, z]}
+
+
+def R3(y, p, r):
+    return {"ypr": [y, p, r]}
+
+
+Z3, Z6 = [0, 0, 0], [0, 0, 0, 0, 0, 0]
+
+gp_prior = [
+    # ---- GaussianProcessPriorPose3 (dt = 0.1, Qc = 0.01 I6: testGaussianProcessPriorPose3.cpp:29-30)
+    dict(src=GP + "testGaussianProcessPriorPose3.cpp:43-65", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6,
+         p2=P3(0, 0, 0, 0, 0, 0), v2=Z6, expect=[0] * 12, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose3.cpp:69-91", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[0, 0, 0, 1, 0, 0], p2=P3(0, 0, 0, 0.1, 0, 0), v2=[0, 0, 0, 1, 0, 0], expect=[0] * 12, tol_e=1e-6,
+         fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose3.cpp:95-117", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[0, 0, 1, 0, 0, 0], p2=P3(0.1, 0, 0, 0, 0, 0), v2=[0, 0, 1, 0, 0, 0], expect=[0] * 12, tol_e=1e-6,
+         fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose3.cpp:121-142", kind="pose3", dt=0.1,
+         p1=P3(-0.1, 1.2, 0.3, -4.0, 2.0, 14.0), v1=[2, 3, 1, 5, 4, 9], p2=P3(2.4, -2.5, 3.7, 9.0, -8.0, -7.0),
+         v2=[1, 3, 8, 0, 6, 4], expect=None, fd=1e-6, tol_H=[1e-5, 1e-6, 1e-5, 1e-6]),
+    # ---- GaussianProcessPriorPose2 (dt = 0.1, Qc = 0.01 I3: testGaussianProcessPriorPose2.cpp:29-30)
+    dict(src=GP + "testGaussianProcessPriorPose2.cpp:43-65", kind="pose2", dt=0.1, p1=[0, 0, 0], v1=Z3, p2=[0, 0, 0],
+         v2=Z3, expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose2.cpp:69-91", kind="pose2", dt=0.1, p1=[0, 0, 0], v1=[1, 0, 0],
+         p2=[0.1, 0, 0], v2=[1, 0, 0], expect=[0] * 6, tol_e=1e-6, fd=1e-4, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose2.cpp:95-117", kind="pose2", dt=0.1, p1=[0, 0, 0], v1=[0, 0, 1],
+         p2=[0, 0, 0.1], v2=[0, 0, 1], expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorPose2.cpp:121-141", kind="pose2", dt=0.1, p1=[-0.1, 1.2, 0.3],
+         v1=[5, 4, 9], p2=[2.4, -2.5, 3.7], v2=[0, 6, 4], expect=None, fd=1e-6, tol_H=[1e-6] * 4),
+    # ---- GaussianProcessPriorRot3 (testGaussianProcessPriorRot3.cpp:29-30)
+    dict(src=GP + "testGaussianProcessPriorRot3.cpp:43-65", kind="rot3", dt=0.1, p1=R3(0, 0, 0), v1=Z3,
+         p2=R3(0, 0, 0), v2=Z3, expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorRot3.cpp:69-91", kind="rot3", dt=0.1, p1=R3(0, 0, 0), v1=[0, 0, 1],
+         p2=R3(0.1, 0, 0), v2=[0, 0, 1], expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorRot3.cpp:94-116", kind="rot3", dt=0.1, p1=R3(0, 0, 0), v1=[1, 0, 0],
+         p2=R3(0, 0, 0.1), v2=[1, 0, 0], expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorRot3.cpp:120-141", kind="rot3", dt=0.1, p1=R3(-0.1, 1.2, 0.3),
+         v1=[2, 3, 1], p2=R3(2.4, -2.5, 3.7), v2=[1, 3, 8], expect=None, fd=1e-6, tol_H=[1e-5, 1e-6, 1e-5, 1e-6]),
+    # ---- GaussianProcessPriorLinear<3> (testGaussianProcessPriorLinear.cpp:32-33)
+    dict(src=GP + "testGaussianProcessPriorLinear.cpp:45-67", kind="linear3", dt=0.1, p1=Z3, v1=Z3, p2=Z3, v2=Z3,
+         expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorLinear.cpp:70-92", kind="linear3", dt=0.1, p1=Z3, v1=[1, 0, 0],
+         p2=[0.1, 0, 0], v2=[1, 0, 0], expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorLinear.cpp:95-117", kind="linear3", dt=0.1, p1=Z3, v1=[0, 0, 1],
+         p2=[0, 0, 0.1], v2=[0, 0, 1], expect=[0] * 6, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessPriorLinear.cpp:120-140", kind="linear3", dt=0.1, p1=[2, -5, 7],
+         v1=[-1, 2, -9], p2=[-8, 4, -8], v2=[3, -4, 7], expect=None, fd=1e-6, tol_H=[1e-6] * 4),
+]
+
+# interpolators: dt = 0.1, tau = 0.03, Qc = 0.01 I
+interpolator = [
+    dict(src=GP + "testGaussianProcessInterpolatorPose3.cpp:33-56", kind="pose3", dt=0.1, tau=0.03, qc=0.01,
+         p1=P3(0, 0, 0, 0, 0, 0), v1=Z6, p2=P3(0, 0, 0, 0, 0, 0), v2=Z6, expect=P3(0, 0, 0, 0, 0, 0), tol_e=1e-6,
+         fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3.cpp:60-83", kind="pose3", dt=0.1, tau=0.03, qc=0.01,
+         p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 0, 1, 0, 0], p2=P3(0, 0, 0, 0.1, 0, 0), v2=[0, 0, 0, 1, 0, 0],
+         expect=P3(0, 0, 0, 0.03, 0, 0), tol_e=1e-6, fd=1e-4, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3.cpp:87-110", kind="pose3", dt=0.1, tau=0.03, qc=0.01,
+         p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 1, 0, 0, 0], p2=P3(0.1, 0, 0, 0, 0, 0), v2=[0, 0, 1, 0, 0, 0],
+         expect=P3(0.03, 0, 0, 0, 0, 0), tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3.cpp:114-135", kind="pose3", dt=0.1, tau=0.03, qc=0.01,
+         p1=P3(0.4, -0.8, 0.2, 3, -8, 2), v1=[0.1, -0.2, -1.4, 0.5, 0.9, 0.7], p2=P3(0.1, 0.3, -0.5, -9, 3, 4),
+         v2=[0.6, 0.3, -0.9, 0.4, -0.2, 0.8], expect=None, fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose2.cpp:33-56", kind="pose2", dt=0.1, tau=0.03, qc=0.01,
+         p1=[0, 0, 0], v1=Z3, p2=[0, 0, 0], v2=Z3, expect=[0, 0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose2.cpp:60-83", kind="pose2", dt=0.1, tau=0.03, qc=0.01,
+         p1=[0, 0, 0], v1=[1, 0, 0], p2=[0.1, 0, 0], v2=[1, 0, 0], expect=[0.03, 0, 0], tol_e=1e-6, fd=1e-4,
+         tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose2.cpp:87-110", kind="pose2", dt=0.1, tau=0.03, qc=0.01,
+         p1=[0, 0, 0], v1=[0, 0, 1], p2=[0, 0, 0.1], v2=[0, 0, 1], expect=[0, 0, 0.03], tol_e=1e-6, fd=1e-6,
+         tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorPose2.cpp:114-135", kind="pose2", dt=0.1, tau=0.03, qc=0.01,
+         p1=[3, -8, 2], v1=[0.5, 0.9, 0.7], p2=[-9, 3, 4], v2=[0.6, -0.2, 0.8], expect=None, fd=1e-6,
+         tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorRot3.cpp:33-56", kind="rot3", dt=0.1, tau=0.03, qc=0.01,
+         p1=R3(0, 0, 0), v1=Z3, p2=R3(0, 0, 0), v2=Z3, expect=R3(0, 0, 0), tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorRot3.cpp:60-83", kind="rot3", dt=0.1, tau=0.03, qc=0.01,
+         p1=R3(0, 0, 0), v1=[1, 0, 0], p2=R3(0, 0, 0.1), v2=[1, 0, 0], expect=R3(0, 0, 0.03), tol_e=1e-6, fd=1e-6,
+         tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorRot3.cpp:87-110", kind="rot3", dt=0.1, tau=0.03, qc=0.01,
+         p1=R3(0, 0, 0), v1=[0, 0, 1], p2=R3(0.1, 0, 0), v2=[0, 0, 1], expect=R3(0.03, 0, 0), tol_e=1e-6, fd=1e-6,
+         tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorRot3.cpp:114-135", kind="rot3", dt=0.1, tau=0.03, qc=0.01,
+         p1=R3(0.4, -0.8, 0.2), v1=[0.1, -0.2, -1.4], p2=R3(0.1, 0.3, -0.5), v2=[0.6, 0.3, -0.9], expect=None,
+         fd=1e-6, tol_H=[1e-8] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorLinear.cpp:58-81", kind="linear3", dt=0.1, tau=0.03, qc=0.01,
+         p1=Z3, v1=Z3, p2=Z3, v2=Z3, expect=[0, 0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorLinear.cpp:84-107", kind="linear3", dt=0.1, tau=0.03, qc=0.01,
+         p1=Z3, v1=[10, 0, 0], p2=[1, 0, 0], v2=[10, 0, 0], expect=[0.3, 0, 0], tol_e=1e-6, fd=1e-6,
+         tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorLinear.cpp:110-133", kind="linear3", dt=0.1, tau=0.03, qc=0.01,
+         p1=Z3, v1=[0, 0, 3], p2=[0, 0, 0.3], v2=[0, 0, 3], expect=[0, 0, 0.09], tol_e=1e-6, fd=1e-6,
+         tol_H=[1e-6] * 4),
+    dict(src=GP + "testGaussianProcessInterpolatorLinear.cpp:136-157", kind="linear3", dt=0.1, tau=0.03, qc=0.01,
+         p1=[2, -5, 7], v1=[-1, 2, -9], p2=[-8, 4, -8], v2=[3, -4, 7], expect=None, fd=1e-6, tol_H=[1e-6] * 4),
+]
+
+# interpolated range factors: dt = 0.1, tau = 0.04, Qc = 0.001 I, sigma 0.1
+_true_r2 = math.hypot(3.4 - 0.6, 1.2)           # Pose2(0.6,0,0).range(Point2(3.4,1.2)), RangeFactorPose2.cpp:146-149
+interp_range = [
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:55-80", kind="pose2", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, 0], v1=Z3, p2=[0, 0, 0], v2=Z3, land=[0, 10], meas=10, sensor=None, expect=0.0, tol_e=1e-6,
+         fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:84-109", kind="pose2", dt=0.1, tau=0.04, qc=0.001,
+         p1=[-0.04, 0, 0], v1=[1, 0, 0], p2=[0.06, 0, 0], v2=[1, 0, 0], land=[0, 10], meas=10, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:113-138", kind="pose2", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, -0.04], v1=[0, 0, 1], p2=[0, 0, 0.06], v2=[0, 0, 1], land=[0, 10], meas=10, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:142-169", kind="pose2", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, 0], v1=[15, 0, 0], p2=[1.5, 0, 0], v2=[15, 0, 0], land=[3.4, 1.2], meas=_true_r2, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:172-195", kind="pose2", dt=0.1, tau=0.04, qc=0.001,
+         p1=[5.34, 7.1, -4.32], v1=[15, 21.3, 32], p2=[1.5, -2.2, 3.0], v2=[-15, 4.2, -30], land=[3.4, 1.2],
+         meas=_true_r2, sensor=None, expect=None, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose3.cpp:56-81", kind="pose3", dt=0.1, tau=0.04, qc=0.001,
+         p1=P3(0, 0, 0, 0, 0, 0), v1=Z6, p2=P3(0, 0, 0, 0, 0, 0), v2=Z6, land=[0, 0, 10], meas=10, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose3.cpp:85-110", kind="pose3", dt=0.1, tau=0.04, qc=0.001,
+         p1=P3(0, 0, 0, -0.04, 0, 0), v1=[0, 0, 0, 1, 0, 0], p2=P3(0, 0, 0, 0.06, 0, 0), v2=[0, 0, 0, 1, 0, 0],
+         land=[0, 0, 10], meas=10, sensor=None, expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactorPose3.cpp:114-139", kind="pose3", dt=0.1, tau=0.04, qc=0.001,
+         p1=P3(-0.04, 0, 0, 0, 0, 0), v1=[0, 0, 1, 0, 0, 0], p2=P3(0.06, 0, 0, 0, 0, 0), v2=[0, 0, 1, 0, 0, 0],
+         land=[0, 0, 10], meas=10, sensor=None, expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    # with body_T_sensor = Pose3(Ypr(1.0,0.4,0.5), (0.3,0.6,-0.7)) (:45); meas = (true_pose * sensor).range(land)
+    dict(src=SL + "testGPInterpolatedRangeFactorPose3.cpp:144-172", kind="pose3", dt=0.1, tau=0.04, qc=0.001,
+         p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 0, 15, 0, 0], p2=P3(0, 0, 0, 1.5, 0, 0), v2=[0, 0, 0, 15, 0, 0],
+         land=[3.4, 1.2, 10], meas={"true_pose": P3(0, 0, 0, 0.6, 0, 0)}, sensor=P3(1.0, 0.4, 0.5, 0.3, 0.6, -0.7),
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6, 1e-6, 1e-6, 1e-5, 1e-6]),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:55-80", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, 0], v1=Z3, p2=[0, 0, 0], v2=Z3, land=[0, 10], meas=10, sensor=None, expect=0.0, tol_e=1e-6,
+         fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:84-109", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[-0.04, 0, 0], v1=[1, 0, 0], p2=[0.06, 0, 0], v2=[1, 0, 0], land=[0, 10], meas=10, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:113-138", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, -0.04], v1=[0, 0, 1], p2=[0, 0, 0.06], v2=[0, 0, 1], land=[0, 10], meas=10, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:142-167", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, 10 * PI - 0.04], v1=[0, 0, 1], p2=[0, 0, 10 * PI + 0.06], v2=[0, 0, 1], land=[0, 10], meas=10,
+         sensor=None, expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:171-198", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[0, 0, 0], v1=[15, 0, 0], p2=[1.5, 0, 0], v2=[15, 0, 0], land=[3.4, 1.2], meas=_true_r2, sensor=None,
+         expect=0.0, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:201-224", kind="linear3", dt=0.1, tau=0.04, qc=0.001,
+         p1=[5.34, 7.1, -4.32], v1=[15, 21.3, 32], p2=[1.5, -2.2, 3.0], v2=[-15, 4.2, -30], land=[3.4, 1.2],
+         meas=_true_r2, sensor=None, expect=None, fd=1e-6, tol_H=[1e-6] * 5),
+]
+
+range2d = [
+    dict(src=SL + "testRangeFactor2DLinear.cpp:39-44", pose=[0, 0, 0], land=[0, 0], meas=0.0, expect=0.0,
+         check_H=False),
+    dict(src=SL + "testRangeFactor2DLinear.cpp:47-60", pose=[3, 4, 5], land=[7, 7], meas=5.0, expect=0.0,
+         check_H=True),
+    dict(src=SL + "testRangeFactor2DLinear.cpp:63-76", pose=[13.1, -4.8, 1.5], land=[-5.4, 6.6], meas=13.1,
+         expect=8.630393461693233, check_H=True),
+]
+bearing_range2d = [
+    dict(src=SL + "testRangeBearingFactor2DLinear.cpp:39-52", pose=[3, 4, 0], land=[7, 7], range=5.0,
+         bearing=0.643501108793284, expect=[0, 0]),
+    dict(src=SL + "testRangeBearingFactor2DLinear.cpp:55-68", pose=[13.1, -4.8, 1.5], land=[-5.4, 6.6], range=13.1,
+         bearing=0.0, expect=[1.089334716657378, 8.630393461693233]),
+]
+odometry2d = [
+    dict(src=SL + "testOdometryFactor2DLinear.cpp:38-44", pose1=[0, 0, 0], pose2=[0, 0, 0], meas=[0, 0, 0],
+         expect=[0, 0, 0], check_H=False),
+    dict(src=SL + "testOdometryFactor2DLinear.cpp:47-61", pose1=[0, 0, 0], pose2=[1, 0, 0], meas=[1, 0, 0],
+         expect=[0, 0, 0], check_H=True),
+    dict(src=SL + "testOdometryFactor2DLinear.cpp:65-79", pose1=[42, 24, 1.570796326794897],
+         pose2=[42, 25, 2.570796326794897], meas=[1, 0, 1.0], expect=[0, 0, 0], check_H=True),
+]
+
+# testPose3Utils.cpp:89-164 (dt = 0.1)
+H = PI / 2.0
+body_centric_velocity = [
+    dict(src=GP + "testPose3Utils.cpp:96-103", p1=P3(0, 0, 0, 0, 0, 0), p2=P3(0, 0, 0, 0, 0, 0), vb=Z6, vs=Z6),
+    dict(src=GP + "testPose3Utils.cpp:106-113", p1=P3(0, 0, 0, 0, 0, 0), p2=P3(0, 0, 0, 0.1, 0, 0),
+         vb=[0, 0, 0, 1, 0, 0], vs=[0, 0, 0, 1, 0, 0]),
+    dict(src=GP + "testPose3Utils.cpp:116-123", p1=P3(0, 0, 0, 0, 0, 0), p2=P3(0.1, 0, 0, 0, 0, 0),
+         vb=[0, 0, 1, 0, 0, 0], vs=[0, 0, 1, 0, 0, 0]),
+    dict(src=GP + "testPose3Utils.cpp:126-133", p1=P3(H, 0, 0, 0, 0, 0), p2=P3(H, 0, 0, 0.1, 0, 0),
+         vb=[0, 0, 0, 0, -1, 0], vs=[0, 0, 0, 1, 0, 0]),
+    dict(src=GP + "testPose3Utils.cpp:136-143", p1=P3(H, 0, 0, 0, 0, 0), p2=P3(H + 0.1, 0, 0, 0, 0, 0),
+         vb=[0, 0, 1, 0, 0, 0], vs=[0, 0, 1, 0, 0, 0]),
+    dict(src=GP + "testPose3Utils.cpp:146-153", p1=P3(H, 0, 0, 1.0, 0, 0), p2=P3(H, 0, 0.1, 1.0, 0, 0),
+         vb=[1, 0, 0, 0, 0, 0], vs=[0, 1, 0, 0, 0, 1]),
+    dict(src=GP + "testPose3Utils.cpp:156-163", p1=P3(0, 0, 0, 0, -1.0, 0), p2=P3(H, 0, 0, 1.0, 0, 0),
+         vb=[0, 0, H * 10, H * 10, 0, 0], vs=[0, 0, H * 10, 0, 0, 0]),
+]
+
+# testPose3Utils.cpp:167-286: right Jacobians vs numericalLieRightJacobian (:44-56), dt = 1e-6
+lie_jacobians = [
+    dict(src=GP + "testPose3Utils.cpp:194-214", group="rot3", x=R3(0, 0, 0), tol=1e-6, tol_inv=1e-6),
+    dict(src=GP + "testPose3Utils.cpp:194-214", group="rot3", x=R3(1.0, 2.0, 3.0), tol=1e-6, tol_inv=1e-6),
+    dict(src=GP + "testPose3Utils.cpp:255-285", group="pose3", x=P3(0, 0, 0, 0, 0, 0), tol=1e-6, tol_inv=1e-6),
+    dict(src=GP + "testPose3Utils.cpp:255-285", group="pose3", x=P3(1e-5, 0, 1e-5, 0, 2e-5, 0), tol=1e-6,
+         tol_inv=1e-8),
+    dict(src=GP + "testPose3Utils.cpp:255-285", group="pose3", x=P3(1.0, 2.0, 3.0, 4.0, 5.0, 6.0), tol=1e-6,
+         tol_inv=1e-5),
+]
+# testPose3Utils.cpp:289-328 (Anderson15iros eq. 8), dt = 0.01
+se3_velocity = [
+    dict(src=GP + "testPose3Utils.cpp:297-305", base=P3(0, 0, 0, 0, 0, 0), dlog=[0, 0, 0, 0, 0, 0], tol=1e-6),
+    dict(src=GP + "testPose3Utils.cpp:308-316", base=P3(0, 0, 0, 0, 0, 0),
+         dlog=[1e-4, 2e-4, -4e-4, 5e-4, 2e-4, 3e-4], tol=1e-6),
+    dict(src=GP + "testPose3Utils.cpp:319-327", base=P3(2.4, 1.2, 3.9, 43, -5, 12),
+         dlog=[1e-4, 2e-4, -4e-4, 5e-4, 2e-4, 3e-4], tol=1e-4),
+]
+
+# 2-state Gauss-Newton problems (GaussNewtonParams defaults), expected fixed points
+optimization = [
+    dict(src=GP + "testGaussianProcessPriorPose3.cpp:146-195", kind="pose3", dt=1.0, qc=0.01, landmark_dim=0,
+         init=dict(pose=[P3(0, 0, 0, 0, 0, 0), P3(0, 0, 0, 1, 0, 0)],
+                   vel=[[0, 0, 0, 1, 0, 0], [0.1, 0.2, -0.3, 2.0, -0.5, 0.6]]),
+         pose_priors=[dict(idx=0, prior=P3(0, 0, 0, 0, 0, 0), sigma=0.001),
+                      dict(idx=1, prior=P3(0, 0, 0, 1, 0, 0), sigma=0.001)],
+         expect=dict(pose=[P3(0, 0, 0, 0, 0, 0), P3(0, 0, 0, 1, 0, 0)],
+                     vel=[[0, 0, 0, 1, 0, 0], [0, 0, 0, 1, 0, 0]]), tol=1e-6, tol_err=1e-6),
+    dict(src=GP + "testGaussianProcessPriorPose2.cpp:146-194", kind="pose2", dt=1.0, qc=0.01, landmark_dim=0,
+         init=dict(pose=[[0, 0, 0], [1, 0, 0]], vel=[[1, 0, 0], [2.0, -0.5, 0.6]]),
+         pose_priors=[dict(idx=0, prior=[0, 0, 0], sigma=0.001), dict(idx=1, prior=[1, 0, 0], sigma=0.001)],
+         expect=dict(pose=[[0, 0, 0], [1, 0, 0]], vel=[[1, 0, 0], [1, 0, 0]]), tol=1e-6, tol_err=1e-6),
+    dict(src=GP + "testGaussianProcessPriorRot3.cpp:145-194", kind="rot3", dt=0.1, qc=0.01, landmark_dim=0,
+         init=dict(pose=[R3(0, 0, 0), R3(0, 0, 0.1)], vel=[[1, 0, 0], [2.0, -0.5, 0.6]]),
+         pose_priors=[dict(idx=0, prior=R3(0, 0, 0), sigma=0.001), dict(idx=1, prior=R3(0, 0, 0.1), sigma=0.001)],
+         expect=dict(pose=[R3(0, 0, 0), R3(0, 0, 0.1)], vel=[[1, 0, 0], [1, 0, 0]]), tol=1e-6, tol_err=1e-6),
+    dict(src=GP + "testGaussianProcessPriorLinear.cpp:144-202", kind="linear3", dt=0.1, qc=0.01, landmark_dim=0,
+         init=dict(pose=[[1, 0, 0], [1.1, 0, 0]], vel=[[1, 0.1, 0.2], [2.1, -1.2, 0.9]]),
+         pose_priors=[dict(idx=0, prior=[1, 0, 0], sigma=0.001), dict(idx=1, prior=[1.1, 0, 0], sigma=0.001)],
+         expect=dict(pose=[[1, 0, 0], [1.1, 0, 0]], vel=[[1, 0, 0], [1, 0, 0]]), tol=1e-6, tol_err=1e-6),
+    # interpolated range, SE(2): 3 ranges at tau = 0.05, 0.25, 0.45 from camera poses on the line
+    dict(src=SL + "testGPInterpolatedRangeFactorPose2.cpp:200-283", kind="pose2", dt=0.5, qc=0.01, landmark_dim=2,
+         init=dict(pose=[[0.1, 0.1, -0.1], [5.1, -0.1, 0.1]], vel=[[9.8, 0, 0.2], [10.2, 0, -0.1]],
+                   land=[[2.3, 3.1]]),
+         pose_priors=[dict(idx=0, prior=[0, 0, 0], sigma=0.01), dict(idx=1, prior=[5, 0, 0], sigma=0.01)],
+         vel_priors=[dict(idx=0, prior=[10, 0, 0], sigma=0.01), dict(idx=1, prior=[10, 0, 0], sigma=0.01)],
+         land_priors=[dict(idx=0, prior=[2.4, 3.2], sigma=0.1)],
+         ranges=[dict(tau=0.05, cam=[0.5, 0, 0]), dict(tau=0.25, cam=[2.5, 0, 0]), dict(tau=0.45, cam=[4.5, 0, 0])],
+         range_sigma=0.1,
+         expect=dict(pose=[[0, 0, 0], [5, 0, 0]], vel=[[10, 0, 0], [10, 0, 0]], land=[[2.4, 3.2]]), tol=1e-4,
+         tol_err=1e-4),
+    # interpolated range, SE(3): tau = -0.1, 0.05, 0.2 with delta_t = 0.1 (extrapolation on both sides)
+    dict(src=SL + "testGPInterpolatedRangeFactorPose3.cpp:177-260", kind="pose3", dt=0.1, qc=0.01, landmark_dim=3,
+         init=dict(pose=[P3(0.1, 0.2, 0.4, 0.2, 0.3, -0.2), P3(-0.1, -0.2, -0.4, 1.2, -0.3, 0.2)],
+                   vel=[[-0.1, 0, 0, 0.8, 0, 0.2], [0, 0, 0.2, 1.2, 0, -0.1]], land=[[0.3, 1.1, 2.9]]),
+         pose_priors=[dict(idx=0, prior=P3(0, 0, 0, 0, 0, 0), sigma=0.01),
+                      dict(idx=1, prior=P3(0, 0, 0, 1, 0, 0), sigma=0.01)],
+         vel_priors=[dict(idx=0, prior=[0, 0, 0, 10, 0, 0], sigma=0.01),
+                     dict(idx=1, prior=[0, 0, 0, 10, 0, 0], sigma=0.01)],
+         land_priors=[dict(idx=0, prior=[0.4, 1.2, 3], sigma=0.1)],
+         ranges=[dict(tau=-0.1, cam=P3(0, 0, 0, -1, 0, 0)), dict(tau=0.05, cam=P3(0, 0, 0, 0.5, 0, 0)),
+                 dict(tau=0.2, cam=P3(0, 0, 0, 2, 0, 0))],
+         range_sigma=0.1,
+         expect=dict(pose=[P3(0, 0, 0, 0, 0, 0), P3(0, 0, 0, 1, 0, 0)],
+                     vel=[[0, 0, 0, 10, 0, 0], [0, 0, 0, 10, 0, 0]], land=[[0.4, 1.2, 3]]), tol=1e-6,
+         tol_err=1e-6),
+    # interpolated range, 2D linear with theta offset 10*pi (:250)
+    dict(src=SL + "testGPInterpolatedRangeFactor2DLinear.cpp:228-317", kind="linear3", dt=0.5, qc=0.01,
+         landmark_dim=2,
+         init=dict(pose=[[0.1, 0.1, 10 * PI - 0.1], [5.1, -0.1, 10 * PI + 0.1]],
+                   vel=[[9.8, 0, 0.2], [10.2, 0, -0.1]], land=[[2.3, 3.1]]),
+         pose_priors=[dict(idx=0, prior=[0, 0, 10 * PI], sigma=0.01), dict(idx=1, prior=[5, 0, 10 * PI], sigma=0.01)],
+         vel_priors=[dict(idx=0, prior=[10, 0, 0], sigma=0.01), dict(idx=1, prior=[10, 0, 0], sigma=0.01)],
+         land_priors=[dict(idx=0, prior=[2.4, 3.2], sigma=0.1)],
+         ranges=[dict(tau=0.05, cam=[0.5, 0, 10 * PI]), dict(tau=0.25, cam=[2.5, 0, 10 * PI]),
+                 dict(tau=0.45, cam=[4.5, 0, 10 * PI])],
+         range_sigma=0.1,
+         expect=dict(pose=[[0, 0, 10 * PI], [5, 0, 10 * PI]], vel=[[10, 0, 0], [10, 0, 0]], land=[[2.4, 3.2]]),
+         tol=1e-4, tol_err=1e-4),
+]
+
+out = dict(
+    _about="Inputs/expected values transcribed from gtrll/gpslam's own unit tests; see transcribe_reference_tests.py",
+    gp_prior=gp_prior, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
+    bearing_range2d=bearing_range2d, odometry2d=odometry2d, body_centric_velocity=body_centric_velocity,
+    lie_jacobians=lie_jacobians, se3_velocity=se3_velocity, optimization=optimization)
+
+if __name__ == "__main__":
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_tests.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
