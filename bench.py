@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""bench.py -- Gauss-Newton iterations over the BASELINE config-3 chain (Pose3 GP prior + synthetic odometry,
+1e5 states per GPU, fp64) on N GPUs of one node.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one full Gauss-Newton iteration of the hot path: linearise every factor (evaluateError + Jacobians),
+assemble the block-tridiagonal normal equations, solve, retract, re-evaluate the error -- exactly what
+matlab/PlazaPose2.m:224-226 brackets with tic/toc around optimizer.iterate().  Inputs are resident in HBM before
+the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(problem, iters=3):
+    """The oracle (CPU restatement of the reference algorithm, 1 thread) timed on the same workload."""
+    from oracle import oracle as O
+    from gpslam_amd import synthetic as S
+    ch = S.apply(problem, O.Chain(problem["kind"]))
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rc, _st = ch.iterate_gn()
+        assert rc == 0
+    dt = time.perf_counter() - t0
+    return dict(value=problem["N"] * iters / dt, unit="state-iterations/s", cores=1, kind="port",
+                sample="%d Gauss-Newton iterations of the full %d-state workload, oracle/liboracle.so (gcc -O2), "
+                       "%.1f s" % (iters, problem["N"], dt), seconds_per_iteration=dt / iters)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--states", type=int, default=100000, help="states per GPU (BASELINE config 3: 100k poses)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import gpslam_amd
+    from gpslam_amd import synthetic as S
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    N = args.states
+    problem = S.pose3_chain(N, seed=rank)
+    solver = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank, rank=rank, nranks=1))
+
+    # convergence run (untimed by the contract clock): iterations until |delta|_inf < 1e-6
+    conv_iters, conv_delta = 0, float("inf")
+    for _ in range(25):
+        _rc, st = solver.iterate_gn()
+        conv_iters += 1
+        conv_delta = st.delta_inf_norm
+        if conv_delta < 1e-6:
+            break
+    final_error = st.error_after
+
+    # timed region: restart from the initial values so the steps do real Newton work
+    solver.set_states(problem["pose"], problem["vel"])
+    if args.warmup > 0:
+        solver.run_gn(args.warmup)
+    solver.set_states(problem["pose"], problem["vel"])
+    barrier()
+    t0 = time.perf_counter()
+    solver.run_gn(args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel device time (hipEvents on the handle's stream), for the roofline of the dominant kernel
+    names = ["k_gp (K1 linearise GP priors)", "k_assemble (K3)", "k_chunk_forward level 0 (K4)",
+             "k_chunk_backward level 0 (K4)", "k_retract (K6)"]
+    kms = [solver.time_kernel(w, reps=5) for w in range(5)]
+    ab = S.algorithmic_bytes_per_state(problem["kind"])
+    blocks = ab["linearize"] - (18 * 8 + 8)
+    alg = [ab["linearize"] * (N - 1),          # K1: read state + dt, write e + H1..H4 (whitened rows)
+           (blocks + blocks) * N,              # K3: read rows, write blocks
+           ab["solve"] * N,                    # K4 forward: SURVEY 8(d) single-pass solve figure, conservative
+           (blocks + 12 * 8) * N,              # back-substitution: read factors, write delta
+           ab["retract"] * N]
+    dom = int(np.argmax(kms))
+    achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
+    _st, phase = solver.run_gn(3, timed=True)
+
+    if rank == 0:
+        total_states = N * world
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "GN state-iterations/sec (states x Gauss-Newton iters/sec), Pose3 GP chain",
+            "value": total_states * args.steps / elapsed,
+            "unit": "state-iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: Pose3/SE(3) GP prior + synthetic odometry, "
+                                   "%d poses per GPU, fp64, Gauss-Newton" % N,
+                       "states_per_gpu": N, "total_states": total_states,
+                       "factors": "N-1 GaussianProcessPriorPose3 + N-1 BetweenFactor<Pose3> + 1 PriorFactor<Pose3>",
+                       "parallelism": "segments x%d" % world},
+            "gn_iters_per_sec": args.steps / elapsed,
+            "iters_to_convergence": conv_iters,
+            "delta_inf_at_convergence": conv_delta,
+            "final_error": final_error,
+            "states_to_convergence_per_sec": total_states / (conv_iters * ms_per_step * 1e-3),
+            "phase_ms_per_iter": {k: float(v) / 3 for k, v in
+                                  zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
+            "kernel_ms": {n: float(v) for n, v in zip(names, kms)},
+            "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom]},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(S.pose3_chain(N, seed=0))
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

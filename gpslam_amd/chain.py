@@ -1,0 +1,280 @@
+"""ctypes binding of libgpslam_hip.so: one ChainSolver = one gpslam_hip_handle = one GPU stream.
+
+Mirrors the reference's usage pattern (NonlinearFactorGraph::add / Values::insert / optimizer.iterate(),
+e.g. gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:172-188) on arrays instead of per-factor objects.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+LINEAR2, LINEAR3, POSE2, POSE3, ROT3 = 0, 1, 2, 3, 4
+CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
+POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9}
+TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3}
+
+# every symbol include/gpslam_hip.h declares
+ABI_SYMBOLS = [
+    "gpslam_hip_create", "gpslam_hip_destroy", "gpslam_hip_default_params", "gpslam_hip_last_error",
+    "gpslam_hip_stream", "gpslam_hip_set_states", "gpslam_hip_get_states", "gpslam_hip_set_landmarks",
+    "gpslam_hip_get_landmarks", "gpslam_hip_set_qc", "gpslam_hip_add_gp_priors", "gpslam_hip_add_pose_priors",
+    "gpslam_hip_add_vel_priors", "gpslam_hip_add_between", "gpslam_hip_add_landmark_priors",
+    "gpslam_hip_add_interp_range", "gpslam_hip_add_range", "gpslam_hip_add_interp_attitude",
+    "gpslam_hip_add_interp_gps", "gpslam_hip_add_odometry2d", "gpslam_hip_add_bearing_range", "gpslam_hip_compile",
+    "gpslam_hip_linearize_gp", "gpslam_hip_error", "gpslam_hip_iterate_gn", "gpslam_hip_iterate_lm",
+    "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_block_tridiag_solve",
+    "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
+    "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
+]
+
+
+class GpslamHipError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [("manifold", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("chart", C.c_int32),
+                ("landmark_dim", C.c_int32), ("chunk", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
+                ("reserved", C.c_int32 * 8)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("error_before", C.c_double), ("error_after", C.c_double), ("delta_inf_norm", C.c_double),
+                ("lambda_", C.c_double), ("iterations", C.c_int32), ("status", C.c_int32),
+                ("accepted", C.c_int32), ("pad", C.c_int32)]
+
+
+class Params(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("relative_error_tol", C.c_double),
+                ("absolute_error_tol", C.c_double), ("error_tol", C.c_double), ("delta_tol", C.c_double),
+                ("lambda_initial", C.c_double), ("lambda_factor", C.c_double), ("lambda_upper_bound", C.c_double),
+                ("lambda_lower_bound", C.c_double), ("min_model_fidelity", C.c_double), ("use_lm", C.c_int32),
+                ("pad", C.c_int32)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libgpslam_hip.so, building it with hipcc if needed.  Raises if that is impossible."""
+    global _lib
+    if _lib is None:
+        path = _build.build()
+        if not os.path.exists(path):
+            raise GpslamHipError("libgpslam_hip.so is missing and could not be built; there is no CPU fallback")
+        _lib = C.CDLL(path)
+        _lib.gpslam_hip_last_error.restype = C.c_char_p
+        _lib.gpslam_hip_stream.restype = C.c_void_p
+    return _lib
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _i32(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.int32))
+
+
+def _p(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+class ChainSolver:
+    def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, device=0, chunk=0, rank=0, nranks=1):
+        self.lib = load_library()
+        self.kind, self.chart, self.ld = kind, chart, landmark_dim
+        self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
+        self.b = 2 * self.d
+        self.N = self.L = self.n_gp = 0
+        cfg = Config(manifold=kind, precision=0, device=device, chart=chart, landmark_dim=landmark_dim, chunk=chunk,
+                     rank=rank, nranks=nranks)
+        self._h = C.c_void_p()
+        rc = self.lib.gpslam_hip_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise GpslamHipError("gpslam_hip_create failed (%d): no usable HIP device, and there is no CPU fallback" % rc)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gpslam_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, what):
+        if rc < 0:
+            msg = self.lib.gpslam_hip_last_error(self._h)
+            raise GpslamHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+        return rc
+
+    # ---- variables
+    def set_qc(self, Qc):
+        Qc = _f64(Qc)
+        return self._chk(self.lib.gpslam_hip_set_qc(self._h, _p(Qc)), "set_qc")
+
+    def set_states(self, pose, vel):
+        pose, vel = _f64(pose).reshape(-1, self.pd), _f64(vel).reshape(-1, self.d)
+        self.N = pose.shape[0]
+        return self._chk(self.lib.gpslam_hip_set_states(self._h, self.N, _p(pose), _p(vel)), "set_states")
+
+    def get_states(self):
+        pose, vel = np.zeros((self.N, self.pd)), np.zeros((self.N, self.d))
+        self._chk(self.lib.gpslam_hip_get_states(self._h, _p(pose), _p(vel)), "get_states")
+        return pose, vel
+
+    def set_landmarks(self, pts):
+        pts = _f64(pts).reshape(-1, self.ld)
+        self.L = pts.shape[0]
+        return self._chk(self.lib.gpslam_hip_set_landmarks(self._h, self.L, _p(pts)), "set_landmarks")
+
+    def get_landmarks(self):
+        pts = np.zeros((self.L, self.ld))
+        self._chk(self.lib.gpslam_hip_get_landmarks(self._h, _p(pts)), "get_landmarks")
+        return pts
+
+    # ---- factors
+    def add_gp_priors(self, left, dt):
+        left, dt = _i32(left), _f64(dt)
+        self.n_gp += len(left)
+        return self._chk(self.lib.gpslam_hip_add_gp_priors(self._h, len(left), _p(left), _p(dt)), "add_gp_priors")
+
+    def add_pose_priors(self, idx, prior, sigmas):
+        idx, prior, sigmas = _i32(idx), _f64(prior), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_pose_priors(self._h, len(idx), _p(idx), _p(prior), _p(sigmas)),
+                         "add_pose_priors")
+
+    def add_vel_priors(self, idx, prior, sigmas):
+        idx, prior, sigmas = _i32(idx), _f64(prior), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_vel_priors(self._h, len(idx), _p(idx), _p(prior), _p(sigmas)),
+                         "add_vel_priors")
+
+    def add_between(self, left, measured, sigmas):
+        left, measured, sigmas = _i32(left), _f64(measured), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_between(self._h, len(left), _p(left), _p(measured), _p(sigmas)),
+                         "add_between")
+
+    def add_landmark_priors(self, idx, prior, sigmas):
+        idx, prior, sigmas = _i32(idx), _f64(prior), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_landmark_priors(self._h, len(idx), _p(idx), _p(prior), _p(sigmas)),
+                         "add_landmark_priors")
+
+    def add_interp_range(self, left, landmark, z, sigma, dt, tau, sensor=None):
+        left, landmark = _i32(left), _i32(landmark)
+        z, sigma, dt, tau = _f64(z), _f64(sigma), _f64(dt), _f64(tau)
+        sensor = None if sensor is None else _f64(sensor)
+        return self._chk(self.lib.gpslam_hip_add_interp_range(self._h, len(left), _p(left), _p(landmark), _p(z),
+                                                              _p(sigma), _p(dt), _p(tau), _p(sensor)),
+                         "add_interp_range")
+
+    def add_range(self, idx, landmark, z, sigma):
+        idx, landmark, z, sigma = _i32(idx), _i32(landmark), _f64(z), _f64(sigma)
+        return self._chk(self.lib.gpslam_hip_add_range(self._h, len(idx), _p(idx), _p(landmark), _p(z), _p(sigma)),
+                         "add_range")
+
+    def add_interp_attitude(self, left, nZ, bRef, sigma, dt, tau):
+        left = _i32(left)
+        nZ, bRef, sigma, dt, tau = _f64(nZ), _f64(bRef), _f64(sigma), _f64(dt), _f64(tau)
+        return self._chk(self.lib.gpslam_hip_add_interp_attitude(self._h, len(left), _p(left), _p(nZ), _p(bRef),
+                                                                 _p(sigma), _p(dt), _p(tau)), "add_interp_attitude")
+
+    def add_interp_gps(self, left, measured, sigmas, dt, tau, sensor=None):
+        left = _i32(left)
+        measured, sigmas, dt, tau = _f64(measured), _f64(sigmas), _f64(dt), _f64(tau)
+        sensor = None if sensor is None else _f64(sensor)
+        return self._chk(self.lib.gpslam_hip_add_interp_gps(self._h, len(left), _p(left), _p(measured), _p(sigmas),
+                                                            _p(dt), _p(tau), _p(sensor)), "add_interp_gps")
+
+    def add_odometry2d(self, left, measured, sigmas):
+        left, measured, sigmas = _i32(left), _f64(measured), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_odometry2d(self._h, len(left), _p(left), _p(measured), _p(sigmas)),
+                         "add_odometry2d")
+
+    def add_bearing_range(self, idx, landmark, bearing, rng, sigmas):
+        idx, landmark = _i32(idx), _i32(landmark)
+        bearing, rng, sigmas = _f64(bearing), _f64(rng), _f64(sigmas)
+        return self._chk(self.lib.gpslam_hip_add_bearing_range(self._h, len(idx), _p(idx), _p(landmark), _p(bearing),
+                                                               _p(rng), _p(sigmas)), "add_bearing_range")
+
+    def compile(self):
+        return self._chk(self.lib.gpslam_hip_compile(self._h), "compile")
+
+    # ---- hot path
+    def linearize_gp(self, jac=True):
+        e = np.zeros((self.n_gp, self.b))
+        H = np.zeros((self.n_gp, 4, self.b, self.d)) if jac else None
+        self._chk(self.lib.gpslam_hip_linearize_gp(self._h, _p(e), _p(H)), "linearize_gp")
+        return e, H
+
+    def error(self):
+        out = C.c_double(0.0)
+        self._chk(self.lib.gpslam_hip_error(self._h, C.byref(out)), "error")
+        return out.value
+
+    def iterate_gn(self):
+        st = Stats()
+        rc = self.lib.gpslam_hip_iterate_gn(self._h, C.byref(st))
+        self._chk(rc, "iterate_gn")
+        return rc, st
+
+    def iterate_lm(self, lam, params=None):
+        st = Stats()
+        p = params or self.default_params(use_lm=1)
+        lam_c = C.c_double(lam)
+        rc = self.lib.gpslam_hip_iterate_lm(self._h, C.byref(lam_c), C.byref(p), C.byref(st))
+        self._chk(rc, "iterate_lm")
+        return rc, st, lam_c.value
+
+    def optimize(self, params=None):
+        st = Stats()
+        p = params or self.default_params()
+        rc = self.lib.gpslam_hip_optimize(self._h, C.byref(p), C.byref(st))
+        self._chk(rc, "optimize")
+        return rc, st
+
+    def run_gn(self, iters, timed=False):
+        st = Stats()
+        t = np.zeros(5) if timed else None
+        self._chk(self.lib.gpslam_hip_run_gn(self._h, int(iters), C.byref(st), _p(t)), "run_gn")
+        return st, t
+
+    def default_params(self, **kw):
+        p = Params()
+        self.lib.gpslam_hip_default_params(C.byref(p))
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    # ---- inspection
+    def normal_equations(self):
+        N, b, nl = self.N, self.b, self.L * self.ld
+        D, O, g = np.zeros((N, b, b)), np.zeros((N, b, b)), np.zeros((N, b))
+        B = np.zeros((N, b, nl)) if nl else None
+        self._chk(self.lib.gpslam_hip_normal_equations(self._h, _p(D), _p(O), _p(g), _p(B)), "normal_equations")
+        return D, O, g, B
+
+    def block_tridiag_solve(self, D, O, g):
+        D, O, g = _f64(D), _f64(O), _f64(g)
+        x = np.zeros_like(g)
+        self._chk(self.lib.gpslam_hip_block_tridiag_solve(self._h, g.shape[0], _p(D), _p(O), _p(g), _p(x)),
+                  "block_tridiag_solve")
+        return x
+
+    def last_timing(self):
+        t = np.zeros(5)
+        self.lib.gpslam_hip_last_timing(self._h, _p(t))
+        return t
+
+    def time_kernel(self, which, reps=10):
+        out = C.c_double(0.0)
+        self._chk(self.lib.gpslam_hip_time_kernel(self._h, int(which), int(reps), C.byref(out)), "time_kernel")
+        return out.value
+
+    def stream(self):
+        return self.lib.gpslam_hip_stream(self._h)

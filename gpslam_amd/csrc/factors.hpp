@@ -1,0 +1,334 @@
+// factors.hpp -- per-thread factor evaluation (error + Jacobians) for the batched linearisation kernels.
+//
+// Every function evaluates ONE factor entirely in registers.  Outputs are unwhitened, in the layout the
+// reference's evaluateError() produces; whitening and the write to the HBM row table happen in kernels.hip.
+// Reference functions restated here (file:line relative to /root/reference):
+//   GaussianProcessPriorLinear<D>::evaluateError   gpslam/gp/GaussianProcessPriorLinear.h:63-83
+//   GaussianProcessPriorPose2::evaluateError       gpslam/gp/GaussianProcessPriorPose2.h:58-82
+//   GaussianProcessPriorRot3::evaluateError        gpslam/gp/GaussianProcessPriorRot3.h:58-79
+//   GaussianProcessPriorPose3::evaluateError       gpslam/gp/GaussianProcessPriorPose3.h:60-98
+//   jacobianMethodNumercialDiff                    gpslam/gp/Pose3utils.cpp:167-179
+#pragma once
+
+#include "lie.hpp"
+
+namespace gps {
+
+enum Manifold : int { LINEAR2 = 0, LINEAR3 = 1, POSE2 = 2, POSE3 = 3, ROT3 = 4 };
+enum Chart : int { CHART_EXPMAP = 0, CHART_FIRST_ORDER = 1 };
+
+template <int M> struct MTraits;
+template <> struct MTraits<LINEAR2> { static constexpr int d = 2, pd = 2; };
+template <> struct MTraits<LINEAR3> { static constexpr int d = 3, pd = 3; };
+template <> struct MTraits<POSE2> { static constexpr int d = 3, pd = 3; };
+template <> struct MTraits<POSE3> { static constexpr int d = 6, pd = 12; };
+template <> struct MTraits<ROT3> { static constexpr int d = 3, pd = 9; };
+
+// ---- conversions between flat register arrays and the Lie types
+template <typename T> GD M3<T> as_m3(const T *p) {
+  M3<T> r;
+#pragma unroll
+  for (int i = 0; i < 9; i++) r.m[i] = p[i];
+  return r;
+}
+template <typename T> GD SE3<T> as_se3(const T *p) { return {as_m3(p), {p[9], p[10], p[11]}}; }
+template <typename T> GD V3<T> as_v3(const T *p) { return {p[0], p[1], p[2]}; }
+template <typename T> GD V6<T> as_v6(const T *p) { return {{p[0], p[1], p[2]}, {p[3], p[4], p[5]}}; }
+template <typename T> GD void put_m3(const M3<T> &a, T *J, int ld, int r0, int c0) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) J[(r0 + i) * ld + c0 + j] = a.m[3 * i + j];
+}
+template <typename T> GD void put_bl6(const BL6<T> &a, T *J, int ld, int r0, int c0) {
+  put_m3(a.A, J, ld, r0, c0);
+  put_m3(a.C, J, ld, r0 + 3, c0);
+  put_m3(a.D, J, ld, r0 + 3, c0 + 3);
+}
+
+// d( Jr^-1(xi) * x ) / d xi by central differences with h = 1e-6, exactly the construction of
+// jacobianMethodNumercialDiff(rightJacobianPose3inv, xi, x) (Pose3utils.cpp:167-179, default dxi Pose3utils.h:57).
+// The result is block lower-triangular: perturbing rho leaves the rotation block of Jr^-1 untouched, so the
+// reference's top-right 3x3 block is an exact zero as well.
+template <typename T> GD BL6<T> se3_jrinv_times_x_fd(V6<T> xi, V6<T> x) {
+  const T h = T(1e-6);
+  BL6<T> D;
+  D.A = M3<T>::zero();
+  D.C = M3<T>::zero();
+  D.D = M3<T>::zero();
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    V6<T> xp = xi, xn = xi;
+    if (i == 0) { xp.w.x += h; xn.w.x -= h; }
+    if (i == 1) { xp.w.y += h; xn.w.y -= h; }
+    if (i == 2) { xp.w.z += h; xn.w.z -= h; }
+    if (i == 3) { xp.v.x += h; xn.v.x -= h; }
+    if (i == 4) { xp.v.y += h; xn.v.y -= h; }
+    if (i == 5) { xp.v.z += h; xn.v.z -= h; }
+    const BL6<T> Jp = se3_jrinv(xp), Jn = se3_jrinv(xn);
+    const T s = T(1) / (T(2) * h);
+    // ((Jp - Jn) / (2h)) * x, same operation order as the reference
+    const BL6<T> dJ = {s * (Jp.A - Jn.A), s * (Jp.C - Jn.C), s * (Jp.D - Jn.D)};
+    const V6<T> col = dJ * x;
+    if (i < 3) {
+      D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
+      D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
+    } else {
+      // top block: (Jp.A - Jn.A) is exactly zero for a rho perturbation -> col.w == 0
+      D.D.m[0 + (i - 3)] = col.v.x; D.D.m[3 + (i - 3)] = col.v.y; D.D.m[6 + (i - 3)] = col.v.z;
+    }
+  }
+  return D;
+}
+
+// GP prior, unwhitened.  x1 = (p1, v1), x2 = (p2, v2) as flat arrays (pose layout of include/gpslam_hip.h).
+// Outputs: e[2d]; if JAC: Jt[d][4d] = top d rows of [H1 H2 | H3 H4], Jb[d][4d] = bottom d rows.
+template <typename T, int MF, bool JAC> struct GpPrior;
+
+template <typename T, int D, bool JAC> struct GpPriorLinear {
+  static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
+#pragma unroll
+    for (int i = 0; i < D; i++) {
+      e[i] = p1[i] + dt * v1[i] - p2[i];
+      e[D + i] = v1[i] - v2[i];
+    }
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < D * 4 * D; i++) { Jt[i] = T(0); Jb[i] = T(0); }
+#pragma unroll
+      for (int i = 0; i < D; i++) {
+        Jt[i * 4 * D + i] = T(1);           // H1 = [I; 0]
+        Jt[i * 4 * D + D + i] = dt;         // H2 = [dt I; I]
+        Jb[i * 4 * D + D + i] = T(1);
+        Jt[i * 4 * D + 2 * D + i] = T(-1);  // H3 = [-I; 0]
+        Jb[i * 4 * D + 3 * D + i] = T(-1);  // H4 = [0; -I]
+      }
+    }
+  }
+};
+template <typename T, bool JAC> struct GpPrior<T, LINEAR2, JAC> : GpPriorLinear<T, 2, JAC> {};
+template <typename T, bool JAC> struct GpPrior<T, LINEAR3, JAC> : GpPriorLinear<T, 3, JAC> {};
+
+// shared tail of the d = 3 groups: e = [r - v1 dt; v2 - v1], H1 = [J1; 0], H2 = [-dt I; -I], H3 = [J3; 0], H4 = [0; I]
+template <typename T, bool JAC>
+GD void gp3_tail(V3<T> r, const T *v1, const T *v2, T dt, const M3<T> &J1, const M3<T> &J3, T *e, T *Jt, T *Jb) {
+  e[0] = r.x - v1[0] * dt; e[1] = r.y - v1[1] * dt; e[2] = r.z - v1[2] * dt;
+#pragma unroll
+  for (int i = 0; i < 3; i++) e[3 + i] = v2[i] - v1[i];
+  if (JAC) {
+#pragma unroll
+    for (int i = 0; i < 36; i++) { Jt[i] = T(0); Jb[i] = T(0); }
+    put_m3(J1, Jt, 12, 0, 0);
+    put_m3(J3, Jt, 12, 0, 6);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      Jt[i * 12 + 3 + i] = -dt;
+      Jb[i * 12 + 3 + i] = T(-1);
+      Jb[i * 12 + 9 + i] = T(1);
+    }
+  }
+}
+
+template <typename T, bool JAC> struct GpPrior<T, POSE2, JAC> {
+  static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
+    const SE2<T> a = {p1[0], p1[1], p1[2]}, b = {p2[0], p2[1], p2[2]};
+    const SE2<T> h = se2_between(a, b);
+    const V3<T> r = se2_log(h);
+    M3<T> J1 = M3<T>::zero(), J3 = M3<T>::zero();
+    if (JAC) {
+      // d(a^-1 b)/da = Ad(b^-1) * (-Ad(a)) = -Ad(h^-1);  d/db = I
+      J3 = se2_dlog(r);
+      J1 = neg(J3 * se2_adjoint(se2_inverse(h)));
+    }
+    gp3_tail<T, JAC>(r, v1, v2, dt, J1, J3, e, Jt, Jb);
+  }
+};
+
+template <typename T, bool JAC> struct GpPrior<T, ROT3, JAC> {
+  static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
+    const M3<T> R1 = as_m3(p1), R2 = as_m3(p2);
+    const M3<T> h = transpose(R1) * R2;
+    const V3<T> r = so3_log(h);
+    M3<T> J1 = M3<T>::zero(), J3 = M3<T>::zero();
+    if (JAC) {
+      // Hcomp1 * Hinv = R2^T * (-R1) = -h^T
+      J3 = so3_jrinv(r);
+      J1 = neg(J3 * transpose(h));
+    }
+    gp3_tail<T, JAC>(r, v1, v2, dt, J1, J3, e, Jt, Jb);
+  }
+};
+
+template <typename T, bool JAC> struct GpPrior<T, POSE3, JAC> {
+  static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
+    const SE3<T> a = as_se3(p1), b = as_se3(p2);
+    const SE3<T> h = se3_between(a, b);
+    const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
+    const BL6<T> Jinv = se3_jrinv(r);           // :76
+    const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+    const V6<T> top = r - dt * u1;              // :97
+    const V6<T> bot = Jinv * u2 - u1;
+    e[0] = top.w.x; e[1] = top.w.y; e[2] = top.w.z; e[3] = top.v.x; e[4] = top.v.y; e[5] = top.v.z;
+    e[6] = bot.w.x; e[7] = bot.w.y; e[8] = bot.w.z; e[9] = bot.v.x; e[10] = bot.v.y; e[11] = bot.v.z;
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < 6 * 24; i++) { Jt[i] = T(0); Jb[i] = T(0); }
+      // Hlogmap = LogmapDerivative = Jr^-1(r) (same closed form, Pose3utils.cpp:192-200)
+      const BL6<T> J_Ti1 = Jinv;                                   // Hlogmap * Hcomp2, Hcomp2 = I   (:89)
+      const BL6<T> J_Ti = neg(Jinv * se3_adjoint(se3_inverse(h))); // Hlogmap * Hcomp1 * Hinv = -Hlog Ad(h^-1) (:80)
+      const BL6<T> FD = se3_jrinv_times_x_fd(r, u2);               // (:81, :90) -- computed once, used twice
+      put_bl6(J_Ti, Jt, 24, 0, 0);                                 // H1 = [J_Ti; FD J_Ti]
+      put_bl6(FD * J_Ti, Jb, 24, 0, 0);
+      put_bl6(J_Ti1, Jt, 24, 0, 12);                               // H3 = [J_Ti1; FD J_Ti1]
+      put_bl6(FD * J_Ti1, Jb, 24, 0, 12);
+      put_bl6(Jinv, Jb, 24, 0, 18);                                // H4 = [0; Jinv] (:95)
+#pragma unroll
+      for (int i = 0; i < 6; i++) {                                // H2 = [-dt I; -I] (:86)
+        Jt[i * 24 + 6 + i] = -dt;
+        Jb[i * 24 + 6 + i] = T(-1);
+      }
+    }
+  }
+};
+
+// ------------------------------------------------------------------ charts (retract / local at the origin)
+
+// v = Local_origin(h) and its derivative for the pose manifolds; used by PriorFactor / BetweenFactor.
+// Flat pose in, tangent out.  HL: d x d row-major (only if JAC).
+template <typename T, int MF, bool JAC> struct ChartLocal;
+
+template <typename T, bool JAC> struct ChartLocal<T, POSE3, JAC> {
+  static GD void eval(const SE3<T> &h, int, T *v, T *HL) {
+    const V6<T> xi = se3_log(h);
+    v[0] = xi.w.x; v[1] = xi.w.y; v[2] = xi.w.z; v[3] = xi.v.x; v[4] = xi.v.y; v[5] = xi.v.z;
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < 36; i++) HL[i] = T(0);
+      put_bl6(se3_jrinv(xi), HL, 6, 0, 0);
+    }
+  }
+};
+
+// PriorFactor<Pose>: e = Local(prior, x) = Local_origin(prior^-1 x), H = dLocal.
+// BetweenFactor<Pose>: hx = x1^-1 x2, e = Local_origin(measured^-1 hx), H1 = -HL Ad(hx^-1), H2 = HL.
+template <typename T, int MF, bool JAC> struct PoseFactors;
+
+template <typename T, int D, bool JAC> struct PoseFactorsLinear {
+  static GD void prior(const T *pr, const T *x, int, T *e, T *H) {
+#pragma unroll
+    for (int i = 0; i < D; i++) e[i] = x[i] - pr[i];
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < D * D; i++) H[i] = T(0);
+#pragma unroll
+      for (int i = 0; i < D; i++) H[i * D + i] = T(1);
+    }
+  }
+  static GD void between(const T *m, const T *x1, const T *x2, int, T *e, T *H1, T *H2) {
+#pragma unroll
+    for (int i = 0; i < D; i++) e[i] = (x2[i] - x1[i]) - m[i];
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < D * D; i++) { H1[i] = T(0); H2[i] = T(0); }
+#pragma unroll
+      for (int i = 0; i < D; i++) { H1[i * D + i] = T(-1); H2[i * D + i] = T(1); }
+    }
+  }
+  static GD void retract(const T *x, const T *dlt, int, T *out) {
+#pragma unroll
+    for (int i = 0; i < D; i++) out[i] = x[i] + dlt[i];
+  }
+};
+template <typename T, bool JAC> struct PoseFactors<T, LINEAR2, JAC> : PoseFactorsLinear<T, 2, JAC> {};
+template <typename T, bool JAC> struct PoseFactors<T, LINEAR3, JAC> : PoseFactorsLinear<T, 3, JAC> {};
+
+template <typename T, bool JAC> struct PoseFactors<T, POSE2, JAC> {
+  static GD void local0(const SE2<T> &h, int chart, T *v, M3<T> &HL) {
+    if (chart == CHART_FIRST_ORDER) {
+      v[0] = h.x; v[1] = h.y; v[2] = wrap_pi(h.th);
+      if (JAC) {
+        const T c = cos(h.th), s = sin(h.th);
+        HL = {{c, s, T(0), -s, c, T(0), T(0), T(0), T(1)}};
+      }
+    } else {
+      const V3<T> xi = se2_log(h);
+      v[0] = xi.x; v[1] = xi.y; v[2] = xi.z;
+      if (JAC) HL = se2_dlog(xi);
+    }
+  }
+  static GD void prior(const T *pr, const T *x, int chart, T *e, T *H) {
+    const SE2<T> h = se2_between<T>({pr[0], pr[1], pr[2]}, {x[0], x[1], x[2]});
+    M3<T> HL = M3<T>::identity();
+    local0(h, chart, e, HL);
+    if (JAC) put_m3(HL, H, 3, 0, 0);
+  }
+  static GD void between(const T *m, const T *x1, const T *x2, int chart, T *e, T *H1, T *H2) {
+    const SE2<T> hx = se2_between<T>({x1[0], x1[1], x1[2]}, {x2[0], x2[1], x2[2]});
+    const SE2<T> h = se2_between<T>({m[0], m[1], m[2]}, hx);
+    M3<T> HL = M3<T>::identity();
+    local0(h, chart, e, HL);
+    if (JAC) {
+      put_m3(neg(HL * se2_adjoint(se2_inverse(hx))), H1, 3, 0, 0);
+      put_m3(HL, H2, 3, 0, 0);
+    }
+  }
+  static GD void retract(const T *x, const T *dlt, int chart, T *out) {
+    SE2<T> ex;
+    if (chart == CHART_FIRST_ORDER) ex = {dlt[0], dlt[1], dlt[2]};
+    else ex = se2_exp<T>({dlt[0], dlt[1], dlt[2]});
+    const SE2<T> r = se2_compose<T>({x[0], x[1], x[2]}, ex);
+    out[0] = r.x; out[1] = r.y; out[2] = r.th;
+  }
+};
+
+template <typename T, bool JAC> struct PoseFactors<T, ROT3, JAC> {
+  static GD void prior(const T *pr, const T *x, int, T *e, T *H) {
+    const M3<T> h = transpose(as_m3(pr)) * as_m3(x);
+    const V3<T> w = so3_log(h);
+    e[0] = w.x; e[1] = w.y; e[2] = w.z;
+    if (JAC) put_m3(so3_jrinv(w), H, 3, 0, 0);
+  }
+  static GD void between(const T *m, const T *x1, const T *x2, int, T *e, T *H1, T *H2) {
+    const M3<T> hx = transpose(as_m3(x1)) * as_m3(x2);
+    const M3<T> h = transpose(as_m3(m)) * hx;
+    const V3<T> w = so3_log(h);
+    e[0] = w.x; e[1] = w.y; e[2] = w.z;
+    if (JAC) {
+      const M3<T> HL = so3_jrinv(w);
+      put_m3(neg(HL * transpose(hx)), H1, 3, 0, 0);
+      put_m3(HL, H2, 3, 0, 0);
+    }
+  }
+  static GD void retract(const T *x, const T *dlt, int, T *out) {
+    const M3<T> r = as_m3(x) * so3_exp<T>({dlt[0], dlt[1], dlt[2]});
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[i] = r.m[i];
+  }
+};
+
+template <typename T, bool JAC> struct PoseFactors<T, POSE3, JAC> {
+  static GD void prior(const T *pr, const T *x, int chart, T *e, T *H) {
+    ChartLocal<T, POSE3, JAC>::eval(se3_between(as_se3(pr), as_se3(x)), chart, e, H);
+  }
+  static GD void between(const T *m, const T *x1, const T *x2, int chart, T *e, T *H1, T *H2) {
+    const SE3<T> hx = se3_between(as_se3(x1), as_se3(x2));
+    const SE3<T> h = se3_between(as_se3(m), hx);
+    const V6<T> xi = se3_log(h);
+    e[0] = xi.w.x; e[1] = xi.w.y; e[2] = xi.w.z; e[3] = xi.v.x; e[4] = xi.v.y; e[5] = xi.v.z;
+    if (JAC) {
+      const BL6<T> HL = se3_jrinv(xi);
+#pragma unroll
+      for (int i = 0; i < 36; i++) { H1[i] = T(0); H2[i] = T(0); }
+      put_bl6(neg(HL * se3_adjoint(se3_inverse(hx))), H1, 6, 0, 0);
+      put_bl6(HL, H2, 6, 0, 0);
+    }
+  }
+  static GD void retract(const T *x, const T *dlt, int, T *out) {
+    const SE3<T> r = se3_compose(as_se3(x), se3_exp(as_v6(dlt)));
+#pragma unroll
+    for (int i = 0; i < 9; i++) out[i] = r.R.m[i];
+    out[9] = r.t.x; out[10] = r.t.y; out[11] = r.t.z;
+  }
+};
+
+}  // namespace gps

@@ -1,0 +1,199 @@
+/*
+ * gpslam_hip.h -- C ABI of the MI355X-native GP-SLAM Gauss-Newton / Levenberg-Marquardt inner loop.
+ *
+ * This is the drop-in boundary.  In the reference (gtrll/gpslam) the hot path
+ * sits behind GTSAM's NonlinearFactor virtual interface: every factor overrides
+ *     gtsam::Vector evaluateError(x1, ..., boost::optional<gtsam::Matrix&> H1, ...)
+ * (e.g. gpslam/gp/GaussianProcessPriorPose3.h:60-64) and GTSAM's optimizers call it factor by
+ * factor, whiten, eliminate and retract on the CPU
+ * (call sites: gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:185-188, matlab/PlazaPose2.m:208-228).
+ * Here the whole chain-structured graph lives in HBM behind an opaque handle and each of those steps
+ * is a batched HIP kernel.  The C++ host classes in gpslam_amd/host/ (same names and ctor signatures
+ * as gpslam.h / GTSAM) and the Python mirror in gpslam_amd/ bind to exactly these entry points.
+ *
+ * Conventions
+ *  - All functions return 0 on success, <0 on failure (GPSLAM_E_*); no exceptions cross the ABI.
+ *  - The caller owns every host buffer; the library owns all device memory behind the handle.
+ *  - One handle = one HIP stream; a handle is thread-compatible, not thread-safe.
+ *  - Host arrays are row-major doubles.  Pose layouts (per state):
+ *        LINEAR2/LINEAR3: D doubles;   POSE2: (x, y, theta);   ROT3: R row-major (9);
+ *        POSE3: R row-major (9) then t (3).   Velocities: d doubles, d = tangent dimension
+ *        (POSE3: (omega, v) rotation first; POSE2: (vx, vy, omega)).
+ *  - State i is the pair (pose_i, vel_i); the variable ordering is the explicit chain order
+ *    [x0, v0, x1, v1, ..., l0, l1, ...].  Factors that couple two states couple i and i+1 only
+ *    (the GP Markov property, gpslam/gp/GaussianProcessPriorPose3.h:43-47).
+ *  - Noise models: the GP prior uses Q(dt) built from the shared Qc (gpslam/gp/GPutils.h:24-41);
+ *    every other factor takes diagonal sigmas.
+ */
+#ifndef GPSLAM_HIP_H
+#define GPSLAM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpslam_hip_handle gpslam_hip_handle;
+
+enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 3, GPSLAM_ROT3 = 4 };
+enum { GPSLAM_CHART_EXPMAP = 0, GPSLAM_CHART_FIRST_ORDER = 1 };
+enum { GPSLAM_FP64 = 0, GPSLAM_FP32 = 1 };
+
+enum {
+  GPSLAM_OK = 0,
+  GPSLAM_E_INVALID = -1,      /* bad argument / wrong manifold for this factor */
+  GPSLAM_E_HIP = -2,          /* a HIP runtime call failed */
+  GPSLAM_E_NOT_SPD = -3,      /* a pivot block was not positive definite (indeterminate system) */
+  GPSLAM_E_NOT_COMPILED = -4, /* gpslam_hip_compile() has not been called since the last change */
+  GPSLAM_E_UNSUPPORTED = -5,
+  GPSLAM_E_NAN = -6
+};
+
+typedef struct {
+  int32_t manifold;      /* GPSLAM_LINEAR2 .. GPSLAM_ROT3 */
+  int32_t precision;     /* GPSLAM_FP64 (GPSLAM_FP32: reserved) */
+  int32_t device;        /* HIP device ordinal */
+  int32_t chart;         /* retract / local chart for POSE2 priors, odometry and retract */
+  int32_t landmark_dim;  /* 0 (no landmarks), 2 or 3 */
+  int32_t chunk;         /* level-0 chunk length of the partitioned solver; 0 = default */
+  int32_t rank, nranks;  /* contiguous-segment sharding: this handle owns segment `rank` of `nranks` */
+  int32_t reserved[8];
+} gpslam_hip_config;
+
+/* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */
+typedef struct {
+  double error_before;    /* 0.5 * sum |R e|^2 at the linearisation point */
+  double error_after;     /* after the accepted update */
+  double delta_inf_norm;  /* max |delta| over all variables */
+  double lambda;          /* LM damping after the step */
+  int32_t iterations;
+  int32_t status;
+  int32_t accepted;
+  int32_t pad;
+} gpslam_hip_stats;
+
+/* GaussNewtonParams / LevenbergMarquardtParams (GTSAM names; defaults = GTSAM 4.0 defaults) */
+typedef struct {
+  int32_t max_iterations;     /* 100 */
+  double relative_error_tol;  /* 1e-5 */
+  double absolute_error_tol;  /* 1e-5 */
+  double error_tol;           /* 0 */
+  double delta_tol;           /* if > 0 additionally stop when |delta|_inf < delta_tol */
+  double lambda_initial;      /* 1e-5 */
+  double lambda_factor;       /* 10 */
+  double lambda_upper_bound;  /* 1e5 */
+  double lambda_lower_bound;  /* 0 */
+  double min_model_fidelity;  /* 1e-3 */
+  int32_t use_lm;             /* 0 Gauss-Newton, 1 Levenberg-Marquardt */
+  int32_t pad;
+} gpslam_hip_params;
+
+/* ---- life cycle ---- */
+int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out);
+int gpslam_hip_destroy(gpslam_hip_handle *h);
+void gpslam_hip_default_params(gpslam_hip_params *p);
+const char *gpslam_hip_last_error(const gpslam_hip_handle *h);
+/* the HIP stream (hipStream_t) all kernels of this handle are launched on */
+void *gpslam_hip_stream(gpslam_hip_handle *h);
+
+/* ---- variables (replaces gtsam::Values::insert / at, e.g. testGaussianProcessPriorPose3.cpp:179-183) ---- */
+int gpslam_hip_set_states(gpslam_hip_handle *h, int32_t N, const double *pose, const double *vel);
+int gpslam_hip_get_states(gpslam_hip_handle *h, double *pose, double *vel);
+int gpslam_hip_set_landmarks(gpslam_hip_handle *h, int32_t L, const double *pts);
+int gpslam_hip_get_landmarks(gpslam_hip_handle *h, double *pts);
+/* power-spectral density Qc (d x d, SPD) shared by all GP priors/interpolators
+ * (replaces the Qc_model ctor argument + getQc, gpslam/gp/GPutils.cpp:16-20) */
+int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc);
+
+/* ---- factors (replace NonlinearFactorGraph::add of the named class) ---- */
+/* GaussianProcessPrior{Linear,Pose2,Pose3,Rot3}(key_i, vel_i, key_i+1, vel_i+1, dt, Qc_model)
+ * gpslam/gp/GaussianProcessPriorPose3.h:43-49 and siblings */
+int gpslam_hip_add_gp_priors(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt);
+/* gtsam::PriorFactor<Pose> on x_idx, diagonal sigmas (count x d) */
+int gpslam_hip_add_pose_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
+                               const double *sigmas);
+/* gtsam::PriorFactor<Vector> on v_idx */
+int gpslam_hip_add_vel_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
+                              const double *sigmas);
+/* gtsam::BetweenFactor<Pose>(x_left, x_left+1, measured) (matlab/PlazaPose2.m:125) */
+int gpslam_hip_add_between(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
+                           const double *sigmas);
+/* gtsam::PriorFactor<Point> on landmark idx (matlab/PlazaPose2.m:63) */
+int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
+                                   const double *sigmas);
+/* GPInterpolatedRangeFactor{Pose2,Pose3,2DLinear}(z, model, Qc, x_i, v_i, x_i+1, v_i+1, l, dt, tau[, body_P_sensor])
+ * gpslam/slam/GPInterpolatedRangeFactorPose2.h:46-54; sensor: one pose for all `count` factors or NULL */
+int gpslam_hip_add_interp_range(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                const double *z, const double *sigma, const double *dt, const double *tau,
+                                const double *sensor);
+/* RangeFactorPose2 / RangeFactor2DLinear (gpslam/slam/RangeFactor2DLinear.h:30-37) */
+int gpslam_hip_add_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
+                         const double *z, const double *sigma);
+/* GPInterpolatedAttitudeFactorRot3(keys, dt, tau, Qc, model, nZ, bRef) -- GPInterpolatedAttitudeFactorRot3.h:44-51 */
+int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *nZ,
+                                   const double *bRef, const double *sigma, const double *dt, const double *tau);
+/* GPInterpolatedGPSFactorPose3 -- gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54 */
+int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
+                              const double *sigmas, const double *dt, const double *tau, const double *sensor);
+/* OdometryFactor2DLinear(x_left, x_left+1, measured) -- gpslam/slam/OdometryFactor2DLinear.h:38-40 */
+int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
+                              const double *sigmas);
+/* RangeBearingFactor2DLinear(x, l, range, bearing) -- gpslam/slam/RangeBearingFactor2DLinear.h:33-37 */
+int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
+                                 const double *bearing, const double *range, const double *sigmas);
+
+/* Graph compile: classify, sort by left state, pack SoA parameter arrays, size the solver hierarchy.
+ * Must be called after the last add_* / set_states and before any of the calls below. */
+int gpslam_hip_compile(gpslam_hip_handle *h);
+
+/* ---- the hot path ---- */
+/* Batched evaluateError + H1..H4 of every GP prior, in the order they were added (unwhitened, exactly what
+ * NoiseModelFactor::unwhitenedError returns): errors count x 2d; jacobians count x 4 x 2d x d row-major
+ * (may be NULL).  Returns the factor count. */
+int gpslam_hip_linearize_gp(gpslam_hip_handle *h, double *errors, double *jacobians);
+/* total graph error 0.5 * sum |R e|^2 (NonlinearFactorGraph::error) */
+int gpslam_hip_error(gpslam_hip_handle *h, double *err);
+/* one GaussNewtonOptimizer::iterate(): linearize, assemble, solve, retract, error */
+int gpslam_hip_iterate_gn(gpslam_hip_handle *h, gpslam_hip_stats *st);
+/* one LevenbergMarquardtOptimizer::iterate() */
+int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *lambda, const gpslam_hip_params *p, gpslam_hip_stats *st);
+/* NonlinearOptimizer::optimize() with GTSAM's stop rules (+ optional |delta|_inf rule) */
+int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam_hip_stats *st);
+
+/* ---- inspection (parity tests, profiling) ---- */
+/* normal equations of the current linearisation: D (N x b x b), O (N x b x b), g (N x b), b = 2d;
+ * with landmarks also B (N x b x nl), nl = L * landmark_dim.  Any pointer may be NULL. */
+int gpslam_hip_normal_equations(gpslam_hip_handle *h, double *D, double *O, double *g, double *B);
+/* solve the block-tridiagonal SPD system D/O/g (host arrays as above, N x b) with the device solver; x: N x b */
+int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double *D, const double *O,
+                                   const double *g, double *x);
+/* time (ms) of the last iterate call's phases measured with hipEvents on the handle's stream:
+ * out[0] linearize, out[1] assemble, out[2] solve, out[3] retract+error, out[4] total */
+int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
+/* run `iters` Gauss-Newton iterations back to back with no host synchronisation in between (the benchmark
+ * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL */
+int gpslam_hip_run_gn(gpslam_hip_handle *h, int32_t iters, gpslam_hip_stats *st, double *out5);
+
+/* average device time (ms, hipEvents on the handle's stream) of ONE launch of a hot kernel over `reps` launches:
+ * which = 0 GP-prior linearisation (K1), 1 normal-equation assembly (K3), 2 level-0 forward elimination (K4),
+ * 3 level-0 back-substitution, 4 retract (K6).  Inputs are re-created (untimed) before every timed launch. */
+int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, double *avg_ms);
+
+/* ---- segment sharding (nranks > 1): one exchange per iteration, performed by the host via RCCL ---- */
+/* device pointer + size (bytes) of this rank's interface record (written by phase 1) */
+int gpslam_hip_interface_send(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes);
+/* device pointer + size of the gathered records of all ranks (nranks * bytes; filled by the host's all-gather) */
+int gpslam_hip_interface_recv(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes);
+/* phase 1: linearize + assemble + local elimination down to the rank separator -> interface record */
+int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double lambda);
+/* phase 2 (after the all-gather): reduced solve, back-substitution, retract, local error */
+int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
+/* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
+int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSLAM_HIP_H */
