@@ -310,7 +310,9 @@ template <typename T> GD M3<T> se2_dlog(V3<T> v) {
   const T al = v.z;
   if (fabs(al) > T(1e-5)) {
     const T ai = T(1) / al;
-    const T hc = T(0.5) * sin(al) / (T(1) - cos(al));
+    // halfCotHalfAlpha = 0.5 sin(a) / (1 - cos(a)) evaluated without the cancellation in (1 - cos(a)):
+    // identical value, but no 2e-16/a^2 relative error ("Pose2 LogmapDerivative")
+    const T hc = T(0.5) / tan(T(0.5) * al);
     return {{al * hc, T(-0.5) * al, v.x * ai - v.x * hc + T(0.5) * v.y, T(0.5) * al, al * hc,
              v.y * ai - T(0.5) * v.x - v.y * hc, T(0), T(0), T(1)}};
   }
