@@ -18,7 +18,7 @@ TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3}
 # every symbol include/gpslam_hip.h declares
 ABI_SYMBOLS = [
     "gpslam_hip_create", "gpslam_hip_destroy", "gpslam_hip_default_params", "gpslam_hip_last_error",
-    "gpslam_hip_stream", "gpslam_hip_set_states", "gpslam_hip_get_states", "gpslam_hip_set_landmarks",
+    "gpslam_hip_stream", "gpslam_hip_set_stream", "gpslam_hip_set_states", "gpslam_hip_get_states", "gpslam_hip_set_landmarks",
     "gpslam_hip_get_landmarks", "gpslam_hip_set_qc", "gpslam_hip_add_gp_priors", "gpslam_hip_add_pose_priors",
     "gpslam_hip_add_vel_priors", "gpslam_hip_add_between", "gpslam_hip_add_landmark_priors",
     "gpslam_hip_add_interp_range", "gpslam_hip_add_range", "gpslam_hip_add_interp_attitude",
@@ -278,3 +278,28 @@ class ChainSolver:
 
     def stream(self):
         return self.lib.gpslam_hip_stream(self._h)
+
+    def set_stream(self, hip_stream):
+        return self._chk(self.lib.gpslam_hip_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")
+
+    # ---- segment sharding (nranks > 1)
+    def set_halo_state(self, pose, vel):
+        pose, vel = _f64(pose), _f64(vel)
+        return self._chk(self.lib.gpslam_hip_set_halo_state(self._h, _p(pose), _p(vel)), "set_halo_state")
+
+    def interface_buffers(self):
+        """(send_ptr, send_bytes, recv_ptr, recv_bytes): device pointers of this rank's interface record and of
+        the gathered records of all ranks."""
+        sp, rp = C.c_void_p(), C.c_void_p()
+        sb, rb = C.c_size_t(), C.c_size_t()
+        self._chk(self.lib.gpslam_hip_interface_send(self._h, C.byref(sp), C.byref(sb)), "interface_send")
+        self._chk(self.lib.gpslam_hip_interface_recv(self._h, C.byref(rp), C.byref(rb)), "interface_recv")
+        return sp.value, sb.value, rp.value, rb.value
+
+    def iterate_phase1(self, lam=0.0):
+        return self._chk(self.lib.gpslam_hip_iterate_phase1(self._h, C.c_double(lam)), "iterate_phase1")
+
+    def iterate_phase2(self, want_stats=True):
+        st = Stats()
+        self._chk(self.lib.gpslam_hip_iterate_phase2(self._h, C.byref(st) if want_stats else None), "iterate_phase2")
+        return st

@@ -51,6 +51,19 @@ struct SimpleSet {  // PriorFactor / BetweenFactor style factors: index + measur
   int width = 0;  // doubles per measurement
   DevBuf d_idx, d_meas, d_sig, d_row0;
   int count() const { return (int)idx.size(); }
+  void release() { d_idx.release(); d_meas.release(); d_sig.release(); d_row0.release(); }
+};
+
+struct MeasSet {  // measurement factors (kernels.hpp FKind)
+  int kind = 0, rows = 1, mw = 1;
+  bool two = false, haslm = false, interp = false;
+  std::vector<int32_t> idx, lm;
+  std::vector<double> meas, sig, dt, tau;
+  bool has_sensor = false;
+  double sensor[12] = {0};
+  DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0;
+  int count() const { return (int)idx.size(); }
+  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); }
 };
 
 }  // namespace
@@ -58,27 +71,35 @@ struct SimpleSet {  // PriorFactor / BetweenFactor style factors: index + measur
 struct gpslam_hip_handle {
   gpslam_hip_config cfg;
   int mf = 0, d = 0, pd = 0, b = 0, ld = 0;
-  int N = 0, L = 0, stride = 0, R = 1;
+  int N = 0, L = 0, stride = 0, R = 1, nl = 0;
+  bool own_stream = true;
   hipStream_t stream = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double Qc[36], U[36];
-  std::vector<double> h_pose, h_vel, h_lmk;
-  DevBuf pose, vel, lmk;
+  std::vector<double> h_lmk;
+  DevBuf pose, vel, lmk, pose_bak, vel_bak, lmk_bak;
   // factors
   std::vector<int32_t> gp_left;
   std::vector<double> gp_dt;
   DevBuf d_gp_left, d_gp_dt, d_gp_row0;
-  SimpleSet pri, vpri, btw;
+  SimpleSet pri, vpri, btw, lpri;
+  MeasSet ms[6];
   // row table
   int M = 0;
-  DevBuf rowLR, rowE, rowptr;
+  DevBuf rowLR, rowE, rowM, rowLm, rowptr;
   DevBuf partial;
-  int np_gp = 0, np_pri = 0, np_vpri = 0, np_btw = 0, np_ret = 0;
+  // landmark border
+  int nlmrows = 0;
+  DevBuf lmrow, lmrow_state, lmrow_ptr, lm_t, lm_S, lm_gL, lm_dL;
   // solver
   std::vector<Level> lv;
+  DevBuf gsave, dvec;
+  // segment sharding
+  DevBuf halo_add, iface_send, iface_recv, top_blk, top_x;
   DevBuf scal, flag, api_e, api_H;
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
+  double ph_lambda = 0.0;
   std::string err;
 };
 
@@ -120,7 +141,6 @@ bool make_U(int n, const double *Qc, double *U) {
   double C[36], Ci[36], Qi[36];
   std::memcpy(C, Qc, sizeof(double) * n * n);
   if (!spd_chol_upper(n, C)) return false;  // Qc = C^T C
-  // Ci = C^-1 (upper triangular)
   std::memset(Ci, 0, sizeof(Ci));
   for (int j = 0; j < n; j++) {
     Ci[j * n + j] = 1.0 / C[j * n + j];
@@ -130,7 +150,6 @@ bool make_U(int n, const double *Qc, double *U) {
       Ci[i * n + j] = -s / C[i * n + i];
     }
   }
-  // Qc^-1 = Ci Ci^T
   for (int i = 0; i < n; i++)
     for (int j = 0; j < n; j++) {
       double s = 0.0;
@@ -141,10 +160,31 @@ bool make_U(int n, const double *Qc, double *U) {
   return spd_chol_upper(n, U);
 }
 
+// First block row of Lambda(tau), Psi(tau) (gpslam/gp/GPutils.h:54-71): [l11 I, l12 I], [p11 I, p12 I].
+// Psi = Q(tau) Phi(dt - tau)^T Q^-1(dt) = (A(tau) Phi2(dt - tau)^T Ainv(dt)) (x) (Qc Qc^-1);  Lambda = Phi(tau) - Psi Phi(dt)
+void interp_coef(double dt, double tau, double *out4) {
+  const double s = dt - tau;
+  const double a11 = tau * tau * tau / 3.0 + s * tau * tau / 2.0, a12 = tau * tau / 2.0;   // first row of A(tau) Phi2(s)^T
+  const double p11 = a11 * (12.0 / (dt * dt * dt)) + a12 * (-6.0 / (dt * dt));
+  const double p12 = a11 * (-6.0 / (dt * dt)) + a12 * (4.0 / dt);
+  out4[0] = 1.0 - p11;
+  out4[1] = tau - p11 * dt - p12;
+  out4[2] = p11;
+  out4[3] = p12;
+}
+
+// synchronous host -> device copy of a vector (the stream is drained so temporaries may die)
 template <typename V> int upload(gpslam_hip_handle *h, DevBuf &buf, const std::vector<V> &v) {
   HIPCHK(buf.reserve(v.size() * sizeof(V)));
-  if (!v.empty()) HIPCHK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, h->stream));
+  if (!v.empty()) {
+    HIPCHK(hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(V), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   return 0;
+}
+int upload_real(gpslam_hip_handle *h, DevBuf &buf, const std::vector<double> &v) {
+  std::vector<Real> t(v.begin(), v.end());
+  return upload(h, buf, t);
 }
 
 inline int nblocks(int n, int bs) { return (n + bs - 1) / bs; }
@@ -166,6 +206,16 @@ template <typename F> void dispatch_b(int b, F &&f) {
     case 12: f(std::integral_constant<int, 12>{}); break;
   }
 }
+template <typename F> void dispatch_fk(int fk, F &&f) {
+  switch (fk) {
+    case 0: f(std::integral_constant<int, 0>{}); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    case 4: f(std::integral_constant<int, 4>{}); break;
+    case 5: f(std::integral_constant<int, 5>{}); break;
+  }
+}
 
 UMat<Real> make_umat(const gpslam_hip_handle *h) {
   UMat<Real> u;
@@ -174,18 +224,41 @@ UMat<Real> make_umat(const gpslam_hip_handle *h) {
   return u;
 }
 
+bool sharded(const gpslam_hip_handle *h) { return h->cfg.nranks > 1; }
+bool has_right_rank(const gpslam_hip_handle *h) { return sharded(h) && h->cfg.rank < h->cfg.nranks - 1; }
+
+GpArgs<Real> gp_args(gpslam_hip_handle *h, Real *partial) {
+  GpArgs<Real> a;
+  a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride;
+  a.count = (int)h->gp_left.size();
+  a.left = h->d_gp_left.as<int>(); a.dt = h->d_gp_dt.as<Real>(); a.row0 = h->d_gp_row0.as<int>();
+  a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
+  a.partial = partial; a.out_e = nullptr; a.out_H = nullptr;
+  a.U = make_umat(h);
+  return a;
+}
+
+LmArgs<Real> lm_args(gpslam_hip_handle *h, double lambda) {
+  LmArgs<Real> a;
+  a.N = h->N; a.R = h->R; a.B = h->b; a.L = h->L; a.ld = h->ld; a.nl = h->nl;
+  a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>();
+  a.lmrow = h->lmrow.as<int>(); a.lmrow_state = h->lmrow_state.as<int>(); a.lmrow_ptr = h->lmrow_ptr.as<int>();
+  a.nlmrows = h->nlmrows;
+  a.x = h->lv.empty() ? nullptr : h->lv[0].x.as<Real>();
+  a.t = h->lm_t.as<Real>();
+  a.npri = h->lpri.count(); a.pri_lm = h->lpri.d_idx.as<int>(); a.pri_meas = h->lpri.d_meas.as<Real>();
+  a.pri_sig = h->lpri.d_sig.as<Real>();
+  a.lmk = h->lmk.as<Real>(); a.S = h->lm_S.as<Real>(); a.gL = h->lm_gL.as<Real>(); a.dL = h->lm_dL.as<Real>();
+  a.lambda = (Real)lambda; a.flag = h->flag.as<int>(); a.partial = nullptr;
+  return a;
+}
+
 // mode 0: Jacobian rows + error, 1: error only.  Error partial sums land in h->partial, reduced into scal[slot].
 int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
   Real *part = h->partial.as<Real>();
   int off = 0;
   if (!h->gp_left.empty()) {
-    GpArgs<Real> a;
-    a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride;
-    a.count = (int)h->gp_left.size();
-    a.left = h->d_gp_left.as<int>(); a.dt = h->d_gp_dt.as<Real>(); a.row0 = h->d_gp_row0.as<int>();
-    a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
-    a.partial = part + off; a.out_e = nullptr; a.out_H = nullptr;
-    a.U = make_umat(h);
+    GpArgs<Real> a = gp_args(h, part + off);
     const int nb = nblocks(a.count, 128);
     dispatch_mf(h->mf, [&](auto tag) {
       constexpr int MF = decltype(tag)::value;
@@ -219,19 +292,53 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     });
     off += nb;
   }
+  for (int fk = 0; fk < 6; fk++) {
+    MeasSet &s = h->ms[fk];
+    if (s.count() == 0) continue;
+    MeasArgs<Real> a;
+    a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride;
+    a.lmk = h->lmk.as<Real>(); a.ld = h->ld; a.count = s.count(); a.chart = h->cfg.chart;
+    a.idx = s.d_idx.as<int>(); a.lm = s.d_lm.as<int>(); a.meas = s.d_meas.as<Real>(); a.mw = s.mw;
+    a.sig = s.d_sig.as<Real>(); a.coef = s.d_coef.as<Real>();
+    for (int k = 0; k < 12; k++) a.sensor[k] = (Real)s.sensor[k];
+    a.has_sensor = s.has_sensor ? 1 : 0;
+    a.row0 = s.d_row0.as<int>();
+    a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>(); a.rowLm = h->rowLm.as<int>();
+    a.partial = part + off;
+    const int nb = nblocks(a.count, 128);
+    dispatch_mf(h->mf, [&](auto tag) {
+      constexpr int MF = decltype(tag)::value;
+      dispatch_fk(fk, [&](auto ftag) {
+        constexpr int FK = decltype(ftag)::value;
+        if (mode == 0) k_meas<Real, MF, FK, true><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+        else k_meas<Real, MF, FK, false><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+      });
+    });
+    off += nb;
+  }
+  if (h->lpri.count() > 0) {
+    LmArgs<Real> a = lm_args(h, 0.0);
+    a.partial = part + off;
+    k_lmprior_err<Real><<<dim3(1), dim3(128), 0, h->stream>>>(a);
+    off += 1;
+  }
   k_final_reduce<Real><<<dim3(1), dim3(256), 0, h->stream>>>(part, off, h->scal.as<double>() + slot, 0);
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-int launch_assemble(gpslam_hip_handle *h) {
+int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   AsmArgs<Real> a;
   a.N = h->N; a.R = h->R;
   a.rowptr = h->rowptr.as<int>();
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
-  a.rowM = nullptr; a.rowLm = nullptr; a.ld = h->ld;
+  a.rowM = h->nl > 0 ? h->rowM.as<Real>() : nullptr;
+  a.rowLm = h->nl > 0 ? h->rowLm.as<int>() : nullptr;
+  a.ld = h->ld;
   a.blk = h->lv[0].blk.as<Real>();
-  const int threads = h->N * h->b;
+  a.gsave = save_g ? h->gsave.as<Real>() : nullptr;
+  a.halo_add = has_right_rank(h) ? h->halo_add.as<Real>() : nullptr;
+  const int threads = (h->N + (a.halo_add ? 1 : 0)) * h->b;
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
     k_assemble<Real, BB><<<dim3(nblocks(threads, 192)), dim3(192), 0, h->stream>>>(a);
@@ -240,54 +347,116 @@ int launch_assemble(gpslam_hip_handle *h) {
   return 0;
 }
 
-// forward elimination through all levels, top solve, back-substitution; solution in lv[0].x
-int launch_solve(gpslam_hip_handle *h, double lambda) {
+void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
+  dispatch_b(h->b, [&](auto tag) {
+    constexpr int BB = decltype(tag)::value;
+    k_chunk_forward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+  });
+}
+void launch_bwd(gpslam_hip_handle *h, const BwdArgs<Real> &a, int grid) {
+  dispatch_b(h->b, [&](auto tag) {
+    constexpr int BB = decltype(tag)::value;
+    k_chunk_backward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+  });
+}
+
+// Forward elimination through the local levels.  Unsharded: the last level is the sequential top solve.
+// Sharded: every level keeps its first block as separator; the last level reduces to the interface record.
+int launch_forward(gpslam_hip_handle *h, double lambda) {
   const int nl = (int)h->lv.size();
+  const bool sh = sharded(h);
+  const size_t BS = (size_t)2 * h->b * h->b + (size_t)h->b * h->R, AS = (size_t)h->b * h->b + (size_t)h->b * h->R;
   for (int l = 0; l < nl; l++) {
     Level &v = h->lv[l];
-    const bool top = (l == nl - 1);
+    const bool last = (l == nl - 1);
     FwdArgs<Real> a;
     a.blk = v.blk.as<Real>();
     a.add = (l > 0) ? v.add.as<Real>() : nullptr;
-    a.up_blk = top ? nullptr : h->lv[l + 1].blk.as<Real>();
-    a.up_add = top ? nullptr : h->lv[l + 1].add.as<Real>();
-    a.n = v.n; a.m = top ? v.n : v.m; a.R = h->R;
-    a.no_sep = top ? 1 : 0; a.last_has_right = 0;
+    a.n = v.n; a.R = h->R;
     a.lambda = (l == 0) ? (Real)lambda : Real(0);
     a.flag = h->flag.as<int>();
-    const int grid = top ? 1 : v.nch;
-    dispatch_b(h->b, [&](auto tag) {
-      constexpr int BB = decltype(tag)::value;
-      k_chunk_forward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
-    });
-  }
-  for (int l = nl - 1; l >= 0; l--) {
-    Level &v = h->lv[l];
-    const bool top = (l == nl - 1);
-    BwdArgs<Real> a;
-    a.blk = v.blk.as<Real>(); a.x = v.x.as<Real>();
-    a.xup = top ? nullptr : h->lv[l + 1].x.as<Real>();
-    a.n = v.n; a.m = top ? v.n : v.m; a.R = h->R; a.no_sep = top ? 1 : 0; a.last_has_right = 0;
-    const int grid = top ? 1 : v.nch;
-    dispatch_b(h->b, [&](auto tag) {
-      constexpr int BB = decltype(tag)::value;
-      k_chunk_backward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
-    });
+    a.remote_add = nullptr;
+    int grid;
+    if (!sh) {
+      a.up_blk = last ? nullptr : h->lv[l + 1].blk.as<Real>();
+      a.up_add = last ? nullptr : h->lv[l + 1].add.as<Real>();
+      a.m = last ? v.n : v.m;
+      a.no_sep = last ? 1 : 0;
+      a.last_has_right = 0;
+      grid = last ? 1 : v.nch;
+    } else {
+      a.up_blk = last ? h->iface_send.as<Real>() : h->lv[l + 1].blk.as<Real>();
+      // the interface record is [blk (BS) | addend slot 1 (AS)]; addend slot 0 is unused, so point one slot back
+      a.up_add = last ? h->iface_send.as<Real>() + BS - AS : h->lv[l + 1].add.as<Real>();
+      a.m = last ? v.n : v.m;
+      a.no_sep = 0;
+      a.last_has_right = has_right_rank(h) ? 1 : 0;
+      if (a.last_has_right) a.remote_add = (l == 0) ? h->halo_add.as<Real>() : v.add.as<Real>() + (size_t)v.n * AS;
+      grid = last ? 1 : v.nch;
+    }
+    launch_fwd(h, a, grid);
   }
   HIPCHK(hipGetLastError());
   return 0;
 }
 
+// Back-substitution through the local levels; xtop = separator solutions for the last level (sharded) or null
+int launch_backward(gpslam_hip_handle *h, const Real *xtop) {
+  const int nl = (int)h->lv.size();
+  const bool sh = sharded(h);
+  for (int l = nl - 1; l >= 0; l--) {
+    Level &v = h->lv[l];
+    const bool last = (l == nl - 1);
+    BwdArgs<Real> a;
+    a.blk = v.blk.as<Real>(); a.x = v.x.as<Real>();
+    a.n = v.n; a.R = h->R;
+    if (!sh) {
+      a.xup = last ? nullptr : h->lv[l + 1].x.as<Real>();
+      a.m = last ? v.n : v.m; a.no_sep = last ? 1 : 0; a.last_has_right = 0;
+    } else {
+      a.xup = last ? xtop : h->lv[l + 1].x.as<Real>();
+      a.m = last ? v.n : v.m; a.no_sep = 0; a.last_has_right = has_right_rank(h) ? 1 : 0;
+    }
+    launch_bwd(h, a, last ? 1 : v.nch);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// landmark Schur complement, landmark solve, pose correction (nl > 0)
+int launch_landmarks(gpslam_hip_handle *h, double lambda) {
+  if (h->nl <= 0) return 0;
+  LmArgs<Real> a = lm_args(h, lambda);
+  if (h->nlmrows > 0) k_lm_t<Real><<<dim3(nblocks(h->nlmrows * h->R, 128)), dim3(128), 0, h->stream>>>(a);
+  k_lm_reduce<Real><<<dim3(nblocks(h->nl * h->R, 128)), dim3(128), 0, h->stream>>>(a);
+  k_lm_solve<Real><<<dim3(1), dim3(64), 0, h->stream>>>(a);
+  k_lm_correct<Real><<<dim3(nblocks(h->N * h->b, 256)), dim3(256), 0, h->stream>>>(a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int launch_solve(gpslam_hip_handle *h, double lambda) {
+  int rc;
+  if ((rc = launch_forward(h, lambda))) return rc;
+  if ((rc = launch_backward(h, nullptr))) return rc;
+  return launch_landmarks(h, lambda);
+}
+
+// x <- x (+) delta for the local states (and landmarks); scal[slot] = |delta|_inf
 int launch_retract(gpslam_hip_handle *h, int slot) {
   RetractArgs<Real> a;
   a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = h->N; a.R = h->R;
-  a.chart = h->cfg.chart; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
+  a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
   const int nb = nblocks(h->N, 128);
   dispatch_mf(h->mf, [&](auto tag) {
     constexpr int MF = decltype(tag)::value;
     k_retract<Real, MF><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
   });
   k_final_reduce<Real><<<dim3(1), dim3(256), 0, h->stream>>>(h->partial.as<Real>(), nb, h->scal.as<double>() + slot, 1);
+  if (h->nl > 0) {
+    LmArgs<Real> la = lm_args(h, 0.0);
+    k_lm_update<Real><<<dim3(1), dim3(64), 0, h->stream>>>(la, h->scal.as<double>() + slot);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -305,7 +474,7 @@ int enqueue_gn(gpslam_hip_handle *h, double lambda, bool timed) {
   if (timed) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   if ((rc = launch_factors(h, 0, 0))) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  if ((rc = launch_assemble(h))) return rc;
+  if ((rc = launch_assemble(h, false))) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
   if ((rc = launch_solve(h, lambda))) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
@@ -332,16 +501,86 @@ int need_compiled(gpslam_hip_handle *h) {
   return 0;
 }
 
-int add_simple(gpslam_hip_handle *h, SimpleSet &s, int width, int32_t count, const int32_t *idx, const double *meas,
-               const double *sig, int max_idx) {
+int add_simple(gpslam_hip_handle *h, SimpleSet &s, int width, int sigw, int32_t count, const int32_t *idx,
+               const double *meas, const double *sig, int max_idx) {
   if (!h || count < 0 || (count > 0 && (!idx || !meas || !sig))) return GPSLAM_E_INVALID;
   for (int k = 0; k < count; k++)
     if (idx[k] < 0 || idx[k] > max_idx) return fail(h, GPSLAM_E_INVALID, "factor index out of range");
+  for (size_t k = 0; k < (size_t)count * sigw; k++)
+    if (!(sig[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "sigmas must be positive");
   s.width = width;
   s.idx.insert(s.idx.end(), idx, idx + count);
   s.meas.insert(s.meas.end(), meas, meas + (size_t)count * width);
-  s.sig.insert(s.sig.end(), sig, sig + (size_t)count * h->d);
+  s.sig.insert(s.sig.end(), sig, sig + (size_t)count * sigw);
   h->compiled = false;
+  return 0;
+}
+
+// index of the last state a two-state factor may start at (the halo state extends a non-final segment by one)
+int max_left(const gpslam_hip_handle *h) { return h->N - 2 + (has_right_rank(h) ? 1 : 0); }
+
+int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool haslm, bool interp, bool ok_mf,
+             int32_t count, const int32_t *idx, const int32_t *lm, const double *meas, const double *sig,
+             const double *dt, const double *tau, const double *sensor) {
+  if (!h || count < 0) return GPSLAM_E_INVALID;
+  if (!ok_mf) return fail(h, GPSLAM_E_INVALID, "this factor does not exist for the handle's manifold / landmark dimension");
+  if (count > 0 && (!idx || !meas || !sig || (haslm && !lm) || (interp && (!dt || !tau)))) return GPSLAM_E_INVALID;
+  MeasSet &s = h->ms[fk];
+  if (s.count() > 0 && ((sensor != nullptr) != s.has_sensor)) return fail(h, GPSLAM_E_UNSUPPORTED, "one body_P_sensor per factor kind");
+  const int mx = two ? max_left(h) : h->N - 1;
+  for (int k = 0; k < count; k++) {
+    if (idx[k] < 0 || idx[k] > mx) return fail(h, GPSLAM_E_INVALID, "factor state index out of range");
+    if (haslm && (lm[k] < 0 || lm[k] >= h->L)) return fail(h, GPSLAM_E_INVALID, "landmark index out of range (set_landmarks first)");
+    if (interp && !(dt[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "delta_t must be positive");
+  }
+  for (size_t k = 0; k < (size_t)count * rows; k++)
+    if (!(sig[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "sigmas must be positive");
+  s.kind = fk; s.rows = rows; s.mw = mw; s.two = two; s.haslm = haslm; s.interp = interp;
+  s.idx.insert(s.idx.end(), idx, idx + count);
+  if (haslm) s.lm.insert(s.lm.end(), lm, lm + count);
+  s.meas.insert(s.meas.end(), meas, meas + (size_t)count * mw);
+  s.sig.insert(s.sig.end(), sig, sig + (size_t)count * rows);
+  if (interp) { s.dt.insert(s.dt.end(), dt, dt + count); s.tau.insert(s.tau.end(), tau, tau + count); }
+  if (sensor) { s.has_sensor = true; std::memcpy(s.sensor, sensor, sizeof(double) * h->pd); }
+  h->compiled = false;
+  return 0;
+}
+
+int sync_landmarks_to_host(gpslam_hip_handle *h) {
+  if (h->L <= 0 || !h->lmk.p) return 0;
+  std::vector<Real> t((size_t)h->L * h->ld);
+  HIPCHK(hipMemcpyAsync(t.data(), h->lmk.p, t.size() * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < t.size(); i++) h->h_lmk[i] = (double)t[i];
+  return 0;
+}
+
+int backup_state(gpslam_hip_handle *h, bool restore) {
+  const size_t np = (size_t)h->pd * h->stride * sizeof(Real), nv = (size_t)h->d * h->stride * sizeof(Real);
+  HIPCHK(h->pose_bak.reserve(np));
+  HIPCHK(h->vel_bak.reserve(nv));
+  if (restore) {
+    HIPCHK(hipMemcpyAsync(h->pose.p, h->pose_bak.p, np, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vel.p, h->vel_bak.p, nv, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(h->pose_bak.p, h->pose.p, np, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(h->vel_bak.p, h->vel.p, nv, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (h->nl > 0) {
+    const size_t nb = (size_t)h->nl * sizeof(Real);
+    HIPCHK(h->lmk_bak.reserve(nb));
+    if (restore) HIPCHK(hipMemcpyAsync(h->lmk.p, h->lmk_bak.p, nb, hipMemcpyDeviceToDevice, h->stream));
+    else HIPCHK(hipMemcpyAsync(h->lmk_bak.p, h->lmk.p, nb, hipMemcpyDeviceToDevice, h->stream));
+  }
+  return 0;
+}
+
+// scal[slot] = sum_i x[i] * y[i]
+int launch_dot(gpslam_hip_handle *h, const Real *x, const Real *y, int n, int slot) {
+  const int nb = nblocks(n, 256);
+  k_dot<Real><<<dim3(nb), dim3(256), 0, h->stream>>>(x, y, n, h->partial.as<Real>());
+  k_final_reduce<Real><<<dim3(1), dim3(256), 0, h->stream>>>(h->partial.as<Real>(), nb, h->scal.as<double>() + slot, 0);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -371,12 +610,14 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (cfg->manifold < 0 || cfg->manifold > 4) return GPSLAM_E_INVALID;
   if (cfg->precision != GPSLAM_FP64) return GPSLAM_E_UNSUPPORTED;
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
+  if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPSLAM_E_HIP;  // no GPU: fail loudly
   if (cfg->device < 0 || cfg->device >= ndev) return GPSLAM_E_INVALID;
   if (hipSetDevice(cfg->device) != hipSuccess) return GPSLAM_E_HIP;
   gpslam_hip_handle *h = new gpslam_hip_handle();
   h->cfg = *cfg;
+  if (h->cfg.nranks < 1) h->cfg.nranks = 1;
   h->mf = cfg->manifold;
   static const int dd[5] = {2, 3, 3, 6, 3}, pdd[5] = {2, 3, 3, 12, 9};
   h->d = dd[h->mf];
@@ -395,6 +636,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   }
   (void)hipMemsetAsync(h->scal.p, 0, 16 * sizeof(double), h->stream);
   (void)hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream);
+  (void)hipStreamSynchronize(h->stream);
   *out = h;
   return 0;
 }
@@ -403,19 +645,33 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   if (!h) return 0;
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf *bufs[] = {&h->pose, &h->vel, &h->lmk, &h->d_gp_left, &h->d_gp_dt, &h->d_gp_row0, &h->rowLR, &h->rowE,
-                    &h->rowptr, &h->partial, &h->scal, &h->flag, &h->api_e, &h->api_H};
+  DevBuf *bufs[] = {&h->pose, &h->vel, &h->lmk, &h->pose_bak, &h->vel_bak, &h->lmk_bak, &h->d_gp_left, &h->d_gp_dt,
+                    &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
+                    &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_gL, &h->lm_dL, &h->gsave, &h->dvec,
+                    &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
+                    &h->api_e, &h->api_H};
   for (DevBuf *b : bufs) b->release();
-  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw}) { s->d_idx.release(); s->d_meas.release(); s->d_sig.release(); s->d_row0.release(); }
+  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
+  for (MeasSet &s : h->ms) s.release();
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
 }
 
 const char *gpslam_hip_last_error(const gpslam_hip_handle *h) { return h ? h->err.c_str() : "null handle"; }
 void *gpslam_hip_stream(gpslam_hip_handle *h) { return h ? (void *)h->stream : nullptr; }
+
+int gpslam_hip_set_stream(gpslam_hip_handle *h, void *stream) {
+  if (!h) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  h->stream = (hipStream_t)stream;
+  h->own_stream = false;
+  return 0;
+}
 
 int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc) {
   if (!h || !Qc) return GPSLAM_E_INVALID;
@@ -429,10 +685,16 @@ int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc) {
 int gpslam_hip_set_states(gpslam_hip_handle *h, int32_t N, const double *pose, const double *vel) {
   if (!h || N <= 0 || !pose || !vel) return GPSLAM_E_INVALID;
   (void)hipSetDevice(h->cfg.device);
+  const bool same = (N == h->N) && h->pose.p;
   if (N != h->N) h->compiled = false;
   h->N = N;
   h->stride = N + 1;  // one halo slot: the first state of the right neighbour segment
   std::vector<Real> sp((size_t)h->pd * h->stride, Real(0)), sv((size_t)h->d * h->stride, Real(0));
+  if (same && sharded(h)) {  // keep the halo state
+    HIPCHK(hipMemcpyAsync(sp.data(), h->pose.p, sp.size() * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(sv.data(), h->vel.p, sv.size() * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
   for (int i = 0; i < N; i++) {
     for (int k = 0; k < h->pd; k++) sp[(size_t)k * h->stride + i] = (Real)pose[(size_t)i * h->pd + k];
     for (int k = 0; k < h->d; k++) sv[(size_t)k * h->stride + i] = (Real)vel[(size_t)i * h->d + k];
@@ -441,6 +703,20 @@ int gpslam_hip_set_states(gpslam_hip_handle *h, int32_t N, const double *pose, c
   HIPCHK(h->vel.reserve(sv.size() * sizeof(Real)));
   HIPCHK(hipMemcpyAsync(h->pose.p, sp.data(), sp.size() * sizeof(Real), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->vel.p, sv.data(), sv.size() * sizeof(Real), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel) {
+  if (!h || h->N <= 0 || !pose || !vel || !h->pose.p) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  std::vector<Real> pv(h->pd), vv(h->d);
+  for (int k = 0; k < h->pd; k++) pv[k] = (Real)pose[k];
+  for (int k = 0; k < h->d; k++) vv[k] = (Real)vel[k];
+  for (int k = 0; k < h->pd; k++)
+    HIPCHK(hipMemcpyAsync(h->pose.as<Real>() + (size_t)k * h->stride + h->N, &pv[k], sizeof(Real), hipMemcpyHostToDevice, h->stream));
+  for (int k = 0; k < h->d; k++)
+    HIPCHK(hipMemcpyAsync(h->vel.as<Real>() + (size_t)k * h->stride + h->N, &vv[k], sizeof(Real), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   return 0;
 }
@@ -461,13 +737,17 @@ int gpslam_hip_get_states(gpslam_hip_handle *h, double *pose, double *vel) {
 
 int gpslam_hip_set_landmarks(gpslam_hip_handle *h, int32_t L, const double *pts) {
   if (!h || L < 0 || (L > 0 && (!pts || h->ld == 0))) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  if (L != h->L) h->compiled = false;
   h->L = L;
   h->h_lmk.assign(pts, pts + (size_t)L * h->ld);
-  h->compiled = false;
-  return 0;
+  return upload_real(h, h->lmk, h->h_lmk);
 }
 int gpslam_hip_get_landmarks(gpslam_hip_handle *h, double *pts) {
   if (!h) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  int rc = sync_landmarks_to_host(h);
+  if (rc) return rc;
   if (h->L > 0 && pts) std::memcpy(pts, h->h_lmk.data(), sizeof(double) * h->h_lmk.size());
   return 0;
 }
@@ -475,7 +755,7 @@ int gpslam_hip_get_landmarks(gpslam_hip_handle *h, double *pts) {
 int gpslam_hip_add_gp_priors(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt) {
   if (!h || count < 0 || (count > 0 && (!left || !dt))) return GPSLAM_E_INVALID;
   for (int k = 0; k < count; k++) {
-    if (left[k] < 0 || left[k] + 1 >= h->N + (h->cfg.nranks > 1 ? 1 : 0)) return fail(h, GPSLAM_E_INVALID, "gp prior index out of range");
+    if (left[k] < 0 || left[k] > max_left(h)) return fail(h, GPSLAM_E_INVALID, "gp prior index out of range");
     if (!(dt[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "gp prior delta_t must be positive");
   }
   h->gp_left.insert(h->gp_left.end(), left, left + count);
@@ -485,97 +765,170 @@ int gpslam_hip_add_gp_priors(gpslam_hip_handle *h, int32_t count, const int32_t 
 }
 int gpslam_hip_add_pose_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                                const double *sigmas) {
-  return add_simple(h, h->pri, h ? h->pd : 0, count, idx, prior, sigmas, h ? h->N - 1 : 0);
+  return h ? add_simple(h, h->pri, h->pd, h->d, count, idx, prior, sigmas, h->N - 1) : GPSLAM_E_INVALID;
 }
 int gpslam_hip_add_vel_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                               const double *sigmas) {
-  return add_simple(h, h->vpri, h ? h->d : 0, count, idx, prior, sigmas, h ? h->N - 1 : 0);
+  return h ? add_simple(h, h->vpri, h->d, h->d, count, idx, prior, sigmas, h->N - 1) : GPSLAM_E_INVALID;
 }
 int gpslam_hip_add_between(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                            const double *sigmas) {
-  return add_simple(h, h->btw, h ? h->pd : 0, count, left, measured, sigmas,
-                    h ? h->N - 2 + (h->cfg.nranks > 1 ? 1 : 0) : 0);
+  return h ? add_simple(h, h->btw, h->pd, h->d, count, left, measured, sigmas, max_left(h)) : GPSLAM_E_INVALID;
 }
-
-int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t, const int32_t *, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "landmark factors: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
+                                   const double *sigmas) {
+  if (!h) return GPSLAM_E_INVALID;
+  if (h->ld == 0) return fail(h, GPSLAM_E_INVALID, "handle was created without landmarks");
+  return add_simple(h, h->lpri, h->ld, h->ld, count, idx, prior, sigmas, h->L - 1);
 }
-int gpslam_hip_add_interp_range(gpslam_hip_handle *h, int32_t, const int32_t *, const int32_t *, const double *,
-                                const double *, const double *, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "interpolated range: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_interp_range(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                const double *z, const double *sigma, const double *dt, const double *tau,
+                                const double *sensor) {
+  if (!h) return GPSLAM_E_INVALID;
+  const bool ok = (h->mf == POSE2 && h->ld == 2) || (h->mf == POSE3 && h->ld == 3) || (h->mf == LINEAR3 && h->ld == 2);
+  if (h->mf == LINEAR3 && sensor) return fail(h, GPSLAM_E_INVALID, "GPInterpolatedRangeFactor2DLinear has no body_P_sensor");
+  return add_meas(h, FK_INTERP_RANGE, 1, 1, true, true, true, ok, count, left, landmark, z, sigma, dt, tau, sensor);
 }
-int gpslam_hip_add_range(gpslam_hip_handle *h, int32_t, const int32_t *, const int32_t *, const double *,
-                         const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "range: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
+                         const double *z, const double *sigma) {
+  if (!h) return GPSLAM_E_INVALID;
+  const bool ok = (h->mf == POSE2 && h->ld == 2) || (h->mf == POSE3 && h->ld == 3) || (h->mf == LINEAR3 && h->ld == 2);
+  return add_meas(h, FK_RANGE, 1, 1, false, true, false, ok, count, idx, landmark, z, sigma, nullptr, nullptr, nullptr);
 }
-int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t, const int32_t *, const double *, const double *,
-                                   const double *, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "interpolated attitude: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *nZ,
+                                   const double *bRef, const double *sigma, const double *dt, const double *tau) {
+  if (!h) return GPSLAM_E_INVALID;
+  if (count > 0 && (!nZ || !bRef)) return GPSLAM_E_INVALID;
+  std::vector<double> m((size_t)std::max(count, 0) * 6);
+  for (int k = 0; k < count; k++) {  // Unit3 normalises its argument
+    for (int part = 0; part < 2; part++) {
+      const double *v = (part == 0 ? nZ : bRef) + 3 * (size_t)k;
+      const double n = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      if (!(n > 0.0)) return fail(h, GPSLAM_E_INVALID, "attitude directions must be non-zero");
+      for (int q = 0; q < 3; q++) m[6 * (size_t)k + 3 * part + q] = v[q] / n;
+    }
+  }
+  return add_meas(h, FK_INTERP_ATT, 2, 6, true, false, true, h->mf == ROT3, count, left, nullptr, m.data(), sigma, dt, tau, nullptr);
 }
-int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t, const int32_t *, const double *, const double *,
-                              const double *, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "interpolated gps: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
+                              const double *sigmas, const double *dt, const double *tau, const double *sensor) {
+  if (!h) return GPSLAM_E_INVALID;
+  return add_meas(h, FK_INTERP_GPS, 3, 3, true, false, true, h->mf == POSE3, count, left, nullptr, measured, sigmas, dt, tau, sensor);
 }
-int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t, const int32_t *, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "odometry2d: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
+                              const double *sigmas) {
+  if (!h) return GPSLAM_E_INVALID;
+  return add_meas(h, FK_ODOM2D, 3, 3, true, false, false, h->mf == LINEAR3, count, left, nullptr, measured, sigmas, nullptr, nullptr, nullptr);
 }
-int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t, const int32_t *, const int32_t *, const double *,
-                                 const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "bearing-range: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
+                                 const double *bearing, const double *range, const double *sigmas) {
+  if (!h) return GPSLAM_E_INVALID;
+  if (count > 0 && (!bearing || !range)) return GPSLAM_E_INVALID;
+  std::vector<double> m((size_t)std::max(count, 0) * 2);
+  for (int k = 0; k < count; k++) { m[2 * (size_t)k] = bearing[k]; m[2 * (size_t)k + 1] = range[k]; }
+  return add_meas(h, FK_BEARING_RANGE, 2, 2, false, true, false, h->mf == LINEAR3 && h->ld == 2, count, idx, landmark, m.data(), sigmas, nullptr, nullptr, nullptr);
 }
 
 int gpslam_hip_compile(gpslam_hip_handle *h) {
   if (!h || h->N <= 0) return GPSLAM_E_INVALID;
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N, d = h->d, b = h->b;
-  h->R = 1;
-  // ---- row layout: rows grouped by left state; inside a state: GP, pose prior, velocity prior, between
+  h->nl = h->L * h->ld;
+  h->R = 1 + h->nl;
+  if (3 * b + h->R > 64 || h->R > kMaxRhs)
+    return fail(h, GPSLAM_E_UNSUPPORTED, "too many landmark columns for the dense border (3*2d + 1 + L*landmark_dim must be <= 64)");
+  if (sharded(h) && h->nl > 0) return fail(h, GPSLAM_E_UNSUPPORTED, "landmarks with segment sharding: not supported yet");
+  // ---- row layout: rows grouped by left state; inside a state: GP, pose prior, velocity prior, between, measurements
   std::vector<int> rows_in(N + 1, 0);
   for (int32_t l : h->gp_left) rows_in[l] += b;
   for (int32_t i : h->pri.idx) rows_in[i] += d;
   for (int32_t i : h->vpri.idx) rows_in[i] += d;
   for (int32_t i : h->btw.idx) rows_in[i] += d;
+  for (MeasSet &s : h->ms) for (int32_t i : s.idx) rows_in[i] += s.rows;
   std::vector<int> rowptr(N + 2, 0);
   for (int s = 0; s <= N; s++) rowptr[s + 1] = rowptr[s] + rows_in[s];
   h->M = rowptr[N + 1];
   std::vector<int> cursor(rowptr.begin(), rowptr.end() - 1);
   std::vector<int> gp_row0(h->gp_left.size());
   for (size_t f = 0; f < h->gp_left.size(); f++) { gp_row0[f] = cursor[h->gp_left[f]]; cursor[h->gp_left[f]] += b; }
-  auto place = [&](SimpleSet &s, std::vector<int> &row0) {
-    row0.resize(s.idx.size());
-    for (size_t f = 0; f < s.idx.size(); f++) { row0[f] = cursor[s.idx[f]]; cursor[s.idx[f]] += d; }
+  auto place = [&](const std::vector<int32_t> &idx, int rows, std::vector<int> &row0) {
+    row0.resize(idx.size());
+    for (size_t f = 0; f < idx.size(); f++) { row0[f] = cursor[idx[f]]; cursor[idx[f]] += rows; }
   };
-  std::vector<int> r_pri, r_vpri, r_btw;
-  place(h->pri, r_pri);
-  place(h->vpri, r_vpri);
-  place(h->btw, r_btw);
+  std::vector<int> r_pri, r_vpri, r_btw, r_ms[6];
+  place(h->pri.idx, d, r_pri);
+  place(h->vpri.idx, d, r_vpri);
+  place(h->btw.idx, d, r_btw);
+  for (int fk = 0; fk < 6; fk++) place(h->ms[fk].idx, h->ms[fk].rows, r_ms[fk]);
   int rc;
   if ((rc = upload(h, h->rowptr, rowptr))) return rc;
   if ((rc = upload(h, h->d_gp_left, h->gp_left))) return rc;
-  { std::vector<Real> t(h->gp_dt.begin(), h->gp_dt.end()); if ((rc = upload(h, h->d_gp_dt, t))) return rc; }
+  if ((rc = upload_real(h, h->d_gp_dt, h->gp_dt))) return rc;
   if ((rc = upload(h, h->d_gp_row0, gp_row0))) return rc;
   auto up_set = [&](SimpleSet &s, const std::vector<int> &row0) -> int {
     int r2;
     if ((r2 = upload(h, s.d_idx, s.idx))) return r2;
-    std::vector<Real> m(s.meas.begin(), s.meas.end()), sg(s.sig.begin(), s.sig.end());
-    if ((r2 = upload(h, s.d_meas, m))) return r2;
-    if ((r2 = upload(h, s.d_sig, sg))) return r2;
+    if ((r2 = upload_real(h, s.d_meas, s.meas))) return r2;
+    if ((r2 = upload_real(h, s.d_sig, s.sig))) return r2;
     return upload(h, s.d_row0, row0);
   };
   if ((rc = up_set(h->pri, r_pri))) return rc;
   if ((rc = up_set(h->vpri, r_vpri))) return rc;
   if ((rc = up_set(h->btw, r_btw))) return rc;
-  HIPCHK(h->rowLR.reserve((size_t)std::max(h->M, 1) * 2 * b * sizeof(Real)));
-  HIPCHK(h->rowE.reserve((size_t)std::max(h->M, 1) * sizeof(Real)));
-  h->np_gp = nblocks((int)h->gp_left.size(), 128);
-  h->np_pri = nblocks(h->pri.count(), 128);
-  h->np_vpri = nblocks(h->vpri.count(), 128);
-  h->np_btw = nblocks(h->btw.count(), 128);
-  h->np_ret = nblocks(N, 128);
-  const int npart = std::max(h->np_gp + h->np_pri + h->np_vpri + h->np_btw, h->np_ret) + 8;
+  { std::vector<int> none; if ((rc = up_set(h->lpri, none))) return rc; }
+  int npart = nblocks((int)h->gp_left.size(), 128) + nblocks(h->pri.count(), 128) + nblocks(h->vpri.count(), 128) +
+              nblocks(h->btw.count(), 128) + 1;
+  for (int fk = 0; fk < 6; fk++) {
+    MeasSet &s = h->ms[fk];
+    if ((rc = upload(h, s.d_idx, s.idx))) return rc;
+    if ((rc = upload(h, s.d_lm, s.lm))) return rc;
+    if ((rc = upload_real(h, s.d_meas, s.meas))) return rc;
+    if ((rc = upload_real(h, s.d_sig, s.sig))) return rc;
+    if ((rc = upload(h, s.d_row0, r_ms[fk]))) return rc;
+    std::vector<double> coef((size_t)(s.interp ? s.count() : 0) * 4);
+    for (int k = 0; k < (s.interp ? s.count() : 0); k++) interp_coef(s.dt[k], s.tau[k], &coef[4 * (size_t)k]);
+    if ((rc = upload_real(h, s.d_coef, coef))) return rc;
+    npart += nblocks(s.count(), 128);
+  }
+  const size_t Mrows = (size_t)std::max(h->M, 1);
+  HIPCHK(h->rowLR.reserve(Mrows * 2 * b * sizeof(Real)));
+  HIPCHK(h->rowE.reserve(Mrows * sizeof(Real)));
+  // ---- landmark border bookkeeping
+  h->nlmrows = 0;
+  if (h->nl > 0) {
+    HIPCHK(h->rowM.reserve(Mrows * h->ld * sizeof(Real)));
+    HIPCHK(h->rowLm.reserve(Mrows * sizeof(int)));
+    HIPCHK(hipMemsetAsync(h->rowM.p, 0, Mrows * h->ld * sizeof(Real), h->stream));
+    HIPCHK(hipMemsetAsync(h->rowLm.p, 0xFF, Mrows * sizeof(int), h->stream));  // -1: row touches no landmark
+    std::vector<std::vector<std::pair<int, int>>> per_lm(h->L);              // (row, state)
+    for (int fk = 0; fk < 6; fk++) {
+      MeasSet &s = h->ms[fk];
+      if (!s.haslm) continue;
+      for (int f = 0; f < s.count(); f++)
+        for (int r = 0; r < s.rows; r++) per_lm[s.lm[f]].push_back({r_ms[fk][f] + r, s.idx[f]});
+    }
+    std::vector<int> lmrow, lmstate, lmptr(h->L + 1, 0);
+    for (int l = 0; l < h->L; l++) {
+      for (auto &pr : per_lm[l]) { lmrow.push_back(pr.first); lmstate.push_back(pr.second); }
+      lmptr[l + 1] = (int)lmrow.size();
+    }
+    h->nlmrows = (int)lmrow.size();
+    if ((rc = upload(h, h->lmrow, lmrow))) return rc;
+    if ((rc = upload(h, h->lmrow_state, lmstate))) return rc;
+    if ((rc = upload(h, h->lmrow_ptr, lmptr))) return rc;
+    HIPCHK(h->lm_t.reserve((size_t)std::max(h->nlmrows, 1) * h->R * sizeof(Real)));
+    HIPCHK(h->lm_S.reserve((size_t)h->nl * h->R * sizeof(Real)));
+    HIPCHK(h->lm_gL.reserve((size_t)h->nl * sizeof(Real)));
+    HIPCHK(h->lm_dL.reserve((size_t)h->nl * sizeof(Real)));
+    if (!h->lmk.p) return fail(h, GPSLAM_E_INVALID, "set_landmarks() before compile()");
+  }
+  npart = std::max(npart, std::max(nblocks(N, 128), nblocks(N * b, 256))) + 4200;
   HIPCHK(h->partial.reserve((size_t)npart * sizeof(Real)));
-  // ---- solver hierarchy: chunks of m0 states at level 0, m1 above, single-wave top level
-  const int m0 = h->cfg.chunk > 1 ? h->cfg.chunk : 16, m1 = 8, top = 32;
+  HIPCHK(h->gsave.reserve((size_t)N * b * sizeof(Real)));
+  HIPCHK(h->dvec.reserve((size_t)N * b * sizeof(Real)));
+  // ---- solver hierarchy: chunks of m0 states at level 0, m1 above.  Unsharded: a single-wave sequential top
+  // level of <= `top` blocks.  Sharded: reduce down to one block per rank (the rank separator).
+  const int m0 = h->cfg.chunk > 1 ? h->cfg.chunk : 16, m1 = 8, top = sharded(h) ? 16 : 32;
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   h->lv.clear();
   const size_t BS = (size_t)2 * b * b + (size_t)b * h->R, AS = (size_t)b * b + (size_t)b * h->R;
@@ -598,6 +951,18 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
       HIPCHK(hipMemsetAsync(v.add.p, 0, (size_t)(v.n + 1) * AS * sizeof(Real), h->stream));
     }
   }
+  if (sharded(h)) {
+    const int P = h->cfg.nranks;
+    HIPCHK(h->halo_add.reserve(AS * sizeof(Real)));
+    HIPCHK(h->iface_send.reserve((BS + AS) * sizeof(Real)));
+    HIPCHK(h->iface_recv.reserve((size_t)P * (BS + AS) * sizeof(Real)));
+    HIPCHK(h->top_blk.reserve((size_t)P * BS * sizeof(Real)));
+    HIPCHK(h->top_x.reserve((size_t)(P + 1) * b * h->R * sizeof(Real)));
+    HIPCHK(hipMemsetAsync(h->halo_add.p, 0, AS * sizeof(Real), h->stream));
+    HIPCHK(hipMemsetAsync(h->iface_send.p, 0, (BS + AS) * sizeof(Real), h->stream));
+    HIPCHK(hipMemsetAsync(h->iface_recv.p, 0, (size_t)P * (BS + AS) * sizeof(Real), h->stream));
+    HIPCHK(hipMemsetAsync(h->top_x.p, 0, (size_t)(P + 1) * b * h->R * sizeof(Real), h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   h->compiled = true;
   return 0;
@@ -612,12 +977,9 @@ int gpslam_hip_linearize_gp(gpslam_hip_handle *h, double *errors, double *jacobi
   if (F == 0) return 0;
   HIPCHK(h->api_e.reserve((size_t)F * b * sizeof(Real)));
   if (jacobians) HIPCHK(h->api_H.reserve((size_t)F * 4 * b * d * sizeof(Real)));
-  GpArgs<Real> a;
-  a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.count = F;
-  a.left = h->d_gp_left.as<int>(); a.dt = h->d_gp_dt.as<Real>(); a.row0 = h->d_gp_row0.as<int>();
-  a.rowLR = nullptr; a.rowE = nullptr; a.partial = nullptr;
+  GpArgs<Real> a = gp_args(h, nullptr);
+  a.rowLR = nullptr; a.rowE = nullptr;
   a.out_e = h->api_e.as<Real>(); a.out_H = jacobians ? h->api_H.as<Real>() : nullptr;
-  a.U = make_umat(h);
   dispatch_mf(h->mf, [&](auto tag) {
     constexpr int MF = decltype(tag)::value;
     k_gp<Real, MF, 2><<<dim3(nblocks(F, 128)), dim3(128), 0, h->stream>>>(a);
@@ -646,6 +1008,7 @@ int gpslam_hip_error(gpslam_hip_handle *h, double *err) {
 int gpslam_hip_iterate_gn(gpslam_hip_handle *h, gpslam_hip_stats *st) {
   int rc = need_compiled(h);
   if (rc) return rc;
+  if (sharded(h)) return fail(h, GPSLAM_E_INVALID, "sharded handle: use iterate_phase1 / iterate_phase2");
   (void)hipSetDevice(h->cfg.device);
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   if ((rc = enqueue_gn(h, 0.0, true))) return rc;
@@ -672,6 +1035,7 @@ int gpslam_hip_run_gn(gpslam_hip_handle *h, int32_t iters, gpslam_hip_stats *st,
   int rc = need_compiled(h);
   if (rc) return rc;
   if (iters <= 0) return GPSLAM_E_INVALID;
+  if (sharded(h)) return fail(h, GPSLAM_E_INVALID, "sharded handle: use iterate_phase1 / iterate_phase2");
   (void)hipSetDevice(h->cfg.device);
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   double acc[5] = {0, 0, 0, 0, 0};
@@ -699,26 +1063,87 @@ int gpslam_hip_run_gn(gpslam_hip_handle *h, int32_t iters, gpslam_hip_stats *st,
   return flag ? fail(h, GPSLAM_E_NOT_SPD, "non-positive pivot in the block elimination") : 0;
 }
 
-int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *, const gpslam_hip_params *, gpslam_hip_stats *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "LM: not in this build yet") : GPSLAM_E_INVALID;
+// LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults: diagonalDamping = false, fixed lambda factor):
+// linearise once; loop { damp with lambda I; solve; rho = (err - newErr) / (linErr(0) - linErr(delta));
+// accept if rho > minModelFidelity and lambda /= factor, else lambda *= factor until lambdaUpperBound }.
+// linErr(0) - linErr(delta) = 0.5 delta.g + 0.5 lambda |delta|^2 because (H + lambda I) delta = g.
+int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *lambda, const gpslam_hip_params *p, gpslam_hip_stats *st) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!lambda || !p) return GPSLAM_E_INVALID;
+  if (sharded(h)) return fail(h, GPSLAM_E_UNSUPPORTED, "LM on a sharded handle: not supported yet");
+  (void)hipSetDevice(h->cfg.device);
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  if ((rc = launch_factors(h, 0, 0))) return rc;        // scal[0] = current error
+  if ((rc = backup_state(h, false))) return rc;
+  double s[8];
+  int flag = 0;
+  bool accepted = false;
+  double err0 = 0, new_err = 0, dinf = 0;
+  const int nx = h->N * h->b;
+  for (;;) {
+    HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+    if ((rc = launch_assemble(h, true))) return rc;      // rows are still those of the linearisation point
+    if ((rc = launch_solve(h, *lambda))) return rc;
+    k_gather_delta<Real><<<dim3(nblocks(nx, 256)), dim3(256), 0, h->stream>>>(h->lv[0].x.as<Real>(), h->N, h->R, h->b, h->dvec.as<Real>());
+    if ((rc = launch_dot(h, h->dvec.as<Real>(), h->gsave.as<Real>(), nx, 3))) return rc;   // delta . g
+    if ((rc = launch_dot(h, h->dvec.as<Real>(), h->dvec.as<Real>(), nx, 4))) return rc;    // |delta|^2
+    if (h->nl > 0) {
+      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_gL.as<Real>(), h->nl, 5))) return rc;
+      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_dL.as<Real>(), h->nl, 6))) return rc;
+    }
+    if ((rc = launch_retract(h, 2))) return rc;
+    if ((rc = launch_factors(h, 1, 1))) return rc;       // scal[1] = trial error
+    if ((rc = read_scal(h, s, 8, &flag))) return rc;
+    err0 = s[0];
+    bool ok = false;
+    if (!flag) {
+      const double dg = s[3] + (h->nl > 0 ? s[5] : 0.0), dd = s[4] + (h->nl > 0 ? s[6] : 0.0);
+      const double lin_change = 0.5 * dg + 0.5 * (*lambda) * dd;
+      if (lin_change >= 0.0) {
+        const double cost_change = err0 - s[1];
+        const double fidelity = (lin_change > 1e-20) ? cost_change / lin_change : 0.0;
+        if (fidelity > p->min_model_fidelity) { ok = true; new_err = s[1]; dinf = s[2]; }
+      }
+    }
+    if (ok) {
+      *lambda /= p->lambda_factor;
+      if (*lambda < p->lambda_lower_bound) *lambda = p->lambda_lower_bound;
+      accepted = true;
+      break;
+    }
+    if ((rc = backup_state(h, true))) return rc;          // reject: restore the linearisation point
+    if (*lambda >= p->lambda_upper_bound) break;
+    *lambda *= p->lambda_factor;
+  }
+  if (st) {
+    std::memset(st, 0, sizeof(*st));
+    st->error_before = err0;
+    st->error_after = accepted ? new_err : err0;
+    st->delta_inf_norm = accepted ? dinf : 0.0;
+    st->lambda = *lambda;
+    st->iterations = 1;
+    st->accepted = accepted ? 1 : 0;
+  }
+  return 0;
 }
 
 int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam_hip_stats *st) {
   int rc = need_compiled(h);
   if (rc) return rc;
   if (!p) return GPSLAM_E_INVALID;
-  if (p->use_lm) return fail(h, GPSLAM_E_UNSUPPORTED, "LM: not in this build yet");
   // NonlinearOptimizer::defaultOptimize: do { cur = error(); iterate(); } while (!converged)
   double err0;
   if ((rc = gpslam_hip_error(h, &err0))) return rc;
   gpslam_hip_stats it;
   std::memset(&it, 0, sizeof(it));
-  double new_err = err0, dinf = 0.0;
+  double new_err = err0, dinf = 0.0, lambda = p->lambda_initial;
   int iters = 0;
   if (!(err0 <= p->error_tol)) {
     for (;;) {
       const double cur = new_err;
-      if ((rc = gpslam_hip_iterate_gn(h, &it))) break;
+      rc = p->use_lm ? gpslam_hip_iterate_lm(h, &lambda, p, &it) : gpslam_hip_iterate_gn(h, &it);
+      if (rc) break;
       iters++;
       new_err = it.error_after;
       dinf = it.delta_inf_norm;
@@ -727,6 +1152,7 @@ int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam
       const double abs_dec = cur - new_err, rel_dec = abs_dec / cur;
       if (rel_dec <= p->relative_error_tol || abs_dec <= p->absolute_error_tol) break;
       if (p->delta_tol > 0.0 && dinf < p->delta_tol) break;
+      if (p->use_lm && !it.accepted) break;
     }
   }
   if (st) {
@@ -734,6 +1160,7 @@ int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam
     st->error_before = err0;
     st->error_after = new_err;
     st->delta_inf_norm = dinf;
+    st->lambda = lambda;
     st->iterations = iters;
     st->status = rc;
     st->accepted = 1;
@@ -746,7 +1173,7 @@ int gpslam_hip_normal_equations(gpslam_hip_handle *h, double *D, double *O, doub
   if (rc) return rc;
   (void)hipSetDevice(h->cfg.device);
   if ((rc = launch_factors(h, 0, 0))) return rc;
-  if ((rc = launch_assemble(h))) return rc;
+  if ((rc = launch_assemble(h, false))) return rc;
   const int N = h->N, b = h->b, R = h->R;
   const size_t BS = (size_t)2 * b * b + (size_t)b * R;
   std::vector<Real> blk((size_t)N * BS);
@@ -768,7 +1195,7 @@ int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double
                                    const double *g, double *x) {
   int rc = need_compiled(h);
   if (rc) return rc;
-  if (N != h->N || h->R != 1 || !D || !O || !g || !x) return GPSLAM_E_INVALID;
+  if (N != h->N || h->R != 1 || sharded(h) || !D || !O || !g || !x) return GPSLAM_E_INVALID;
   (void)hipSetDevice(h->cfg.device);
   const int b = h->b;
   const size_t BS = (size_t)2 * b * b + b;
@@ -799,29 +1226,23 @@ int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5) {
 int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, double *avg_ms) {
   int rc = need_compiled(h);
   if (rc) return rc;
-  if (reps <= 0 || !avg_ms || which < 0 || which > 4) return GPSLAM_E_INVALID;
+  if (reps <= 0 || !avg_ms || which < 0 || which > 4 || sharded(h)) return GPSLAM_E_INVALID;
   (void)hipSetDevice(h->cfg.device);
   double total = 0.0;
   for (int r = 0; r < reps; r++) {
     // bring the inputs of the timed kernel into their real state (untimed)
     if (which >= 1 && (rc = launch_factors(h, 0, 0))) return rc;
-    if (which >= 2 && (rc = launch_assemble(h))) return rc;
+    if (which >= 2 && (rc = launch_assemble(h, false))) return rc;
     HIPCHK(hipEventRecord(h->ev[0], h->stream));
     if (which == 0) {
-      GpArgs<Real> a;
-      a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride;
-      a.count = (int)h->gp_left.size();
-      a.left = h->d_gp_left.as<int>(); a.dt = h->d_gp_dt.as<Real>(); a.row0 = h->d_gp_row0.as<int>();
-      a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
-      a.partial = h->partial.as<Real>(); a.out_e = nullptr; a.out_H = nullptr;
-      a.U = make_umat(h);
+      GpArgs<Real> a = gp_args(h, h->partial.as<Real>());
       const int nb = nblocks(a.count, 128);
       dispatch_mf(h->mf, [&](auto tag) {
         constexpr int MF = decltype(tag)::value;
         k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
       });
     } else if (which == 1) {
-      if ((rc = launch_assemble(h))) return rc;
+      if ((rc = launch_assemble(h, false))) return rc;
     } else if (which == 2 || which == 3) {
       Level &v = h->lv[0];
       const bool top = (h->lv.size() == 1);
@@ -830,28 +1251,22 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
       a.up_blk = top ? nullptr : h->lv[1].blk.as<Real>();
       a.up_add = top ? nullptr : h->lv[1].add.as<Real>();
       a.n = v.n; a.m = top ? v.n : v.m; a.R = h->R; a.no_sep = top ? 1 : 0; a.last_has_right = 0;
-      a.lambda = Real(0); a.flag = h->flag.as<int>();
+      a.remote_add = nullptr; a.lambda = Real(0); a.flag = h->flag.as<int>();
       const int grid = top ? 1 : v.nch;
-      dispatch_b(h->b, [&](auto tag) {
-        constexpr int BB = decltype(tag)::value;
-        k_chunk_forward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
-      });
+      launch_fwd(h, a, grid);
       if (which == 3) {  // time the level-0 back-substitution instead (separator solutions = whatever lv[1].x holds)
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         BwdArgs<Real> bw;
         bw.blk = v.blk.as<Real>(); bw.x = v.x.as<Real>(); bw.xup = top ? nullptr : h->lv[1].x.as<Real>();
         bw.n = v.n; bw.m = top ? v.n : v.m; bw.R = h->R; bw.no_sep = top ? 1 : 0; bw.last_has_right = 0;
-        dispatch_b(h->b, [&](auto tag) {
-          constexpr int BB = decltype(tag)::value;
-          k_chunk_backward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(bw);
-        });
+        launch_bwd(h, bw, grid);
       }
     } else {
       HIPCHK(hipMemsetAsync(h->lv[0].x.p, 0, (size_t)h->N * h->b * h->R * sizeof(Real), h->stream));
       HIPCHK(hipEventRecord(h->ev[0], h->stream));
       RetractArgs<Real> a;
       a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = h->N; a.R = h->R;
-      a.chart = h->cfg.chart; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
+      a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
       dispatch_mf(h->mf, [&](auto tag) {
         constexpr int MF = decltype(tag)::value;
         k_retract<Real, MF><<<dim3(nblocks(h->N, 128)), dim3(128), 0, h->stream>>>(a);
@@ -867,20 +1282,90 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
   return 0;
 }
 
-int gpslam_hip_interface_send(gpslam_hip_handle *h, void **, size_t *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "sharding: not in this build yet") : GPSLAM_E_INVALID;
+// ---------------------------------------------------------------- segment sharding
+
+int gpslam_hip_interface_send(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h) || !dev_ptr || !bytes) return GPSLAM_E_INVALID;
+  const size_t BS = (size_t)2 * h->b * h->b + (size_t)h->b * h->R, AS = (size_t)h->b * h->b + (size_t)h->b * h->R;
+  *dev_ptr = h->iface_send.p;
+  *bytes = (BS + AS) * sizeof(Real);
+  return 0;
 }
-int gpslam_hip_interface_recv(gpslam_hip_handle *h, void **, size_t *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "sharding: not in this build yet") : GPSLAM_E_INVALID;
+int gpslam_hip_interface_recv(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h) || !dev_ptr || !bytes) return GPSLAM_E_INVALID;
+  const size_t BS = (size_t)2 * h->b * h->b + (size_t)h->b * h->R, AS = (size_t)h->b * h->b + (size_t)h->b * h->R;
+  *dev_ptr = h->iface_recv.p;
+  *bytes = (size_t)h->cfg.nranks * (BS + AS) * sizeof(Real);
+  return 0;
 }
-int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "sharding: not in this build yet") : GPSLAM_E_INVALID;
+
+// phase 1: linearise, assemble, eliminate the local segment down to its separator -> interface record
+int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double lambda) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  h->ph_lambda = lambda;
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  if ((rc = launch_factors(h, 0, 0))) return rc;
+  if ((rc = launch_assemble(h, false))) return rc;
+  return launch_forward(h, lambda);
 }
-int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "sharding: not in this build yet") : GPSLAM_E_INVALID;
-}
-int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *, const double *) {
-  return h ? fail(h, GPSLAM_E_UNSUPPORTED, "sharding: not in this build yet") : GPSLAM_E_INVALID;
+
+// phase 2 (after the all-gather of the records into interface_recv): every rank solves the P-block reduced
+// system redundantly, back-substitutes its segment, retracts its states and its copy of the halo state.
+// st (optional) returns THIS RANK's error terms and |delta|_inf; the caller reduces them across ranks.
+int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  const int P = h->cfg.nranks, b = h->b, R = h->R;
+  const size_t BS = (size_t)2 * b * b + (size_t)b * R;
+  k_iface_build<Real><<<dim3(nblocks(P * (int)BS, 256)), dim3(256), 0, h->stream>>>(h->iface_recv.as<Real>(), P, b, R, h->top_blk.as<Real>());
+  {
+    FwdArgs<Real> a;
+    a.blk = h->top_blk.as<Real>(); a.add = nullptr; a.up_blk = nullptr; a.up_add = nullptr;
+    a.n = P; a.m = P; a.R = R; a.no_sep = 1; a.last_has_right = 0; a.remote_add = nullptr; a.lambda = Real(0);
+    a.flag = h->flag.as<int>();
+    launch_fwd(h, a, 1);
+    BwdArgs<Real> bw;
+    bw.blk = h->top_blk.as<Real>(); bw.x = h->top_x.as<Real>(); bw.xup = nullptr;
+    bw.n = P; bw.m = P; bw.R = R; bw.no_sep = 1; bw.last_has_right = 0;
+    launch_bwd(h, bw, 1);
+  }
+  const Real *xtop = h->top_x.as<Real>() + (size_t)h->cfg.rank * b * R;   // [x_sep(rank), x_sep(rank + 1)]
+  if ((rc = launch_backward(h, xtop))) return rc;
+  if ((rc = launch_retract(h, 2))) return rc;
+  if (has_right_rank(h)) {  // keep the local copy of the neighbour's first state in step with its owner
+    RetractArgs<Real> a;
+    a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = 1; a.R = R;
+    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4;
+    dispatch_mf(h->mf, [&](auto tag) {
+      constexpr int MF = decltype(tag)::value;
+      k_retract<Real, MF><<<dim3(1), dim3(128), 0, h->stream>>>(a);
+    });
+  }
+  if ((rc = launch_factors(h, 1, 1))) return rc;
+  HIPCHK(hipGetLastError());
+  if (st) {
+    double s[4];
+    int flag = 0;
+    if ((rc = read_scal(h, s, 4, &flag))) return rc;
+    std::memset(st, 0, sizeof(*st));
+    st->error_before = s[0];
+    st->error_after = s[1];
+    st->delta_inf_norm = s[2];
+    st->iterations = 1;
+    st->accepted = 1;
+    st->status = flag ? GPSLAM_E_NOT_SPD : 0;
+    if (flag) return fail(h, GPSLAM_E_NOT_SPD, "non-positive pivot in the block elimination");
+  }
+  return 0;
 }
 
 }  // extern "C"

@@ -332,3 +332,108 @@ template <typename T, bool JAC> struct PoseFactors<T, POSE3, JAC> {
 };
 
 }  // namespace gps
+
+// =====================================================================================================
+// GP interpolators and the measurement factors that sit on an interpolated pose.
+//   GaussianProcessInterpolatorLinear<D>::interpolatePose   gpslam/gp/GaussianProcessInterpolatorLinear.h:70-90
+//   GaussianProcessInterpolatorPose2::interpolatePose       gpslam/gp/GaussianProcessInterpolatorPose2.h:56-89
+//   GaussianProcessInterpolatorRot3::interpolatePose        gpslam/gp/GaussianProcessInterpolatorRot3.h:56-86
+//   GaussianProcessInterpolatorPose3::interpolatePose       gpslam/gp/GaussianProcessInterpolatorPose3.h:57-105
+// Lambda(tau) and Psi(tau) (gpslam/gp/GPutils.h:54-71) are Kronecker products P (x) (Qc Qc^-1) = P (x) I of a
+// 2x2 matrix with the identity for ANY Qc, so only the first block row is needed and it is four scalars:
+//   Lambda_1 = [l11 I, l12 I],  Psi_1 = [p11 I, p12 I]   (computed on the host per factor, see api.hip).
+// =====================================================================================================
+namespace gps {
+
+template <typename T> struct ICoef { T l11, l12, p11, p12; };
+
+// row-vector (1x3) times 3x3
+template <typename T> GD V3<T> rowmul(V3<T> a, const M3<T> &m) {
+  return {a.x * m.m[0] + a.y * m.m[3] + a.z * m.m[6], a.x * m.m[1] + a.y * m.m[4] + a.z * m.m[7],
+          a.x * m.m[2] + a.y * m.m[5] + a.z * m.m[8]};
+}
+// row-vector (1x6) times block lower-triangular 6x6
+template <typename T> GD V6<T> rowmul(V6<T> a, const BL6<T> &m) { return {rowmul(a.w, m.A) + rowmul(a.v, m.C), rowmul(a.v, m.D)}; }
+
+// ---- d = 3 groups: interpolated pose + Hint1..4 as 3x3 matrices
+template <typename T, bool JAC> struct Interp3Out { M3<T> H1, H2, H3, H4; };
+
+template <typename T, bool JAC>
+GD SE2<T> interp_pose2(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, Interp3Out<T, JAC> &o) {
+  const SE2<T> a = {p1[0], p1[1], p1[2]}, b = {p2[0], p2[1], p2[2]};
+  const SE2<T> h = se2_between(a, b);
+  const V3<T> r = se2_log(h);
+  const V3<T> xi = {k.l12 * v1[0] + k.p11 * r.x + k.p12 * v2[0], k.l12 * v1[1] + k.p11 * r.y + k.p12 * v2[1],
+                    k.l12 * v1[2] + k.p11 * r.z + k.p12 * v2[2]};
+  const SE2<T> ex = se2_exp(xi);
+  if (JAC) {
+    const M3<T> He = se2_dexp(xi);                         // Hcomp22 * Hexp, Hcomp22 = I
+    const M3<T> J3 = se2_dlog(r);
+    const M3<T> J1 = neg(J3 * se2_adjoint(se2_inverse(h)));
+    o.H1 = se2_adjoint(se2_inverse(ex)) + k.p11 * (He * J1);   // Hcomp21 + Hexpr1 Psi11 Hlog Hcomp11 Hinv
+    o.H2 = k.l12 * He;
+    o.H3 = k.p11 * (He * J3);
+    o.H4 = k.p12 * He;
+  }
+  return se2_compose(a, ex);
+}
+
+template <typename T, bool JAC>
+GD M3<T> interp_rot3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, Interp3Out<T, JAC> &o) {
+  const M3<T> R1 = as_m3(p1), R2 = as_m3(p2);
+  const M3<T> h = transpose(R1) * R2;
+  const V3<T> r = so3_log(h);
+  const V3<T> xi = {k.l12 * v1[0] + k.p11 * r.x + k.p12 * v2[0], k.l12 * v1[1] + k.p11 * r.y + k.p12 * v2[1],
+                    k.l12 * v1[2] + k.p11 * r.z + k.p12 * v2[2]};
+  const M3<T> ex = so3_exp(xi);
+  if (JAC) {
+    const M3<T> He = so3_jr(xi);
+    const M3<T> J3 = so3_jrinv(r);
+    const M3<T> J1 = neg(J3 * transpose(h));
+    o.H1 = transpose(ex) + k.p11 * (He * J1);               // Rot3::compose H1 = R2^T
+    o.H2 = k.l12 * He;
+    o.H3 = k.p11 * (He * J3);
+    o.H4 = k.p12 * He;
+  }
+  return R1 * ex;
+}
+
+// ---- SE(3): Hint1..4 are block lower-triangular
+template <typename T, bool JAC> struct Interp6Out { BL6<T> H1, H2, H3, H4; };
+
+template <typename T, bool JAC>
+GD SE3<T> interp_pose3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, Interp6Out<T, JAC> &o) {
+  const SE3<T> a = as_se3(p1), b = as_se3(p2);
+  const SE3<T> h = se3_between(a, b);
+  const V6<T> r = se3_log(h);                                          // :68
+  const BL6<T> Jinv = se3_jrinv(r);                                    // :72
+  const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+  const V6<T> xi = k.l12 * u1 + k.p11 * r + k.p12 * (Jinv * u2);       // Lambda_1 r1 + Psi_1 r2, r1 = [0; v1], r2 = [r; Jinv v2]
+  const SE3<T> ex = se3_exp(xi);
+  if (JAC) {
+    const BL6<T> He = se3_jr(xi);                                      // Hcomp22 * Hexp (:80)
+    const BL6<T> FD = se3_jrinv_times_x_fd(r, u2);                     // (:84, :93) computed once
+    const BL6<T> tmp1 = neg(Jinv * se3_adjoint(se3_inverse(h)));       // Hlogmap Hcomp11 Hinv
+    const BL6<T> s1 = k.p11 * tmp1 + k.p12 * (FD * tmp1);              // Psi_1 * dr2_dT1
+    o.H1 = se3_adjoint(se3_inverse(ex)) + He * s1;                     // Hcomp21 + ... (:87)
+    o.H2 = k.l12 * He;                                                 // (:89)
+    const BL6<T> s3 = k.p11 * Jinv + k.p12 * (FD * Jinv);              // Psi_1 * dr2_dT2, Hlogmap Hcomp12 = Jinv
+    o.H3 = He * s3;                                                    // (:96)
+    o.H4 = k.p12 * (He * Jinv);                                        // (:98)
+  }
+  return se3_compose(a, ex);
+}
+
+// ---- Unit3 basis (GTSAM Unit3::basis): B = [b1 b2], b1 = n x axis_min, b2 = n x b1
+template <typename T> GD void unit3_basis(V3<T> n, V3<T> &b1, V3<T> &b2) {
+  const T mx = fabs(n.x), my = fabs(n.y), mz = fabs(n.z);
+  V3<T> axis = {T(0), T(0), T(1)};
+  if (mx <= my && mx <= mz) axis = {T(1), T(0), T(0)};
+  else if (my <= mx && my <= mz) axis = {T(0), T(1), T(0)};
+  b1 = cross(n, axis);
+  b1 = (T(1) / sqrt(dot(b1, b1))) * b1;
+  b2 = cross(n, b1);
+  b2 = (T(1) / sqrt(dot(b2, b2))) * b2;
+}
+
+}  // namespace gps

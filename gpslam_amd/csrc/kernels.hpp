@@ -226,6 +226,382 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
   if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
 }
 
+// ------------------------------------------------------------------ K2: measurement factors
+
+enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5 };
+template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE) ? 2 : 3); };
+
+template <typename T> struct MeasArgs {
+  const T *pose, *vel;
+  int stride;
+  const T *lmk;        // L x ld (AoS)
+  int ld, count, chart;
+  const int *idx;      // left (or only) state
+  const int *lm;       // landmark or null
+  const T *meas;       // count x mw
+  int mw;
+  const T *sig;        // count x rows
+  const T *coef;       // count x 4: l11, l12, p11, p12 (interpolated kinds)
+  T sensor[12];
+  int has_sensor;
+  const int *row0;
+  T *rowLR, *rowE, *rowM;
+  int *rowLm;
+  T *partial;
+};
+
+// valid (manifold, kind) pairs; everything else is rejected on the host and compiles to an empty kernel
+template <int MF, int FK> struct MeasValid {
+  static constexpr bool v = ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && (MF == POSE2 || MF == POSE3 || MF == LINEAR3)) ||
+                            (FK == FK_INTERP_ATT && MF == ROT3) || (FK == FK_INTERP_GPS && MF == POSE3) ||
+                            ((FK == FK_ODOM2D || FK == FK_BEARING_RANGE) && MF == LINEAR3);
+};
+
+template <typename T> __device__ __forceinline__ void put_v3(V3<T> a, T *row) { row[0] = a.x; row[1] = a.y; row[2] = a.z; }
+template <typename T> __device__ __forceinline__ void put_v6(V6<T> a, T *row) { put_v3(a.w, row); put_v3(a.v, row + 3); }
+
+// GPInterpolatedRangeFactorPose2/Pose3/2DLinear, RangeFactorPose2 / RangeFactor2DLinear,
+// GPInterpolatedAttitudeFactorRot3, GPInterpolatedGPSFactorPose3, OdometryFactor2DLinear, RangeBearingFactor2DLinear
+// (gpslam/slam/*.h, see the per-branch citations).  One thread per factor.
+template <typename T, int MF, int FK, bool JAC>
+__global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
+  constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d, rows = FKRows<FK>::rows;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  T err = T(0);
+  if constexpr (MeasValid<MF, FK>::v) {
+    if (f < a.count) {
+      const int i = a.idx[f];
+      constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D);
+      constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE);
+      T p1[pd], v1[d], p2[pd], v2[d];
+#pragma unroll
+      for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = two ? a.pose[(size_t)k * a.stride + i + 1] : T(0); }
+#pragma unroll
+      for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = two ? a.vel[(size_t)k * a.stride + i + 1] : T(0); }
+      int lm = -1;
+      T pt[3] = {T(0), T(0), T(0)};
+      if (haslm) {
+        lm = a.lm[f];
+        for (int q = 0; q < a.ld; q++) pt[q] = a.lmk[(size_t)lm * a.ld + q];
+      }
+      ICoef<T> kc = {T(0), T(0), T(0), T(0)};
+      if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS)
+        kc = {a.coef[4 * (size_t)f], a.coef[4 * (size_t)f + 1], a.coef[4 * (size_t)f + 2], a.coef[4 * (size_t)f + 3]};
+      const T *ms = a.meas + (size_t)f * a.mw;
+      T e[rows];
+      T JL[JAC ? rows * b : 1], JR[JAC ? rows * b : 1], Jm[JAC ? rows * 3 : 1];
+      if (JAC) {
+#pragma unroll
+        for (int k = 0; k < rows * b; k++) { JL[k] = T(0); JR[k] = T(0); }
+#pragma unroll
+        for (int k = 0; k < rows * 3; k++) Jm[k] = T(0);
+      }
+
+      if constexpr ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && MF == POSE3) {
+        // GPInterpolatedRangeFactorPose3::evaluateError, gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
+        Interp6Out<T, JAC> o;
+        SE3<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o) : as_se3(p1);
+        const SE3<T> S = as_se3(a.sensor);
+        const SE3<T> sp = a.has_sensor ? se3_compose(pose, S) : pose;
+        const V3<T> pw = {pt[0], pt[1], pt[2]};
+        const V3<T> q = tmul(sp.R, pw - sp.t);                       // Pose3::transform_to
+        const T r = sqrt(dot(q, q));
+        const V3<T> qh = (T(1) / r) * q;
+        e[0] = r - ms[0];
+        if (JAC) {
+          V6<T> Hr = {rowmul(qh, skew(q)), -qh};                     // D_r_local * [skew(q), -I]
+          if (a.has_sensor) Hr = rowmul(Hr, se3_adjoint(se3_inverse(S)));   // Hpose * H0 (:87)
+          put_v3(sp.R * qh, Jm);                                     // D_r_local * R^T
+          if (FK == FK_INTERP_RANGE) {
+            put_v6(rowmul(Hr, o.H1), JL); put_v6(rowmul(Hr, o.H2), JL + 6);
+            put_v6(rowmul(Hr, o.H3), JR); put_v6(rowmul(Hr, o.H4), JR + 6);
+          } else {
+            put_v6(Hr, JL);
+          }
+        }
+      } else if constexpr ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && MF == POSE2) {
+        // GPInterpolatedRangeFactorPose2::evaluateError, gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98
+        Interp3Out<T, JAC> o;
+        SE2<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose2<T, JAC>(p1, v1, p2, v2, kc, o) : SE2<T>{p1[0], p1[1], p1[2]};
+        const SE2<T> S = {a.sensor[0], a.sensor[1], a.sensor[2]};
+        const SE2<T> sp = a.has_sensor ? se2_compose(pose, S) : pose;
+        const T dx = pt[0] - sp.x, dy = pt[1] - sp.y;
+        const T r = sqrt(dx * dx + dy * dy);
+        const T hx = dx / r, hy = dy / r;
+        e[0] = r - ms[0];
+        if (JAC) {
+          const T c = cos(sp.th), sn = sin(sp.th);
+          V3<T> Hr = {-c * hx - sn * hy, sn * hx - c * hy, T(0)};   // D_r_d * [[-c, s, 0], [-s, -c, 0]]
+          if (a.has_sensor) Hr = rowmul(Hr, se2_adjoint(se2_inverse(S)));
+          Jm[0] = hx; Jm[1] = hy;
+          if (FK == FK_INTERP_RANGE) {
+            put_v3(rowmul(Hr, o.H1), JL); put_v3(rowmul(Hr, o.H2), JL + 3);
+            put_v3(rowmul(Hr, o.H3), JR); put_v3(rowmul(Hr, o.H4), JR + 3);
+          } else {
+            put_v3(Hr, JL);
+          }
+        }
+      } else if constexpr ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && MF == LINEAR3) {
+        // GPInterpolatedRangeFactor2DLinear (GPInterpolatedRangeFactor2DLinear.h:60-88) / RangeFactor2DLinear (:43-56)
+        T px, py;
+        if (FK == FK_INTERP_RANGE) {
+          px = kc.l11 * p1[0] + kc.l12 * v1[0] + kc.p11 * p2[0] + kc.p12 * v2[0];
+          py = kc.l11 * p1[1] + kc.l12 * v1[1] + kc.p11 * p2[1] + kc.p12 * v2[1];
+        } else { px = p1[0]; py = p1[1]; }
+        const T dx = pt[0] - px, dy = pt[1] - py;
+        const T r = sqrt(dx * dx + dy * dy);
+        const T hx = dx / r, hy = dy / r;
+        e[0] = r - ms[0];
+        if (JAC) {
+          Jm[0] = hx; Jm[1] = hy;
+          if (FK == FK_INTERP_RANGE) {
+            JL[0] = -kc.l11 * hx; JL[1] = -kc.l11 * hy; JL[3] = -kc.l12 * hx; JL[4] = -kc.l12 * hy;
+            JR[0] = -kc.p11 * hx; JR[1] = -kc.p11 * hy; JR[3] = -kc.p12 * hx; JR[4] = -kc.p12 * hy;
+          } else { JL[0] = -hx; JL[1] = -hy; }
+        }
+      } else if constexpr (FK == FK_INTERP_ATT) {
+        // GPInterpolatedAttitudeFactorRot3::evaluateError, gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:61-83
+        Interp3Out<T, JAC> o;
+        const M3<T> R = interp_rot3<T, JAC>(p1, v1, p2, v2, kc, o);
+        const V3<T> nZ = {ms[0], ms[1], ms[2]}, bRef = {ms[3], ms[4], ms[5]};
+        V3<T> q = R * bRef;
+        q = (T(1) / sqrt(dot(q, q))) * q;
+        V3<T> z1, z2;
+        unit3_basis(nZ, z1, z2);
+        e[0] = dot(z1, q); e[1] = dot(z2, q);
+        if (JAC) {
+          V3<T> q1, q2;
+          unit3_basis(q, q1, q2);
+          const M3<T> RS = R * skew(bRef);
+          const V3<T> n1 = -rowmul(q1, RS), n2 = -rowmul(q2, RS);       // D_nRef_R = -Bq^T R [bRef]x
+          const T d00 = dot(z1, q1), d01 = dot(z1, q2), d10 = dot(z2, q1), d11 = dot(z2, q2);   // Bz^T Bq
+          const V3<T> h0 = d00 * n1 + d01 * n2, h1 = d10 * n1 + d11 * n2;
+          put_v3(rowmul(h0, o.H1), JL); put_v3(rowmul(h0, o.H2), JL + 3); put_v3(rowmul(h0, o.H3), JR); put_v3(rowmul(h0, o.H4), JR + 3);
+          put_v3(rowmul(h1, o.H1), JL + b); put_v3(rowmul(h1, o.H2), JL + b + 3); put_v3(rowmul(h1, o.H3), JR + b); put_v3(rowmul(h1, o.H4), JR + b + 3);
+        }
+      } else if constexpr (FK == FK_INTERP_GPS) {
+        // GPInterpolatedGPSFactorPose3::evaluateError, gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
+        Interp6Out<T, JAC> o;
+        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
+        const SE3<T> S = as_se3(a.sensor);
+        const SE3<T> sp = a.has_sensor ? se3_compose(pose, S) : pose;
+        e[0] = sp.t.x - ms[0]; e[1] = sp.t.y - ms[1]; e[2] = sp.t.z - ms[2];
+        if (JAC) {
+          const BL6<T> AdS = se3_adjoint(se3_inverse(S));
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            V6<T> Hp = {{T(0), T(0), T(0)}, {sp.R.m[3 * r], sp.R.m[3 * r + 1], sp.R.m[3 * r + 2]}};   // translation(H) = [0, R]
+            if (a.has_sensor) Hp = rowmul(Hp, AdS);
+            put_v6(rowmul(Hp, o.H1), JL + r * b); put_v6(rowmul(Hp, o.H2), JL + r * b + 6);
+            put_v6(rowmul(Hp, o.H3), JR + r * b); put_v6(rowmul(Hp, o.H4), JR + r * b + 6);
+          }
+        }
+      } else if constexpr (FK == FK_ODOM2D) {
+        // OdometryFactor2DLinear::evaluateError, gpslam/slam/OdometryFactor2DLinear.h:50-75
+        const T dx = p2[0] - p1[0], dy = p2[1] - p1[1], dth = p2[2] - p1[2];
+        const T c = cos(p1[2]), sn = sin(p1[2]);
+        const T qx = c * dx + sn * dy, qy = -sn * dx + c * dy;
+        e[0] = qx - ms[0]; e[1] = qy - ms[1]; e[2] = dth - ms[2];
+        if (JAC) {
+          JL[0] = -c; JL[1] = -sn; JL[2] = qy;
+          JL[b + 0] = sn; JL[b + 1] = -c; JL[b + 2] = -qx;
+          JL[2 * b + 2] = T(-1);
+          JR[0] = c; JR[1] = sn;
+          JR[b + 0] = -sn; JR[b + 1] = c;
+          JR[2 * b + 2] = T(1);
+        }
+      } else if constexpr (FK == FK_BEARING_RANGE) {
+        // RangeBearingFactor2DLinear::evaluateError, gpslam/slam/RangeBearingFactor2DLinear.h:47-84; meas = (bearing, range)
+        const T c = cos(p1[2]), sn = sin(p1[2]);
+        const T dx = pt[0] - p1[0], dy = pt[1] - p1[1];
+        const T rx = c * dx + sn * dy, ry = -sn * dx + c * dy;           // pose2.transform_to(point)
+        const T ed = sqrt(dx * dx + dy * dy);
+        const T hx = dx / ed, hy = dy / ed;
+        const T df = atan2(ry, rx) - ms[0];
+        e[0] = atan2(sin(df), cos(df));
+        e[1] = ed - ms[1];
+        if (JAC) {
+          T t0 = T(0), t1 = T(0);
+          if (ed > T(1e-5)) { t0 = -ry / (ed * ed); t1 = rx / (ed * ed); }   // :62
+          JL[0] = t0 * (-c) + t1 * sn; JL[1] = t0 * (-sn) + t1 * (-c); JL[2] = t0 * ry + t1 * (-rx);   // tmp * [-R^T, t]
+          JL[b + 0] = -hx; JL[b + 1] = -hy;
+          Jm[0] = t0 * c + t1 * (-sn); Jm[1] = t0 * sn + t1 * c;       // tmp * R^T
+          Jm[3 + 0] = hx; Jm[3 + 1] = hy;
+        }
+      }
+
+      const int row0 = JAC ? a.row0[f] : 0;
+#pragma unroll
+      for (int r = 0; r < rows; r++) {
+        const T w = T(1) / a.sig[(size_t)f * rows + r];
+        const T we = e[r] * w;
+        err += we * we;
+        if (JAC) {
+          a.rowE[row0 + r] = we;
+          T *row = a.rowLR + (size_t)(row0 + r) * 2 * b;
+#pragma unroll
+          for (int c = 0; c < b; c++) { row[c] = w * JL[r * b + c]; row[b + c] = w * JR[r * b + c]; }
+          if (a.ld > 0) {
+            a.rowLm[row0 + r] = lm;
+            for (int q = 0; q < a.ld; q++) a.rowM[(size_t)(row0 + r) * a.ld + q] = w * Jm[r * 3 + q];
+          }
+        }
+      }
+    }
+  }
+  const T tot = block_sum(T(0.5) * err);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+}
+
+// ------------------------------------------------------------------ landmark border (Schur complement)
+
+template <typename T> struct LmArgs {
+  int N, R, B, L, ld, nl;   // R = 1 + nl
+  const T *rowLR, *rowE, *rowM;
+  const int *lmrow;         // row ids of rows that touch a landmark, grouped by landmark
+  const int *lmrow_state;   // left state of each such row
+  const int *lmrow_ptr;     // L + 1
+  int nlmrows;
+  T *x;                     // level-0 solutions, N x R x B (column 0 is corrected in place)
+  T *t;                     // nlmrows x R
+  // landmark priors
+  int npri;
+  const int *pri_lm;
+  const T *pri_meas, *pri_sig;
+  T *lmk;                   // L x ld
+  T *S;                     // nl x (nl + 1): column 0 = rhs, columns 1.. = Schur complement
+  T *gL;                    // nl (undamped gradient, for LM)
+  T *dL;                    // nl solution
+  T lambda;
+  int *flag;
+  T *partial;
+};
+
+// t[j][c] = JL_rho . X_s[:, c] + JR_rho . X_{s+1}[:, c]
+template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = tid / a.R, c = tid - j * a.R;
+  if (j >= a.nlmrows) return;
+  const int rho = a.lmrow[j], s = a.lmrow_state[j];
+  const T *row = a.rowLR + (size_t)rho * 2 * a.B;
+  const T *x0 = a.x + ((size_t)s * a.R + c) * a.B;
+  T acc = T(0);
+  for (int k = 0; k < a.B; k++) acc += row[k] * x0[k];
+  if (s + 1 < a.N) {
+    const T *x1 = a.x + ((size_t)(s + 1) * a.R + c) * a.B;
+    for (int k = 0; k < a.B; k++) acc += row[a.B + k] * x1[k];
+  }
+  a.t[(size_t)j * a.R + c] = acc;
+}
+
+// S[al][c]: c = 0 -> rhs gL - B^T x0; c >= 1 -> (H_LL + lambda I - B^T Z)[al][c-1].  Fixed summation order.
+template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce(LmArgs<T> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int al = tid / a.R, c = tid - al * a.R;
+  if (al >= a.nl) return;
+  const int lm = al / a.ld, q = al - lm * a.ld;
+  const int cl = c - 1;                                   // landmark column
+  const bool same = (c >= 1) && (cl / a.ld == lm);
+  const int q2 = same ? cl - lm * a.ld : 0;
+  T acc = T(0), g = T(0);
+  for (int j = a.lmrow_ptr[lm]; j < a.lmrow_ptr[lm + 1]; j++) {
+    const int rho = a.lmrow[j];
+    const T m = a.rowM[(size_t)rho * a.ld + q];
+    if (c == 0) { g -= m * a.rowE[rho]; }
+    else if (same) acc += m * a.rowM[(size_t)rho * a.ld + q2];
+    acc -= m * a.t[(size_t)j * a.R + c];
+  }
+  for (int k = 0; k < a.npri; k++) {
+    if (a.pri_lm[k] != lm) continue;
+    const T w = T(1) / a.pri_sig[(size_t)k * a.ld + q];
+    if (c == 0) g -= w * w * (a.lmk[(size_t)lm * a.ld + q] - a.pri_meas[(size_t)k * a.ld + q]);
+    else if (cl == al) acc += w * w;
+  }
+  if (c == 0) { a.gL[al] = g; acc += g; }
+  else if (cl == al) acc += a.lambda;
+  a.S[(size_t)al * a.R + c] = acc;
+}
+
+// dense SPD solve of the (tiny) landmark system in one thread, then dL; nl <= 27
+template <typename T> __global__ void k_lm_solve(LmArgs<T> a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int n = a.nl, R = a.R;
+  T *S = a.S;
+  // in-place Cholesky on columns 1..n (upper part used), rhs in column 0
+  for (int j = 0; j < n; j++) {
+    T dd = S[(size_t)j * R + 1 + j];
+    for (int k = 0; k < j; k++) dd -= S[(size_t)k * R + 1 + j] * S[(size_t)k * R + 1 + j];
+    if (!(dd > T(0))) { *a.flag = 1; dd = T(1); }
+    dd = sqrt(dd);
+    S[(size_t)j * R + 1 + j] = dd;
+    for (int i = j + 1; i < n; i++) {
+      T sv = S[(size_t)j * R + 1 + i];
+      for (int k = 0; k < j; k++) sv -= S[(size_t)k * R + 1 + j] * S[(size_t)k * R + 1 + i];
+      S[(size_t)j * R + 1 + i] = sv / dd;
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    T sv = S[(size_t)i * R];
+    for (int k = 0; k < i; k++) sv -= S[(size_t)k * R + 1 + i] * a.dL[k];
+    a.dL[i] = sv / S[(size_t)i * R + 1 + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    T sv = a.dL[i];
+    for (int k = i + 1; k < n; k++) sv -= S[(size_t)i * R + 1 + k] * a.dL[k];
+    a.dL[i] = sv / S[(size_t)i * R + 1 + i];
+  }
+}
+
+// delta_p = x0 - Z dL  (in place in column 0 of x)
+template <typename T> __global__ void __launch_bounds__(256) k_lm_correct(LmArgs<T> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = tid / a.B, k = tid - s * a.B;
+  if (s >= a.N) return;
+  T *xs = a.x + (size_t)s * a.R * a.B;
+  T v = xs[k];
+  for (int q = 0; q < a.nl; q++) v -= xs[(size_t)(1 + q) * a.B + k] * a.dL[q];
+  xs[k] = v;
+}
+
+// landmarks += dL; out[0] = max |dL| (single block)
+template <typename T> __global__ void __launch_bounds__(64) k_lm_update(LmArgs<T> a, double *out_max) {
+  T mx = T(0);
+  for (int i = threadIdx.x; i < a.nl; i += 64) {
+    a.lmk[i] += a.dL[i];
+    mx = fmax(mx, fabs(a.dL[i]));
+  }
+  mx = wave_max(mx);
+  if (threadIdx.x == 0) *out_max = fmax(*out_max, (double)mx);
+}
+
+// error of the landmark priors (PriorFactor<Point>), single block
+template <typename T> __global__ void __launch_bounds__(128) k_lmprior_err(LmArgs<T> a) {
+  T err = T(0);
+  for (int k = threadIdx.x; k < a.npri; k += 128)
+    for (int q = 0; q < a.ld; q++) {
+      const T we = (a.lmk[(size_t)a.pri_lm[k] * a.ld + q] - a.pri_meas[(size_t)k * a.ld + q]) / a.pri_sig[(size_t)k * a.ld + q];
+      err += we * we;
+    }
+  const T tot = block_sum(T(0.5) * err);
+  if (threadIdx.x == 0) a.partial[0] = tot;
+}
+
+// ---- small utilities for Levenberg-Marquardt
+// partial[b] = sum over this block of a[i] * b[i]  (stride-aware: element i lives at a[i * sa], b[i * sb])
+template <typename T> __global__ void __launch_bounds__(256) k_dot(const T *x, const T *y, int n, T *partial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const T v = (i < n) ? x[i] * y[i] : T(0);
+  const T tot = block_sum(v);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+// gather column 0 of the N x R x B solution array into a dense N x B vector
+template <typename T> __global__ void __launch_bounds__(256) k_gather_delta(const T *x, int N, int R, int B, T *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * B) return;
+  const int s = i / B, k = i - s * B;
+  out[i] = x[(size_t)s * R * B + k];
+}
+
 // ------------------------------------------------------------------ K3: assemble normal equations
 
 template <typename T> struct AsmArgs {
@@ -236,6 +612,8 @@ template <typename T> struct AsmArgs {
   const int *rowLm;       // landmark id per row or -1
   int ld;
   T *blk;                 // N records [D | O | G]
+  T *gsave;               // N x B copy of the gradient column (for the LM model-fidelity test) or null
+  T *halo_add;            // segment sharding: [RD | Rg] the rows of state N-1 owe to the next rank's first state
 };
 
 // thread (s, c) builds row c of D_s and O_s and entry c of every rhs column of state s
@@ -243,7 +621,25 @@ template <typename T, int B>
 __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = t / B, c = t - s * B;
-  if (s >= a.N) return;
+  if (s > a.N || (s == a.N && !a.halo_add)) return;
+  if (s == a.N) {  // right blocks of the rows of state N-1 -> addend for the neighbour's first state
+    T Dh[B];
+    T gh = T(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) Dh[k] = T(0);
+    for (int rho = a.rowptr[s - 1]; rho < a.rowptr[s]; rho++) {
+      const T *row = a.rowLR + (size_t)rho * 2 * B + B;
+      const T Rc = row[c];
+#pragma unroll
+      for (int k = 0; k < B; k++) Dh[k] += Rc * row[k];
+      gh -= Rc * a.rowE[rho];
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = Dh[k];
+    a.halo_add[B * B + c] = gh;
+    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
+    return;
+  }
   const int BS = 2 * B * B + B * a.R;
   T *bp = a.blk + (size_t)s * BS;
   T D[B], O[B];
@@ -288,6 +684,7 @@ __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
 #pragma unroll
   for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
   bp[2 * B * B + c] = g;
+  if (a.gsave) a.gsave[(size_t)s * B + c] = g;
 }
 
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan
@@ -310,6 +707,7 @@ template <typename T> struct FwdArgs {
   int n, m, R;
   int no_sep;        // 1: top level, a single chunk with no separator (plain sequential elimination)
   int last_has_right;// the last chunk has a right separator outside this level (next rank)
+  const T *remote_add; // [RD | Rg] already owed to that outside separator by lower levels / the assembly, or null
   T lambda;          // LM damping added to the diagonal of D while loading (level 0 only)
   int *flag;         // set to 1 if a pivot is not positive
 };
@@ -466,12 +864,13 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
       const int tswap = dbase; dbase = obase; obase = tswap;
     } else if (right_exists && has_sep) {
       T *ua = a.up_add + (size_t)(c + 1) * AS;
+      const T *ra = (e == a.n) ? a.remote_add : nullptr;   // carry what is already owed to the outside separator
       if (isO) {
 #pragma unroll
-        for (int k = 0; k < B; k++) ua[cO * B + k] = nw[k];              // -O U  (symmetric)
+        for (int k = 0; k < B; k++) ua[cO * B + k] = nw[k] + (ra ? ra[cO * B + k] : T(0));              // -O U  (symmetric)
       } else if (isR) {
 #pragma unroll
-        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = nw[k];      // -O Y
+        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = nw[k] + (ra ? ra[B * B + cR * B + k] : T(0));      // -O Y
       } else if (isF) {
         T *uo = a.up_blk + (size_t)c * BS + B * B;
 #pragma unroll
@@ -502,14 +901,16 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
         for (int k = 0; k < B; k++) ub[B * B + lane * B + k] = right_exists ? orow[k] : T(0);
         if (right_exists) {
           T *ua = a.up_add + (size_t)(c + 1) * AS;
+          const T *ra = (e == a.n) ? a.remote_add : nullptr;
 #pragma unroll
-          for (int k = 0; k < B; k++) ua[lane * B + k] = T(0);
+          for (int k = 0; k < B; k++) ua[lane * B + k] = ra ? ra[lane * B + k] : T(0);
         }
       }
       if (isR && right_exists) {
         T *ua = a.up_add + (size_t)(c + 1) * AS;
+        const T *ra = (e == a.n) ? a.remote_add : nullptr;
 #pragma unroll
-        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = T(0);
+        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = ra ? ra[B * B + cR * B + k] : T(0);
       }
     } else if (!right_exists) {
       if (lane < B) {
@@ -577,22 +978,44 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   }
 }
 
+// ------------------------------------------------------------------ segment sharding: reduced interface system
+
+// Every rank contributes one record [D | C | G | RD | Rg] (BS + AS values): its separator block (first state) after
+// the local elimination, the coupling C to the next rank's separator and the addend it owes that separator.
+// top[r] = [D_r + RD_{r-1} | C_r | G_r + Rg_{r-1}]
+template <typename T> __global__ void __launch_bounds__(256) k_iface_build(const T *rec, int P, int B, int R, T *top) {
+  const int BS = 2 * B * B + B * R, AS = B * B + B * R, RS = BS + AS;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P * BS) return;
+  const int r = i / BS, k = i - r * BS;
+  T v = rec[(size_t)r * RS + k];
+  if (r > 0) {
+    const T *pa = rec + (size_t)(r - 1) * RS + BS;
+    if (k < B * B) v += pa[k];
+    else if (k >= 2 * B * B) v += pa[B * B + (k - 2 * B * B)];
+  }
+  if (r == P - 1 && k >= B * B && k < 2 * B * B) v = T(0);   // no coupling beyond the last rank
+  top[i] = v;
+}
+
 // ------------------------------------------------------------------ K6: retract
 
 template <typename T> struct RetractArgs {
   T *pose, *vel;
   int stride, N, R, chart;
-  const T *x;       // N x R x b, column 0 = delta
+  int first;        // first state to update (the halo state of a segment is updated by its own launch)
+  const T *x;       // N x R x b, column 0 = delta (indexed from `first`)
   T *partial;       // per-block max |delta|
 };
 
 template <typename T, int MF>
 __global__ void __launch_bounds__(128) k_retract(RetractArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = a.first + li;
   T mx = T(0);
-  if (i < a.N) {
-    const T *dl = a.x + (size_t)i * a.R * b;
+  if (li < a.N) {
+    const T *dl = a.x + (size_t)li * a.R * b;
     T dlt[b], x[pd], out[pd];
 #pragma unroll
     for (int k = 0; k < b; k++) { dlt[k] = dl[k]; mx = fmax(mx, fabs(dlt[k])); }

@@ -179,6 +179,7 @@ template <typename T> GD BL6<T> operator*(const BL6<T> &x, const BL6<T> &y) {
 template <typename T> GD V6<T> operator*(const BL6<T> &x, V6<T> u) { return {x.A * u.w, x.C * u.w + x.D * u.v}; }
 template <typename T> GD BL6<T> neg(const BL6<T> &x) { return {neg(x.A), neg(x.C), neg(x.D)}; }
 template <typename T> GD BL6<T> operator-(const BL6<T> &x, const BL6<T> &y) { return {x.A - y.A, x.C - y.C, x.D - y.D}; }
+template <typename T> GD BL6<T> operator+(const BL6<T> &x, const BL6<T> &y) { return {x.A + y.A, x.C + y.C, x.D + y.D}; }
 template <typename T> GD BL6<T> operator*(T s, const BL6<T> &x) { return {s * x.A, s * x.C, s * x.D}; }
 // entry (i, j) of the 6x6
 template <typename T> GD T bl6_at(const BL6<T> &x, int i, int j) {

@@ -97,6 +97,8 @@ void gpslam_hip_default_params(gpslam_hip_params *p);
 const char *gpslam_hip_last_error(const gpslam_hip_handle *h);
 /* the HIP stream (hipStream_t) all kernels of this handle are launched on */
 void *gpslam_hip_stream(gpslam_hip_handle *h);
+/* run on a caller-owned stream instead (e.g. the stream RCCL collectives are ordered against) */
+int gpslam_hip_set_stream(gpslam_hip_handle *h, void *hip_stream);
 
 /* ---- variables (replaces gtsam::Values::insert / at, e.g. testGaussianProcessPriorPose3.cpp:179-183) ---- */
 int gpslam_hip_set_states(gpslam_hip_handle *h, int32_t N, const double *pose, const double *vel);
