@@ -945,7 +945,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   for (size_t l = 0; l < h->lv.size(); l++) {
     Level &v = h->lv[l];
     HIPCHK(v.blk.reserve((size_t)v.n * BS * sizeof(Real)));
-    HIPCHK(v.x.reserve((size_t)v.n * b * h->R * sizeof(Real)));
+    HIPCHK(v.x.reserve((size_t)(v.n + 1) * b * h->R * sizeof(Real)));   // + 1: solution of the neighbour rank's separator
     if (l > 0) {
       HIPCHK(v.add.reserve((size_t)(v.n + 1) * AS * sizeof(Real)));
       HIPCHK(hipMemsetAsync(v.add.p, 0, (size_t)(v.n + 1) * AS * sizeof(Real), h->stream));

@@ -952,6 +952,10 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   __syncthreads();
   if (has_sep)
     for (int idx = lane; idx < R * B; idx += 64) a.x[(size_t)s * R * B + idx] = xs[idx];
+  // the right separator of the last chunk lives on the next rank: park its solution in the extra slot x[n] so
+  // that the level below finds it where it expects the solution of "separator n"
+  if (right_exists && e == a.n)
+    for (int idx = lane; idx < R * B; idx += 64) a.x[(size_t)a.n * R * B + idx] = xa[idx];
   const int j0 = has_sep ? s + 1 : s;
   int ping = 0;
   for (int j = e - 1; j >= j0; --j) {

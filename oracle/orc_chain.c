@@ -184,8 +184,12 @@ int orc_chain_add_interp_attitude(orc_chain *c, int count, const int32_t *left, 
   for (int k = 0; k < count; k++) {
     orc_factor *f = new_factor(c, F_INTERP_ATT);
     f->idx = left[k];
-    orc_copy(3, nZ + 3 * (size_t)k, f->aux);
-    orc_copy(3, bRef + 3 * (size_t)k, f->aux + 3);
+    /* gtsam::Unit3 normalises its argument on construction (GPInterpolatedAttitudeFactorRot3.h:47-48) */
+    for (int part = 0; part < 2; part++) {
+      const double *v = (part == 0 ? nZ : bRef) + 3 * (size_t)k;
+      double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      for (int q = 0; q < 3; q++) f->aux[3 * part + q] = v[q] / n;
+    }
     f->sig[0] = sigma[2 * (size_t)k]; f->sig[1] = sigma[2 * (size_t)k + 1];
     f->dt = dt[k]; f->tau = tau[k];
   }
