@@ -9,7 +9,9 @@
 One "step" = one full Gauss-Newton iteration of the hot path: linearise every factor (evaluateError + Jacobians),
 assemble the block-tridiagonal normal equations, solve, retract, re-evaluate the error -- exactly what
 matlab/PlazaPose2.m:224-226 brackets with tic/toc around optimizer.iterate().  Inputs are resident in HBM before
-the timed region.  Rank 0 prints ONE JSON line.
+the timed region.  With N > 1 the ONE chain of N x 1e5 states is cut into N contiguous segments (weak scaling) and
+every iteration performs one RCCL all-gather of the 3.6 KB interface records (gpslam_amd/sharded.py).
+Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -52,7 +54,7 @@ def main():
 
     import torch
     import gpslam_amd
-    from gpslam_amd import synthetic as S
+    from gpslam_amd import sharded, synthetic as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,27 +73,59 @@ def main():
         torch.cuda.synchronize()
 
     N = args.states
-    problem = S.pose3_chain(N, seed=rank)
-    solver = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank, rank=rank, nranks=1))
+    total_states = N * world
 
-    # convergence run (untimed by the contract clock): iterations until |delta|_inf < 1e-6
-    conv_iters, conv_delta = 0, float("inf")
+    if world == 1:
+        problem = S.pose3_chain(N)
+        solver = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank))
+
+        def reset():
+            solver.set_states(problem["pose"], problem["vel"])
+
+        def one_with_stats():
+            _rc, st = solver.iterate_gn()
+            return st.error_after, st.delta_inf_norm
+
+        def run(k):
+            solver.run_gn(k)
+    else:
+        problem = S.pose3_chain(total_states)           # ONE chain, cut into `world` contiguous segments
+        lp = sharded.local_problem(problem, rank, world)
+        solver = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank, rank=rank, nranks=world)
+        solver.set_stream(torch.cuda.current_stream().cuda_stream)   # order kernels against the RCCL collective
+        sharded.apply_local(lp, solver)
+        send, recv = sharded.device_tensors(solver)
+        sv = sharded.ShardedSolver(solver, send, recv, rank, world, dist=dist)
+
+        def reset():
+            solver.set_states(lp["pose"], lp["vel"])
+            if "halo_pose" in lp:
+                solver.set_halo_state(lp["halo_pose"], lp["halo_vel"])
+
+        def one_with_stats():
+            st = sv.iterate()
+            return st["error_after"], st["delta_inf_norm"]
+
+        def run(k):
+            for _ in range(k):
+                sv.iterate(want_stats=False)
+
+    # convergence run (outside the contract clock): iterations until |delta|_inf < 1e-6
+    conv_iters, conv_delta, final_error = 0, float("inf"), float("nan")
     for _ in range(25):
-        _rc, st = solver.iterate_gn()
+        final_error, conv_delta = one_with_stats()
         conv_iters += 1
-        conv_delta = st.delta_inf_norm
         if conv_delta < 1e-6:
             break
-    final_error = st.error_after
 
     # timed region: restart from the initial values so the steps do real Newton work
-    solver.set_states(problem["pose"], problem["vel"])
+    reset()
     if args.warmup > 0:
-        solver.run_gn(args.warmup)
-    solver.set_states(problem["pose"], problem["vel"])
+        run(args.warmup)
+    reset()
     barrier()
     t0 = time.perf_counter()
-    solver.run_gn(args.steps)
+    run(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -99,23 +133,26 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel device time (hipEvents on the handle's stream), for the roofline of the dominant kernel
-    names = ["k_gp (K1 linearise GP priors)", "k_assemble (K3)", "k_chunk_forward level 0 (K4)",
-             "k_chunk_backward level 0 (K4)", "k_retract (K6)"]
-    kms = [solver.time_kernel(w, reps=5) for w in range(5)]
-    ab = S.algorithmic_bytes_per_state(problem["kind"])
-    blocks = ab["linearize"] - (18 * 8 + 8)
-    alg = [ab["linearize"] * (N - 1),          # K1: read state + dt, write e + H1..H4 (whitened rows)
-           (blocks + blocks) * N,              # K3: read rows, write blocks
-           ab["solve"] * N,                    # K4 forward: SURVEY 8(d) single-pass solve figure, conservative
-           (blocks + 12 * 8) * N,              # back-substitution: read factors, write delta
-           ab["retract"] * N]
-    dom = int(np.argmax(kms))
-    achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
-    _st, phase = solver.run_gn(3, timed=True)
-
     if rank == 0:
-        total_states = N * world
+        # per-kernel device time (hipEvents on the handle's stream) of the per-GPU workload, for the roofline
+        if world == 1:
+            probe, pproblem = solver, problem
+        else:
+            pproblem = S.pose3_chain(N)
+            probe = S.apply(pproblem, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank))
+        names = ["k_gp (K1 linearise GP priors)", "k_assemble (K3)", "k_chunk_forward level 0 (K4)",
+                 "k_chunk_backward level 0 (K4)", "k_retract (K6)"]
+        kms = [probe.time_kernel(w, reps=5) for w in range(5)]
+        ab = S.algorithmic_bytes_per_state(S.POSE3)
+        blocks = ab["linearize"] - (18 * 8 + 8)
+        alg = [ab["linearize"] * (N - 1),          # K1: read state + dt, write e + H1..H4 (whitened rows)
+               (blocks + blocks) * N,              # K3: read rows, write blocks
+               ab["solve"] * N,                    # K4 forward: SURVEY 8(d) single-pass solve figure (conservative)
+               (blocks + 12 * 8) * N,              # back-substitution: read factors, write delta
+               ab["retract"] * N]
+        dom = int(np.argmax(kms))
+        achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
+        _st, phase = probe.run_gn(3, timed=True)
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "GN state-iterations/sec (states x Gauss-Newton iters/sec), Pose3 GP chain",
@@ -134,21 +171,22 @@ def main():
                                    "%d poses per GPU, fp64, Gauss-Newton" % N,
                        "states_per_gpu": N, "total_states": total_states,
                        "factors": "N-1 GaussianProcessPriorPose3 + N-1 BetweenFactor<Pose3> + 1 PriorFactor<Pose3>",
-                       "parallelism": "segments x%d" % world},
+                       "parallelism": "1 chain in %d contiguous segments, 1 all-gather of interface records per "
+                                      "iteration" % world if world > 1 else "single GPU"},
             "gn_iters_per_sec": args.steps / elapsed,
             "iters_to_convergence": conv_iters,
             "delta_inf_at_convergence": conv_delta,
             "final_error": final_error,
             "states_to_convergence_per_sec": total_states / (conv_iters * ms_per_step * 1e-3),
-            "phase_ms_per_iter": {k: float(v) / 3 for k, v in
-                                  zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
+            "phase_ms_per_iter_1gpu": {k: float(v) / 3 for k, v in
+                                       zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
             "kernel_ms": {n: float(v) for n, v in zip(names, kms)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom]},
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S.pose3_chain(N, seed=0))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(problem)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -224,7 +224,8 @@ UMat<Real> make_umat(const gpslam_hip_handle *h) {
   return u;
 }
 
-bool sharded(const gpslam_hip_handle *h) { return h->cfg.nranks > 1; }
+// reserved[0] = 1 forces the sharded code path on a single segment (self-test of the exchange plumbing)
+bool sharded(const gpslam_hip_handle *h) { return h->cfg.nranks > 1 || h->cfg.reserved[0] == 1; }
 bool has_right_rank(const gpslam_hip_handle *h) { return sharded(h) && h->cfg.rank < h->cfg.nranks - 1; }
 
 GpArgs<Real> gp_args(gpslam_hip_handle *h, Real *partial) {

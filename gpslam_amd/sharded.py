@@ -100,7 +100,7 @@ class ShardedSolver:
         self.rank, self.nranks, self.dist, self.group = rank, nranks, dist, group
 
     def exchange(self):
-        if self.nranks == 1:
+        if self.dist is None:
             self.recv.copy_(self.send)
             return
         chunks = list(self.recv.view(self.nranks, -1).unbind(0))
@@ -113,7 +113,7 @@ class ShardedSolver:
         if not want_stats:
             return None
         vals = np.array([st.error_before, st.error_after, st.delta_inf_norm], dtype=np.float64)
-        if self.nranks > 1:
+        if self.dist is not None:
             import torch
             t = torch.from_numpy(vals.copy())
             if self.send.is_cuda:

@@ -45,6 +45,18 @@ def se3_exp(xi):
     return R, t
 
 
+def se3_prefix(R, t):
+    """Inclusive prefix products T_0, T_0 T_1, ... of a batch of SE(3) elements (N x 3 x 3, N x 3)."""
+    R, t = R.copy(), t.copy()
+    n, shift = len(R), 1
+    while shift < n:
+        Ra, ta = R[:-shift], t[:-shift]
+        t[shift:] = ta + np.einsum("nij,nj->ni", Ra, t[shift:])
+        R[shift:] = Ra @ R[shift:]
+        shift *= 2
+    return R, t
+
+
 def flat_pose3(R, t):
     return np.concatenate([R.reshape(R.shape[:-2] + (9,)), t], -1)
 
@@ -61,16 +73,13 @@ def pose3_chain(N, seed=0, dt=0.1, qc=0.01, sigma_odo=1e-3, sigma_prior=1e-3):
     nR, nt = se3_exp(sigma_odo * rng.standard_normal((N - 1, 6)))
     mR = Rs @ nR                                           # measured odometry = true * Exp(noise)
     mt = ts + np.einsum("nij,nj->ni", Rs, nt)
-    # dead reckoning from the measured odometry (initial values), starting at the prior pose
+    # dead reckoning from the measured odometry (initial values), starting at the prior pose:
+    # inclusive prefix product of the measured relative motions (Hillis-Steele doubling, vectorised)
     R0, t0 = np.eye(3), np.zeros(3)
+    PR, Pt = se3_prefix(mR, mt)
     pose = np.zeros((N, 12))
     pose[0] = flat_pose3(R0, t0)
-    R, t = R0, t0
-    for k in range(N - 1):
-        t = t + R @ mt[k]
-        R = R @ mR[k]
-        pose[k + 1, :9] = R.reshape(9)
-        pose[k + 1, 9:] = t
+    pose[1:] = flat_pose3(PR, Pt)
     return dict(kind=POSE3, name="C3 pose3 GP prior + synthetic odometry", N=N, qc=qc * np.eye(6),
                 pose=pose, vel=np.zeros((N, 6)),
                 gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),

@@ -91,3 +91,35 @@ def test_sharded_linear_chain_and_interface_records_match_numpy_model():
     pose = np.vstack([r[0].get_states()[0] for r in ranks])
     p0, _ = orc.get_states()
     assert np.abs(pose - p0).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+
+
+def test_rccl_exchange_plumbing_world_size_one():
+    """The real torch.distributed (RCCL) all-gather on the library's device buffers, world_size 1 on one GPU:
+    a forced-sharded single segment must reproduce the unsharded solver."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        problem = S.pose3_chain(3000)
+        s = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=0, rank=0, nranks=1, force_sharded=True)
+        s.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharded.apply_local(sharded.local_problem(problem, 0, 1), s)
+        send, recv = sharded.device_tensors(s)
+        sv = sharded.ShardedSolver(s, send, recv, 0, 1, dist=dist)
+        single = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE3))
+        for _ in range(4):
+            st = sv.iterate()
+            rc, s1 = single.iterate_gn()
+            assert abs(st["error_after"] - s1.error_after) <= 1e-6 * max(1.0, s1.error_after)
+        sv.run(3)
+        single.run_gn(3)
+        p0, v0 = single.get_states()
+        p1, v1 = s.get_states()
+        assert np.abs(p0 - p1).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+    finally:
+        dist.destroy_process_group()
