@@ -24,7 +24,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_add_interp_range", "gpslam_hip_add_range", "gpslam_hip_add_interp_attitude",
     "gpslam_hip_add_interp_gps", "gpslam_hip_add_odometry2d", "gpslam_hip_add_bearing_range", "gpslam_hip_compile",
     "gpslam_hip_linearize_gp", "gpslam_hip_error", "gpslam_hip_iterate_gn", "gpslam_hip_iterate_lm",
-    "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_block_tridiag_solve",
+    "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_get_rows", "gpslam_hip_block_tridiag_solve",
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
 ]
@@ -260,6 +260,17 @@ class ChainSolver:
         B = np.zeros((N, b, nl)) if nl else None
         self._chk(self.lib.gpslam_hip_normal_equations(self._h, _p(D), _p(O), _p(g), _p(B)), "normal_equations")
         return D, O, g, B
+
+    def get_rows(self):
+        """(rowLR, rowE, rowM, rowLm) of the current linearisation (whitened)."""
+        n = C.c_int32(0)
+        self._chk(self.lib.gpslam_hip_get_rows(self._h, C.byref(n), None, None, None, None), "get_rows")
+        M = n.value
+        LR, E = np.zeros((M, 2 * self.b)), np.zeros(M)
+        Mm = np.zeros((M, self.ld)) if self.ld else None
+        Lm = np.full(M, -1, dtype=np.int32) if self.ld else None
+        self._chk(self.lib.gpslam_hip_get_rows(self._h, C.byref(n), _p(LR), _p(E), _p(Mm), _p(Lm)), "get_rows")
+        return LR, E, Mm, Lm
 
     def block_tridiag_solve(self, D, O, g):
         D, O, g = _f64(D), _f64(O), _f64(g)

@@ -1192,6 +1192,27 @@ int gpslam_hip_normal_equations(gpslam_hip_handle *h, double *D, double *O, doub
   return 0;
 }
 
+// whitened Jacobian rows of the current linearisation, in row-table order (rows grouped by left state; inside a
+// state: GP priors, pose priors, velocity priors, between, then the measurement kinds in FKind order)
+int gpslam_hip_get_rows(gpslam_hip_handle *h, int32_t *n_rows, double *rowLR, double *rowE, double *rowM, int32_t *rowLm) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  (void)hipSetDevice(h->cfg.device);
+  if (n_rows) *n_rows = h->M;
+  if (!rowLR && !rowE && !rowM && !rowLm) return 0;
+  if ((rc = launch_factors(h, 0, 0))) return rc;
+  const size_t M = (size_t)h->M;
+  if (M == 0) return 0;
+  if (rowLR) HIPCHK(hipMemcpyAsync(rowLR, h->rowLR.p, M * 2 * h->b * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+  if (rowE) HIPCHK(hipMemcpyAsync(rowE, h->rowE.p, M * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+  if (h->nl > 0) {
+    if (rowM) HIPCHK(hipMemcpyAsync(rowM, h->rowM.p, M * h->ld * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    if (rowLm) HIPCHK(hipMemcpyAsync(rowLm, h->rowLm.p, M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
 int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double *D, const double *O,
                                    const double *g, double *x) {
   int rc = need_compiled(h);

@@ -1,0 +1,631 @@
+// gpslam_host.hpp -- C++ host classes with the gpslam / GTSAM names, constructor signatures and call pattern,
+// implemented on top of the C ABI (include/gpslam_hip.h).  Header-only, C++17, no Eigen/Boost/GTSAM needed.
+//
+// What a user of gtrll/gpslam writes (gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:162-194):
+//     NonlinearFactorGraph graph;
+//     graph.add(PriorFactor<Pose3>(Symbol('x', 1), pose1, model_prior));
+//     graph.add(GaussianProcessPriorPose3(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), delta_t, Qc_model));
+//     Values init_values;  init_values.insert(Symbol('x', 1), pose1); ...
+//     GaussNewtonOptimizer optimizer(graph, init_values, parameters);  optimizer.optimize();
+//     Values values = optimizer.values();
+// compiles against this header unchanged; the optimizer's constructor is the "graph compile" pass (classify the
+// factors, map keys to chain positions, pack SoA arrays, upload) and every iterate() is HIP kernels.
+//
+// Key convention (the one every gpslam test and script uses): pose i = Symbol('x', i), velocity i = Symbol('v', i),
+// landmark j = Symbol('l', j).  States are ordered by index; factors may couple a state only with its successor
+// (the GP Markov structure, GaussianProcessPriorPose3.h:43-47).  Anything else throws std::invalid_argument,
+// the analogue of GTSAM's exceptions; HIP failures throw std::runtime_error.
+#pragma once
+
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/gpslam_hip.h"
+
+namespace gtsam {
+
+typedef uint64_t Key;
+/// gtsam::Symbol(c, j) -> Key = (c << 56) | j
+inline Key Symbol(unsigned char c, uint64_t j) { return (Key(c) << 56) | j; }
+inline unsigned char symbolChr(Key k) { return (unsigned char)(k >> 56); }
+inline uint64_t symbolIndex(Key k) { return k & ((Key(1) << 56) - 1); }
+
+template <int N> struct VectorN : std::array<double, N> {
+  VectorN() { this->fill(0.0); }
+  VectorN(std::initializer_list<double> l) { this->fill(0.0); int i = 0; for (double v : l) if (i < N) (*this)[i++] = v; }
+};
+typedef VectorN<2> Vector2;
+typedef VectorN<3> Vector3;
+typedef VectorN<6> Vector6;
+typedef std::vector<double> Vector;
+
+struct Matrix {  // dynamic, row-major
+  int rows = 0, cols = 0;
+  std::vector<double> a;
+  Matrix() {}
+  Matrix(int r, int c) : rows(r), cols(c), a((size_t)r * c, 0.0) {}
+  double &operator()(int i, int j) { return a[(size_t)i * cols + j]; }
+  double operator()(int i, int j) const { return a[(size_t)i * cols + j]; }
+  static Matrix Identity(int n) { Matrix m(n, n); for (int i = 0; i < n; i++) m(i, i) = 1.0; return m; }
+  Matrix operator*(double s) const { Matrix m = *this; for (double &v : m.a) v *= s; return m; }
+};
+inline Matrix operator*(double s, const Matrix &m) { return m * s; }
+
+struct Point2 { double x = 0, y = 0; Point2() {} Point2(double x_, double y_) : x(x_), y(y_) {} };
+struct Point3 { double x = 0, y = 0, z = 0; Point3() {} Point3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {} };
+
+struct Rot3 {
+  double R[9];
+  Rot3() { std::memset(R, 0, sizeof(R)); R[0] = R[4] = R[8] = 1.0; }
+  /// Rot3::Ypr(y, p, r) = Rz(y) Ry(p) Rx(r)
+  static Rot3 Ypr(double y, double p, double r) {
+    const double cy = std::cos(y), sy = std::sin(y), cp = std::cos(p), sp = std::sin(p), cr = std::cos(r), sr = std::sin(r);
+    Rot3 o;
+    o.R[0] = cy * cp; o.R[1] = cy * sp * sr - sy * cr; o.R[2] = cy * sp * cr + sy * sr;
+    o.R[3] = sy * cp; o.R[4] = sy * sp * sr + cy * cr; o.R[5] = sy * sp * cr - cy * sr;
+    o.R[6] = -sp;     o.R[7] = cp * sr;                o.R[8] = cp * cr;
+    return o;
+  }
+};
+struct Pose2 {
+  double x = 0, y = 0, theta = 0;
+  Pose2() {}
+  Pose2(double x_, double y_, double th) : x(x_), y(y_), theta(th) {}
+  double range(const Point2 &p) const { return std::hypot(p.x - x, p.y - y); }
+};
+struct Pose3 {
+  Rot3 R;
+  Point3 t;
+  Pose3() {}
+  Pose3(const Rot3 &r, const Point3 &p) : R(r), t(p) {}
+  const Rot3 &rotation() const { return R; }
+  const Point3 &translation() const { return t; }
+  Pose3 compose(const Pose3 &o) const {
+    Pose3 c;
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) c.R.R[3 * i + j] = R.R[3 * i] * o.R.R[j] + R.R[3 * i + 1] * o.R.R[3 + j] + R.R[3 * i + 2] * o.R.R[6 + j];
+    c.t.x = t.x + R.R[0] * o.t.x + R.R[1] * o.t.y + R.R[2] * o.t.z;
+    c.t.y = t.y + R.R[3] * o.t.x + R.R[4] * o.t.y + R.R[5] * o.t.z;
+    c.t.z = t.z + R.R[6] * o.t.x + R.R[7] * o.t.y + R.R[8] * o.t.z;
+    return c;
+  }
+  double range(const Point3 &p) const {
+    const double dx = p.x - t.x, dy = p.y - t.y, dz = p.z - t.z;
+    return std::sqrt(dx * dx + dy * dy + dz * dz);
+  }
+};
+struct Unit3 {
+  double p[3];
+  Unit3(double x = 0, double y = 0, double z = 1) { const double n = std::sqrt(x * x + y * y + z * z); p[0] = x / n; p[1] = y / n; p[2] = z / n; }
+};
+
+// ---------------------------------------------------------------- noise models
+namespace noiseModel {
+struct Base {
+  int dim_ = 0;
+  std::vector<double> sigmas_;   // diagonal models
+  Matrix cov_;                   // full Gaussian (used for Qc)
+  bool diagonal_ = true;
+  int dim() const { return dim_; }
+  Matrix covariance() const {
+    if (!diagonal_) return cov_;
+    Matrix m(dim_, dim_);
+    for (int i = 0; i < dim_; i++) m(i, i) = sigmas_[i] * sigmas_[i];
+    return m;
+  }
+};
+typedef std::shared_ptr<Base> shared_ptr_base;
+struct Isotropic { typedef std::shared_ptr<Base> shared_ptr;
+  static shared_ptr Sigma(int dim, double sigma) { auto b = std::make_shared<Base>(); b->dim_ = dim; b->sigmas_.assign(dim, sigma); return b; } };
+struct Diagonal { typedef std::shared_ptr<Base> shared_ptr;
+  static shared_ptr Sigmas(const Vector &s) { auto b = std::make_shared<Base>(); b->dim_ = (int)s.size(); b->sigmas_ = s; return b; } };
+struct Gaussian { typedef std::shared_ptr<Base> shared_ptr;
+  static shared_ptr Covariance(const Matrix &c) {
+    auto b = std::make_shared<Base>(); b->dim_ = c.rows; b->cov_ = c; b->diagonal_ = true;
+    for (int i = 0; i < c.rows; i++) for (int j = 0; j < c.cols; j++) if (i != j && c(i, j) != 0.0) b->diagonal_ = false;
+    if (b->diagonal_) { b->sigmas_.resize(c.rows); for (int i = 0; i < c.rows; i++) b->sigmas_[i] = std::sqrt(c(i, i)); }
+    return b;
+  } };
+}  // namespace noiseModel
+typedef std::shared_ptr<noiseModel::Base> SharedNoiseModel;
+
+// ---------------------------------------------------------------- Values
+namespace detail {
+enum VType { T_NONE, T_VEC2, T_VEC3, T_VEC6, T_POSE2, T_POSE3, T_ROT3, T_POINT2, T_POINT3 };
+template <typename T> struct VT;
+template <> struct VT<Vector2> { static constexpr VType t = T_VEC2; static std::vector<double> pack(const Vector2 &v) { return {v[0], v[1]}; } static Vector2 un(const std::vector<double> &d) { return {d[0], d[1]}; } };
+template <> struct VT<Vector3> { static constexpr VType t = T_VEC3; static std::vector<double> pack(const Vector3 &v) { return {v[0], v[1], v[2]}; } static Vector3 un(const std::vector<double> &d) { return {d[0], d[1], d[2]}; } };
+template <> struct VT<Vector6> { static constexpr VType t = T_VEC6; static std::vector<double> pack(const Vector6 &v) { return std::vector<double>(v.begin(), v.end()); } static Vector6 un(const std::vector<double> &d) { return {d[0], d[1], d[2], d[3], d[4], d[5]}; } };
+template <> struct VT<Pose2> { static constexpr VType t = T_POSE2; static std::vector<double> pack(const Pose2 &p) { return {p.x, p.y, p.theta}; } static Pose2 un(const std::vector<double> &d) { return Pose2(d[0], d[1], d[2]); } };
+template <> struct VT<Rot3> { static constexpr VType t = T_ROT3; static std::vector<double> pack(const Rot3 &r) { return std::vector<double>(r.R, r.R + 9); } static Rot3 un(const std::vector<double> &d) { Rot3 r; for (int i = 0; i < 9; i++) r.R[i] = d[i]; return r; } };
+template <> struct VT<Pose3> { static constexpr VType t = T_POSE3;
+  static std::vector<double> pack(const Pose3 &p) { std::vector<double> d(p.R.R, p.R.R + 9); d.push_back(p.t.x); d.push_back(p.t.y); d.push_back(p.t.z); return d; }
+  static Pose3 un(const std::vector<double> &d) { Pose3 p; for (int i = 0; i < 9; i++) p.R.R[i] = d[i]; p.t = Point3(d[9], d[10], d[11]); return p; } };
+template <> struct VT<Point2> { static constexpr VType t = T_POINT2; static std::vector<double> pack(const Point2 &p) { return {p.x, p.y}; } static Point2 un(const std::vector<double> &d) { return Point2(d[0], d[1]); } };
+template <> struct VT<Point3> { static constexpr VType t = T_POINT3; static std::vector<double> pack(const Point3 &p) { return {p.x, p.y, p.z}; } static Point3 un(const std::vector<double> &d) { return Point3(d[0], d[1], d[2]); } };
+struct Value { VType type = T_NONE; std::vector<double> d; };
+}  // namespace detail
+
+class Values {
+ public:
+  template <typename T> void insert(Key k, const T &v) {
+    if (m_.count(k)) throw std::invalid_argument("Values::insert: key already exists");
+    detail::Value val; val.type = detail::VT<T>::t; val.d = detail::VT<T>::pack(v); m_[k] = val;
+  }
+  template <typename T> T at(Key k) const {
+    auto it = m_.find(k);
+    if (it == m_.end()) throw std::out_of_range("Values::at: key does not exist");   // ValuesKeyDoesNotExist
+    if (it->second.type != detail::VT<T>::t) throw std::invalid_argument("Values::at: wrong type");
+    return detail::VT<T>::un(it->second.d);
+  }
+  bool exists(Key k) const { return m_.count(k) != 0; }
+  size_t size() const { return m_.size(); }
+  const std::map<Key, detail::Value> &raw() const { return m_; }
+  std::map<Key, detail::Value> &raw() { return m_; }
+ private:
+  std::map<Key, detail::Value> m_;
+};
+
+// ---------------------------------------------------------------- factors
+namespace detail {
+enum FType { F_GP, F_POSE_PRIOR, F_VEL_PRIOR, F_LM_PRIOR, F_BETWEEN, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT, F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE };
+struct Desc {   // what a factor hands to the graph compiler
+  FType type;
+  int manifold = -1;                 // GPSLAM_* the factor requires, -1 = any
+  Key k[5] = {0, 0, 0, 0, 0};        // pose1, vel1, pose2, vel2, landmark (as applicable)
+  std::vector<double> meas, sig, sensor, aux;
+  double dt = 0, tau = 0;
+  Matrix Qc;
+};
+}  // namespace detail
+
+class NonlinearFactor {
+ public:
+  typedef std::shared_ptr<NonlinearFactor> shared_ptr;
+  virtual ~NonlinearFactor() {}
+  virtual detail::Desc describe() const = 0;
+  virtual size_t size() const = 0;
+  virtual shared_ptr clone() const = 0;
+};
+
+inline std::vector<double> sigmas_of(const SharedNoiseModel &m) {
+  if (!m || !m->diagonal_) throw std::invalid_argument("measurement noise models must be diagonal (Isotropic / Diagonal)");
+  return m->sigmas_;
+}
+
+#define GPSLAM_FACTOR_BOILERPLATE(CLS, NKEYS)                                                           \
+  size_t size() const override { return NKEYS; }                                                        \
+  gtsam::NonlinearFactor::shared_ptr clone() const override { return std::make_shared<CLS>(*this); }    \
+  gtsam::detail::Desc describe() const override { return d_; }                                          \
+ protected:                                                                                             \
+  gtsam::detail::Desc d_;                                                                               \
+ public:
+
+template <typename T> class PriorFactor : public NonlinearFactor {
+ public:
+  PriorFactor(Key key, const T &prior, const SharedNoiseModel &model) {
+    constexpr detail::VType vt = detail::VT<T>::t;
+    const unsigned char c = symbolChr(key);
+    if (vt == detail::T_POINT2 || vt == detail::T_POINT3) d_.type = detail::F_LM_PRIOR;
+    else if (c == 'v') d_.type = detail::F_VEL_PRIOR;
+    else d_.type = detail::F_POSE_PRIOR;
+    d_.k[0] = key; d_.meas = detail::VT<T>::pack(prior); d_.sig = sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(PriorFactor<T>, 1)
+};
+
+template <typename T> class BetweenFactor : public NonlinearFactor {
+ public:
+  BetweenFactor(Key key1, Key key2, const T &measured, const SharedNoiseModel &model) {
+    d_.type = detail::F_BETWEEN; d_.k[0] = key1; d_.k[2] = key2; d_.meas = detail::VT<T>::pack(measured); d_.sig = sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(BetweenFactor<T>, 2)
+};
+
+// ---------------------------------------------------------------- optimizer parameters (GTSAM names and defaults)
+struct NonlinearOptimizerParams {
+  int maxIterations = 100;
+  double relativeErrorTol = 1e-5, absoluteErrorTol = 1e-5, errorTol = 0.0;
+  std::string verbosity = "SILENT";
+  void setVerbosity(const std::string &v) { verbosity = v; }
+  void setMaxIterations(int v) { maxIterations = v; }
+  void setRelativeErrorTol(double v) { relativeErrorTol = v; }
+  void setAbsoluteErrorTol(double v) { absoluteErrorTol = v; }
+};
+struct GaussNewtonParams : NonlinearOptimizerParams {};
+struct LevenbergMarquardtParams : NonlinearOptimizerParams {
+  double lambdaInitial = 1e-5, lambdaFactor = 10.0, lambdaUpperBound = 1e5, lambdaLowerBound = 0.0, minModelFidelity = 1e-3;
+  void setlambdaInitial(double v) { lambdaInitial = v; }
+  void setlambdaFactor(double v) { lambdaFactor = v; }
+  void setlambdaUpperBound(double v) { lambdaUpperBound = v; }
+};
+
+class NonlinearFactorGraph {
+ public:
+  template <typename F> void add(const F &f) { f_.push_back(std::make_shared<F>(f)); }
+  void push_back(const NonlinearFactor::shared_ptr &f) { f_.push_back(f); }
+  size_t size() const { return f_.size(); }
+  const std::vector<NonlinearFactor::shared_ptr> &factors() const { return f_; }
+  inline double error(const Values &values) const;   // 0.5 * sum |R e|^2, evaluated on the GPU
+ private:
+  std::vector<NonlinearFactor::shared_ptr> f_;
+};
+
+// ---------------------------------------------------------------- graph compile + device session
+namespace detail {
+
+inline void check(int rc, gpslam_hip_handle *h, const char *what) {
+  if (rc < 0) {
+    std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + (h ? gpslam_hip_last_error(h) : "");
+    if (rc == GPSLAM_E_INVALID || rc == GPSLAM_E_UNSUPPORTED) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);   // GPSLAM_E_NOT_SPD ~ IndeterminantLinearSystemException, GPSLAM_E_HIP
+  }
+}
+
+struct Session {
+  gpslam_hip_handle *h = nullptr;
+  int manifold = -1, d = 0, pd = 0, ld = 0, N = 0, L = 0;
+  std::vector<uint64_t> state_index;        // sorted symbol indices of the states
+  std::vector<uint64_t> lm_index;
+  std::vector<bool> has_vel;                // velocity key present in the user's Values
+  Values values;
+  ~Session() { if (h) gpslam_hip_destroy(h); }
+
+  static int manifold_of(VType t) {
+    switch (t) { case T_VEC2: return GPSLAM_LINEAR2; case T_VEC3: return GPSLAM_LINEAR3; case T_POSE2: return GPSLAM_POSE2;
+      case T_POSE3: return GPSLAM_POSE3; case T_ROT3: return GPSLAM_ROT3; default: return -1; }
+  }
+  int state_of(Key k) const {
+    const uint64_t idx = symbolIndex(k);
+    for (size_t i = 0; i < state_index.size(); i++) if (state_index[i] == idx) return (int)i;
+    throw std::invalid_argument("factor refers to a state that is not in the Values");
+  }
+  int lm_of(Key k) const {
+    const uint64_t idx = symbolIndex(k);
+    for (size_t i = 0; i < lm_index.size(); i++) if (lm_index[i] == idx) return (int)i;
+    throw std::invalid_argument("factor refers to a landmark that is not in the Values");
+  }
+
+  // classify the variables, map keys to chain positions, create the handle, upload states
+  void build(const NonlinearFactorGraph &graph, const Values &init, int device = 0) {
+    values = init;
+    std::map<uint64_t, const Value *> poses, vels, lms;
+    for (auto &kv : init.raw()) {
+      const unsigned char c = symbolChr(kv.first);
+      if (kv.second.type == T_POINT2 || kv.second.type == T_POINT3) lms[symbolIndex(kv.first)] = &kv.second;
+      else if (c == 'v') vels[symbolIndex(kv.first)] = &kv.second;
+      else poses[symbolIndex(kv.first)] = &kv.second;
+    }
+    if (poses.empty()) throw std::invalid_argument("no pose variables (keys other than 'v' / landmarks) in the Values");
+    manifold = manifold_of(poses.begin()->second->type);
+    if (manifold < 0) throw std::invalid_argument("unsupported pose type");
+    static const int dd[5] = {2, 3, 3, 6, 3}, pdd[5] = {2, 3, 3, 12, 9};
+    d = dd[manifold]; pd = pdd[manifold];
+    ld = lms.empty() ? 0 : (lms.begin()->second->type == T_POINT2 ? 2 : 3);
+    N = (int)poses.size(); L = (int)lms.size();
+    std::vector<double> P((size_t)N * pd), V((size_t)N * d, 0.0), LM((size_t)L * (ld ? ld : 1));
+    int i = 0;
+    for (auto &kv : poses) {
+      if (manifold_of(kv.second->type) != manifold) throw std::invalid_argument("mixed pose types");
+      state_index.push_back(kv.first);
+      std::memcpy(&P[(size_t)i * pd], kv.second->d.data(), sizeof(double) * pd);
+      auto vi = vels.find(kv.first);
+      has_vel.push_back(vi != vels.end());
+      if (vi != vels.end()) {
+        if ((int)vi->second->d.size() != d) throw std::invalid_argument("velocity dimension does not match the pose manifold");
+        std::memcpy(&V[(size_t)i * d], vi->second->d.data(), sizeof(double) * d);
+      }
+      i++;
+    }
+    i = 0;
+    for (auto &kv : lms) { lm_index.push_back(kv.first); std::memcpy(&LM[(size_t)i * ld], kv.second->d.data(), sizeof(double) * ld); i++; }
+    gpslam_hip_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.manifold = manifold; cfg.precision = GPSLAM_FP64; cfg.device = device;
+    cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;   // GTSAM's default charts
+    cfg.landmark_dim = ld; cfg.nranks = 1;
+    int rc = gpslam_hip_create(&cfg, &h);
+    if (rc < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+    check(gpslam_hip_set_states(h, N, P.data(), V.data()), h, "set_states");
+    if (L > 0) check(gpslam_hip_set_landmarks(h, L, LM.data()), h, "set_landmarks");
+    // ---- factors
+    bool qc_set = false;
+    for (auto &fp : graph.factors()) {
+      const Desc f = fp->describe();
+      if (f.manifold >= 0 && f.manifold != manifold) throw std::invalid_argument("factor type does not match the pose type in the Values");
+      auto set_qc = [&](const Matrix &Qc) {
+        if (Qc.rows != d) throw std::invalid_argument("Qc_model dimension does not match the manifold");
+        if (!qc_set) { check(gpslam_hip_set_qc(h, Qc.a.data()), h, "set_qc"); qc_set = true; }
+      };
+      auto adjacent = [&](Key k1, Key k2) {
+        const int s1 = state_of(k1), s2 = state_of(k2);
+        if (s2 != s1 + 1) throw std::invalid_argument("factors may couple a state only with its successor (chain structure)");
+        return s1;
+      };
+      const double *sens = f.sensor.empty() ? nullptr : f.sensor.data();
+      switch (f.type) {
+        case F_GP: {
+          set_qc(f.Qc);
+          if (symbolIndex(f.k[0]) != symbolIndex(f.k[1]) || symbolIndex(f.k[2]) != symbolIndex(f.k[3]))
+            throw std::invalid_argument("GP prior: pose and velocity keys of a state must share their index");
+          int32_t l = adjacent(f.k[0], f.k[2]);
+          check(gpslam_hip_add_gp_priors(h, 1, &l, &f.dt), h, "add_gp_priors");
+        } break;
+        case F_POSE_PRIOR: { int32_t s = state_of(f.k[0]); check(gpslam_hip_add_pose_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_pose_priors"); } break;
+        case F_VEL_PRIOR: { int32_t s = state_of(f.k[0]); check(gpslam_hip_add_vel_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_vel_priors"); } break;
+        case F_LM_PRIOR: { int32_t s = lm_of(f.k[0]); check(gpslam_hip_add_landmark_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_landmark_priors"); } break;
+        case F_BETWEEN: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_between(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_between"); } break;
+        case F_INTERP_RANGE: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
+          check(gpslam_hip_add_interp_range(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_range"); } break;
+        case F_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]); check(gpslam_hip_add_range(h, 1, &s, &m, f.meas.data(), f.sig.data()), h, "add_range"); } break;
+        case F_INTERP_ATT: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]);
+          check(gpslam_hip_add_interp_attitude(h, 1, &l, f.aux.data(), f.aux.data() + 3, f.sig.data(), &f.dt, &f.tau), h, "add_interp_attitude"); } break;
+        case F_INTERP_GPS: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]);
+          check(gpslam_hip_add_interp_gps(h, 1, &l, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_gps"); } break;
+        case F_ODOM2D: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_odometry2d(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_odometry2d"); } break;
+        case F_BEARING_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]);
+          check(gpslam_hip_add_bearing_range(h, 1, &s, &m, &f.meas[0], &f.meas[1], f.sig.data()), h, "add_bearing_range"); } break;
+      }
+    }
+    // states whose velocity is not a variable of the user's graph: pin a zero velocity (decoupled, zero error)
+    for (int s = 0; s < N; s++) {
+      if (has_vel[s]) continue;
+      std::vector<double> z(d, 0.0), one(d, 1.0);
+      int32_t idx = s;
+      check(gpslam_hip_add_vel_priors(h, 1, &idx, z.data(), one.data()), h, "add_vel_priors");
+    }
+    check(gpslam_hip_compile(h), h, "compile");
+  }
+
+  // copy the device state back into `values`
+  void pull() {
+    std::vector<double> P((size_t)N * pd), V((size_t)N * d), LM((size_t)L * (ld ? ld : 1));
+    check(gpslam_hip_get_states(h, P.data(), V.data()), h, "get_states");
+    if (L > 0) check(gpslam_hip_get_landmarks(h, LM.data()), h, "get_landmarks");
+    for (auto &kv : values.raw()) {
+      const unsigned char c = symbolChr(kv.first);
+      if (kv.second.type == T_POINT2 || kv.second.type == T_POINT3) {
+        const int j = lm_of(kv.first);
+        kv.second.d.assign(LM.begin() + (size_t)j * ld, LM.begin() + (size_t)(j + 1) * ld);
+      } else if (c == 'v') {
+        const int s = state_of(kv.first);
+        kv.second.d.assign(V.begin() + (size_t)s * d, V.begin() + (size_t)(s + 1) * d);
+      } else {
+        const int s = state_of(kv.first);
+        kv.second.d.assign(P.begin() + (size_t)s * pd, P.begin() + (size_t)(s + 1) * pd);
+      }
+    }
+  }
+};
+}  // namespace detail
+
+inline double NonlinearFactorGraph::error(const Values &values) const {
+  detail::Session s;
+  s.build(*this, values);
+  double e = 0.0;
+  detail::check(gpslam_hip_error(s.h, &e), s.h, "error");
+  return e;
+}
+
+class NonlinearOptimizer {
+ public:
+  const Values &values() { if (dirty_) { s_.pull(); dirty_ = false; } return s_.values; }
+  double error() const { return error_; }
+  int iterations() const { return iterations_; }
+  const Values &optimize() {
+    // NonlinearOptimizer::defaultOptimize: do { cur = error(); iterate(); } while (iters < max && !converged)
+    if (error_ <= params_.errorTol) return values();
+    for (;;) {
+      const double cur = error_;
+      iterate();
+      if (iterations_ >= params_.maxIterations) break;
+      if (error_ <= params_.errorTol) break;
+      const double abs_dec = cur - error_, rel_dec = abs_dec / cur;
+      if (rel_dec <= params_.relativeErrorTol || abs_dec <= params_.absoluteErrorTol) break;
+      if (stop_) break;
+    }
+    return values();
+  }
+  virtual void iterate() = 0;
+  virtual ~NonlinearOptimizer() {}
+ protected:
+  NonlinearOptimizer(const NonlinearFactorGraph &g, const Values &v, const NonlinearOptimizerParams &p) : params_(p) {
+    s_.build(g, v);
+    detail::check(gpslam_hip_error(s_.h, &error_), s_.h, "error");
+  }
+  detail::Session s_;
+  NonlinearOptimizerParams params_;
+  double error_ = 0.0;
+  int iterations_ = 0;
+  bool dirty_ = false, stop_ = false;
+};
+
+class GaussNewtonOptimizer : public NonlinearOptimizer {
+ public:
+  GaussNewtonOptimizer(const NonlinearFactorGraph &graph, const Values &initial, const GaussNewtonParams &params = GaussNewtonParams())
+      : NonlinearOptimizer(graph, initial, params) {}
+  void iterate() override {
+    gpslam_hip_stats st;
+    detail::check(gpslam_hip_iterate_gn(s_.h, &st), s_.h, "iterate_gn");
+    error_ = st.error_after; iterations_++; dirty_ = true;
+  }
+};
+
+class LevenbergMarquardtOptimizer : public NonlinearOptimizer {
+ public:
+  LevenbergMarquardtOptimizer(const NonlinearFactorGraph &graph, const Values &initial,
+                              const LevenbergMarquardtParams &params = LevenbergMarquardtParams())
+      : NonlinearOptimizer(graph, initial, params), lm_(params), lambda_(params.lambdaInitial) {}
+  double lambda() const { return lambda_; }
+  void iterate() override {
+    gpslam_hip_params p;
+    gpslam_hip_default_params(&p);
+    p.use_lm = 1; p.lambda_factor = lm_.lambdaFactor; p.lambda_upper_bound = lm_.lambdaUpperBound;
+    p.lambda_lower_bound = lm_.lambdaLowerBound; p.min_model_fidelity = lm_.minModelFidelity;
+    gpslam_hip_stats st;
+    detail::check(gpslam_hip_iterate_lm(s_.h, &lambda_, &p, &st), s_.h, "iterate_lm");
+    error_ = st.error_after; iterations_++; dirty_ = true; stop_ = !st.accepted;
+  }
+ private:
+  LevenbergMarquardtParams lm_;
+  double lambda_;
+};
+
+}  // namespace gtsam
+
+// =====================================================================================================
+// gpslam factor classes: same names and constructor argument order as the reference headers / gpslam.h
+// =====================================================================================================
+namespace gpslam {
+
+namespace detail_g {
+inline gtsam::detail::Desc gp(int manifold, gtsam::Key p1, gtsam::Key v1, gtsam::Key p2, gtsam::Key v2, double dt,
+                              const gtsam::SharedNoiseModel &Qc) {
+  gtsam::detail::Desc d;
+  d.type = gtsam::detail::F_GP; d.manifold = manifold; d.k[0] = p1; d.k[1] = v1; d.k[2] = p2; d.k[3] = v2; d.dt = dt;
+  d.Qc = Qc->covariance();      // getQc(Qc_model), gpslam/gp/GPutils.cpp:16-20
+  return d;
+}
+}  // namespace detail_g
+
+#define GPSLAM_GP_PRIOR(CLS, MANIFOLD)                                                                          \
+  class CLS : public gtsam::NonlinearFactor {                                                                   \
+   public:                                                                                                      \
+    CLS(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,      \
+        const gtsam::SharedNoiseModel &Qc_model) { d_ = detail_g::gp(MANIFOLD, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model); } \
+    GPSLAM_FACTOR_BOILERPLATE(CLS, 4)                                                                           \
+  };
+/// gpslam/gp/GaussianProcessPriorPose3.h:43-49
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose3, GPSLAM_POSE3)
+/// gpslam/gp/GaussianProcessPriorPose2.h:41-47
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose2, GPSLAM_POSE2)
+/// gpslam/gp/GaussianProcessPriorRot3.h:41-47
+GPSLAM_GP_PRIOR(GaussianProcessPriorRot3, GPSLAM_ROT3)
+
+/// gpslam/gp/GaussianProcessPriorLinear.h:47-53 (Dim = 2 or 3, gpslam.h:177-181)
+template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFactor {
+ public:
+  GaussianProcessPriorLinear(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,
+                             const gtsam::SharedNoiseModel &Qc_model) {
+    static_assert(Dim == 2 || Dim == 3, "GaussianProcessPriorLinear<DOF = {2, 3}>");
+    d_ = detail_g::gp(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GaussianProcessPriorLinear<Dim>, 4)
+};
+
+/// gpslam/slam/GPInterpolatedRangeFactorPose2.h:46-54
+class GPInterpolatedRangeFactorPose2 : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedRangeFactorPose2(double measured, const gtsam::SharedNoiseModel &meas_model, const gtsam::SharedNoiseModel &Qc_model,
+                                 gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, gtsam::Key pointKey,
+                                 double delta_t, double tau, const gtsam::Pose2 *body_P_sensor = nullptr) {
+    d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_POSE2;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
+    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    if (body_P_sensor) d_.sensor = {body_P_sensor->x, body_P_sensor->y, body_P_sensor->theta};
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose2, 5)
+};
+
+/// gpslam/slam/GPInterpolatedRangeFactorPose3.h:46-54
+class GPInterpolatedRangeFactorPose3 : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedRangeFactorPose3(double measured, const gtsam::SharedNoiseModel &meas_model, const gtsam::SharedNoiseModel &Qc_model,
+                                 gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, gtsam::Key pointKey,
+                                 double delta_t, double tau, const gtsam::Pose3 *body_P_sensor = nullptr) {
+    d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_POSE3;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
+    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose3, 5)
+};
+
+/// gpslam/slam/GPInterpolatedRangeFactor2DLinear.h:42-50 -- NOTE: keys come before the noise models here
+class GPInterpolatedRangeFactor2DLinear : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedRangeFactor2DLinear(double measured, gtsam::Key pose1Key, gtsam::Key vel1Key, gtsam::Key pose2Key, gtsam::Key vel2Key,
+                                    gtsam::Key pointKey, const gtsam::SharedNoiseModel &meas_model,
+                                    const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau) {
+    d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_LINEAR3;
+    d_.k[0] = pose1Key; d_.k[1] = vel1Key; d_.k[2] = pose2Key; d_.k[3] = vel2Key; d_.k[4] = pointKey;
+    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactor2DLinear, 5)
+};
+
+/// gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:44-51
+class GPInterpolatedAttitudeFactorRot3 : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedAttitudeFactorRot3(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,
+                                   double tau, const gtsam::SharedNoiseModel &Qc_model, const gtsam::SharedNoiseModel &meas_model,
+                                   const gtsam::Unit3 &nZ, const gtsam::Unit3 &bRef = gtsam::Unit3(0, 0, 1)) {
+    d_.type = gtsam::detail::F_INTERP_ATT; d_.manifold = GPSLAM_ROT3;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2;
+    d_.aux = {nZ.p[0], nZ.p[1], nZ.p[2], bRef.p[0], bRef.p[1], bRef.p[2]};
+    d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedAttitudeFactorRot3, 4)
+};
+
+/// gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54
+class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedGPSFactorPose3(const gtsam::Point3 &measured, const gtsam::SharedNoiseModel &meas_model, const gtsam::SharedNoiseModel &Qc_model,
+                               gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t, double tau,
+                               const gtsam::Pose3 *body_P_sensor = nullptr) {
+    d_.type = gtsam::detail::F_INTERP_GPS; d_.manifold = GPSLAM_POSE3;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2;
+    d_.meas = {measured.x, measured.y, measured.z}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance();
+    d_.dt = delta_t; d_.tau = tau;
+    if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3, 4)
+};
+
+/// gpslam/slam/RangeFactor2DLinear.h:30-37
+class RangeFactor2DLinear : public gtsam::NonlinearFactor {
+ public:
+  RangeFactor2DLinear(gtsam::Key poseKey, gtsam::Key pointKey, double measured, const gtsam::SharedNoiseModel &model) {
+    d_.type = gtsam::detail::F_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
+    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(RangeFactor2DLinear, 2)
+};
+/// gpslam/slam/RangeFactorPose2.h:15 (typedef gtsam::RangeFactor<Pose2, Point2>)
+class RangeFactorPose2 : public gtsam::NonlinearFactor {
+ public:
+  RangeFactorPose2(gtsam::Key poseKey, gtsam::Key pointKey, double measured, const gtsam::SharedNoiseModel &model) {
+    d_.type = gtsam::detail::F_RANGE; d_.manifold = GPSLAM_POSE2; d_.k[0] = poseKey; d_.k[4] = pointKey;
+    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(RangeFactorPose2, 2)
+};
+/// gpslam/slam/RangeBearingFactor2DLinear.h:33-37 (range first, then bearing)
+class RangeBearingFactor2DLinear : public gtsam::NonlinearFactor {
+ public:
+  RangeBearingFactor2DLinear(gtsam::Key poseKey, gtsam::Key pointKey, double range, double bearing, const gtsam::SharedNoiseModel &model) {
+    d_.type = gtsam::detail::F_BEARING_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
+    d_.meas = {bearing, range}; d_.sig = gtsam::sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(RangeBearingFactor2DLinear, 2)
+};
+/// gpslam/slam/OdometryFactor2DLinear.h:38-40
+class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
+ public:
+  OdometryFactor2DLinear(gtsam::Key pose1Key, gtsam::Key pose2Key, const gtsam::Vector3 &betweenMeasured, const gtsam::SharedNoiseModel &model) {
+    d_.type = gtsam::detail::F_ODOM2D; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = pose1Key; d_.k[2] = pose2Key;
+    d_.meas = {betweenMeasured[0], betweenMeasured[1], betweenMeasured[2]}; d_.sig = gtsam::sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(OdometryFactor2DLinear, 2)
+};
+
+}  // namespace gpslam

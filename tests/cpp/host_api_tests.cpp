@@ -1,0 +1,255 @@
+// End-to-end tests of the C++ host classes (gpslam_amd/host/gpslam_host.hpp), written the way the reference's own
+// CppUnitLite tests are: build a NonlinearFactorGraph with the gpslam factor classes, optimise with
+// GaussNewtonOptimizer / LevenbergMarquardtOptimizer, compare with the ground truth.  Scenarios and numbers are those
+// of gpslam/gp/tests/testGaussianProcessPrior{Pose3,Pose2,Rot3,Linear}.cpp (Optimization),
+// gpslam/slam/tests/testGPInterpolatedRangeFactorPose{2,3}.cpp (optimization) and
+// gpslam/slam/tests/testRangeBearingFactor2DLinear.cpp (optimization).
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+#include "../../gpslam_amd/host/gpslam_host.hpp"
+
+using namespace gtsam;
+using namespace gpslam;
+
+static int failures = 0;
+#define EXPECT(cond)                                                                  \
+  do {                                                                                \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); failures++; } \
+  } while (0)
+#define EXPECT_NEAR(a, b, tol) EXPECT(std::fabs((a) - (b)) <= (tol))
+
+static bool near3(const Point3 &a, const Point3 &b, double tol) {
+  return std::fabs(a.x - b.x) <= tol && std::fabs(a.y - b.y) <= tol && std::fabs(a.z - b.z) <= tol;
+}
+static bool nearR(const Rot3 &a, const Rot3 &b, double tol) {
+  for (int i = 0; i < 9; i++) if (std::fabs(a.R[i] - b.R[i]) > tol) return false;
+  return true;
+}
+template <int N> static bool nearV(const VectorN<N> &a, const VectorN<N> &b, double tol) {
+  for (int i = 0; i < N; i++) if (std::fabs(a[i] - b[i]) > tol) return false;
+  return true;
+}
+
+static void test_gp_prior_pose3_optimization() {
+  auto model_prior = noiseModel::Isotropic::Sigma(6, 0.001);
+  double delta_t = 1;
+  Matrix Qc = 0.01 * Matrix::Identity(6);
+  auto Qc_model = noiseModel::Gaussian::Covariance(Qc);
+  Pose3 pose1(Rot3(), Point3(0, 0, 0)), pose2(Rot3(), Point3(1, 0, 0));
+  Vector6 v1 = {0, 0, 0, 1, 0, 0};
+  Vector6 v2 = {0.1, 0.2, -0.3, 2.0, -0.5, 0.6};
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Pose3>(Symbol('x', 1), pose1, model_prior));
+  graph.add(PriorFactor<Pose3>(Symbol('x', 2), pose2, model_prior));
+  graph.add(GaussianProcessPriorPose3(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), delta_t, Qc_model));
+  Values init_values;
+  init_values.insert(Symbol('x', 1), pose1);
+  init_values.insert(Symbol('v', 1), v1);
+  init_values.insert(Symbol('x', 2), pose2);
+  init_values.insert(Symbol('v', 2), v2);
+  GaussNewtonParams parameters;
+  GaussNewtonOptimizer optimizer(graph, init_values, parameters);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-6);
+  EXPECT(near3(pose1.t, values.at<Pose3>(Symbol('x', 1)).t, 1e-6) && nearR(pose1.R, values.at<Pose3>(Symbol('x', 1)).R, 1e-6));
+  EXPECT(near3(pose2.t, values.at<Pose3>(Symbol('x', 2)).t, 1e-6) && nearR(pose2.R, values.at<Pose3>(Symbol('x', 2)).R, 1e-6));
+  EXPECT(nearV(v1, values.at<Vector6>(Symbol('v', 1)), 1e-6));
+  EXPECT(nearV(v1, values.at<Vector6>(Symbol('v', 2)), 1e-6));
+  EXPECT(optimizer.iterations() > 0 && optimizer.iterations() < 100);
+}
+
+static void test_gp_prior_pose2_rot3_linear_optimization() {
+  {
+    auto model_prior = noiseModel::Isotropic::Sigma(3, 0.001);
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    Pose2 pose1(0, 0, 0), pose2(1, 0, 0);
+    Vector3 v1 = {1, 0, 0}, v2 = {2.0, -0.5, 0.6};
+    NonlinearFactorGraph graph;
+    graph.add(PriorFactor<Pose2>(Symbol('x', 1), pose1, model_prior));
+    graph.add(PriorFactor<Pose2>(Symbol('x', 2), pose2, model_prior));
+    graph.add(GaussianProcessPriorPose2(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 1.0, Qc_model));
+    Values init;
+    init.insert(Symbol('x', 1), pose1); init.insert(Symbol('v', 1), v1); init.insert(Symbol('x', 2), pose2); init.insert(Symbol('v', 2), v2);
+    GaussNewtonOptimizer optimizer(graph, init);
+    Values values = optimizer.optimize();
+    EXPECT_NEAR(0, graph.error(values), 1e-6);
+    EXPECT_NEAR(values.at<Pose2>(Symbol('x', 2)).x, 1.0, 1e-6);
+    EXPECT(nearV(v1, values.at<Vector3>(Symbol('v', 2)), 1e-6));
+  }
+  {
+    auto model_prior = noiseModel::Isotropic::Sigma(3, 0.001);
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    Rot3 pose1, pose2(Rot3::Ypr(0, 0, 0.1));
+    Vector3 v1 = {1, 0, 0}, v2 = {2.0, -0.5, 0.6};
+    NonlinearFactorGraph graph;
+    graph.add(PriorFactor<Rot3>(Symbol('x', 1), pose1, model_prior));
+    graph.add(PriorFactor<Rot3>(Symbol('x', 2), pose2, model_prior));
+    graph.add(GaussianProcessPriorRot3(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc_model));
+    Values init;
+    init.insert(Symbol('x', 1), pose1); init.insert(Symbol('v', 1), v1); init.insert(Symbol('x', 2), pose2); init.insert(Symbol('v', 2), v2);
+    GaussNewtonOptimizer optimizer(graph, init);
+    Values values = optimizer.optimize();
+    EXPECT_NEAR(0, graph.error(values), 1e-6);
+    EXPECT(nearR(pose2, values.at<Rot3>(Symbol('x', 2)), 1e-6));
+    EXPECT(nearV(v1, values.at<Vector3>(Symbol('v', 1)), 1e-6) && nearV(v1, values.at<Vector3>(Symbol('v', 2)), 1e-6));
+  }
+  {
+    auto model_prior = noiseModel::Isotropic::Sigma(3, 0.001);
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    Vector3 p1 = {1, 0, 0}, p2 = {1.1, 0, 0}, v1 = {1, 0, 0}, v1init = {1, 0.1, 0.2}, v2init = {2.1, -1.2, 0.9};
+    NonlinearFactorGraph graph;
+    graph.add(PriorFactor<Vector3>(Symbol('x', 1), p1, model_prior));
+    graph.add(PriorFactor<Vector3>(Symbol('x', 2), p2, model_prior));
+    graph.add(GaussianProcessPriorLinear<3>(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc_model));
+    Values init;
+    init.insert(Symbol('x', 1), p1); init.insert(Symbol('v', 1), v1init); init.insert(Symbol('x', 2), p2); init.insert(Symbol('v', 2), v2init);
+    LevenbergMarquardtOptimizer optimizer(graph, init);   // the linear problem through the LM path
+    Values values = optimizer.optimize();
+    EXPECT_NEAR(0, graph.error(values), 1e-6);
+    EXPECT(nearV(v1, values.at<Vector3>(Symbol('v', 1)), 1e-5) && nearV(v1, values.at<Vector3>(Symbol('v', 2)), 1e-5));
+  }
+}
+
+static void test_interp_range_pose2_optimization() {
+  auto model_prior = noiseModel::Isotropic::Sigma(3, 0.01);
+  auto model_prior2_loss = noiseModel::Isotropic::Sigma(2, 0.1);
+  auto model_cam = noiseModel::Isotropic::Sigma(1, 0.1);
+  double delta_t = 0.5, tau1 = 0.05, tau2 = 0.25, tau3 = 0.45;
+  auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+  Pose2 p1(0, 0, 0), p2(5, 0, 0), pcam1(0.5, 0, 0), pcam2(2.5, 0, 0), pcam3(4.5, 0, 0);
+  Vector3 v1 = {10, 0, 0}, v2 = {10, 0, 0};
+  Pose2 p1i(0.1, 0.1, -0.1), p2i(5.1, -0.1, 0.1);
+  Vector3 v1i = {9.8, 0, 0.2}, v2i = {10.2, 0, -0.1};
+  Point2 land(2.4, 3.2), landi(2.3, 3.1);
+  double meas1 = pcam1.range(land), meas2 = pcam2.range(land), meas3 = pcam3.range(land);
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Pose2>(Symbol('x', 1), p1, model_prior));
+  graph.add(PriorFactor<Pose2>(Symbol('x', 2), p2, model_prior));
+  graph.add(PriorFactor<Point2>(Symbol('l', 1), land, model_prior2_loss));
+  graph.add(PriorFactor<Vector3>(Symbol('v', 1), v1, model_prior));
+  graph.add(PriorFactor<Vector3>(Symbol('v', 2), v2, model_prior));
+  graph.add(GaussianProcessPriorPose2(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), delta_t, Qc_model));
+  graph.add(GPInterpolatedRangeFactorPose2(meas1, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau1));
+  graph.add(GPInterpolatedRangeFactorPose2(meas2, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau2));
+  graph.add(GPInterpolatedRangeFactorPose2(meas3, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau3));
+  Values init_values;
+  init_values.insert(Symbol('x', 1), p1i); init_values.insert(Symbol('v', 1), v1i);
+  init_values.insert(Symbol('x', 2), p2i); init_values.insert(Symbol('v', 2), v2i);
+  init_values.insert(Symbol('l', 1), landi);
+  GaussNewtonParams parameters;
+  parameters.setVerbosity("ERROR");
+  GaussNewtonOptimizer optimizer(graph, init_values, parameters);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-4);
+  EXPECT_NEAR(values.at<Pose2>(Symbol('x', 1)).x, 0.0, 1e-4);
+  EXPECT_NEAR(values.at<Pose2>(Symbol('x', 2)).x, 5.0, 1e-4);
+  EXPECT(nearV(v1, values.at<Vector3>(Symbol('v', 1)), 1e-4) && nearV(v2, values.at<Vector3>(Symbol('v', 2)), 1e-4));
+  EXPECT_NEAR(values.at<Point2>(Symbol('l', 1)).x, 2.4, 1e-4);
+  EXPECT_NEAR(values.at<Point2>(Symbol('l', 1)).y, 3.2, 1e-4);
+}
+
+static void test_interp_range_pose3_optimization_with_extrapolation() {
+  auto model_prior = noiseModel::Isotropic::Sigma(6, 0.01);
+  auto model_prior3_loss = noiseModel::Isotropic::Sigma(3, 0.1);
+  auto model_cam = noiseModel::Isotropic::Sigma(1, 0.1);
+  double delta_t = 0.1, tau1 = -0.1, tau2 = 0.05, tau3 = 0.2;    // tau outside [0, delta_t] on both sides
+  auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+  Pose3 p1(Rot3(), Point3(0, 0, 0)), p2(Rot3(), Point3(1, 0, 0));
+  Pose3 pcam1(Rot3(), Point3(-1, 0, 0)), pcam2(Rot3(), Point3(0.5, 0, 0)), pcam3(Rot3(), Point3(2, 0, 0));
+  Vector6 v1 = {0, 0, 0, 10, 0, 0}, v2 = {0, 0, 0, 10, 0, 0};
+  Pose3 p1i(Rot3::Ypr(0.1, 0.2, 0.4), Point3(0.2, 0.3, -0.2)), p2i(Rot3::Ypr(-0.1, -0.2, -0.4), Point3(1.2, -0.3, 0.2));
+  Vector6 v1i = {-0.1, 0, 0, 0.8, 0, 0.2}, v2i = {0, 0, 0.2, 1.2, 0, -0.1};
+  Point3 land(0.4, 1.2, 3), landi(0.3, 1.1, 2.9);
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Pose3>(Symbol('x', 1), p1, model_prior));
+  graph.add(PriorFactor<Pose3>(Symbol('x', 2), p2, model_prior));
+  graph.add(PriorFactor<Point3>(Symbol('l', 1), land, model_prior3_loss));
+  graph.add(PriorFactor<Vector6>(Symbol('v', 1), v1, model_prior));
+  graph.add(PriorFactor<Vector6>(Symbol('v', 2), v2, model_prior));
+  graph.add(GaussianProcessPriorPose3(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), delta_t, Qc_model));
+  const double taus[3] = {tau1, tau2, tau3};
+  const Pose3 cams[3] = {pcam1, pcam2, pcam3};
+  for (int k = 0; k < 3; k++)
+    graph.add(GPInterpolatedRangeFactorPose3(cams[k].range(land), model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2),
+                                             Symbol('v', 2), Symbol('l', 1), delta_t, taus[k]));
+  Values init_values;
+  init_values.insert(Symbol('x', 1), p1i); init_values.insert(Symbol('v', 1), v1i);
+  init_values.insert(Symbol('x', 2), p2i); init_values.insert(Symbol('v', 2), v2i);
+  init_values.insert(Symbol('l', 1), landi);
+  GaussNewtonOptimizer optimizer(graph, init_values);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-6);
+  EXPECT(near3(p2.t, values.at<Pose3>(Symbol('x', 2)).t, 1e-6) && nearR(p2.R, values.at<Pose3>(Symbol('x', 2)).R, 1e-6));
+  EXPECT(nearV(v1, values.at<Vector6>(Symbol('v', 1)), 1e-6) && nearV(v2, values.at<Vector6>(Symbol('v', 2)), 1e-6));
+  EXPECT(near3(land, values.at<Point3>(Symbol('l', 1)), 1e-6));
+}
+
+static void test_range_bearing_2dlinear_optimization() {
+  // gpslam/slam/tests/testRangeBearingFactor2DLinear.cpp:86-132: three poses without velocities
+  auto meas_model = noiseModel::Isotropic::Sigma(2, 0.1);
+  auto prior_model = noiseModel::Isotropic::Sigma(3, 1.0);
+  auto between_model = noiseModel::Isotropic::Sigma(3, 0.1);
+  Key key_p1 = Symbol('x', 1), key_p2 = Symbol('x', 2), key_p3 = Symbol('x', 3), key_lnd = Symbol('l', 1);
+  Vector3 p1 = {0, 0, 0}, p2 = {1, 0, 0}, p3 = {2, 1, 0};
+  Point2 lnd(0, 2);
+  double dist1 = 2.0, dist2 = std::sqrt(5.0), dist3 = std::sqrt(5.0);
+  double bear1 = 1.570796326794897, bear2 = 2.034443935795703, bear3 = 2.677945044588987;
+  Vector3 btw12 = {1, 0, 0}, btw23 = {1, 1, 0};
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Vector3>(key_p1, p1, prior_model));
+  graph.add(BetweenFactor<Vector3>(key_p1, key_p2, btw12, between_model));
+  graph.add(BetweenFactor<Vector3>(key_p2, key_p3, btw23, between_model));
+  graph.add(RangeBearingFactor2DLinear(key_p1, key_lnd, dist1, bear1, meas_model));
+  graph.add(RangeBearingFactor2DLinear(key_p2, key_lnd, dist2, bear2, meas_model));
+  graph.add(RangeBearingFactor2DLinear(key_p3, key_lnd, dist3, bear3, meas_model));
+  Values init_values;
+  init_values.insert(key_p1, Vector3{0.2, -0.5, 0.3});
+  init_values.insert(key_p2, Vector3{0.8, 0.2, 0.1});
+  init_values.insert(key_p3, Vector3{2.4, 1.3, -0.4});
+  init_values.insert(key_lnd, Point2(0.1, 2.2));
+  GaussNewtonOptimizer optimizer(graph, init_values);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-6);
+  EXPECT(nearV(p1, values.at<Vector3>(key_p1), 1e-6) && nearV(p2, values.at<Vector3>(key_p2), 1e-6) && nearV(p3, values.at<Vector3>(key_p3), 1e-6));
+  EXPECT_NEAR(values.at<Point2>(key_lnd).x, 0.0, 1e-6);
+  EXPECT_NEAR(values.at<Point2>(key_lnd).y, 2.0, 1e-6);
+}
+
+static void test_error_conventions() {
+  auto model = noiseModel::Isotropic::Sigma(3, 0.1);
+  auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+  Values v;
+  v.insert(Symbol('x', 1), Pose2(0, 0, 0)); v.insert(Symbol('v', 1), Vector3{0, 0, 0});
+  v.insert(Symbol('x', 2), Pose2(1, 0, 0)); v.insert(Symbol('v', 2), Vector3{0, 0, 0});
+  v.insert(Symbol('x', 3), Pose2(2, 0, 0)); v.insert(Symbol('v', 3), Vector3{0, 0, 0});
+  bool threw = false;
+  try { (void)v.at<Pose2>(Symbol('x', 9)); } catch (const std::out_of_range &) { threw = true; }   // ValuesKeyDoesNotExist
+  EXPECT(threw);
+  NonlinearFactorGraph g;
+  g.add(GaussianProcessPriorPose2(Symbol('x', 1), Symbol('v', 1), Symbol('x', 3), Symbol('v', 3), 0.1, Qc_model));   // skips a state
+  threw = false;
+  try { GaussNewtonOptimizer o(g, v); } catch (const std::invalid_argument &) { threw = true; }
+  EXPECT(threw);
+  NonlinearFactorGraph g2;   // velocity of x1..x3 unconstrained and no priors: indeterminate system
+  g2.add(PriorFactor<Pose2>(Symbol('x', 1), Pose2(0, 0, 0), model));
+  threw = false;
+  try { GaussNewtonOptimizer o(g2, v); o.iterate(); } catch (const std::runtime_error &) { threw = true; }   // IndeterminantLinearSystemException
+  EXPECT(threw);
+}
+
+int main() {
+  test_gp_prior_pose3_optimization();
+  test_gp_prior_pose2_rot3_linear_optimization();
+  test_interp_range_pose2_optimization();
+  test_interp_range_pose3_optimization_with_extrapolation();
+  test_range_bearing_2dlinear_optimization();
+  test_error_conventions();
+  if (failures == 0) std::printf("host_api_tests: all tests passed\n");
+  return failures == 0 ? 0 : 1;
+}
