@@ -84,7 +84,7 @@ def _p(a):
 
 class ChainSolver:
     def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, device=0, chunk=0, rank=0, nranks=1,
-                 force_sharded=False):
+                 force_sharded=False, upper_chunk=0, top_blocks=0):
         self.lib = load_library()
         self.kind, self.chart, self.ld = kind, chart, landmark_dim
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
@@ -93,6 +93,8 @@ class ChainSolver:
         cfg = Config(manifold=kind, precision=0, device=device, chart=chart, landmark_dim=landmark_dim, chunk=chunk,
                      rank=rank, nranks=nranks)
         cfg.reserved[0] = 1 if force_sharded else 0
+        cfg.reserved[1] = upper_chunk
+        cfg.reserved[2] = top_blocks
         self._h = C.c_void_p()
         rc = self.lib.gpslam_hip_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

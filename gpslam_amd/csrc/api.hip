@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -86,6 +87,7 @@ struct gpslam_hip_handle {
   MeasSet ms[6];
   // row table
   int M = 0;
+  int asm_tile_rows = 0;      // largest row slice one assembly workgroup stages in LDS (0: use the direct kernel)
   DevBuf rowLR, rowE, rowM, rowLm, rowptr;
   DevBuf partial;
   // landmark border
@@ -339,19 +341,34 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   a.blk = h->lv[0].blk.as<Real>();
   a.gsave = save_g ? h->gsave.as<Real>() : nullptr;
   a.halo_add = has_right_rank(h) ? h->halo_add.as<Real>() : nullptr;
-  const int threads = (h->N + (a.halo_add ? 1 : 0)) * h->b;
+  const int nstates = h->N + (a.halo_add ? 1 : 0);
+  const int threads = nstates * h->b;
+  const int tile_rows = h->asm_tile_rows;
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
-    k_assemble<Real, BB><<<dim3(nblocks(threads, 192)), dim3(192), 0, h->stream>>>(a);
+    static const int amode = getenv("GPSLAM_ASM_MODE") ? atoi(getenv("GPSLAM_ASM_MODE")) : 0;   // 0 shfl, 1 lds, 2 direct
+    if (amode == 0) {
+      constexpr int G = 64 / BB;
+      const int waves = nblocks(nstates, G);
+      k_assemble_shfl<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);
+    } else if (tile_rows > 0 && amode == 1) {
+      const size_t lds = (size_t)tile_rows * (2 * BB + 1) * sizeof(Real);
+      static const int dbg = getenv("GPSLAM_ASM_DEBUG") ? atoi(getenv("GPSLAM_ASM_DEBUG")) : 0;
+      k_assemble_lds<Real, BB><<<dim3(nblocks(nstates, 192 / BB)), dim3(192), lds, h->stream>>>(a, tile_rows, dbg);
+    } else {
+      k_assemble<Real, BB><<<dim3(nblocks(threads, 192)), dim3(192), 0, h->stream>>>(a);
+    }
   });
   HIPCHK(hipGetLastError());
   return 0;
 }
 
 void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
+  const bool fast = (4 * h->b + 2 * h->R <= 64);   // room for the separator sums in spare lanes
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
-    k_chunk_forward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+    if (fast) k_chunk_forward<Real, BB, true><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+    else k_chunk_forward<Real, BB, false><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
   });
 }
 void launch_bwd(gpslam_hip_handle *h, const BwdArgs<Real> &a, int grid) {
@@ -891,6 +908,15 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     if ((rc = upload_real(h, s.d_coef, coef))) return rc;
     npart += nblocks(s.count(), 128);
   }
+  {  // largest contiguous row slice of an assembly tile (states s0-1 .. s0+TS-1); staged in LDS if it fits
+    const int TS = 192 / b;
+    int mx = 0;
+    for (int s0 = 0; s0 < N + 1; s0 += TS) {
+      const int slo = s0 > 0 ? s0 - 1 : 0, shi = std::min(s0 + TS, N);
+      if (shi > slo) mx = std::max(mx, rowptr[shi] - rowptr[slo]);
+    }
+    h->asm_tile_rows = ((size_t)mx * (2 * b + 1) * sizeof(Real) <= 64 * 1024) ? std::max(mx, 1) : 0;
+  }
   const size_t Mrows = (size_t)std::max(h->M, 1);
   HIPCHK(h->rowLR.reserve(Mrows * 2 * b * sizeof(Real)));
   HIPCHK(h->rowE.reserve(Mrows * sizeof(Real)));
@@ -929,7 +955,10 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   HIPCHK(h->dvec.reserve((size_t)N * b * sizeof(Real)));
   // ---- solver hierarchy: chunks of m0 states at level 0, m1 above.  Unsharded: a single-wave sequential top
   // level of <= `top` blocks.  Sharded: reduce down to one block per rank (the rank separator).
-  const int m0 = h->cfg.chunk > 1 ? h->cfg.chunk : 16, m1 = 8, top = sharded(h) ? 16 : 32;
+  // reserved[1] / reserved[2] override the upper-level chunk length and the size of the sequential top level
+  const int m0 = h->cfg.chunk > 1 ? h->cfg.chunk : 16;
+  const int m1 = h->cfg.reserved[1] > 1 ? h->cfg.reserved[1] : 4;
+  const int top = h->cfg.reserved[2] > 0 ? h->cfg.reserved[2] : 16;
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   h->lv.clear();
   const size_t BS = (size_t)2 * b * b + (size_t)b * h->R, AS = (size_t)b * b + (size_t)b * h->R;

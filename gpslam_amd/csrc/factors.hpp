@@ -46,12 +46,54 @@ template <typename T> GD void put_bl6(const BL6<T> &a, T *J, int ld, int r0, int
   put_m3(a.D, J, ld, r0 + 3, c0 + 3);
 }
 
-// d( Jr^-1(xi) * x ) / d xi by central differences with h = 1e-6, exactly the construction of
-// jacobianMethodNumercialDiff(rightJacobianPose3inv, xi, x) (Pose3utils.cpp:167-179, default dxi Pose3utils.h:57).
-// The result is block lower-triangular: perturbing rho leaves the rotation block of Jr^-1 untouched, so the
-// reference's top-right 3x3 block is an exact zero as well.
+// Jr^-1(xi) * x without forming the 6x6 matrix:  Jr^-1 = [[Jw, 0], [-Jw Q Jw, Jw]] (Pose3utils.cpp:192-200), so
+//   top = Jw x_w,   bottom = Jw (x_v - Q (Jw x_w)),
+// with Jw a = a + 1/2 w x a + c w x (w x a) (Pose3utils.cpp:215-224) and every product with the skew matrices of
+// rightJacobianPose3Q (Pose3utils.cpp:92-113) written as nested cross products.
+template <typename T> GD V3<T> so3_jrinv_apply(V3<T> w, V3<T> a) {
+  const T th2 = dot(w, w);
+  if (th2 <= Eps<T>::v) return a;
+  const T th = sqrt(th2);
+  const T c = T(1) / th2 - (T(1) + cos(th)) / (T(2) * th * sin(th));
+  const V3<T> wa = cross(w, a);
+  return a + T(0.5) * wa + c * cross(w, wa);
+}
+template <typename T> GD V3<T> se3_Q_apply(V3<T> w, V3<T> rho, V3<T> b) {
+  const T th = sqrt(dot(w, w));
+  T ca, cb, cc;
+  if (fabs(th) > T(1e-5)) {
+    const T s = sin(th), co = cos(th);
+    const T t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
+    ca = (th - s) / t3;
+    cb = (T(1) - T(0.5) * t2 - co) / t4;
+    cc = T(-0.5) * ((T(1) - T(0.5) * t2 - co) / t4 - T(3) * (th - s - t3 / T(6)) / t5);
+  } else {
+    ca = T(1) / T(6);
+    cb = T(1) / T(24);
+    cc = T(-0.5) * (T(1) / T(24) + T(3) / T(120));
+  }
+  const V3<T> Yb = cross(rho, b), Xb = cross(w, b);
+  const V3<T> XYb = cross(w, Yb), YXb = cross(rho, Xb), XXb = cross(w, Xb);
+  const V3<T> XYXb = cross(w, YXb);
+  const V3<T> XXYb = cross(w, XYb), YXXb = cross(rho, XXb);
+  const V3<T> XYXXb = cross(w, cross(rho, cross(w, Xb))), XXYXb = cross(w, XYXb);
+  return T(-0.5) * Yb + ca * (XYb + YXb - XYXb) + cb * (XXYb + YXXb - T(3) * XYXb) + cc * (XYXXb + XXYXb);
+}
+template <typename T> GD V6<T> se3_jrinv_apply(V6<T> xi, V6<T> x) {
+  const V3<T> top = so3_jrinv_apply(xi.w, x.w);
+  return {top, so3_jrinv_apply(xi.w, x.v - se3_Q_apply(xi.w, xi.v, top))};
+}
+
+// d( Jr^-1(xi) * x ) / d xi by central differences with h = 1e-6: the construction of
+// jacobianMethodNumercialDiff(rightJacobianPose3inv, xi, x) (Pose3utils.cpp:167-179, default dxi Pose3utils.h:57),
+// column i = (Jr^-1(xi + h e_i) x - Jr^-1(xi - h e_i) x) / (2h).  The reference subtracts the two 6x6 matrices
+// before multiplying by x; here the two matrix-vector products are formed directly (a third of the flops, no 6x6
+// temporaries) -- the same number up to rounding of order eps/h = 1e-10, which is the noise floor of this finite
+// difference in the reference as well.  The result is block lower-triangular: perturbing rho leaves the rotation
+// block untouched, so the top-right 3x3 block is an exact zero in the reference too.
 template <typename T> GD BL6<T> se3_jrinv_times_x_fd(V6<T> xi, V6<T> x) {
   const T h = T(1e-6);
+  const T s = T(1) / (T(2) * h);
   BL6<T> D;
   D.A = M3<T>::zero();
   D.C = M3<T>::zero();
@@ -65,16 +107,12 @@ template <typename T> GD BL6<T> se3_jrinv_times_x_fd(V6<T> xi, V6<T> x) {
     if (i == 3) { xp.v.x += h; xn.v.x -= h; }
     if (i == 4) { xp.v.y += h; xn.v.y -= h; }
     if (i == 5) { xp.v.z += h; xn.v.z -= h; }
-    const BL6<T> Jp = se3_jrinv(xp), Jn = se3_jrinv(xn);
-    const T s = T(1) / (T(2) * h);
-    // ((Jp - Jn) / (2h)) * x, same operation order as the reference
-    const BL6<T> dJ = {s * (Jp.A - Jn.A), s * (Jp.C - Jn.C), s * (Jp.D - Jn.D)};
-    const V6<T> col = dJ * x;
+    const V6<T> col = s * (se3_jrinv_apply(xp, x) - se3_jrinv_apply(xn, x));
     if (i < 3) {
       D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
       D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
     } else {
-      // top block: (Jp.A - Jn.A) is exactly zero for a rho perturbation -> col.w == 0
+      // a rho perturbation does not change Jw: the top half of the column is exactly zero
       D.D.m[0 + (i - 3)] = col.v.x; D.D.m[3 + (i - 3)] = col.v.y; D.D.m[6 + (i - 3)] = col.v.z;
     }
   }

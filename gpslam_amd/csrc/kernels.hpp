@@ -504,7 +504,8 @@ template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce(LmArgs<
   const bool same = (c >= 1) && (cl / a.ld == lm);
   const int q2 = same ? cl - lm * a.ld : 0;
   T acc = T(0), g = T(0);
-  for (int j = a.lmrow_ptr[lm]; j < a.lmrow_ptr[lm + 1]; j++) {
+  const int j_lo = a.lmrow_ptr[lm], j_hi = a.lmrow_ptr[lm + 1];
+  for (int j = j_lo; j < j_hi; j++) {
     const int rho = a.lmrow[j];
     const T m = a.rowM[(size_t)rho * a.ld + q];
     if (c == 0) { g -= m * a.rowE[rho]; }
@@ -622,12 +623,14 @@ __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = t / B, c = t - s * B;
   if (s > a.N || (s == a.N && !a.halo_add)) return;
+  // loop bounds in registers: re-reading rowptr from HBM every iteration serialises the row loop on memory latency
+  const int rp_s = a.rowptr[s], rp_sm = s > 0 ? a.rowptr[s - 1] : a.rowptr[s], rp_s1 = a.rowptr[s + 1];
   if (s == a.N) {  // right blocks of the rows of state N-1 -> addend for the neighbour's first state
     T Dh[B];
     T gh = T(0);
 #pragma unroll
     for (int k = 0; k < B; k++) Dh[k] = T(0);
-    for (int rho = a.rowptr[s - 1]; rho < a.rowptr[s]; rho++) {
+    for (int rho = rp_sm; rho < rp_s; rho++) {
       const T *row = a.rowLR + (size_t)rho * 2 * B + B;
       const T Rc = row[c];
 #pragma unroll
@@ -648,7 +651,7 @@ __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
   for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
   for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
   // rows whose factor has left state s: left block -> D_s, O_s (with the right block), g_s
-  for (int rho = a.rowptr[s]; rho < a.rowptr[s + 1]; rho++) {
+  for (int rho = rp_s; rho < rp_s1; rho++) {
     const T *row = a.rowLR + (size_t)rho * 2 * B;
     const T Lc = row[c], Rc = row[B + c];
     const T e = a.rowE[rho];
@@ -667,7 +670,7 @@ __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
   }
   // rows whose factor has left state s-1: right block -> D_s, g_s
   if (s > 0) {
-    for (int rho = a.rowptr[s - 1]; rho < a.rowptr[s]; rho++) {
+    for (int rho = rp_sm; rho < rp_s; rho++) {
       const T *row = a.rowLR + (size_t)rho * 2 * B + B;
       const T Rc = row[c];
       const T e = a.rowE[rho];
@@ -687,6 +690,241 @@ __global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
   if (a.gsave) a.gsave[(size_t)s * B + c] = g;
 }
 
+// Wave-cooperative assembly: the B lanes of a state each load ONE element of a Jacobian row (a coalesced 8B-per-lane
+// load of the row's left / right half) and obtain the other B - 1 through the cross-lane network (ds_bpermute),
+// so every row is fetched from HBM exactly once, nothing is staged and the kernel runs at full occupancy.
+// 64 / B states per wave (B = 12: 5 states, 60 live lanes).
+template <typename T, int B>
+__global__ void __launch_bounds__(256) k_assemble_shfl(AsmArgs<T> a) {
+  constexpr int G = 64 / B;                       // states per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int g = lane / B, c = lane - g * B;
+  const int nstates = a.N + (a.halo_add ? 1 : 0);
+  const int s = wave * G + g;
+  const bool live = (g < G) && (s < nstates);
+  const int sc = live ? s : 0;
+  const int gb = g * B;                           // first lane of this state's group
+  // every lane of the wave runs the same trip counts (cross-lane ops need all participants converged)
+  int rp_s = 0, rp_s1 = 0, rp_sm = 0;
+  if (live) {
+    rp_s = a.rowptr[sc];
+    rp_s1 = (sc < a.N) ? a.rowptr[sc + 1] : rp_s;  // the virtual halo state owns no rows
+    rp_sm = sc > 0 ? a.rowptr[sc - 1] : rp_s;
+  }
+  int n_own = rp_s1 - rp_s, n_prev = rp_s - rp_sm;
+  int n_own_max = n_own, n_prev_max = n_prev;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    n_own_max = max(n_own_max, __shfl_xor(n_own_max, o, 64));
+    n_prev_max = max(n_prev_max, __shfl_xor(n_prev_max, o, 64));
+  }
+  T D[B], O[B];
+  T gsum = T(0);
+#pragma unroll
+  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
+  // per-wave exchange buffer: each lane publishes its element, the B lanes of a state read the whole row back with
+  // 16-byte LDS reads (DS operations of one wave execute in order, so no barrier is needed; two buffers alternate)
+  __shared__ T xch[4][2][64];
+  T *xw = &xch[threadIdx.x >> 6][0][0];
+  const int BS = 2 * B * B + B * a.R;
+  T *bp = a.blk + (size_t)sc * BS;
+  const bool isblk = live && sc < a.N;
+  if (isblk) for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
+  // rows whose factor has left state s (the operands of row i+2 are in flight while row i is accumulated)
+  auto ld_own = [&](int i, T &Lc, T &Rc, T &e) {
+    Lc = T(0); Rc = T(0); e = T(0);
+    if (i < n_own) {
+      const T *row = a.rowLR + (size_t)(rp_s + i) * 2 * B;
+      Lc = row[c];
+      Rc = row[B + c];
+      e = a.rowE[rp_s + i];
+    }
+  };
+  {
+    T Lc0, Rc0, e0, Lc1, Rc1, e1;
+    ld_own(0, Lc0, Rc0, e0);
+    ld_own(1, Lc1, Rc1, e1);
+    for (int i = 0; i < n_own_max; i++) {
+      const T Lc = Lc0, Rc = Rc0, e = e0;
+      Lc0 = Lc1; Rc0 = Rc1; e0 = e1;
+      ld_own(i + 2, Lc1, Rc1, e1);
+      T *buf = xw + (i & 1) * 64;
+      buf[lane] = Lc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const T *rowv = buf + gb;
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        const T Lk = rowv[k];
+        D[k] += Lc * Lk;
+        O[k] += Rc * Lk;
+      }
+      gsum -= Lc * e;
+      if (a.rowM && i < n_own && isblk) {
+        const int rho = rp_s + i;
+        const int lm = a.rowLm[rho];
+        if (lm >= 0)
+          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+      }
+    }
+  }
+  // rows whose factor has left state s-1: right blocks
+  auto ld_prev = [&](int i, T &Rc, T &e) {
+    Rc = T(0); e = T(0);
+    if (i < n_prev) {
+      Rc = a.rowLR[(size_t)(rp_sm + i) * 2 * B + B + c];
+      e = a.rowE[rp_sm + i];
+    }
+  };
+  {
+    T Rc0, e0, Rc1, e1;
+    ld_prev(0, Rc0, e0);
+    ld_prev(1, Rc1, e1);
+    for (int i = 0; i < n_prev_max; i++) {
+      const T Rc = Rc0, e = e0;
+      Rc0 = Rc1; e0 = e1;
+      ld_prev(i + 2, Rc1, e1);
+      T *buf = xw + ((i + n_own_max) & 1) * 64;
+      buf[lane] = Rc;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const T *rowv = buf + gb;
+#pragma unroll
+      for (int k = 0; k < B; k++) D[k] += Rc * rowv[k];
+      gsum -= Rc * e;
+      if (a.rowM && i < n_prev && isblk) {
+        const int rho = rp_sm + i;
+        const int lm = a.rowLm[rho];
+        if (lm >= 0)
+          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Rc * a.rowM[(size_t)rho * a.ld + q];
+      }
+    }
+  }
+  if (!live) return;
+  if (sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
+#pragma unroll
+    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
+    a.halo_add[B * B + c] = gsum;
+    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
+  bp[2 * B * B + c] = gsum;
+  if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
+}
+
+// LDS-staged assembly: a workgroup owns TS = 192 / B consecutive states.  The rows it needs (those of states
+// s0-1 .. s0+TS-1) are one contiguous slice of the row table; the slice is copied into LDS once with 16-byte
+// coalesced loads and every thread (state, row c) then forms its row of D_s / O_s from LDS (6 ds_read_b128 + 24 FMA
+// per Jacobian row instead of 14 global loads), so the kernel reads each row from HBM exactly once.
+template <typename T, int B>
+__global__ void __launch_bounds__(192) k_assemble_lds(AsmArgs<T> a, int max_rows, int dbg = 0) {
+  constexpr int TS = 192 / B;
+  extern __shared__ double lds_raw[];
+  T *lrow = reinterpret_cast<T *>(lds_raw);            // [rows][2B]
+  T *lE = lrow + (size_t)max_rows * 2 * B;             // [rows]
+  const int tid = threadIdx.x;
+  const int s0 = blockIdx.x * TS;
+  const int nstates = a.N + (a.halo_add ? 1 : 0);
+  const int slo = s0 > 0 ? s0 - 1 : 0;
+  const int shi = min(s0 + TS, a.N);                   // rows of left states [slo, shi)
+  const int r_lo = a.rowptr[slo], r_hi = a.rowptr[shi];
+  const int nrows = r_hi - r_lo;
+  {
+    typedef double __attribute__((ext_vector_type(2))) dbl2;
+    const dbl2 *src = reinterpret_cast<const dbl2 *>(a.rowLR + (size_t)r_lo * 2 * B);
+    dbl2 *dst = reinterpret_cast<dbl2 *>(lrow);
+    const int n2 = (dbg == 3) ? 0 : nrows * B;                          // 2B doubles per row = B double2
+    // 8 independent 16-byte loads in flight per thread before the first LDS store (memory-level parallelism)
+    for (int base = 0; base < n2; base += 192 * 8) {
+      dbl2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + u * 192 + tid;
+        if (i < n2) v[u] = src[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = base + u * 192 + tid;
+        if (i < n2) dst[i] = v[u];
+      }
+    }
+    for (int i = tid; i < nrows; i += 192) lE[i] = a.rowE[r_lo + i];
+  }
+  __syncthreads();
+  const int sl = tid / B, c = tid - sl * B;
+  const int s = s0 + sl;
+  if (sl >= TS || s >= nstates) return;
+  int rp_s = a.rowptr[s], rp_sm = s > 0 ? a.rowptr[s - 1] : a.rowptr[s], rp_s1 = a.rowptr[s + 1];
+  if (dbg == 1) { rp_sm = rp_s; rp_s1 = rp_s; }
+  if (s == a.N) {  // right blocks of the rows of state N-1 -> addend for the neighbour's first state
+    T Dh[B];
+    T gh = T(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) Dh[k] = T(0);
+    for (int rho = rp_sm; rho < rp_s; rho++) {
+      const T *row = lrow + (size_t)(rho - r_lo) * 2 * B + B;
+      const T Rc = row[c];
+#pragma unroll
+      for (int k = 0; k < B; k++) Dh[k] += Rc * row[k];
+      gh -= Rc * lE[rho - r_lo];
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = Dh[k];
+    a.halo_add[B * B + c] = gh;
+    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
+    return;
+  }
+  const int BS = 2 * B * B + B * a.R;
+  T *bp = a.blk + (size_t)s * BS;
+  T D[B], O[B];
+  T g = T(0);
+#pragma unroll
+  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
+  for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
+  for (int rho = rp_s; rho < rp_s1; rho++) {
+    const T *row = lrow + (size_t)(rho - r_lo) * 2 * B;
+    const T Lc = row[c], Rc = row[B + c];
+    const T e = lE[rho - r_lo];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const T Lk = row[k];
+      D[k] += Lc * Lk;
+      O[k] += Rc * Lk;
+    }
+    g -= Lc * e;
+    if (a.rowM) {
+      const int lm = a.rowLm[rho];
+      if (lm >= 0)
+        for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+    }
+  }
+  if (s > 0) {
+    for (int rho = rp_sm; rho < rp_s; rho++) {
+      const T *row = lrow + (size_t)(rho - r_lo) * 2 * B + B;
+      const T Rc = row[c];
+      const T e = lE[rho - r_lo];
+#pragma unroll
+      for (int k = 0; k < B; k++) D[k] += Rc * row[k];
+      g -= Rc * e;
+      if (a.rowM) {
+        const int lm = a.rowLm[rho];
+        if (lm >= 0)
+          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Rc * a.rowM[(size_t)rho * a.ld + q];
+      }
+    }
+  }
+  if (dbg == 2) { T acc2 = g; for (int k = 0; k < B; k++) acc2 += D[k] + O[k]; if (acc2 == T(1.2345e300)) bp[0] = acc2; return; }
+#pragma unroll
+  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
+  bp[2 * B * B + c] = g;
+  if (a.gsave) a.gsave[(size_t)s * B + c] = g;
+}
+
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan
 
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
@@ -697,6 +935,19 @@ __device__ __forceinline__ double lane_bcast(double v, int lane) {
 }
 __device__ __forceinline__ float lane_bcast(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// 1 / p to full precision: hardware reciprocal + two Newton steps (the 15-instruction IEEE division sequence is
+// the single most expensive piece of a pivot step; p is a positive pivot, no special values to honour)
+__device__ __forceinline__ double fast_rcp(double p) {
+  double r = __builtin_amdgcn_rcp(p);
+  r = fma(fma(-p, r, 1.0), r, r);
+  r = fma(fma(-p, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float p) {
+  float r = __builtin_amdgcn_rcpf(p);
+  r = fmaf(fmaf(-p, r, 1.0f), r, r);
+  return r;
 }
 
 template <typename T> struct FwdArgs {
@@ -718,8 +969,12 @@ template <typename T> struct FwdArgs {
 //   D~_{j+1} = D_{j+1} - O_j U_j,  F_{j+1} = -O_j V_j,  g~_{j+1} = g_{j+1} - O_j Y_j,
 //   separator:  D_sep -= F_j^T V_j,  g_sep -= F_j^T Y_j.
 // The lanes that held O^T become the D~ lanes of the next block (roles swap), so nothing moves.
-template <typename T, int B>
-__global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
+// FAST (4B + 2R <= 64): the separator sums live in B + R otherwise idle lanes ("A lanes") and are formed by the
+// very same instruction stream as the next-block update -- every lane executes  nxt -= Mat * col, the update lanes
+// with Mat = O_j and their own column, the A lanes with Mat = F_j^T and a V_j / Y_j column fetched from LDS --
+// which removes a whole B x B multiply-accumulate pass per block and keeps the live state at two B-vectors per lane.
+template <typename T, int B, bool FAST>
+__global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
   const int R = a.R;
   const int BS = 2 * B * B + B * R;
   const int AS = B * B + B * R;
@@ -729,16 +984,24 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
   const int lane = threadIdx.x;
   const bool has_sep = !a.no_sep;
   const bool right_exists = (e < a.n) || (a.last_has_right != 0);
+  constexpr int kVCols = FAST ? B + (64 - 4 * B) / 2 : 1;
   __shared__ T ldsO[B * B];
   __shared__ T ldsF[B * B];
+  __shared__ T ldsV[kVCols * B];
   int dbase = 0, obase = B;
   const int cF = lane - 2 * B;
   const bool isF = has_sep && cF >= 0 && cF < B;
   const int cR = lane - 3 * B;
   const bool isR = cR >= 0 && cR < R;
-  T col[B], acc[B];
+  const int cA = lane - (3 * B + R);                      // < B: column of the separator's D; >= B: rhs column
+  const bool isA = FAST && has_sep && cA >= 0 && cA < B + R;
+  T col[B];
+  T nxt[B];                 // update lanes: operand of block j+1;  A lanes: minus the separator sums (persistent)
+  T acc[FAST ? 1 : B];      // !FAST: separator sums in the F / rhs lanes
 #pragma unroll
-  for (int k = 0; k < B; k++) { col[k] = T(0); acc[k] = T(0); }
+  for (int k = 0; k < B; k++) { col[k] = T(0); nxt[k] = T(0); }
+#pragma unroll
+  for (int k = 0; k < (FAST ? 1 : B); k++) acc[k] = T(0);
 
   auto load_D_row = [&](int j, int r, T *out) {
     const T *p = a.blk + (size_t)j * BS + r * B;
@@ -784,9 +1047,10 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
     const bool last = (j == e - 1);
     const int cD = lane - dbase, cO = lane - obase;
     const bool isD = cD >= 0 && cD < B, isO = cO >= 0 && cO < B;
-    T nxt[B];
+    if (!isA) {
 #pragma unroll
-    for (int k = 0; k < B; k++) nxt[k] = T(0);
+      for (int k = 0; k < B; k++) nxt[k] = T(0);
+    }
     if (!last) {  // operands of block j+1, fetched early so the HBM latency hides under the elimination
       if (isD) load_O_row(j + 1, cD, nxt);
       else if (isO) load_D_row(j + 1, cO, nxt);
@@ -806,7 +1070,7 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
     for (int k = 0; k < B; k++) {
       const T p = lane_bcast(col[k], db + k);
       if (!(p > T(0)) && lane == 0) *a.flag = 1;
-      const T rowk = col[k] / p;
+      const T rowk = col[k] * fast_rcp(p);
 #pragma unroll
       for (int i = 0; i < B; i++) {
         if (i != k) {
@@ -823,12 +1087,20 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
     } else if (isF) {
 #pragma unroll
       for (int k = 0; k < B; k++) bp[cF * B + k] = col[k];          // V_j, column cF
+      if (FAST) {
+#pragma unroll
+        for (int k = 0; k < B; k++) ldsV[cF * B + k] = col[k];
+      }
     } else if (isR) {
 #pragma unroll
       for (int k = 0; k < B; k++) bp[2 * B * B + cR * B + k] = col[k];  // Y_j
+      if (FAST && has_sep) {
+#pragma unroll
+        for (int k = 0; k < B; k++) ldsV[(B + cR) * B + k] = col[k];
+      }
     }
     __syncthreads();
-    if (has_sep && (isF || isR)) {
+    if (!FAST && has_sep && (isF || isR)) {   // wide borders: separator sums in a pass of their own
 #pragma unroll
       for (int q = 0; q < B; q++) {
         T sacc = T(0);
@@ -837,27 +1109,24 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
         acc[q] += sacc;
       }
     }
-    T nw[B];
-    if (isO || isF || isR) {
+    // one B x B product per lane:  nxt -= Mat * col
+    const T *Mat = isA ? ldsF : ldsO;
+    if (isA) {
 #pragma unroll
-      for (int r = 0; r < B; r++) {
-        T sacc = T(0);
+      for (int k = 0; k < B; k++) col[k] = ldsV[cA * B + k];
+    } else if (!(isO || isF || isR)) {
 #pragma unroll
-        for (int k = 0; k < B; k++) sacc += ldsO[r * B + k] * col[k];
-        nw[r] = -sacc;
-      }
-    } else {
+      for (int k = 0; k < B; k++) col[k] = T(0);     // D lanes (and spare lanes) take the operand unchanged
+    }
 #pragma unroll
-      for (int r = 0; r < B; r++) nw[r] = T(0);
+    for (int r = 0; r < B; r++) {
+      T sacc = T(0);
+#pragma unroll
+      for (int k = 0; k < B; k++) sacc += Mat[r * B + k] * col[k];
+      nxt[r] -= sacc;
     }
     if (!last) {
-      if (isO || isR) {
-#pragma unroll
-        for (int r = 0; r < B; r++) col[r] = nxt[r] + nw[r];
-      } else if (isF) {
-#pragma unroll
-        for (int r = 0; r < B; r++) col[r] = nw[r];
-      } else if (isD) {
+      if (!isA) {
 #pragma unroll
         for (int r = 0; r < B; r++) col[r] = nxt[r];
       }
@@ -867,14 +1136,14 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
       const T *ra = (e == a.n) ? a.remote_add : nullptr;   // carry what is already owed to the outside separator
       if (isO) {
 #pragma unroll
-        for (int k = 0; k < B; k++) ua[cO * B + k] = nw[k] + (ra ? ra[cO * B + k] : T(0));              // -O U  (symmetric)
+        for (int k = 0; k < B; k++) ua[cO * B + k] = (ra ? ra[cO * B + k] : T(0)) + nxt[k];              // -O U  (symmetric)
       } else if (isR) {
 #pragma unroll
-        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = nw[k] + (ra ? ra[B * B + cR * B + k] : T(0));      // -O Y
+        for (int k = 0; k < B; k++) ua[B * B + cR * B + k] = (ra ? ra[B * B + cR * B + k] : T(0)) + nxt[k];      // -O Y
       } else if (isF) {
         T *uo = a.up_blk + (size_t)c * BS + B * B;
 #pragma unroll
-        for (int r = 0; r < B; r++) uo[r * B + cF] = nw[r];              // C = -O V, couples sep c -> sep c+1
+        for (int r = 0; r < B; r++) uo[r * B + cF] = nxt[r];             // C = -O V, couples sep c -> sep c+1
       }
     }
     __syncthreads();
@@ -882,16 +1151,20 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
 
   if (has_sep) {
     T *ub = a.up_blk + (size_t)c * BS;
-    if (isF) {
+    // separator block of the next level: D_sep - sum F^T V (row = column by symmetry), g_sep - sum F^T Y
+    const bool wD = FAST ? (isA && cA < B) : isF;
+    const bool wG = FAST ? (isA && cA >= B) : isR;
+    const int rD = FAST ? cA : cF, rG = FAST ? cA - B : cR;
+    if (wD) {
       T dr[B];
-      load_D_row(s, cF, dr);
+      load_D_row(s, rD, dr);
 #pragma unroll
-      for (int k = 0; k < B; k++) ub[cF * B + k] = dr[k] - acc[k];
-    } else if (isR) {
+      for (int k = 0; k < B; k++) ub[rD * B + k] = FAST ? dr[k] + nxt[k] : dr[k] - acc[FAST ? 0 : k];
+    } else if (wG) {
       T gr[B];
-      load_G_col(s, cR, gr);
+      load_G_col(s, rG, gr);
 #pragma unroll
-      for (int k = 0; k < B; k++) ub[2 * B * B + cR * B + k] = gr[k] - acc[k];
+      for (int k = 0; k < B; k++) ub[2 * B * B + rG * B + k] = FAST ? gr[k] + nxt[k] : gr[k] - acc[FAST ? 0 : k];
     }
     if (j0 >= e) {  // chunk without interior: the separator keeps its original coupling
       if (lane < B) {
@@ -923,12 +1196,13 @@ __global__ void __launch_bounds__(64) k_chunk_forward(FwdArgs<T> a) {
 
 template <typename T> struct BwdArgs {
   const T *blk;   // eliminated records of this level
-  T *x;           // n x R x B solutions of this level
+  T *x;           // n x R x B solutions of this level (+ one slot for the neighbour rank's separator)
   const T *xup;   // solutions of the next level (separators) or null at the top
   int n, m, R, no_sep, last_has_right;
 };
 
-// x_j = Y_j - U_j x_{j+1} - V_j x_sep, right to left through the chunk
+// x_j = Y_j - U_j x_{j+1} - V_j x_sep, right to left through the chunk.  Lane (k, rr) owns component k of the rhs
+// columns rr, rr + RG, ...; the factors of block j-1 are fetched while block j is being substituted.
 template <typename T, int B>
 __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   const int R = a.R;
@@ -958,17 +1232,24 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
     for (int idx = lane; idx < R * B; idx += 64) a.x[(size_t)a.n * R * B + idx] = xa[idx];
   const int j0 = has_sep ? s + 1 : s;
   int ping = 0;
+  T Ur[B], Vr[B], Un[B], Vn[B];
+#pragma unroll
+  for (int q = 0; q < B; q++) { Ur[q] = T(0); Vr[q] = T(0); Un[q] = T(0); Vn[q] = T(0); }
+  if (active && e - 1 >= j0) {
+    const T *bp = a.blk + (size_t)(e - 1) * BS;
+#pragma unroll
+    for (int q = 0; q < B; q++) { Ur[q] = bp[B * B + q * B + k]; Vr[q] = has_sep ? bp[q * B + k] : T(0); }
+  }
   for (int j = e - 1; j >= j0; --j) {
     const T *bp = a.blk + (size_t)j * BS;
     const T *cur = ping ? xb : xa;
     T *nx = ping ? xa : xb;
-    if (active) {
-      T Ur[B], Vr[B];
+    if (active && j - 1 >= j0) {   // prefetch the factors of block j-1
+      const T *bq = a.blk + (size_t)(j - 1) * BS;
 #pragma unroll
-      for (int q = 0; q < B; q++) {
-        Ur[q] = bp[B * B + q * B + k];
-        Vr[q] = has_sep ? bp[q * B + k] : T(0);
-      }
+      for (int q = 0; q < B; q++) { Un[q] = bq[B * B + q * B + k]; Vn[q] = has_sep ? bq[q * B + k] : T(0); }
+    }
+    if (active) {
       for (int r = rr; r < R; r += RG) {
         T v = bp[2 * B * B + r * B + k];
 #pragma unroll
@@ -977,6 +1258,8 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
         a.x[(size_t)j * R * B + r * B + k] = v;
       }
     }
+#pragma unroll
+    for (int q = 0; q < B; q++) { Ur[q] = Un[q]; Vr[q] = Vn[q]; }
     __syncthreads();
     ping ^= 1;
   }
