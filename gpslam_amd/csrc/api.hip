@@ -346,8 +346,13 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   const int tile_rows = h->asm_tile_rows;
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
-    static const int amode = getenv("GPSLAM_ASM_MODE") ? atoi(getenv("GPSLAM_ASM_MODE")) : 0;   // 0 shfl, 1 lds, 2 direct
+    static const int amode = getenv("GPSLAM_ASM_MODE") ? atoi(getenv("GPSLAM_ASM_MODE")) : 0;   // 0 ghost, 1 lds, 2 direct, 3 shfl
     if (amode == 0) {
+      if constexpr (64 / BB >= 2) {
+        const int waves = nblocks(nstates, 64 / BB - 1);
+        k_assemble_ghost<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);
+      }
+    } else if (amode == 3) {
       constexpr int G = 64 / BB;
       const int waves = nblocks(nstates, G);
       k_assemble_shfl<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);

@@ -83,25 +83,61 @@ template <typename T> struct GpArgs {
   UMat<T> U;
 };
 
+// Cooperative row store: every lane of a wave has deposited one row (W doubles, W even) of ITS factor in the wave's
+// LDS staging buffer; the wave then writes the 64 rows as 16-byte pieces, consecutive lanes on consecutive pieces of
+// the same row, so that each store instruction covers whole 64-byte sectors instead of 64 scattered 16-byte
+// fragments (per-lane row stores are store-issue bound and write 2.4x the bytes to HBM: profiles/round1_v2).
+// srow[l] = first row of lane l's factor in the row table, or -1.
+template <typename T, int W>
+__device__ __forceinline__ void wave_store_rows(const T *st, const int *srow, int lane, int roff, T *table) {
+  constexpr int P = W / 2, LS = W + 2;
+  typedef T V2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int t = 0; t < P; t++) {
+    const int q = t * 64 + lane;
+    const int fl = q / P, piece = q - fl * P;
+    const int r0 = srow[fl];
+    if (r0 >= 0) {
+      const V2 v = *reinterpret_cast<const V2 *>(st + fl * LS + piece * 2);
+      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + piece * 2) = v;
+    }
+  }
+}
+
 // MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
 template <typename T, int MF, int MODE>
 __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   constexpr bool JAC = (MODE != 1);
+  constexpr int LS = 2 * b + 2;                       // staging stride (16-byte aligned, conflict-free for b128)
+  __shared__ T stage[MODE == 0 ? 2 * 64 * LS : 1];
+  __shared__ int srow[MODE == 0 ? 128 : 1];
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool valid = f < a.count;
   T err = T(0);
-  if (f < a.count) {
+  T e[b];
+  T Jt[JAC ? d * 2 * b : 1], Jb[JAC ? d * 2 * b : 1];
+  T dt = T(1);
+  if (valid) {
     const int i = a.left[f];
-    const T dt = a.dt[f];
+    dt = a.dt[f];
     T p1[pd], p2[pd], v1[d], v2[d];
 #pragma unroll
     for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
 #pragma unroll
     for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
-    T e[b];
-    T Jt[JAC ? d * 2 * b : 1], Jb[JAC ? d * 2 * b : 1];
     GpPrior<T, MF, JAC>::eval(p1, v1, p2, v2, dt, e, Jt, Jb);
-    if (MODE == 2) {
+  } else {
+#pragma unroll
+    for (int k = 0; k < b; k++) e[k] = T(0);
+    if (JAC) {
+#pragma unroll
+      for (int k = 0; k < d * 2 * b; k++) { Jt[k] = T(0); Jb[k] = T(0); }
+    }
+  }
+  if (MODE == 2) {
+    if (valid) {
 #pragma unroll
       for (int k = 0; k < b; k++) a.out_e[(size_t)f * b + k] = e[k];
       if (a.out_H) {
@@ -116,41 +152,53 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
               H[(q * b + d + r) * d + c] = Jb[r * 2 * b + q * d + c];
             }
       }
-    } else {
-      // whitening R = chol_upper(Q^-1(dt)) = [[sa, sb], [0, sc]] (x) U, U = chol_upper(Qc^-1)
-      // (noiseModel::Gaussian::Covariance(calcQ(Qc, dt)), GaussianProcessPriorPose3.h:46)
-      const T sq = sqrt(dt);
-      const T sa = T(3.4641016151377545870548926830117) / (dt * sq);  // sqrt(12 / dt^3)
-      const T sb = T(-1.7320508075688772935274463415059) / sq;        // (-6 / dt^2) / sa
-      const T sc = T(1) / sq;                                          // sqrt(4/dt - sb^2)
-      const int row0 = (MODE == 0) ? a.row0[f] : 0;
+    }
+  } else {
+    // whitening R = chol_upper(Q^-1(dt)) = [[sa, sb], [0, sc]] (x) U, U = chol_upper(Qc^-1)
+    // (noiseModel::Gaussian::Covariance(calcQ(Qc, dt)), GaussianProcessPriorPose3.h:46)
+    const T sq = sqrt(dt);
+    const T sa = T(3.4641016151377545870548926830117) / (dt * sq);  // sqrt(12 / dt^3)
+    const T sb = T(-1.7320508075688772935274463415059) / sq;        // (-6 / dt^2) / sa
+    const T sc = T(1) / sq;                                          // sqrt(4/dt - sb^2)
+    T *st = stage + (MODE == 0 ? wv * 64 * LS : 0);
+    T *mine = st + (MODE == 0 ? lane * LS : 0);
+    const int *sr = srow + (MODE == 0 ? wv * 64 : 0);
+    int row0 = 0;
+    if (MODE == 0) {
+      row0 = valid ? a.row0[f] : -1;
+      srow[threadIdx.x] = row0;
+    }
 #pragma unroll
-      for (int rho = 0; rho < d; rho++) {
-        T wt = T(0), wb = T(0);
+    for (int rho = 0; rho < d; rho++) {
+      T wt = T(0), wb = T(0);
 #pragma unroll
-        for (int r = rho; r < d; r++) {
-          wt += a.U.u[rho * d + r] * (sa * e[r] + sb * e[d + r]);
-          wb += a.U.u[rho * d + r] * e[d + r];
-        }
-        wb *= sc;
-        err += wt * wt + wb * wb;
-        if (MODE == 0) {
+      for (int r = rho; r < d; r++) {
+        wt += a.U.u[rho * d + r] * (sa * e[r] + sb * e[d + r]);
+        wb += a.U.u[rho * d + r] * e[d + r];
+      }
+      wb *= sc;
+      err += wt * wt + wb * wb;
+      if (MODE == 0) {
+        if (valid) {
           a.rowE[row0 + rho] = wt;
           a.rowE[row0 + d + rho] = wb;
-          T *rt = a.rowLR + (size_t)(row0 + rho) * 2 * b;
-          T *rb = a.rowLR + (size_t)(row0 + d + rho) * 2 * b;
-#pragma unroll
-          for (int col = 0; col < 2 * b; col++) {
-            T vt = T(0), vb = T(0);
-#pragma unroll
-            for (int r = rho; r < d; r++) {
-              vt += a.U.u[rho * d + r] * (sa * Jt[r * 2 * b + col] + sb * Jb[r * 2 * b + col]);
-              vb += a.U.u[rho * d + r] * Jb[r * 2 * b + col];
-            }
-            rt[col] = vt;
-            rb[col] = sc * vb;
-          }
         }
+#pragma unroll
+        for (int col = 0; col < 2 * b; col++) {
+          T vt = T(0);
+#pragma unroll
+          for (int r = rho; r < d; r++) vt += a.U.u[rho * d + r] * (sa * Jt[r * 2 * b + col] + sb * Jb[r * 2 * b + col]);
+          mine[col] = vt;
+        }
+        wave_store_rows<T, 2 * b>(st, sr, lane, rho, a.rowLR);
+#pragma unroll
+        for (int col = 0; col < 2 * b; col++) {
+          T vb = T(0);
+#pragma unroll
+          for (int r = rho; r < d; r++) vb += a.U.u[rho * d + r] * Jb[r * 2 * b + col];
+          mine[col] = sc * vb;
+        }
+        wave_store_rows<T, 2 * b>(st, sr, lane, d + rho, a.rowLR);
       }
     }
   }
@@ -177,11 +225,22 @@ template <typename T> struct FacArgs {
 template <typename T, int MF, int KIND, bool JAC>
 __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
+  constexpr int LS = 2 * b + 2;
+  __shared__ T stage[JAC ? 2 * 64 * LS : 1];
+  __shared__ int srow[JAC ? 128 : 1];
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool valid = f < a.count;
   T err = T(0);
-  if (f < a.count) {
+  T e[d], H1[JAC ? d * d : 1], H2[JAC ? d * d : 1];
+#pragma unroll
+  for (int k = 0; k < d; k++) e[k] = T(0);
+  if (JAC) {
+#pragma unroll
+    for (int k = 0; k < d * d; k++) { H1[k] = T(0); H2[k] = T(0); }
+  }
+  if (valid) {
     const int i = a.idx[f];
-    T e[d], H1[JAC ? d * d : 1], H2[JAC ? d * d : 1];
     if (KIND == 1) {
 #pragma unroll
       for (int k = 0; k < d; k++) e[k] = a.vel[(size_t)k * a.stride + i] - a.meas[(size_t)f * d + k];
@@ -198,28 +257,31 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
         PoseFactors<T, MF, JAC>::between(m, x1, x2, a.chart, e, H1, H2);
       }
     }
-    const int row0 = JAC ? a.row0[f] : 0;
+  }
+  const int row0 = (JAC && valid) ? a.row0[f] : -1;
+  T *st = stage + (JAC ? wv * 64 * LS : 0);
+  T *mine = st + (JAC ? lane * LS : 0);
+  if (JAC) srow[threadIdx.x] = row0;
 #pragma unroll
-    for (int r = 0; r < d; r++) {
-      const T w = T(1) / a.sig[(size_t)f * d + r];
-      const T we = e[r] * w;
-      err += we * we;
-      if (JAC) {
-        a.rowE[row0 + r] = we;
-        T *row = a.rowLR + (size_t)(row0 + r) * 2 * b;
+  for (int r = 0; r < d; r++) {
+    const T w = valid ? T(1) / a.sig[(size_t)f * d + r] : T(0);
+    const T we = e[r] * w;
+    err += we * we;
+    if (JAC) {
+      if (valid) a.rowE[row0 + r] = we;
 #pragma unroll
-        for (int c = 0; c < 2 * b; c++) row[c] = T(0);
-        if (KIND == 1) {
-          row[d + r] = w;
-        } else {
+      for (int c = 0; c < 2 * b; c++) mine[c] = T(0);
+      if (KIND == 1) {
+        mine[d + r] = w;
+      } else {
 #pragma unroll
-          for (int c = 0; c < d; c++) row[c] = w * H1[r * d + c];
-          if (KIND == 2) {
+        for (int c = 0; c < d; c++) mine[c] = w * H1[r * d + c];
+        if (KIND == 2) {
 #pragma unroll
-            for (int c = 0; c < d; c++) row[b + c] = w * H2[r * d + c];
-          }
+          for (int c = 0; c < d; c++) mine[b + c] = w * H2[r * d + c];
         }
       }
+      wave_store_rows<T, 2 * b>(st, srow + wv * 64, lane, r, a.rowLR);
     }
   }
   const T tot = block_sum(T(0.5) * err);
@@ -804,6 +866,113 @@ __global__ void __launch_bounds__(256) k_assemble_shfl(AsmArgs<T> a) {
     }
   }
   if (!live) return;
+  if (sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
+#pragma unroll
+    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
+    a.halo_add[B * B + c] = gsum;
+    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
+  bp[2 * B * B + c] = gsum;
+  if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
+}
+
+// Wave-cooperative assembly, every row fetched once.  A wave owns G - 1 = 64 / B - 1 consecutive states plus, in
+// its first lane group, the state before them as a "ghost" that only contributes its rows' right halves.  The B
+// lanes of a group each load ONE element of the left and of the right half of their state's current Jacobian row
+// (coalesced 8-byte-per-lane loads, two rows in flight) and publish them in a per-wave LDS exchange buffer; a lane
+// then reads back its own row's left half (-> D_s += L^T L, O_s += R^T L) and the right half published by the
+// group of state s - 1 (-> D_s += R^T R).  Compared with letting every group re-read the rows of s - 1 this
+// removes the second pass over the row table (2x HBM over-fetch measured, profiles/round1_v3) and a third of the
+// loop iterations.  DS operations of one wave execute in order, so no barrier is needed; two buffers alternate.
+template <typename T, int B>
+__global__ void __launch_bounds__(256) k_assemble_ghost(AsmArgs<T> a) {
+  constexpr int G = 64 / B;                       // lane groups per wave (the first one is the ghost)
+  static_assert(G >= 2, "needs at least one real state per wave");
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int g = lane / B, c = lane - g * B;
+  const int nstates = a.N + (a.halo_add ? 1 : 0);
+  const int s = wave * (G - 1) + g - 1;           // ghost: the state before the wave's first
+  const bool owner = (g < G) && s >= 0 && s < a.N;           // has rows to load
+  const bool out = (g >= 1) && (g < G) && s < nstates;       // produces a block (or the halo addend)
+  const int sc = out ? s : 0;
+  const int gb = g * B, gp = (g >= 1 ? g - 1 : 0) * B;
+  int rp_s = 0, n_own = 0;
+  if (owner) {
+    rp_s = a.rowptr[s];
+    n_own = a.rowptr[s + 1] - rp_s;
+  }
+  int n_max = n_own;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
+  const int rp_prev = __shfl(rp_s, gp, 64);       // first row of state s - 1 (landmark columns of its rows)
+  const int n_prev = __shfl(n_own, gp, 64);
+  T D[B], O[B];
+  T gsum = T(0);
+#pragma unroll
+  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
+  constexpr int XS = 128 + ((G + 1) & ~1);        // per wave and parity: L[64] | R[64] | e[G]
+  __shared__ T xch[4][2][XS];
+  T *xw = &xch[threadIdx.x >> 6][0][0];
+  const int BS = 2 * B * B + B * a.R;
+  T *bp = a.blk + (size_t)sc * BS;
+  const bool isblk = out && sc < a.N;
+  if (isblk) for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
+  auto ld = [&](int i, T &Lc, T &Rc, T &e) {
+    Lc = T(0); Rc = T(0); e = T(0);
+    if (i < n_own) {
+      const T *row = a.rowLR + (size_t)(rp_s + i) * 2 * B;
+      if (g >= 1) Lc = row[c];
+      Rc = row[B + c];
+      e = a.rowE[rp_s + i];
+    }
+  };
+  T Lc0, Rc0, e0, Lc1, Rc1, e1;
+  ld(0, Lc0, Rc0, e0);
+  ld(1, Lc1, Rc1, e1);
+  for (int i = 0; i < n_max; i++) {
+    const T Lc = Lc0, Rc = Rc0, e = e0;
+    Lc0 = Lc1; Rc0 = Rc1; e0 = e1;
+    ld(i + 2, Lc1, Rc1, e1);
+    T *buf = xw + (i & 1) * XS;
+    buf[lane] = Lc;
+    buf[64 + lane] = Rc;
+    if (c == 0 && g < G) buf[128 + g] = e;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const T *Lrow = buf + gb;
+    const T *Prow = buf + 64 + gp;                // right half of the current row of state s - 1
+    const T Pc = Prow[c];
+    const T ep = buf[128 + (g >= 1 ? g - 1 : 0)];
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      const T Lk = Lrow[k];
+      D[k] += Lc * Lk;
+      O[k] += Rc * Lk;
+      D[k] += Pc * Prow[k];
+    }
+    gsum -= Lc * e;
+    gsum -= Pc * ep;
+    if (a.rowM && isblk) {
+      if (i < n_own) {
+        const int rho = rp_s + i;
+        const int lm = a.rowLm[rho];
+        if (lm >= 0)
+          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+      }
+      if (i < n_prev) {
+        const int rho = rp_prev + i;
+        const int lm = a.rowLm[rho];
+        if (lm >= 0)
+          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Pc * a.rowM[(size_t)rho * a.ld + q];
+      }
+    }
+  }
+  if (!out) return;
   if (sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
 #pragma unroll
     for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
