@@ -27,6 +27,28 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
+# rocprofv3 kernel names of the kernels bench.py times itself (time_kernel order); the per-launch HBM traffic of the
+# same kernels on the same workload comes from the committed PMC passes (scripts/collect_profiles.sh ->
+# profiles/<round>_pmc.json; explicit-size L2->fabric request counters TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ{,_64B}).
+PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
+PMC_KEYS = ["k_gp<double, 3, 0>", "k_assemble", "k_chunk_forward<double, 12, true>@%d", "k_chunk_backward<double, 12>@%d",
+            "k_retract<double, 3>"]
+
+
+def pmc_traffic(which, n_states, chunk=16):
+    """HBM bytes per launch of kernel `which` from the committed counter passes, or None if they do not cover it."""
+    try:
+        kern = json.load(open(PMC_FILE))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    key = PMC_KEYS[which]
+    if "%d" in key:
+        key = key % (64 * ((n_states + chunk - 1) // chunk))
+    for k, c in kern.items():
+        if k.startswith(key) and "ea_read_bytes" in c and c.get("states", n_states) == n_states:
+            return float(c["ea_read_bytes"] + c["ea_write_bytes"])
+    return None
+
 
 def cpu_baseline(problem, iters=3):
     """The oracle (CPU restatement of the reference algorithm, 1 thread) timed on the same workload."""
@@ -182,7 +204,9 @@ def main():
                                        zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
             "kernel_ms": {n: float(v) for n, v in zip(names, kms)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N),
+                         "traffic_source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum, "
+                                           "profiles/latest_pmc.json (bytes per launch, same workload)",
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:

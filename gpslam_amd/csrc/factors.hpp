@@ -84,6 +84,96 @@ template <typename T> GD V6<T> se3_jrinv_apply(V6<T> xi, V6<T> x) {
   return {top, so3_jrinv_apply(xi.w, x.v - se3_Q_apply(xi.w, xi.v, top))};
 }
 
+// The same maps with the trigonometric coefficients hoisted: one sincos per distinct rotation vector instead of one
+// sin and one cos inside every so3 / Q evaluation (the finite difference below needs 7 distinct angles, not 78
+// inlined trig call sites -- two thirds of the K1 instruction stream before this change, profiles/round1_v3).
+template <typename T> struct JrK {
+  T c;            // so3 Jr^-1: 1/th^2 - (1 + cos th) / (2 th sin th)         (Pose3utils.cpp:215-224)
+  T qa, qb, qc;   // rightJacobianPose3Q coefficients incl. the |th| > 1e-5 branch (Pose3utils.cpp:92-113)
+  bool ident;     // th^2 <= eps: Jr^-1 = I exactly
+};
+GD void sincos_t(double x, double *s, double *c) { sincos(x, s, c); }
+GD void sincos_t(float x, float *s, float *c) { sincosf(x, s, c); }
+template <typename T> GD JrK<T> jr_coefs(V3<T> w) {
+  JrK<T> k;
+  const T th2 = dot(w, w);
+  const T th = sqrt(th2);
+  T s, co;
+  sincos_t(th, &s, &co);
+  k.ident = th2 <= Eps<T>::v;
+  k.c = k.ident ? T(0) : T(1) / th2 - (T(1) + co) / (T(2) * th * s);
+  if (fabs(th) > T(1e-5)) {
+    const T t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
+    k.qa = (th - s) / t3;
+    k.qb = (T(1) - T(0.5) * t2 - co) / t4;
+    k.qc = T(-0.5) * ((T(1) - T(0.5) * t2 - co) / t4 - T(3) * (th - s - t3 / T(6)) / t5);
+  } else {
+    k.qa = T(1) / T(6);
+    k.qb = T(1) / T(24);
+    k.qc = T(-0.5) * (T(1) / T(24) + T(3) / T(120));
+  }
+  return k;
+}
+template <typename T> GD V3<T> so3_jrinv_apply_k(const JrK<T> &k, V3<T> w, V3<T> a) {
+  if (k.ident) return a;
+  const V3<T> wa = cross(w, a);
+  return a + T(0.5) * wa + k.c * cross(w, wa);
+}
+template <typename T> GD V3<T> se3_Q_apply_k(const JrK<T> &k, V3<T> w, V3<T> rho, V3<T> b) {
+  const V3<T> Yb = cross(rho, b), Xb = cross(w, b);
+  const V3<T> XYb = cross(w, Yb), YXb = cross(rho, Xb), XXb = cross(w, Xb);
+  const V3<T> XYXb = cross(w, YXb);
+  const V3<T> XXYb = cross(w, XYb), YXXb = cross(rho, XXb);
+  const V3<T> XYXXb = cross(w, cross(rho, cross(w, Xb))), XXYXb = cross(w, XYXb);
+  return T(-0.5) * Yb + k.qa * (XYb + YXb - XYXb) + k.qb * (XXYb + YXXb - T(3) * XYXb) + k.qc * (XYXXb + XXYXb);
+}
+template <typename T> GD V6<T> se3_jrinv_apply_k(const JrK<T> &k, V6<T> xi, V6<T> x) {
+  const V3<T> top = so3_jrinv_apply_k(k, xi.w, x.w);
+  return {top, so3_jrinv_apply_k(k, xi.w, x.v - se3_Q_apply_k(k, xi.w, xi.v, top))};
+}
+// rightJacobianPose3inv as a matrix from hoisted coefficients (same formulas as se3_jrinv / se3_Q in lie.hpp)
+template <typename T> GD BL6<T> se3_jrinv_k(const JrK<T> &k, V6<T> xi) {
+  const M3<T> X = skew(xi.w), Y = skew(xi.v);
+  const M3<T> Jw = k.ident ? M3<T>::identity() : M3<T>::identity() + T(0.5) * X + k.c * (X * X);
+  const M3<T> XY = X * Y, YX = Y * X, XYX = X * YX;
+  const M3<T> t1 = XY + YX - XYX;
+  const M3<T> t2m = X * XY + YX * X - T(3) * XYX;
+  const M3<T> t3m = XYX * X + X * XYX;
+  const M3<T> Q = T(-0.5) * Y + k.qa * t1 + k.qb * t2m + k.qc * t3m;
+  return {Jw, neg(Jw * Q * Jw), Jw};
+}
+// central-difference derivative of Jr^-1(xi) x (see se3_jrinv_times_x_fd below); k0 = jr_coefs(xi.w) serves the six
+// evaluations that perturb only the translational half
+template <typename T> GD BL6<T> se3_jrinv_times_x_fd_k(const JrK<T> &k0, V6<T> xi, V6<T> x) {
+  const T h = T(1e-6);
+  const T s = T(1) / (T(2) * h);
+  BL6<T> D;
+  D.A = M3<T>::zero();
+  D.C = M3<T>::zero();
+  D.D = M3<T>::zero();
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    V6<T> xp = xi, xn = xi;
+    if (i == 0) { xp.w.x += h; xn.w.x -= h; }
+    if (i == 1) { xp.w.y += h; xn.w.y -= h; }
+    if (i == 2) { xp.w.z += h; xn.w.z -= h; }
+    if (i == 3) { xp.v.x += h; xn.v.x -= h; }
+    if (i == 4) { xp.v.y += h; xn.v.y -= h; }
+    if (i == 5) { xp.v.z += h; xn.v.z -= h; }
+    V6<T> col;
+    if (i < 3) {
+      const JrK<T> kp = jr_coefs(xp.w), kn = jr_coefs(xn.w);
+      col = s * (se3_jrinv_apply_k(kp, xp, x) - se3_jrinv_apply_k(kn, xn, x));
+      D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
+      D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
+    } else {
+      col = s * (se3_jrinv_apply_k(k0, xp, x) - se3_jrinv_apply_k(k0, xn, x));
+      D.D.m[0 + (i - 3)] = col.v.x; D.D.m[3 + (i - 3)] = col.v.y; D.D.m[6 + (i - 3)] = col.v.z;
+    }
+  }
+  return D;
+}
+
 // d( Jr^-1(xi) * x ) / d xi by central differences with h = 1e-6: the construction of
 // jacobianMethodNumercialDiff(rightJacobianPose3inv, xi, x) (Pose3utils.cpp:167-179, default dxi Pose3utils.h:57),
 // column i = (Jr^-1(xi + h e_i) x - Jr^-1(xi - h e_i) x) / (2h).  The reference subtracts the two 6x6 matrices

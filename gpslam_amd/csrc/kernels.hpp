@@ -88,9 +88,11 @@ template <typename T> struct GpArgs {
 // the same row, so that each store instruction covers whole 64-byte sectors instead of 64 scattered 16-byte
 // fragments (per-lane row stores are store-issue bound and write 2.4x the bytes to HBM: profiles/round1_v2).
 // srow[l] = first row of lane l's factor in the row table, or -1.
-template <typename T, int W>
-__device__ __forceinline__ void wave_store_rows(const T *st, const int *srow, int lane, int roff, T *table) {
-  constexpr int P = W / 2, LS = W + 2;
+// wave_store_part: the lanes staged HW (even) doubles each with stride HW + 2; they land at columns
+// [coloff, coloff + HW) of row (first row of the lane's factor) + roff of a table with W doubles per row.
+template <typename T, int W, int HW>
+__device__ __forceinline__ void wave_store_part(const T *st, const int *srow, int lane, int roff, int coloff, T *table) {
+  constexpr int P = HW / 2, LS = HW + 2;
   typedef T V2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int t = 0; t < P; t++) {
@@ -99,7 +101,128 @@ __device__ __forceinline__ void wave_store_rows(const T *st, const int *srow, in
     const int r0 = srow[fl];
     if (r0 >= 0) {
       const V2 v = *reinterpret_cast<const V2 *>(st + fl * LS + piece * 2);
-      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + piece * 2) = v;
+      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + coloff + piece * 2) = v;
+    }
+  }
+}
+template <typename T, int W>
+__device__ __forceinline__ void wave_store_rows(const T *st, const int *srow, int lane, int roff, T *table) {
+  wave_store_part<T, W, W>(st, srow, lane, roff, 0, table);
+}
+// HW consecutive scalars per lane (stride HW + 2) to table[first row + k]: 8-byte pieces (the first row may be odd)
+template <typename T, int HW>
+__device__ __forceinline__ void wave_store_scalars(const T *st, const int *srow, int lane, T *table) {
+  constexpr int LS = HW + 2;
+#pragma unroll
+  for (int t = 0; t < HW; t++) {
+    const int q = t * 64 + lane;
+    const int fl = q / HW, k = q - fl * HW;
+    const int r0 = srow[fl];
+    if (r0 >= 0) table[r0 + k] = st[fl * LS + k];
+  }
+}
+
+// Row rho of U * M, U upper triangular d x d (row-major, d = 6), M block lower-triangular [[A, 0], [C, D]]:
+// only the structurally non-zero products are formed.
+template <typename T>
+__device__ __forceinline__ void utri_times_bl6_row(const T *U, const BL6<T> &M, int rho, T *out) {
+#pragma unroll
+  for (int c = 0; c < 6; c++) {
+    T acc = T(0);
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+      if (r < rho) continue;
+      if (r < 3 && c >= 3) continue;
+      acc += U[rho * 6 + r] * bl6_at(M, r, c);
+    }
+    out[c] = acc;
+  }
+}
+
+// K1 for GaussianProcessPriorPose3 (GaussianProcessPriorPose3.h:60-98), whitened rows straight into the row table.
+// The 12 x 24 Jacobian is never held as a whole: with Jinv = Jr^-1(r), FD = d(Jinv v2)/dr, the right half
+// [H3 H4] = [[Jinv, 0], [FD Jinv, Jinv]] is whitened and stored first, then the left half
+// [H1 H2] = [[J, -dt I], [FD J, -I]], J = -Jinv Ad(h^-1); whitening R = [[sa U, sb U], [0, sc U]] is applied as
+// U x (block lower-triangular) products row by row, skipping the structural zeros.  Peak live state is FD + two
+// 6x6 blocks instead of two 6 x 24 arrays, which is what lets two waves share a SIMD.
+template <typename T>
+__device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, int f, T *st, const int *sr, int lane, T &err) {
+  constexpr int LS = 14;
+  T *mine = st + lane * LS;
+  const T *U = a.U.u;
+  T p1[12], p2[12], v1[6], v2[6];
+  T dt = T(1);
+#pragma unroll
+  for (int k = 0; k < 12; k++) { p1[k] = (k == 0 || k == 4 || k == 8) ? T(1) : T(0); p2[k] = p1[k]; }   // idle lane: identity
+#pragma unroll
+  for (int k = 0; k < 6; k++) { v1[k] = T(0); v2[k] = T(0); }
+  if (valid) {
+    const int i = a.left[f];
+    dt = a.dt[f];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+  }
+  const SE3<T> h = se3_between(as_se3(p1), as_se3(p2));
+  const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
+  const JrK<T> k0 = jr_coefs(r.w);
+  const BL6<T> Jinv = se3_jrinv_k(k0, r);     // :76
+  const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+  const T sq = sqrt(dt);
+  const T sa = T(3.4641016151377545870548926830117) / (dt * sq);  // sqrt(12 / dt^3)
+  const T sb = T(-1.7320508075688772935274463415059) / sq;        // (-6 / dt^2) / sa
+  const T sc = T(1) / sq;                                          // sqrt(4/dt - sb^2)
+  {
+    const V6<T> top = r - dt * u1;            // :97
+    const V6<T> bot = Jinv * u2 - u1;
+    const T e[12] = {top.w.x, top.w.y, top.w.z, top.v.x, top.v.y, top.v.z, bot.w.x, bot.w.y, bot.w.z, bot.v.x, bot.v.y, bot.v.z};
+#pragma unroll
+    for (int rho = 0; rho < 6; rho++) {
+      T wt = T(0), wb = T(0);
+#pragma unroll
+      for (int q = rho; q < 6; q++) {
+        wt += U[rho * 6 + q] * (sa * e[q] + sb * e[6 + q]);
+        wb += U[rho * 6 + q] * e[6 + q];
+      }
+      wb *= sc;
+      err += wt * wt + wb * wb;
+      mine[rho] = wt;
+      mine[6 + rho] = wb;
+    }
+    wave_store_scalars<T, 12>(st, sr, lane, a.rowE);
+  }
+  const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90) -- computed once, used twice
+  {   // right state: H3 = [Jinv; FD Jinv] (:88-93), H4 = [0; Jinv] (:95)
+    const BL6<T> P3 = FD * Jinv;
+#pragma unroll
+    for (int rho = 0; rho < 6; rho++) {
+      T x[6], y[6];
+      utri_times_bl6_row(U, Jinv, rho, x);
+      utri_times_bl6_row(U, P3, rho, y);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sb * x[c]; }
+      wave_store_part<T, 24, 12>(st, sr, lane, rho, 12, a.rowLR);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { mine[c] = sc * y[c]; mine[6 + c] = sc * x[c]; }
+      wave_store_part<T, 24, 12>(st, sr, lane, 6 + rho, 12, a.rowLR);
+    }
+  }
+  {   // left state: H1 = [J; FD J], J = Hlog Hcomp1 Hinv = -Jinv Ad(h^-1) (:79-84), H2 = [-dt I; -I] (:86)
+    const BL6<T> J = neg(Jinv * se3_adjoint(se3_inverse(h)));
+    const BL6<T> P1 = FD * J;
+    const T k2 = -(sa * dt + sb);
+#pragma unroll
+    for (int rho = 0; rho < 6; rho++) {
+      T x[6], y[6];
+      utri_times_bl6_row(U, J, rho, x);
+      utri_times_bl6_row(U, P1, rho, y);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = (c >= rho) ? k2 * U[rho * 6 + c] : T(0); }
+      wave_store_part<T, 24, 12>(st, sr, lane, rho, 0, a.rowLR);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { mine[c] = sc * y[c]; mine[6 + c] = (c >= rho) ? -sc * U[rho * 6 + c] : T(0); }
+      wave_store_part<T, 24, 12>(st, sr, lane, 6 + rho, 0, a.rowLR);
     }
   }
 }
@@ -116,6 +239,13 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool valid = f < a.count;
   T err = T(0);
+  if constexpr (MF == POSE3 && MODE == 0) {
+    srow[threadIdx.x] = valid ? a.row0[f] : -1;
+    gp_pose3_rows<T>(a, valid, f, stage + wv * 64 * LS, srow + wv * 64, lane, err);
+    const T tot = block_sum(T(0.5) * err);
+    if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+    return;
+  }
   T e[b];
   T Jt[JAC ? d * 2 * b : 1], Jb[JAC ? d * 2 * b : 1];
   T dt = T(1);

@@ -182,7 +182,10 @@ int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double
  * out[0] linearize, out[1] assemble, out[2] solve, out[3] retract+error, out[4] total */
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
 /* run `iters` Gauss-Newton iterations back to back with no host synchronisation in between (the benchmark
- * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL */
+ * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL.
+ * The error of the state an iteration produces is the error the next iteration's linearisation evaluates, so
+ * inside the run it is computed once (by that linearisation) and only the last iteration is followed by an
+ * error-only pass; st->error_before / error_after refer to the last iteration. */
 int gpslam_hip_run_gn(gpslam_hip_handle *h, int32_t iters, gpslam_hip_stats *st, double *out5);
 
 /* average device time (ms, hipEvents on the handle's stream) of ONE launch of a hot kernel over `reps` launches:

@@ -96,8 +96,12 @@ if pmc:
             100.0 * c.get("SQ_WAIT_ANY", 0) / wc if wc else 0))
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 open(os.path.join(root, "profiles", name + "_kernel_stats.md"), "w").write("\n".join(out) + "\n")
-json.dump(dict(source="rocprofv3 --pmc passes, scripts/collect_profiles.sh", fetch_size_correction=2.0, unit="KB",
-               kernels=pmc, kernel_trace=per), open(os.path.join(root, "profiles", name + "_pmc.json"), "w"), indent=1, sort_keys=True)
+for c in pmc.values():
+    c["states"] = 100000          # scripts/profile_iter.py default workload (BASELINE config 3)
+blob = dict(source="rocprofv3 --pmc passes over scripts/profile_iter.py (scripts/collect_profiles.sh), mean per launch",
+            fetch_size_correction=2.0, unit="FETCH_SIZE/WRITE_SIZE in KB, ea_*_bytes in bytes", kernels=pmc, kernel_trace=per)
+for fn in (name + "_pmc.json", "latest_pmc.json"):
+    json.dump(blob, open(os.path.join(root, "profiles", fn), "w"), indent=1, sort_keys=True)
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
     lines = [l for l in open(bj) if l.startswith("{")]
