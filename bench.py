@@ -31,23 +31,24 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # same kernels on the same workload comes from the committed PMC passes (scripts/collect_profiles.sh ->
 # profiles/<round>_pmc.json; explicit-size L2->fabric request counters TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ{,_64B}).
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
-PMC_KEYS = ["k_gp<double, 3, 0>", "k_assemble", "k_chunk_forward<double, 12, true>@%d", "k_chunk_backward<double, 12>@%d",
+PMC_KEYS = ["k_gp<double, 3, 0>", "k_assemble", "k_chunk_forward<double, 12, true>", "k_chunk_backward<double, 12>",
             "k_retract<double, 3>"]
 
 
-def pmc_traffic(which, n_states, chunk=16):
-    """HBM bytes per launch of kernel `which` from the committed counter passes, or None if they do not cover it."""
+def pmc_traffic(which, n_states):
+    """HBM bytes per launch of kernel `which` from the committed counter passes, or None if they do not cover it.
+    The solver kernels run once per hierarchy level; level 0 is the launch with the largest grid."""
     try:
         kern = json.load(open(PMC_FILE))["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    key = PMC_KEYS[which]
-    if "%d" in key:
-        key = key % (64 * ((n_states + chunk - 1) // chunk))
+    best = None
     for k, c in kern.items():
-        if k.startswith(key) and "ea_read_bytes" in c and c.get("states", n_states) == n_states:
-            return float(c["ea_read_bytes"] + c["ea_write_bytes"])
-    return None
+        if k.startswith(PMC_KEYS[which]) and "ea_read_bytes" in c and c.get("states", n_states) == n_states:
+            grid = int(k.rsplit("@", 1)[1])
+            if best is None or grid > best[0]:
+                best = (grid, float(c["ea_read_bytes"] + c["ea_write_bytes"]))
+    return best[1] if best else None
 
 
 def cpu_baseline(problem, iters=3):

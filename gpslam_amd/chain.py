@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_get_rows", "gpslam_hip_block_tridiag_solve",
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
+    "gpslam_hip_interpolate_poses",
 ]
 
 
@@ -280,6 +281,14 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_block_tridiag_solve(self._h, g.shape[0], _p(D), _p(O), _p(g), _p(x)),
                   "block_tridiag_solve")
         return x
+
+    def interpolate_poses(self, left, dt, tau):
+        """Batched interpolatePose of the current estimate: (count, pose_dim)."""
+        left, dt, tau = _i32(left), _f64(dt), _f64(tau)
+        out = np.zeros((len(left), self.pd))
+        self._chk(self.lib.gpslam_hip_interpolate_poses(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out)),
+                  "interpolate_poses")
+        return out
 
     def last_timing(self):
         t = np.zeros(5)

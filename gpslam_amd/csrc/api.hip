@@ -963,9 +963,26 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   // ---- solver hierarchy: chunks of m0 states at level 0, m1 above.  Unsharded: a single-wave sequential top
   // level of <= `top` blocks.  Sharded: reduce down to one block per rank (the rank separator).
   // reserved[1] / reserved[2] override the upper-level chunk length and the size of the sequential top level
-  const int m0 = h->cfg.chunk > 1 ? h->cfg.chunk : 16;
+  // Level-0 chunk length: the forward kernel keeps 4 waves per SIMD resident, i.e. `slots` chunks run at once and a
+  // launch costs (rounds of slots) x (block steps per chunk); pick the length in [16, 32] that minimises that
+  // product (1e5 states on 256 CUs: 25 -> 4000 chunks, one round of 24 steps instead of two rounds of 15).
+  int m0 = 16;
+  if (h->cfg.chunk > 1) {
+    m0 = h->cfg.chunk;
+  } else {
+    hipDeviceProp_t prop;
+    const int cus = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
+                        ? prop.multiProcessorCount : 256;
+    const long slots = (long)cus * 16;
+    long best = -1;
+    for (int m = 16; m <= 32; m++) {
+      const long chunks = (N + m - 1) / m;
+      const long cost = ((chunks + slots - 1) / slots) * (m - 1);
+      if (best < 0 || cost < best) { best = cost; m0 = m; }
+    }
+  }
   const int m1 = h->cfg.reserved[1] > 1 ? h->cfg.reserved[1] : 4;
-  const int top = h->cfg.reserved[2] > 0 ? h->cfg.reserved[2] : 16;
+  const int top = h->cfg.reserved[2] > 0 ? h->cfg.reserved[2] : 8;
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   h->lv.clear();
   const size_t BS = (size_t)2 * b * b + (size_t)b * h->R, AS = (size_t)b * b + (size_t)b * h->R;
@@ -1273,6 +1290,45 @@ int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double
   HIPCHK(hipStreamSynchronize(h->stream));
   for (size_t i = 0; i < xs.size(); i++) x[i] = xs[i];
   return flag ? fail(h, GPSLAM_E_NOT_SPD, "non-positive pivot") : 0;
+}
+
+int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                 const double *tau, double *out_pose) {
+  if (!h || count < 0 || (count > 0 && (!left || !dt || !tau || !out_pose))) return GPSLAM_E_INVALID;
+  if (h->N < 2) return fail(h, GPSLAM_E_INVALID, "interpolation needs at least two states");
+  const int mx = max_left(h);
+  for (int q = 0; q < count; q++) {
+    if (left[q] < 0 || left[q] > mx) return fail(h, GPSLAM_E_INVALID, "query interval out of range");
+    if (!(dt[q] > 0.0)) return fail(h, GPSLAM_E_INVALID, "delta_t must be positive");
+  }
+  if (count == 0) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  const int pd = h->pd;
+  std::vector<double> coef((size_t)count * 4);
+  for (int q = 0; q < count; q++) interp_coef(dt[q], tau[q], &coef[4 * (size_t)q]);
+  std::vector<int> li(left, left + count);
+  struct Scratch {   // query buffers live for this call only
+    DevBuf left, coef, out;
+    ~Scratch() { left.release(); coef.release(); out.release(); }
+  } sc;
+  DevBuf &d_left = sc.left, &d_coef = sc.coef, &d_out = sc.out;
+  int rc;
+  if ((rc = upload(h, d_left, li))) return rc;
+  if ((rc = upload_real(h, d_coef, coef))) return rc;
+  HIPCHK(d_out.reserve((size_t)count * pd * sizeof(Real)));
+  QueryArgs<Real> a;
+  a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.count = count;
+  a.left = d_left.as<int>(); a.coef = d_coef.as<Real>(); a.out = d_out.as<Real>();
+  dispatch_mf(h->mf, [&](auto tag) {
+    constexpr int MF = decltype(tag)::value;
+    k_interp_query<Real, MF><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
+  });
+  HIPCHK(hipGetLastError());
+  std::vector<Real> out((size_t)count * pd);
+  HIPCHK(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t k = 0; k < out.size(); k++) out_pose[k] = out[k];
+  return 0;
 }
 
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5) {

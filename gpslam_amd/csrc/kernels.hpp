@@ -1224,6 +1224,53 @@ __global__ void __launch_bounds__(192) k_assemble_lds(AsmArgs<T> a, int max_rows
   if (a.gsave) a.gsave[(size_t)s * B + c] = g;
 }
 
+// ------------------------------------------------------------------ trajectory queries
+
+template <typename T> struct QueryArgs {
+  const T *pose, *vel;   // SoA states
+  int stride, count;
+  const int *left;       // query q lies in the interval (left[q], left[q] + 1)
+  const T *coef;         // count x 4: l11, l12, p11, p12 for (dt[q], tau[q])
+  T *out;                // count x pose_dim (AoS, the layout of gpslam_hip_get_states' rows)
+};
+
+// Batched GaussianProcessInterpolator{Linear,Pose2,Pose3,Rot3}::interpolatePose without Jacobians (the public
+// query use of the interpolators, gpslam.h:57-86): thread per query.
+template <typename T, int MF>
+__global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
+  constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.count) return;
+  const int i = a.left[q];
+  const ICoef<T> k = {a.coef[4 * (size_t)q], a.coef[4 * (size_t)q + 1], a.coef[4 * (size_t)q + 2], a.coef[4 * (size_t)q + 3]};
+  T p1[pd], p2[pd], v1[d], v2[d];
+#pragma unroll
+  for (int c = 0; c < pd; c++) { p1[c] = a.pose[(size_t)c * a.stride + i]; p2[c] = a.pose[(size_t)c * a.stride + i + 1]; }
+#pragma unroll
+  for (int c = 0; c < d; c++) { v1[c] = a.vel[(size_t)c * a.stride + i]; v2[c] = a.vel[(size_t)c * a.stride + i + 1]; }
+  T *o = a.out + (size_t)q * pd;
+  if constexpr (MF == LINEAR2 || MF == LINEAR3) {
+    // p(tau) = Lambda_1 [p1; v1] + Psi_1 [p2; v2]   (GaussianProcessInterpolatorLinear.h:70-90)
+#pragma unroll
+    for (int c = 0; c < d; c++) o[c] = k.l11 * p1[c] + k.l12 * v1[c] + k.p11 * p2[c] + k.p12 * v2[c];
+  } else if constexpr (MF == POSE2) {
+    Interp3Out<T, false> unused;
+    const SE2<T> r = interp_pose2<T, false>(p1, v1, p2, v2, k, unused);
+    o[0] = r.x; o[1] = r.y; o[2] = r.th;
+  } else if constexpr (MF == ROT3) {
+    Interp3Out<T, false> unused;
+    const M3<T> r = interp_rot3<T, false>(p1, v1, p2, v2, k, unused);
+#pragma unroll
+    for (int c = 0; c < 9; c++) o[c] = r.m[c];
+  } else {
+    Interp6Out<T, false> unused;
+    const SE3<T> r = interp_pose3<T, false>(p1, v1, p2, v2, k, unused);
+#pragma unroll
+    for (int c = 0; c < 9; c++) o[c] = r.R.m[c];
+    o[9] = r.t.x; o[10] = r.t.y; o[11] = r.t.z;
+  }
+}
+
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan
 
 __device__ __forceinline__ double lane_bcast(double v, int lane) {

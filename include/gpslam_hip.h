@@ -178,6 +178,13 @@ int gpslam_hip_get_rows(gpslam_hip_handle *h, int32_t *n_rows, double *rowLR, do
 /* solve the block-tridiagonal SPD system D/O/g (host arrays as above, N x b) with the device solver; x: N x b */
 int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double *D, const double *O,
                                    const double *g, double *x);
+/* Batched GaussianProcessInterpolator{Linear<D>,Pose2,Pose3,Rot3}::interpolatePose (gpslam.h:57-86; e.g.
+ * gpslam/gp/GaussianProcessInterpolatorPose3.h:57-105 without the Jacobians): the pose of the current estimate at
+ * time tau[q] after state left[q], inside the interval (left[q], left[q] + 1) of duration dt[q], with the handle's
+ * Qc.  out_pose: count x pose_dim, rows in the layout of gpslam_hip_get_states.  Dense trajectory output after
+ * an optimisation is the use the MATLAB wrapper exports the interpolators for. */
+int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                 const double *tau, double *out_pose);
 /* time (ms) of the last iterate call's phases measured with hipEvents on the handle's stream:
  * out[0] linearize, out[1] assemble, out[2] solve, out[3] retract+error, out[4] total */
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);

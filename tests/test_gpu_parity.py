@@ -293,3 +293,33 @@ def test_full_size_linear_chain_one_step():
     p0, v0 = orc.get_states()
     p1, v1 = dev.get_states()
     states_close(O.LINEAR3, p0, v0, p1, v1, 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [O.LINEAR3, O.POSE2, O.ROT3, O.POSE3])
+def test_interpolate_poses_query(kind):
+    """gpslam_hip_interpolate_poses = batched GaussianProcessInterpolator*::interpolatePose (gpslam.h:57-86)
+    against the oracle's per-call interpolators, on a perturbed chain."""
+    orc, dev, c = build_pair(kind, 40, seed=5)
+    rng = np.random.default_rng(11)
+    Q = 64
+    left = rng.integers(0, 39, Q).astype(np.int32)
+    dt = np.full(Q, 0.1)
+    tau = rng.uniform(0.0, 0.1, Q)
+    tau[:2] = [0.0, 0.1]                      # the interval's end points reproduce the states themselves
+    pose, vel = dev.get_states()
+    d = O.TANGENT_DIM[kind]
+    Qc = np.diag(0.01 + 0.02 * np.random.default_rng(5 + 77).random(d))   # build_pair's Qc
+    Qc[0, 1] = Qc[1, 0] = 0.003
+    dt = np.asarray(c["dt"])[left]
+    tau = tau / 0.1 * dt
+    got = dev.interpolate_poses(left, dt, tau)
+    for q in range(Q):
+        Lam, Psi = O.lambda_psi(d, Qc, dt[q], tau[q])
+        want, _ = O.interpolate(kind, Lam, Psi, pose[left[q]], vel[left[q]], pose[left[q] + 1], vel[left[q] + 1], jac=False)
+        assert np.abs(got[q] - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+    assert np.abs(got[0] - pose[left[0]]).max() <= 1e-12
+    if kind != O.POSE2:
+        assert np.abs(got[1] - pose[left[1] + 1]).max() <= 1e-10
+    with pytest.raises(Exception):
+        dev.interpolate_poses([39], [0.1], [0.05])
