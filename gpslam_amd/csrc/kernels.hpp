@@ -1273,6 +1273,17 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
 
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan
 
+// The solver kernels run one wave per workgroup and exchange data between lanes through LDS.  DS operations of one
+// wave execute in order, so a compiler-level ordering point is all that is needed; __syncthreads() would add an
+// s_barrier and, worse, drain vmcnt to zero, i.e. wait for the prefetched next-block operands and for the factor
+// stores of the current block at every step.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+
 __device__ __forceinline__ double lane_bcast(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
   lo = __builtin_amdgcn_readlane(lo, lane);
@@ -1331,9 +1342,9 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
   const bool has_sep = !a.no_sep;
   const bool right_exists = (e < a.n) || (a.last_has_right != 0);
   constexpr int kVCols = FAST ? B + (64 - 4 * B) / 2 : 1;
-  __shared__ T ldsO[B * B];
-  __shared__ T ldsF[B * B];
-  __shared__ T ldsV[kVCols * B];
+  __shared__ __attribute__((aligned(16))) T ldsM[2 * B * B];   // [O_j | F_j]: one array, so that Mat below is an offset
+  T *const ldsO = ldsM, *const ldsF = ldsM + B * B;
+  __shared__ __attribute__((aligned(16))) T ldsV[kVCols * B];
   int dbase = 0, obase = B;
   const int cF = lane - 2 * B;
   const bool isF = has_sep && cF >= 0 && cF < B;
@@ -1414,16 +1425,17 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
     const int db = __builtin_amdgcn_readfirstlane(dbase);
 #pragma unroll
     for (int k = 0; k < B; k++) {
+      // the whole pivot column goes to SGPRs first, then the row operations: back-to-back v_readlane / v_fma pairs
+      // on one SGPR pair cost a hazard nop each and serialise on the write-after-read of that pair
       const T p = lane_bcast(col[k], db + k);
+      T mlt[B];
+#pragma unroll
+      for (int i = 0; i < B; i++) mlt[i] = (i != k) ? lane_bcast(col[i], db + k) : T(0);
       if (!(p > T(0)) && lane == 0) *a.flag = 1;
       const T rowk = col[k] * fast_rcp(p);
 #pragma unroll
-      for (int i = 0; i < B; i++) {
-        if (i != k) {
-          const T mlt = lane_bcast(col[i], db + k);
-          col[i] -= mlt * rowk;
-        }
-      }
+      for (int i = 0; i < B; i++)
+        if (i != k) col[i] -= mlt[i] * rowk;
       col[k] = rowk;
     }
     T *bp = a.blk + (size_t)j * BS;
@@ -1445,7 +1457,7 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
         for (int k = 0; k < B; k++) ldsV[(B + cR) * B + k] = col[k];
       }
     }
-    __syncthreads();
+    wave_lds_sync();
     if (!FAST && has_sep && (isF || isR)) {   // wide borders: separator sums in a pass of their own
 #pragma unroll
       for (int q = 0; q < B; q++) {
@@ -1456,7 +1468,7 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
       }
     }
     // one B x B product per lane:  nxt -= Mat * col
-    const T *Mat = isA ? ldsF : ldsO;
+    const int moff = isA ? B * B : 0;
     if (isA) {
 #pragma unroll
       for (int k = 0; k < B; k++) col[k] = ldsV[cA * B + k];
@@ -1464,12 +1476,30 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
 #pragma unroll
       for (int k = 0; k < B; k++) col[k] = T(0);     // D lanes (and spare lanes) take the operand unchanged
     }
+    {
+      // rows of Mat are wave-uniform (broadcast) 16-byte LDS reads; row r + 1 is in flight while row r is used, so
+      // the loop waits on LDS once per row instead of once per operand pair
+      typedef T V2 __attribute__((ext_vector_type(2)));
+      const V2 *M2 = reinterpret_cast<const V2 *>(ldsM + moff);
+      V2 cur[B / 2], nx[B / 2];
 #pragma unroll
-    for (int r = 0; r < B; r++) {
-      T sacc = T(0);
+      for (int k = 0; k < B / 2; k++) cur[k] = M2[k];
 #pragma unroll
-      for (int k = 0; k < B; k++) sacc += Mat[r * B + k] * col[k];
-      nxt[r] -= sacc;
+      for (int r = 0; r < B; r++) {
+        if (r + 1 < B) {
+#pragma unroll
+          for (int k = 0; k < B / 2; k++) nx[k] = M2[(r + 1) * (B / 2) + k];
+        }
+        T sacc = T(0);
+#pragma unroll
+        for (int k = 0; k < B / 2; k++) {
+          sacc += cur[k].x * col[2 * k];
+          sacc += cur[k].y * col[2 * k + 1];
+        }
+        nxt[r] -= sacc;
+#pragma unroll
+        for (int k = 0; k < B / 2; k++) cur[k] = nx[k];
+      }
     }
     if (!last) {
       if (!isA) {
@@ -1492,7 +1522,7 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
         for (int r = 0; r < B; r++) uo[r * B + cF] = nxt[r];             // C = -O V, couples sep c -> sep c+1
       }
     }
-    __syncthreads();
+    wave_lds_sync();
   }
 
   if (has_sep) {
@@ -1569,7 +1599,7 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
     xs[idx] = has_sep ? a.xup[(size_t)c * R * B + idx] : T(0);
     xa[idx] = right_exists ? a.xup[(size_t)(c + 1) * R * B + idx] : T(0);
   }
-  __syncthreads();
+  wave_lds_sync();
   if (has_sep)
     for (int idx = lane; idx < R * B; idx += 64) a.x[(size_t)s * R * B + idx] = xs[idx];
   // the right separator of the last chunk lives on the next rank: park its solution in the extra slot x[n] so
@@ -1606,7 +1636,7 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
     }
 #pragma unroll
     for (int q = 0; q < B; q++) { Ur[q] = Un[q]; Vr[q] = Vn[q]; }
-    __syncthreads();
+    wave_lds_sync();
     ping ^= 1;
   }
 }
