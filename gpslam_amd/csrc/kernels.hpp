@@ -1017,8 +1017,8 @@ __global__ void __launch_bounds__(256) k_assemble_shfl(AsmArgs<T> a) {
 // group of state s - 1 (-> D_s += R^T R).  Compared with letting every group re-read the rows of s - 1 this
 // removes the second pass over the row table (2x HBM over-fetch measured, profiles/round1_v3) and a third of the
 // loop iterations.  DS operations of one wave execute in order, so no barrier is needed; two buffers alternate.
-template <typename T, int B>
-__global__ void __launch_bounds__(256) k_assemble_ghost(AsmArgs<T> a) {
+template <typename T, int B, int WPB = 4>
+__global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   constexpr int G = 64 / B;                       // lane groups per wave (the first one is the ghost)
   static_assert(G >= 2, "needs at least one real state per wave");
   const int lane = threadIdx.x & 63;
@@ -1045,7 +1045,7 @@ __global__ void __launch_bounds__(256) k_assemble_ghost(AsmArgs<T> a) {
 #pragma unroll
   for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
   constexpr int XS = 128 + ((G + 1) & ~1);        // per wave and parity: L[64] | R[64] | e[G]
-  __shared__ T xch[4][2][XS];
+  __shared__ T xch[WPB][2][XS];
   T *xw = &xch[threadIdx.x >> 6][0][0];
   const int BS = 2 * B * B + B * a.R;
   T *bp = a.blk + (size_t)sc * BS;
