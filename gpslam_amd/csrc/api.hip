@@ -87,7 +87,6 @@ struct gpslam_hip_handle {
   MeasSet ms[6];
   // row table
   int M = 0;
-  int asm_tile_rows = 0;      // largest row slice one assembly workgroup stages in LDS (0: use the direct kernel)
   DevBuf rowLR, rowE, rowM, rowLm, rowptr;
   DevBuf partial;
   // landmark border
@@ -342,27 +341,10 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   a.gsave = save_g ? h->gsave.as<Real>() : nullptr;
   a.halo_add = has_right_rank(h) ? h->halo_add.as<Real>() : nullptr;
   const int nstates = h->N + (a.halo_add ? 1 : 0);
-  const int threads = nstates * h->b;
-  const int tile_rows = h->asm_tile_rows;
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
-    static const int amode = getenv("GPSLAM_ASM_MODE") ? atoi(getenv("GPSLAM_ASM_MODE")) : 0;   // 0 ghost, 1 lds, 2 direct, 3 shfl
-    if (amode == 0) {
-      if constexpr (64 / BB >= 2) {
-        const int waves = nblocks(nstates, 64 / BB - 1);
-        k_assemble_ghost<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);   // 1 / 8 / 16 waves per block measured slower
-      }
-    } else if (amode == 3) {
-      constexpr int G = 64 / BB;
-      const int waves = nblocks(nstates, G);
-      k_assemble_shfl<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);
-    } else if (tile_rows > 0 && amode == 1) {
-      const size_t lds = (size_t)tile_rows * (2 * BB + 1) * sizeof(Real);
-      static const int dbg = getenv("GPSLAM_ASM_DEBUG") ? atoi(getenv("GPSLAM_ASM_DEBUG")) : 0;
-      k_assemble_lds<Real, BB><<<dim3(nblocks(nstates, 192 / BB)), dim3(192), lds, h->stream>>>(a, tile_rows, dbg);
-    } else {
-      k_assemble<Real, BB><<<dim3(nblocks(threads, 192)), dim3(192), 0, h->stream>>>(a);
-    }
+    const int waves = nblocks(nstates, 64 / BB - 1);
+    k_assemble_ghost<Real, BB><<<dim3(nblocks(waves, 4)), dim3(256), 0, h->stream>>>(a);   // 1 / 8 / 16 waves per block measured slower
   });
   HIPCHK(hipGetLastError());
   return 0;
@@ -914,15 +896,6 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     for (int k = 0; k < (s.interp ? s.count() : 0); k++) interp_coef(s.dt[k], s.tau[k], &coef[4 * (size_t)k]);
     if ((rc = upload_real(h, s.d_coef, coef))) return rc;
     npart += nblocks(s.count(), 128);
-  }
-  {  // largest contiguous row slice of an assembly tile (states s0-1 .. s0+TS-1); staged in LDS if it fits
-    const int TS = 192 / b;
-    int mx = 0;
-    for (int s0 = 0; s0 < N + 1; s0 += TS) {
-      const int slo = s0 > 0 ? s0 - 1 : 0, shi = std::min(s0 + TS, N);
-      if (shi > slo) mx = std::max(mx, rowptr[shi] - rowptr[slo]);
-    }
-    h->asm_tile_rows = ((size_t)mx * (2 * b + 1) * sizeof(Real) <= 64 * 1024) ? std::max(mx, 1) : 0;
   }
   const size_t Mrows = (size_t)std::max(h->M, 1);
   HIPCHK(h->rowLR.reserve(Mrows * 2 * b * sizeof(Real)));

@@ -9,8 +9,10 @@
 //
 // Kernels:
 //   k_gp          batched GaussianProcessPrior*::evaluateError + H1..H4 (+ whitening)     [K1]
-//   k_unary/k_between   PriorFactor / BetweenFactor rows
-//   k_assemble    J^T J / J^T e per state from the row table (no atomics, fixed order)     [K3]
+//   k_simple      PriorFactor / BetweenFactor rows;  k_meas  measurement factors           [K2]
+//   k_assemble_ghost   J^T J / J^T e per state from the row table (no atomics, fixed order) [K3]
+//   k_lm_*        landmark border: Schur complement on the chain solution                 [K5]
+//   k_interp_query     batched interpolatePose of the current estimate
 //   k_chunk_forward / k_chunk_backward   partitioned block Gauss-Jordan, one wave per chunk,
 //                 one panel column per lane, pivot broadcast through v_readlane            [K4]
 //   k_retract     x <- x (+) delta, |delta|_inf                                            [K6]
@@ -809,206 +811,6 @@ template <typename T> struct AsmArgs {
   T *halo_add;            // segment sharding: [RD | Rg] the rows of state N-1 owe to the next rank's first state
 };
 
-// thread (s, c) builds row c of D_s and O_s and entry c of every rhs column of state s
-template <typename T, int B>
-__global__ void __launch_bounds__(192) k_assemble(AsmArgs<T> a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  const int s = t / B, c = t - s * B;
-  if (s > a.N || (s == a.N && !a.halo_add)) return;
-  // loop bounds in registers: re-reading rowptr from HBM every iteration serialises the row loop on memory latency
-  const int rp_s = a.rowptr[s], rp_sm = s > 0 ? a.rowptr[s - 1] : a.rowptr[s], rp_s1 = a.rowptr[s + 1];
-  if (s == a.N) {  // right blocks of the rows of state N-1 -> addend for the neighbour's first state
-    T Dh[B];
-    T gh = T(0);
-#pragma unroll
-    for (int k = 0; k < B; k++) Dh[k] = T(0);
-    for (int rho = rp_sm; rho < rp_s; rho++) {
-      const T *row = a.rowLR + (size_t)rho * 2 * B + B;
-      const T Rc = row[c];
-#pragma unroll
-      for (int k = 0; k < B; k++) Dh[k] += Rc * row[k];
-      gh -= Rc * a.rowE[rho];
-    }
-#pragma unroll
-    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = Dh[k];
-    a.halo_add[B * B + c] = gh;
-    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
-    return;
-  }
-  const int BS = 2 * B * B + B * a.R;
-  T *bp = a.blk + (size_t)s * BS;
-  T D[B], O[B];
-  T g = T(0);
-#pragma unroll
-  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
-  for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
-  // rows whose factor has left state s: left block -> D_s, O_s (with the right block), g_s
-  for (int rho = rp_s; rho < rp_s1; rho++) {
-    const T *row = a.rowLR + (size_t)rho * 2 * B;
-    const T Lc = row[c], Rc = row[B + c];
-    const T e = a.rowE[rho];
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-      const T Lk = row[k];
-      D[k] += Lc * Lk;
-      O[k] += Rc * Lk;
-    }
-    g -= Lc * e;
-    if (a.rowM) {
-      const int lm = a.rowLm[rho];
-      if (lm >= 0)
-        for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
-    }
-  }
-  // rows whose factor has left state s-1: right block -> D_s, g_s
-  if (s > 0) {
-    for (int rho = rp_sm; rho < rp_s; rho++) {
-      const T *row = a.rowLR + (size_t)rho * 2 * B + B;
-      const T Rc = row[c];
-      const T e = a.rowE[rho];
-#pragma unroll
-      for (int k = 0; k < B; k++) D[k] += Rc * row[k];
-      g -= Rc * e;
-      if (a.rowM) {
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Rc * a.rowM[(size_t)rho * a.ld + q];
-      }
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
-  bp[2 * B * B + c] = g;
-  if (a.gsave) a.gsave[(size_t)s * B + c] = g;
-}
-
-// Wave-cooperative assembly: the B lanes of a state each load ONE element of a Jacobian row (a coalesced 8B-per-lane
-// load of the row's left / right half) and obtain the other B - 1 through the cross-lane network (ds_bpermute),
-// so every row is fetched from HBM exactly once, nothing is staged and the kernel runs at full occupancy.
-// 64 / B states per wave (B = 12: 5 states, 60 live lanes).
-template <typename T, int B>
-__global__ void __launch_bounds__(256) k_assemble_shfl(AsmArgs<T> a) {
-  constexpr int G = 64 / B;                       // states per wave
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const int g = lane / B, c = lane - g * B;
-  const int nstates = a.N + (a.halo_add ? 1 : 0);
-  const int s = wave * G + g;
-  const bool live = (g < G) && (s < nstates);
-  const int sc = live ? s : 0;
-  const int gb = g * B;                           // first lane of this state's group
-  // every lane of the wave runs the same trip counts (cross-lane ops need all participants converged)
-  int rp_s = 0, rp_s1 = 0, rp_sm = 0;
-  if (live) {
-    rp_s = a.rowptr[sc];
-    rp_s1 = (sc < a.N) ? a.rowptr[sc + 1] : rp_s;  // the virtual halo state owns no rows
-    rp_sm = sc > 0 ? a.rowptr[sc - 1] : rp_s;
-  }
-  int n_own = rp_s1 - rp_s, n_prev = rp_s - rp_sm;
-  int n_own_max = n_own, n_prev_max = n_prev;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    n_own_max = max(n_own_max, __shfl_xor(n_own_max, o, 64));
-    n_prev_max = max(n_prev_max, __shfl_xor(n_prev_max, o, 64));
-  }
-  T D[B], O[B];
-  T gsum = T(0);
-#pragma unroll
-  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
-  // per-wave exchange buffer: each lane publishes its element, the B lanes of a state read the whole row back with
-  // 16-byte LDS reads (DS operations of one wave execute in order, so no barrier is needed; two buffers alternate)
-  __shared__ T xch[4][2][64];
-  T *xw = &xch[threadIdx.x >> 6][0][0];
-  const int BS = 2 * B * B + B * a.R;
-  T *bp = a.blk + (size_t)sc * BS;
-  const bool isblk = live && sc < a.N;
-  if (isblk) for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
-  // rows whose factor has left state s (the operands of row i+2 are in flight while row i is accumulated)
-  auto ld_own = [&](int i, T &Lc, T &Rc, T &e) {
-    Lc = T(0); Rc = T(0); e = T(0);
-    if (i < n_own) {
-      const T *row = a.rowLR + (size_t)(rp_s + i) * 2 * B;
-      Lc = row[c];
-      Rc = row[B + c];
-      e = a.rowE[rp_s + i];
-    }
-  };
-  {
-    T Lc0, Rc0, e0, Lc1, Rc1, e1;
-    ld_own(0, Lc0, Rc0, e0);
-    ld_own(1, Lc1, Rc1, e1);
-    for (int i = 0; i < n_own_max; i++) {
-      const T Lc = Lc0, Rc = Rc0, e = e0;
-      Lc0 = Lc1; Rc0 = Rc1; e0 = e1;
-      ld_own(i + 2, Lc1, Rc1, e1);
-      T *buf = xw + (i & 1) * 64;
-      buf[lane] = Lc;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const T *rowv = buf + gb;
-#pragma unroll
-      for (int k = 0; k < B; k++) {
-        const T Lk = rowv[k];
-        D[k] += Lc * Lk;
-        O[k] += Rc * Lk;
-      }
-      gsum -= Lc * e;
-      if (a.rowM && i < n_own && isblk) {
-        const int rho = rp_s + i;
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
-      }
-    }
-  }
-  // rows whose factor has left state s-1: right blocks
-  auto ld_prev = [&](int i, T &Rc, T &e) {
-    Rc = T(0); e = T(0);
-    if (i < n_prev) {
-      Rc = a.rowLR[(size_t)(rp_sm + i) * 2 * B + B + c];
-      e = a.rowE[rp_sm + i];
-    }
-  };
-  {
-    T Rc0, e0, Rc1, e1;
-    ld_prev(0, Rc0, e0);
-    ld_prev(1, Rc1, e1);
-    for (int i = 0; i < n_prev_max; i++) {
-      const T Rc = Rc0, e = e0;
-      Rc0 = Rc1; e0 = e1;
-      ld_prev(i + 2, Rc1, e1);
-      T *buf = xw + ((i + n_own_max) & 1) * 64;
-      buf[lane] = Rc;
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      const T *rowv = buf + gb;
-#pragma unroll
-      for (int k = 0; k < B; k++) D[k] += Rc * rowv[k];
-      gsum -= Rc * e;
-      if (a.rowM && i < n_prev && isblk) {
-        const int rho = rp_sm + i;
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Rc * a.rowM[(size_t)rho * a.ld + q];
-      }
-    }
-  }
-  if (!live) return;
-  if (sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
-#pragma unroll
-    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
-    a.halo_add[B * B + c] = gsum;
-    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
-    return;
-  }
-#pragma unroll
-  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
-  bp[2 * B * B + c] = gsum;
-  if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
-}
-
 // Wave-cooperative assembly, every row fetched once.  A wave owns G - 1 = 64 / B - 1 consecutive states plus, in
 // its first lane group, the state before them as a "ghost" that only contributes its rows' right halves.  The B
 // lanes of a group each load ONE element of the left and of the right half of their state's current Jacobian row
@@ -1114,114 +916,6 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
   bp[2 * B * B + c] = gsum;
   if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
-}
-
-// LDS-staged assembly: a workgroup owns TS = 192 / B consecutive states.  The rows it needs (those of states
-// s0-1 .. s0+TS-1) are one contiguous slice of the row table; the slice is copied into LDS once with 16-byte
-// coalesced loads and every thread (state, row c) then forms its row of D_s / O_s from LDS (6 ds_read_b128 + 24 FMA
-// per Jacobian row instead of 14 global loads), so the kernel reads each row from HBM exactly once.
-template <typename T, int B>
-__global__ void __launch_bounds__(192) k_assemble_lds(AsmArgs<T> a, int max_rows, int dbg = 0) {
-  constexpr int TS = 192 / B;
-  extern __shared__ double lds_raw[];
-  T *lrow = reinterpret_cast<T *>(lds_raw);            // [rows][2B]
-  T *lE = lrow + (size_t)max_rows * 2 * B;             // [rows]
-  const int tid = threadIdx.x;
-  const int s0 = blockIdx.x * TS;
-  const int nstates = a.N + (a.halo_add ? 1 : 0);
-  const int slo = s0 > 0 ? s0 - 1 : 0;
-  const int shi = min(s0 + TS, a.N);                   // rows of left states [slo, shi)
-  const int r_lo = a.rowptr[slo], r_hi = a.rowptr[shi];
-  const int nrows = r_hi - r_lo;
-  {
-    typedef double __attribute__((ext_vector_type(2))) dbl2;
-    const dbl2 *src = reinterpret_cast<const dbl2 *>(a.rowLR + (size_t)r_lo * 2 * B);
-    dbl2 *dst = reinterpret_cast<dbl2 *>(lrow);
-    const int n2 = (dbg == 3) ? 0 : nrows * B;                          // 2B doubles per row = B double2
-    // 8 independent 16-byte loads in flight per thread before the first LDS store (memory-level parallelism)
-    for (int base = 0; base < n2; base += 192 * 8) {
-      dbl2 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = base + u * 192 + tid;
-        if (i < n2) v[u] = src[i];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = base + u * 192 + tid;
-        if (i < n2) dst[i] = v[u];
-      }
-    }
-    for (int i = tid; i < nrows; i += 192) lE[i] = a.rowE[r_lo + i];
-  }
-  __syncthreads();
-  const int sl = tid / B, c = tid - sl * B;
-  const int s = s0 + sl;
-  if (sl >= TS || s >= nstates) return;
-  int rp_s = a.rowptr[s], rp_sm = s > 0 ? a.rowptr[s - 1] : a.rowptr[s], rp_s1 = a.rowptr[s + 1];
-  if (dbg == 1) { rp_sm = rp_s; rp_s1 = rp_s; }
-  if (s == a.N) {  // right blocks of the rows of state N-1 -> addend for the neighbour's first state
-    T Dh[B];
-    T gh = T(0);
-#pragma unroll
-    for (int k = 0; k < B; k++) Dh[k] = T(0);
-    for (int rho = rp_sm; rho < rp_s; rho++) {
-      const T *row = lrow + (size_t)(rho - r_lo) * 2 * B + B;
-      const T Rc = row[c];
-#pragma unroll
-      for (int k = 0; k < B; k++) Dh[k] += Rc * row[k];
-      gh -= Rc * lE[rho - r_lo];
-    }
-#pragma unroll
-    for (int k = 0; k < B; k++) a.halo_add[c * B + k] = Dh[k];
-    a.halo_add[B * B + c] = gh;
-    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
-    return;
-  }
-  const int BS = 2 * B * B + B * a.R;
-  T *bp = a.blk + (size_t)s * BS;
-  T D[B], O[B];
-  T g = T(0);
-#pragma unroll
-  for (int k = 0; k < B; k++) { D[k] = T(0); O[k] = T(0); }
-  for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
-  for (int rho = rp_s; rho < rp_s1; rho++) {
-    const T *row = lrow + (size_t)(rho - r_lo) * 2 * B;
-    const T Lc = row[c], Rc = row[B + c];
-    const T e = lE[rho - r_lo];
-#pragma unroll
-    for (int k = 0; k < B; k++) {
-      const T Lk = row[k];
-      D[k] += Lc * Lk;
-      O[k] += Rc * Lk;
-    }
-    g -= Lc * e;
-    if (a.rowM) {
-      const int lm = a.rowLm[rho];
-      if (lm >= 0)
-        for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
-    }
-  }
-  if (s > 0) {
-    for (int rho = rp_sm; rho < rp_s; rho++) {
-      const T *row = lrow + (size_t)(rho - r_lo) * 2 * B + B;
-      const T Rc = row[c];
-      const T e = lE[rho - r_lo];
-#pragma unroll
-      for (int k = 0; k < B; k++) D[k] += Rc * row[k];
-      g -= Rc * e;
-      if (a.rowM) {
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Rc * a.rowM[(size_t)rho * a.ld + q];
-      }
-    }
-  }
-  if (dbg == 2) { T acc2 = g; for (int k = 0; k < B; k++) acc2 += D[k] + O[k]; if (acc2 == T(1.2345e300)) bp[0] = acc2; return; }
-#pragma unroll
-  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
-  bp[2 * B * B + c] = g;
-  if (a.gsave) a.gsave[(size_t)s * B + c] = g;
 }
 
 // ------------------------------------------------------------------ trajectory queries
