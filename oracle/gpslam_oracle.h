@@ -101,6 +101,27 @@ void orc_gp_prior_rot3(const double *R1, const double *v1, const double *R2, con
 void orc_gp_prior_pose3(const double *p1, const double *v1, const double *p2, const double *v2, double dt, double *e,
                         double *H1, double *H2, double *H3, double *H4);
 
+void orc_convertVWtoVb(const double v[3], const double w[3], const double pose[12], double v6[6], double *Hv,
+                       double *Hw, double *Hpose);
+void orc_gp_prior_pose3vw(const double *p1, const double *vel1, const double *omega1, const double *p2,
+                          const double *vel2, const double *omega2, double dt, double *e, double *H1, double *H2,
+                          double *H3, double *H4, double *H5, double *H6);
+void orc_interp_pose3vw(const double *Lambda, const double *Psi, const double *p1, const double *v1,
+                        const double *omega1, const double *p2, const double *v2, const double *omega2, double *pose,
+                        double *H1, double *H2, double *H3, double *H4, double *H5, double *H6);
+
+void orc_gp_prior_pose3vw_packed(const double *p1, const double *s1, const double *p2, const double *s2, double dt,
+                                 double *e, double *H1, double *H2, double *H3, double *H4);
+void orc_interp_pose3vw_packed(const double *Lambda, const double *Psi, const double *p1, const double *s1,
+                               const double *p2, const double *s2, double *pose, double *H1, double *H2, double *H3,
+                               double *H4);
+void orc_interp_gps_pose3vw(const double *Lambda, const double *Psi, const double *measured, const double *sensor,
+                            const double *p1, const double *s1, const double *p2, const double *s2, double *e,
+                            double *H1, double *H2, double *H3, double *H4);
+double orc_interp_range_pose3vw(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                                const double *p1, const double *s1, const double *p2, const double *s2,
+                                const double *point, double *H1, double *H2, double *H3, double *H4, double *H5);
+
 void orc_interp_linear(int D, const double *Lambda, const double *Psi, const double *p1, const double *v1,
                        const double *p2, const double *v2, double *pose, double *H1, double *H2, double *H3,
                        double *H4);
@@ -179,6 +200,8 @@ void orc_default_params(orc_params *p);
 orc_chain *orc_chain_create(int kind, int chart, int landmark_dim);
 void orc_chain_destroy(orc_chain *c);
 int orc_chain_set_qc(orc_chain *c, const double *Qc);
+/* velocities are world-frame (v, w) 3-vectors: the *Pose3VW factor family (Pose3 chains only) */
+int orc_chain_set_velocity_world(orc_chain *c, int on);
 int orc_chain_set_states(orc_chain *c, int N, const double *pose, const double *vel);
 int orc_chain_get_states(const orc_chain *c, double *pose, double *vel);
 int orc_chain_set_landmarks(orc_chain *c, int L, const double *pts);

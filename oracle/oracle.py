@@ -41,7 +41,7 @@ def lib():
         _lib.orc_pose3_range.restype = C.c_double
         _lib.orc_pose2_range.restype = C.c_double
         for n in ("orc_interp_range_pose2", "orc_interp_range_pose3", "orc_interp_range_2dlinear",
-                  "orc_range_2dlinear", "orc_range_pose2"):
+                  "orc_range_2dlinear", "orc_range_pose2", "orc_interp_range_pose3vw"):
             getattr(_lib, n).restype = C.c_double
         _lib.orc_chain_create.restype = C.c_void_p
     return _lib
@@ -161,6 +161,22 @@ def gp_prior(kind, p1, v1, p2, v2, dt, jac=True):
     return e, H
 
 
+def gp_prior_vw(p1, v1, w1, p2, v2, w2, dt, jac=True):
+    """GaussianProcessPriorPose3VW::evaluateError: (e, [H1 (12x6), H2, H3 (12x3), H4 (12x6), H5, H6 (12x3)])."""
+    e = np.zeros(12)
+    H = [np.zeros((12, n)) for n in (6, 3, 3, 6, 3, 3)] if jac else [None] * 6
+    call("orc_gp_prior_pose3vw", A(p1), A(v1), A(w1), A(p2), A(v2), A(w2), float(dt), e, *H)
+    return e, H
+
+
+def interpolate_vw(Lam, Psi, p1, v1, w1, p2, v2, w2, jac=True):
+    """GaussianProcessInterpolatorPose3VW::interpolatePose: (pose, [H1 (6x6), H2, H3 (6x3), H4 (6x6), H5, H6])."""
+    out = np.zeros(12)
+    H = [np.zeros((6, n)) for n in (6, 3, 3, 6, 3, 3)] if jac else [None] * 6
+    call("orc_interp_pose3vw", A(Lam), A(Psi), A(p1), A(v1), A(w1), A(p2), A(v2), A(w2), out, *H)
+    return out, H
+
+
 def interpolate(kind, Lam, Psi, p1, v1, p2, v2, jac=True):
     d = TANGENT_DIM[kind]
     out = np.zeros(POSE_DIM[kind])
@@ -177,7 +193,7 @@ def interpolate(kind, Lam, Psi, p1, v1, p2, v2, jac=True):
 class Chain:
     """Oracle-side chain problem; same call surface as gpslam_amd.ChainSolver."""
 
-    def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0):
+    def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, velocity_world=False):
         self.kind, self.chart, self.ld = kind, chart, landmark_dim
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
         self.b = 2 * self.d
@@ -185,6 +201,8 @@ class Chain:
         self.n_gp = 0
         self._h = C.c_void_p(lib().orc_chain_create(kind, chart, landmark_dim))
         assert self._h
+        if velocity_world:
+            assert lib().orc_chain_set_velocity_world(self._h, 1) == 0
 
     def __del__(self):
         try:

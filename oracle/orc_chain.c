@@ -38,6 +38,7 @@ typedef struct {
 
 struct orc_chain {
   int kind, chart, d, pd, b, ld;
+  int vw;      /* Pose3 only: state velocity = world-frame [v; w] (GaussianProcessPriorPose3VW family) */
   int N, L;
   double *pose, *vel, *lmk;
   double Qc[36];
@@ -82,6 +83,11 @@ void orc_chain_destroy(orc_chain *c) {
 }
 
 int orc_chain_set_qc(orc_chain *c, const double *Qc) { orc_copy(c->d * c->d, Qc, c->Qc); return 0; }
+int orc_chain_set_velocity_world(orc_chain *c, int on) {
+  if (on && c->kind != ORC_POSE3) return -2;
+  c->vw = on ? 1 : 0;
+  return 0;
+}
 
 int orc_chain_set_states(orc_chain *c, int N, const double *pose, const double *vel) {
   free(c->pose); free(c->vel);
@@ -236,7 +242,10 @@ static void gp_eval(const orc_chain *c, const orc_factor *f, double *e, double *
     case ORC_LINEAR2: orc_gp_prior_linear(2, p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
     case ORC_LINEAR3: orc_gp_prior_linear(3, p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
     case ORC_POSE2: orc_gp_prior_pose2(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
-    case ORC_POSE3: orc_gp_prior_pose3(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
+    case ORC_POSE3:
+      if (c->vw) orc_gp_prior_pose3vw_packed(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4);
+      else orc_gp_prior_pose3(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4);
+      break;
     case ORC_ROT3: orc_gp_prior_rot3(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
   }
 }
@@ -318,8 +327,8 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
         e[0] = orc_interp_range_pose2(Lam, Psi, f->meas[0], f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt,
                                       H1, H2, H3, H4, H5);
       else if (c->kind == ORC_POSE3)
-        e[0] = orc_interp_range_pose3(Lam, Psi, f->meas[0], f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt,
-                                      H1, H2, H3, H4, H5);
+        e[0] = (c->vw ? orc_interp_range_pose3vw : orc_interp_range_pose3)(
+            Lam, Psi, f->meas[0], f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt, H1, H2, H3, H4, H5);
       else if (c->kind == ORC_LINEAR3)
         e[0] = orc_interp_range_2dlinear(Lam, Psi, f->meas[0], p1, v1, p2, v2, pt, H1, H2, H3, H4,
                                          H5);
@@ -349,8 +358,8 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
       if (c->kind != ORC_POSE3) return -2;
       rows = 3;
       if (orc_calcLambda(d, c->Qc, f->dt, f->tau, Lam) || orc_calcPsi(d, c->Qc, f->dt, f->tau, Psi)) return -1;
-      orc_interp_gps_pose3(Lam, Psi, f->meas, f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, e,
-                           H1, H2, H3, H4);
+      (c->vw ? orc_interp_gps_pose3vw : orc_interp_gps_pose3)(Lam, Psi, f->meas, f->has_sensor ? f->sensor : NULL, p1,
+                                                                 v1, p2, v2, e, H1, H2, H3, H4);
       *uses_right = 1;
       if (want_jac) { PUT(JL, H1, 0, d); PUT(JL, H2, d, d); PUT(JR, H3, 0, d); PUT(JR, H4, d, d); }
       break;

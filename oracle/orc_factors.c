@@ -109,6 +109,48 @@ void orc_interp_gps_pose3(const double *Lambda, const double *Psi, const double 
   if (want) update_pose_jacobians(3, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
 }
 
+/* GPInterpolatedGPSFactorPose3VW::evaluateError -- GPInterpolatedGPSFactorPose3VW.h:73-103 (state velocities packed
+ * as s = [v; w], Jacobians [H_v | H_w]) */
+void orc_interp_gps_pose3vw(const double *Lambda, const double *Psi, const double *measured, const double *sensor,
+                            const double *p1, const double *s1, const double *p2, const double *s2, double *e,
+                            double *H1, double *H2, double *H3, double *H4) {
+  double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], Hpose[18], t[3];
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose3vw_packed(Lambda, Psi, p1, s1, p2, s2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL,
+                            want ? Hi3 : NULL, want ? Hi4 : NULL);
+  if (sensor) {
+    double H0[36], sp[12], Ht[18];
+    orc_pose3_compose(pose, sensor, sp, H0, NULL);
+    orc_pose3_translation(sp, t, Ht);
+    orc_mm(3, 6, 6, Ht, H0, Hpose);
+  } else {
+    orc_pose3_translation(pose, t, Hpose);
+  }
+  for (int i = 0; i < 3; i++) e[i] = t[i] - measured[i];
+  if (want) update_pose_jacobians(3, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+}
+
+/* Range to a landmark from the VW-interpolated pose: GPInterpolatedRangeFactorPose3.h:64-98 with the interpolator
+ * of GaussianProcessInterpolatorPose3VW.h (the reference ships no such class; it is the same composition). */
+double orc_interp_range_pose3vw(const double *Lambda, const double *Psi, double measured, const double *sensor,
+                                const double *p1, const double *s1, const double *p2, const double *s2,
+                                const double *point, double *H1, double *H2, double *H3, double *H4, double *H5) {
+  double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], Hpose[6], hx;
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose3vw_packed(Lambda, Psi, p1, s1, p2, s2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL,
+                            want ? Hi3 : NULL, want ? Hi4 : NULL);
+  if (sensor) {
+    double H0[36], sp[12], Hr[6];
+    orc_pose3_compose(pose, sensor, sp, H0, NULL);
+    hx = orc_pose3_range(sp, point, Hr, H5);
+    orc_mm(1, 6, 6, Hr, H0, Hpose);
+  } else {
+    hx = orc_pose3_range(pose, point, Hpose, H5);
+  }
+  if (want) update_pose_jacobians(1, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+  return hx - measured;
+}
+
 /* RangeFactor2DLinear::evaluateError -- RangeFactor2DLinear.h:43-56 */
 double orc_range_2dlinear(double measured, const double *pose, const double *point, double *H1, double *H2) {
   double d[2] = {point[0] - pose[0], point[1] - pose[1]};

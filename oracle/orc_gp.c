@@ -246,6 +246,78 @@ void orc_gp_prior_pose3(const double *p1, const double *v1, const double *p2, co
   }
 }
 
+/* convertVWtoVb -- gpslam/gp/Pose3utils.cpp:47-64: world-frame translational / rotational velocity (v, w) to the
+ * body-frame 6-velocity [R^T w; R^T v].  Rot3::unrotate(p, H1, H2): q = R^T p, H1 = skew(q), H2 = R^T (GTSAM).
+ * Hv, Hw: 6x3; Hpose: 6x6; any may be NULL. */
+void orc_convertVWtoVb(const double v[3], const double w[3], const double pose[12], double v6[6], double *Hv,
+                       double *Hw, double *Hpose) {
+  const double *R = pose;
+  double qw[3], qv[3];
+  for (int j = 0; j < 3; j++) {
+    qw[j] = R[0 * 3 + j] * w[0] + R[1 * 3 + j] * w[1] + R[2 * 3 + j] * w[2];
+    qv[j] = R[0 * 3 + j] * v[0] + R[1 * 3 + j] * v[1] + R[2 * 3 + j] * v[2];
+  }
+  for (int j = 0; j < 3; j++) { v6[j] = qw[j]; v6[3 + j] = qv[j]; }
+  if (Hv) {                                             /* :58  [0; Hrv], Hrv = R^T */
+    orc_zero(18, Hv);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Hv[(3 + i) * 3 + j] = R[j * 3 + i];
+  }
+  if (Hw) {                                             /* :59  [Hrw; 0] */
+    orc_zero(18, Hw);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Hw[i * 3 + j] = R[j * 3 + i];
+  }
+  if (Hpose) {                                          /* :60  [Hpw 0; Hpv 0], Hp* = skew(q*) */
+    orc_zero(36, Hpose);
+    const double sw[9] = {0, -qw[2], qw[1], qw[2], 0, -qw[0], -qw[1], qw[0], 0};
+    const double sv[9] = {0, -qv[2], qv[1], qv[2], 0, -qv[0], -qv[1], qv[0], 0};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { Hpose[i * 6 + j] = sw[i * 3 + j]; Hpose[(3 + i) * 6 + j] = sv[i * 3 + j]; }
+  }
+}
+
+/* GaussianProcessPriorPose3VW::evaluateError -- GaussianProcessPriorPose3VW.h:62-117.
+ * H1, H4: 12x6; H2, H3, H5, H6: 12x3. */
+void orc_gp_prior_pose3vw(const double *p1, const double *vel1, const double *omega1, const double *p2,
+                          const double *vel2, const double *omega2, double dt, double *e, double *H1, double *H2,
+                          double *H3, double *H4, double *H5, double *H6) {
+  double Hinv[36], Hc1[36], Hc2[36], Hlog[36], inv[12], btw[12], r[6], Jinv[36], Jv2[6];
+  double H1v[18], H1w[18], H2v[18], H2w[18], H1p[36], H2p[36], v1[6], v2[6], Hv1[72], Hv2[72];
+  orc_pose3_inverse(p1, inv, Hinv);
+  orc_pose3_compose(inv, p2, btw, Hc1, Hc2);
+  orc_pose3_logmap(btw, r, Hlog);                      /* :75-78 */
+  orc_rightJacobianPose3inv(r, Jinv);                  /* :80 */
+  orc_convertVWtoVb(vel1, omega1, p1, v1, H1v, H1w, H1p);   /* :87-88 */
+  orc_convertVWtoVb(vel2, omega2, p2, v2, H2v, H2w, H2p);
+  orc_zero(72, Hv1);                                   /* :89-90 */
+  orc_zero(72, Hv2);
+  for (int i = 0; i < 6; i++) { Hv1[i * 6 + i] = -dt; Hv1[(6 + i) * 6 + i] = -1.0; }
+  orc_blk(6, 6, Jinv, 6, 0, 0, Hv2, 6, 6, 0);
+  if (H1) {                                            /* :97-102 */
+    double T[36], J_Ti[36], FD[36], Jdiff[36];
+    orc_mm(6, 6, 6, Hlog, Hc1, T);
+    orc_mm(6, 6, 6, T, Hinv, J_Ti);
+    orc_jacobianNumDiff_Pose3inv(r, v2, 1e-6, FD);
+    orc_mm(6, 6, 6, FD, J_Ti, Jdiff);
+    for (int i = 0; i < 36; i++) { H1[i] = J_Ti[i] - dt * H1p[i]; H1[36 + i] = Jdiff[i] - H1p[i]; }
+  }
+  if (H2) orc_mm(12, 6, 3, Hv1, H1v, H2);              /* :104 */
+  if (H3) orc_mm(12, 6, 3, Hv1, H1w, H3);              /* :105 */
+  if (H4) {                                            /* :107-112 */
+    double J_Ti1[36], FD[36], Jdiff[36], JH[36];
+    orc_mm(6, 6, 6, Hlog, Hc2, J_Ti1);
+    orc_jacobianNumDiff_Pose3inv(r, v2, 1e-6, FD);
+    orc_mm(6, 6, 6, FD, J_Ti1, Jdiff);
+    orc_mm(6, 6, 6, Jinv, H2p, JH);
+    for (int i = 0; i < 36; i++) { H4[i] = J_Ti1[i]; H4[36 + i] = Jdiff[i] + JH[i]; }
+  }
+  if (H5) orc_mm(12, 6, 3, Hv2, H2v, H5);              /* :114 */
+  if (H6) orc_mm(12, 6, 3, Hv2, H2w, H6);              /* :115 */
+  orc_mm(6, 6, 1, Jinv, v2, Jv2);                      /* :117 */
+  for (int i = 0; i < 6; i++) {
+    e[i] = r[i] - v1[i] * dt;
+    e[6 + i] = Jv2[i] - v1[i];
+  }
+}
+
 /* ------------------------------------------------------------------ GP interpolators */
 
 /* GaussianProcessInterpolatorLinear<D>::interpolatePose -- GaussianProcessInterpolatorLinear.h:70-90
@@ -402,5 +474,101 @@ void orc_interp_pose3(const double *Lambda, const double *Psi, const double *p1,
       orc_mm(6, 6, 6, He, P12, T);
       orc_mm(6, 6, 6, T, Jinv, H4);
     }
+  }
+}
+
+/* GaussianProcessInterpolatorPose3VW::interpolatePose -- GaussianProcessInterpolatorPose3VW.h:58-124.
+ * H1, H4: 6x6; H2, H3, H5, H6: 6x3. */
+void orc_interp_pose3vw(const double *Lambda, const double *Psi, const double *p1, const double *v1,
+                        const double *omega1, const double *p2, const double *v2, const double *omega2, double *pose,
+                        double *H1, double *H2, double *H3, double *H4, double *H5, double *H6) {
+  double Hinv[36], Hc11[36], Hc12[36], Hlog[36], inv[12], btw[12], r[6], Jinv[36], Jv2[6];
+  double H1v[18], H1w[18], H2v[18], H2w[18], H1p[36], H2p[36], vel1[6], vel2[6];
+  double r1[12], r2[12], xi[6], ex[12], Hexp[36], Hc21[36], Hc22[36];
+  const int want = H1 || H2 || H3 || H4 || H5 || H6;
+  orc_pose3_inverse(p1, inv, Hinv);
+  orc_pose3_compose(inv, p2, btw, Hc11, Hc12);
+  orc_pose3_logmap(btw, r, Hlog);                      /* :68-71 */
+  orc_rightJacobianPose3inv(r, Jinv);                  /* :73 */
+  orc_convertVWtoVb(v1, omega1, p1, vel1, H1v, H1w, H1p);   /* :79-80 */
+  orc_convertVWtoVb(v2, omega2, p2, vel2, H2v, H2w, H2p);
+  orc_mm(6, 6, 1, Jinv, vel2, Jv2);
+  for (int i = 0; i < 6; i++) { r1[i] = 0.0; r1[6 + i] = vel1[i]; r2[i] = r[i]; r2[6 + i] = Jv2[i]; }   /* :85-86 */
+  for (int i = 0; i < 6; i++) {
+    double s = 0.0;
+    for (int j = 0; j < 12; j++) s += Lambda[i * 12 + j] * r1[j] + Psi[i * 12 + j] * r2[j];
+    xi[i] = s;
+  }
+  orc_pose3_expmap(xi, ex, Hexp);
+  orc_pose3_compose(p1, ex, pose, Hc21, Hc22);         /* :92 */
+  if (want) {
+    double He[36], L12[36], P12[36], Hvel1[36], Hvel2[36], T[36], Psi1[72], FD[36];
+    orc_mm(6, 6, 6, Hc22, Hexp, He);                   /* :93 */
+    orc_blk(6, 6, Lambda, 12, 0, 6, L12, 6, 0, 0);
+    orc_blk(6, 6, Psi, 12, 0, 6, P12, 6, 0, 0);
+    orc_mm(6, 6, 6, He, L12, Hvel1);                   /* :94 */
+    orc_mm(6, 6, 6, He, P12, T);
+    orc_mm(6, 6, 6, T, Jinv, Hvel2);                   /* :95 */
+    orc_blk(6, 12, Psi, 12, 0, 0, Psi1, 12, 0, 0);
+    orc_jacobianNumDiff_Pose3inv(r, vel2, 1e-6, FD);
+    if (H1) {                                          /* :97-102 */
+      double A[36], tmp[36], FDtmp[36], dr2[72], PD[36], HPD[36], HH[36];
+      orc_mm(6, 6, 6, Hlog, Hc11, A);
+      orc_mm(6, 6, 6, A, Hinv, tmp);
+      orc_mm(6, 6, 6, FD, tmp, FDtmp);
+      orc_blk(6, 6, tmp, 6, 0, 0, dr2, 6, 0, 0);
+      orc_blk(6, 6, FDtmp, 6, 0, 0, dr2, 6, 6, 0);
+      orc_mm(6, 12, 6, Psi1, dr2, PD);
+      orc_mm(6, 6, 6, He, PD, HPD);
+      orc_mm(6, 6, 6, Hvel1, H1p, HH);
+      for (int i = 0; i < 36; i++) H1[i] = Hc21[i] + HPD[i] + HH[i];
+    }
+    if (H2) orc_mm(6, 6, 3, Hvel1, H1v, H2);           /* :104 */
+    if (H3) orc_mm(6, 6, 3, Hvel1, H1w, H3);           /* :105 */
+    if (H4) {                                          /* :107-112 */
+      double tmp[36], FDtmp[36], dr2[72], PD[36], HPD[36], HH[36];
+      orc_mm(6, 6, 6, Hlog, Hc12, tmp);
+      orc_mm(6, 6, 6, FD, tmp, FDtmp);
+      orc_blk(6, 6, tmp, 6, 0, 0, dr2, 6, 0, 0);
+      orc_blk(6, 6, FDtmp, 6, 0, 0, dr2, 6, 6, 0);
+      orc_mm(6, 12, 6, Psi1, dr2, PD);
+      orc_mm(6, 6, 6, He, PD, HPD);
+      orc_mm(6, 6, 6, Hvel2, H2p, HH);
+      for (int i = 0; i < 36; i++) H4[i] = HPD[i] + HH[i];
+    }
+    if (H5) orc_mm(6, 6, 3, Hvel2, H2v, H5);           /* :114 */
+    if (H6) orc_mm(6, 6, 3, Hvel2, H2w, H6);           /* :115 */
+  }
+}
+
+/* The VW factors with the two 3-vectors of a state stored as one 6-vector s = [v; w] and their Jacobians packed
+ * side by side ([H_v | H_w], rows x 6): the call shape of the body-velocity versions, used by the chain problem. */
+void orc_gp_prior_pose3vw_packed(const double *p1, const double *s1, const double *p2, const double *s2, double dt,
+                                 double *e, double *H1, double *H2, double *H3, double *H4) {
+  double Hv1[36], Hw1[36], Hv2[36], Hw2[36];
+  const int jac = H1 || H2 || H3 || H4;
+  orc_gp_prior_pose3vw(p1, s1, s1 + 3, p2, s2, s2 + 3, dt, e, jac ? H1 : NULL, jac ? Hv1 : NULL, jac ? Hw1 : NULL,
+                       jac ? H3 : NULL, jac ? Hv2 : NULL, jac ? Hw2 : NULL);
+  if (jac) {
+    for (int i = 0; i < 12; i++)
+      for (int j = 0; j < 3; j++) {
+        H2[i * 6 + j] = Hv1[i * 3 + j]; H2[i * 6 + 3 + j] = Hw1[i * 3 + j];
+        H4[i * 6 + j] = Hv2[i * 3 + j]; H4[i * 6 + 3 + j] = Hw2[i * 3 + j];
+      }
+  }
+}
+void orc_interp_pose3vw_packed(const double *Lambda, const double *Psi, const double *p1, const double *s1,
+                               const double *p2, const double *s2, double *pose, double *H1, double *H2, double *H3,
+                               double *H4) {
+  double Hv1[18], Hw1[18], Hv2[18], Hw2[18];
+  const int jac = H1 || H2 || H3 || H4;
+  orc_interp_pose3vw(Lambda, Psi, p1, s1, s1 + 3, p2, s2, s2 + 3, pose, jac ? H1 : NULL, jac ? Hv1 : NULL,
+                     jac ? Hw1 : NULL, jac ? H3 : NULL, jac ? Hv2 : NULL, jac ? Hw2 : NULL);
+  if (jac) {
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 3; j++) {
+        H2[i * 6 + j] = Hv1[i * 3 + j]; H2[i * 6 + 3 + j] = Hw1[i * 3 + j];
+        H4[i * 6 + j] = Hv2[i * 3 + j]; H4[i * 6 + 3 + j] = Hw2[i * 3 + j];
+      }
   }
 }

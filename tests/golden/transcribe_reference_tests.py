@@ -32,6 +32,38 @@ def R3(y, p, r):
 
 Z3, Z6 = [0, 0, 0], [0, 0, 0, 0, 0, 0]
 
+# ---- GaussianProcessPriorPose3VW (dt = 0.1, Qc = 0.01 I6: testGaussianProcessPriorPose3VW.cpp:35-36).
+# The last case transcribes the reference's statements literally: `w1` is assigned twice and `w2` keeps the value of the
+# previous case (:124-125).
+gp_prior_vw = [
+    dict(src=GP + "testGaussianProcessPriorPose3VW.cpp:49-74", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 0], w1=[0, 0, 0],
+         p2=P3(0, 0, 0, 0, 0, 0), v2=[0, 0, 0], w2=[0, 0, 0], expect=[0] * 12, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 6),
+    dict(src=GP + "testGaussianProcessPriorPose3VW.cpp:77-103", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=[1, 0, 0], w1=[0, 0, 0],
+         p2=P3(0, 0, 0, 0.1, 0, 0), v2=[1, 0, 0], w2=[0, 0, 0], expect=[0] * 12, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 6),
+    dict(src=GP + "testGaussianProcessPriorPose3VW.cpp:106-132", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 0], w1=[0, 0, 1],
+         p2=P3(0.1, 0, 0, 0, 0, 0), v2=[0, 0, 0], w2=[0, 0, 1], expect=[0] * 12, tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 6),
+    dict(src=GP + "testGaussianProcessPriorPose3VW.cpp:135-139", dt=0.1, p1=P3(-0.1, 1.2, 0.3, -4.0, 2.0, 14.0),
+         v1=[2, 3, 1], w1=[0, 6, 4], p2=P3(2.4, -2.5, 3.7, 9.0, -8.0, -7.0), v2=[1, 3, 8], w2=[0, 0, 1], expect=None,
+         fd=1e-6, tol_H=[1e-5, 1e-6, 1e-6, 1e-5, 1e-6, 1e-6]),
+]
+
+# ---- GaussianProcessInterpolatorPose3VW (dt = 0.1, tau = 0.03, Qc = 0.01 I6: ...InterpolatorPose3VW.cpp:33-35);
+# last case literal again: v1 / w1 assigned twice, v2 / w2 left from the previous case (:127-128)
+interpolator_vw = [
+    dict(src=GP + "testGaussianProcessInterpolatorPose3VW.cpp:39-64", dt=0.1, tau=0.03, qc=0.01, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[0, 0, 0], w1=[0, 0, 0], p2=P3(0, 0, 0, 0, 0, 0), v2=[0, 0, 0], w2=[0, 0, 0], expect=P3(0, 0, 0, 0, 0, 0),
+         tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 6),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3VW.cpp:67-93", dt=0.1, tau=0.03, qc=0.01, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[1, 2, 0], w1=[0, 0, 0], p2=P3(0, 0, 0, 0.1, 0.2, 0), v2=[1, 2, 0], w2=[0, 0, 0],
+         expect=P3(0, 0, 0, 0.03, 0.06, 0), tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 6),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3VW.cpp:96-121", dt=0.1, tau=0.03, qc=0.01, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[0, 0, 0], w1=[0, 0, 1], p2=P3(0.1, 0, 0, 0, 0, 0), v2=[0, 0, 0], w2=[0, 0, 1],
+         expect=P3(0.03, 0, 0, 0, 0, 0), tol_e=1e-6, fd=1e-6, tol_H=[1e-8] * 6),
+    dict(src=GP + "testGaussianProcessInterpolatorPose3VW.cpp:125-148", dt=0.1, tau=0.03, qc=0.01,
+         p1=P3(0.4, -0.8, 0.2, 3, -8, 2), v1=[0.6, 0.3, -0.9], w1=[0.4, -0.2, 0.8], p2=P3(0.1, 0.3, -0.5, -9, 3, 4),
+         v2=[0, 0, 0], w2=[0, 0, 1], expect=None, fd=1e-6, tol_H=[1e-8] * 6),
+]
+
 gp_prior = [
     # ---- GaussianProcessPriorPose3 (dt = 0.1, Qc = 0.01 I6: testGaussianProcessPriorPose3.cpp:29-30)
     dict(src=GP + "testGaussianProcessPriorPose3.cpp:43-65", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6,
@@ -298,7 +330,7 @@ optimization = [
 
 out = dict(
     _about="Inputs/expected values transcribed from gtrll/gpslam's own unit tests; see transcribe_reference_tests.py",
-    gp_prior=gp_prior, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
+    gp_prior=gp_prior, gp_prior_vw=gp_prior_vw, interpolator_vw=interpolator_vw, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
     bearing_range2d=bearing_range2d, odometry2d=odometry2d, body_centric_velocity=body_centric_velocity,
     lie_jacobians=lie_jacobians, se3_velocity=se3_velocity, optimization=optimization)
 
