@@ -72,6 +72,7 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
 struct gpslam_hip_handle {
   gpslam_hip_config cfg;
   int mf = 0, d = 0, pd = 0, b = 0, ld = 0;
+  int vw = 0;                 // Pose3: velocities are world-frame [v; w] (cfg.reserved[3], the *Pose3VW factors)
   int N = 0, L = 0, stride = 0, R = 1, nl = 0;
   bool own_stream = true;
   hipStream_t stream = nullptr;
@@ -237,6 +238,7 @@ GpArgs<Real> gp_args(gpslam_hip_handle *h, Real *partial) {
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
   a.partial = partial; a.out_e = nullptr; a.out_H = nullptr;
   a.U = make_umat(h);
+  a.vw = h->vw;
   return a;
 }
 
@@ -264,8 +266,12 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     const int nb = nblocks(a.count, 128);
     dispatch_mf(h->mf, [&](auto tag) {
       constexpr int MF = decltype(tag)::value;
-      if (mode == 0) k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
-      else k_gp<Real, MF, 1><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+      if (mode == 0) {
+        if (MF == POSE3 && h->vw) k_gp<Real, MF, 0, true><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+        else k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+      } else {
+        k_gp<Real, MF, 1><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+      }
     });
     off += nb;
   }
@@ -304,6 +310,7 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     a.sig = s.d_sig.as<Real>(); a.coef = s.d_coef.as<Real>();
     for (int k = 0; k < 12; k++) a.sensor[k] = (Real)s.sensor[k];
     a.has_sensor = s.has_sensor ? 1 : 0;
+    a.vw = h->vw;
     a.row0 = s.d_row0.as<int>();
     a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>(); a.rowLm = h->rowLm.as<int>();
     a.partial = part + off;
@@ -618,6 +625,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (cfg->precision != GPSLAM_FP64) return GPSLAM_E_UNSUPPORTED;
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
+  if (cfg->reserved[3] != 0 && (cfg->reserved[3] != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPSLAM_E_HIP;  // no GPU: fail loudly
   if (cfg->device < 0 || cfg->device >= ndev) return GPSLAM_E_INVALID;
@@ -631,6 +639,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   h->pd = pdd[h->mf];
   h->b = 2 * h->d;
   h->ld = cfg->landmark_dim;
+  h->vw = (cfg->reserved[3] == GPSLAM_VELOCITY_WORLD_VW) ? 1 : 0;
   std::memset(h->Qc, 0, sizeof(h->Qc));
   std::memset(h->U, 0, sizeof(h->U));
   for (int i = 0; i < h->d; i++) h->Qc[i * h->d + i] = h->U[i * h->d + i] = 1.0;
@@ -1291,7 +1300,7 @@ int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int3
   HIPCHK(d_out.reserve((size_t)count * pd * sizeof(Real)));
   QueryArgs<Real> a;
   a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.count = count;
-  a.left = d_left.as<int>(); a.coef = d_coef.as<Real>(); a.out = d_out.as<Real>();
+  a.left = d_left.as<int>(); a.coef = d_coef.as<Real>(); a.out = d_out.as<Real>(); a.vw = h->vw;
   dispatch_mf(h->mf, [&](auto tag) {
     constexpr int MF = decltype(tag)::value;
     k_interp_query<Real, MF><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
@@ -1326,7 +1335,8 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
       const int nb = nblocks(a.count, 128);
       dispatch_mf(h->mf, [&](auto tag) {
         constexpr int MF = decltype(tag)::value;
-        k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+        if (MF == POSE3 && h->vw) k_gp<Real, MF, 0, true><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+        else k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
       });
     } else if (which == 1) {
       if ((rc = launch_assemble(h, false))) return rc;

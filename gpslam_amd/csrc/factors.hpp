@@ -209,6 +209,28 @@ template <typename T> GD BL6<T> se3_jrinv_times_x_fd(V6<T> xi, V6<T> x) {
   return D;
 }
 
+// ---- world-frame velocity parameterisation: the *Pose3VW factor family (GaussianProcessPriorPose3VW.h,
+// GaussianProcessInterpolatorPose3VW.h, GPInterpolatedGPSFactorPose3VW.h).  A state carries s = [v; w], world-frame
+// translational and rotational velocity; every VW factor is the body-velocity factor evaluated at
+// Vb = convertVWtoVb(v, w, pose) = [R^T w; R^T v] (Pose3utils.cpp:47-64), and its Jacobians follow by the chain rule
+//   dVb/dpose = [[skew(R^T w), 0], [skew(R^T v), 0]],   dVb/d(v, w) = [[0, R^T], [R^T, 0]]        (:56-60)
+// -- exactly the H1p / H1v / H1w terms of GaussianProcessPriorPose3VW.h:97-115.
+template <typename T> GD void vw_to_vb(const T *pose, const T *s, T *vb) {
+  const M3<T> R = as_m3(pose);
+  const V3<T> wb = tmul(R, V3<T>{s[3], s[4], s[5]}), tb = tmul(R, V3<T>{s[0], s[1], s[2]});
+  vb[0] = wb.x; vb[1] = wb.y; vb[2] = wb.z; vb[3] = tb.x; vb[4] = tb.y; vb[5] = tb.z;
+}
+// one state's segment of a Jacobian row, a[12] = [d/dpose (6) | d/dVb (6)]  ->  [d/dpose | d/dv (3) | d/dw (3)]
+template <typename T> GD void vw_row_transform(const T *pose, const T *vb, T *a) {
+  const M3<T> R = as_m3(pose);
+  const V3<T> aw = {a[6], a[7], a[8]}, at = {a[9], a[10], a[11]};
+  const V3<T> wb = {vb[0], vb[1], vb[2]}, tb = {vb[3], vb[4], vb[5]};
+  const V3<T> dp = cross(aw, wb) + cross(at, tb);          // x^T skew(u) = (x cross u)^T
+  a[0] += dp.x; a[1] += dp.y; a[2] += dp.z;
+  const V3<T> nv = R * at, nw = R * aw;                    // x^T R^T = (R x)^T
+  a[6] = nv.x; a[7] = nv.y; a[8] = nv.z; a[9] = nw.x; a[10] = nw.y; a[11] = nw.z;
+}
+
 // GP prior, unwhitened.  x1 = (p1, v1), x2 = (p2, v2) as flat arrays (pose layout of include/gpslam_hip.h).
 // Outputs: e[2d]; if JAC: Jt[d][4d] = top d rows of [H1 H2 | H3 H4], Jb[d][4d] = bottom d rows.
 template <typename T, int MF, bool JAC> struct GpPrior;

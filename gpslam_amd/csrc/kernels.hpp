@@ -83,6 +83,7 @@ template <typename T> struct GpArgs {
   T *partial;             // per-block error partial sums
   T *out_e, *out_H;       // MODE 2: API layout
   UMat<T> U;
+  int vw;                 // Pose3 only: velocities are world-frame [v; w] (the *Pose3VW factors)
 };
 
 // Cooperative row store: every lane of a wave has deposited one row (W doubles, W even) of ITS factor in the wave's
@@ -147,7 +148,7 @@ __device__ __forceinline__ void utri_times_bl6_row(const T *U, const BL6<T> &M, 
 // [H1 H2] = [[J, -dt I], [FD J, -I]], J = -Jinv Ad(h^-1); whitening R = [[sa U, sb U], [0, sc U]] is applied as
 // U x (block lower-triangular) products row by row, skipping the structural zeros.  Peak live state is FD + two
 // 6x6 blocks instead of two 6 x 24 arrays, which is what lets two waves share a SIMD.
-template <typename T>
+template <typename T, bool VW>
 __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, int f, T *st, const int *sr, int lane, T &err) {
   constexpr int LS = 14;
   T *mine = st + lane * LS;
@@ -165,6 +166,13 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
     for (int k = 0; k < 12; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
 #pragma unroll
     for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+  }
+  if (VW) {   // GaussianProcessPriorPose3VW.h:87-88: body velocities of the world-frame (v, w)
+    T b1[6], b2[6];
+    vw_to_vb(p1, v1, b1);
+    vw_to_vb(p2, v2, b2);
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v1[k] = b1[k]; v2[k] = b2[k]; }
   }
   const SE3<T> h = se3_between(as_se3(p1), as_se3(p2));
   const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
@@ -204,9 +212,11 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       utri_times_bl6_row(U, P3, rho, y);
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sb * x[c]; }
+      if (VW) vw_row_transform(p2, v2, mine);
       wave_store_part<T, 24, 12>(st, sr, lane, rho, 12, a.rowLR);
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sc * y[c]; mine[6 + c] = sc * x[c]; }
+      if (VW) vw_row_transform(p2, v2, mine);
       wave_store_part<T, 24, 12>(st, sr, lane, 6 + rho, 12, a.rowLR);
     }
   }
@@ -221,16 +231,18 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       utri_times_bl6_row(U, P1, rho, y);
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = (c >= rho) ? k2 * U[rho * 6 + c] : T(0); }
+      if (VW) vw_row_transform(p1, v1, mine);
       wave_store_part<T, 24, 12>(st, sr, lane, rho, 0, a.rowLR);
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sc * y[c]; mine[6 + c] = (c >= rho) ? -sc * U[rho * 6 + c] : T(0); }
+      if (VW) vw_row_transform(p1, v1, mine);
       wave_store_part<T, 24, 12>(st, sr, lane, 6 + rho, 0, a.rowLR);
     }
   }
 }
 
 // MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
-template <typename T, int MF, int MODE>
+template <typename T, int MF, int MODE, bool VW = false>
 __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   constexpr bool JAC = (MODE != 1);
@@ -243,7 +255,7 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   T err = T(0);
   if constexpr (MF == POSE3 && MODE == 0) {
     srow[threadIdx.x] = valid ? a.row0[f] : -1;
-    gp_pose3_rows<T>(a, valid, f, stage + wv * 64 * LS, srow + wv * 64, lane, err);
+    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * LS, srow + wv * 64, lane, err);
     const T tot = block_sum(T(0.5) * err);
     if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
     return;
@@ -259,7 +271,25 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
     for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
 #pragma unroll
     for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+    if constexpr (MF == POSE3) {
+      if (a.vw) {
+        T b1[6], b2[6];
+        vw_to_vb(p1, v1, b1);
+        vw_to_vb(p2, v2, b2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { v1[k] = b1[k]; v2[k] = b2[k]; }
+      }
+    }
     GpPrior<T, MF, JAC>::eval(p1, v1, p2, v2, dt, e, Jt, Jb);
+    if constexpr (MF == POSE3 && JAC) {
+      if (a.vw) {
+#pragma unroll
+        for (int r = 0; r < d; r++) {
+          vw_row_transform(p1, v1, Jt + r * 2 * b); vw_row_transform(p2, v2, Jt + r * 2 * b + b);
+          vw_row_transform(p1, v1, Jb + r * 2 * b); vw_row_transform(p2, v2, Jb + r * 2 * b + b);
+        }
+      }
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < b; k++) e[k] = T(0);
@@ -438,6 +468,7 @@ template <typename T> struct MeasArgs {
   const T *coef;       // count x 4: l11, l12, p11, p12 (interpolated kinds)
   T sensor[12];
   int has_sensor;
+  int vw;              // Pose3 only: velocities are world-frame [v; w]
   const int *row0;
   T *rowLR, *rowE, *rowM;
   int *rowLm;
@@ -472,6 +503,15 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = two ? a.pose[(size_t)k * a.stride + i + 1] : T(0); }
 #pragma unroll
       for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = two ? a.vel[(size_t)k * a.stride + i + 1] : T(0); }
+      if constexpr (MF == POSE3 && two) {
+        if (a.vw) {     // GaussianProcessInterpolatorPose3VW.h:79-80
+          T b1[6], b2[6];
+          vw_to_vb(p1, v1, b1);
+          vw_to_vb(p2, v2, b2);
+#pragma unroll
+          for (int k = 0; k < 6; k++) { v1[k] = b1[k]; v2[k] = b2[k]; }
+        }
+      }
       int lm = -1;
       T pt[3] = {T(0), T(0), T(0)};
       if (haslm) {
@@ -624,6 +664,12 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         }
       }
 
+      if constexpr (MF == POSE3 && two && JAC) {
+        if (a.vw) {     // chain rule through convertVWtoVb (v1 / v2 hold the body velocities here)
+#pragma unroll
+          for (int r = 0; r < rows; r++) { vw_row_transform(p1, v1, JL + r * b); vw_row_transform(p2, v2, JR + r * b); }
+        }
+      }
       const int row0 = JAC ? a.row0[f] : 0;
 #pragma unroll
       for (int r = 0; r < rows; r++) {
@@ -925,6 +971,7 @@ template <typename T> struct QueryArgs {
   int stride, count;
   const int *left;       // query q lies in the interval (left[q], left[q] + 1)
   const T *coef;         // count x 4: l11, l12, p11, p12 for (dt[q], tau[q])
+  int vw;                // Pose3 only: velocities are world-frame [v; w]
   T *out;                // count x pose_dim (AoS, the layout of gpslam_hip_get_states' rows)
 };
 
@@ -942,6 +989,15 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
   for (int c = 0; c < pd; c++) { p1[c] = a.pose[(size_t)c * a.stride + i]; p2[c] = a.pose[(size_t)c * a.stride + i + 1]; }
 #pragma unroll
   for (int c = 0; c < d; c++) { v1[c] = a.vel[(size_t)c * a.stride + i]; v2[c] = a.vel[(size_t)c * a.stride + i + 1]; }
+  if constexpr (MF == POSE3) {
+    if (a.vw) {
+      T b1[6], b2[6];
+      vw_to_vb(p1, v1, b1);
+      vw_to_vb(p2, v2, b2);
+#pragma unroll
+      for (int c = 0; c < 6; c++) { v1[c] = b1[c]; v2[c] = b2[c]; }
+    }
+  }
   T *o = a.out + (size_t)q * pd;
   if constexpr (MF == LINEAR2 || MF == LINEAR3) {
     // p(tau) = Lambda_1 [p1; v1] + Psi_1 [p2; v2]   (GaussianProcessInterpolatorLinear.h:70-90)

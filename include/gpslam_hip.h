@@ -40,6 +40,12 @@ typedef struct gpslam_hip_handle gpslam_hip_handle;
 enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 3, GPSLAM_ROT3 = 4 };
 enum { GPSLAM_CHART_EXPMAP = 0, GPSLAM_CHART_FIRST_ORDER = 1 };
 enum { GPSLAM_FP64 = 0, GPSLAM_FP32 = 1 };
+/* velocity parameterisation of a POSE3 chain (config.reserved[3]):
+ * BODY      6-vector body-frame velocity (w, v): GaussianProcessPriorPose3 / InterpolatorPose3 (gpslam.h:32-35, :72-77)
+ * WORLD_VW  world-frame translational v and rotational w, stored as [v; w]: GaussianProcessPriorPose3VW,
+ *           GaussianProcessInterpolatorPose3VW, GPInterpolatedGPSFactorPose3VW (gpslam.h:38-41, :65-70;
+ *           gpslam/gp/GaussianProcessPriorPose3VW.h:62-117).  gtsam keys (x_i, v_i, w_i) map to one state. */
+enum { GPSLAM_VELOCITY_BODY = 0, GPSLAM_VELOCITY_WORLD_VW = 1 };
 
 enum {
   GPSLAM_OK = 0,
@@ -59,7 +65,8 @@ typedef struct {
   int32_t landmark_dim;  /* 0 (no landmarks), 2 or 3 */
   int32_t chunk;         /* level-0 chunk length of the partitioned solver; 0 = default */
   int32_t rank, nranks;  /* contiguous-segment sharding: this handle owns segment `rank` of `nranks` */
-  int32_t reserved[8];
+  int32_t reserved[8];   /* [0] force the sharded code path, [1] upper-level chunk length, [2] sequential top size,
+                          * [3] GPSLAM_VELOCITY_* (POSE3 only); others must be 0 */
 } gpslam_hip_config;
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */
