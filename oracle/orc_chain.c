@@ -21,7 +21,7 @@
 
 enum {
   F_GP = 0, F_POSE_PRIOR, F_VEL_PRIOR, F_BETWEEN, F_LM_PRIOR, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT,
-  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE
+  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ
 };
 
 typedef struct {
@@ -232,6 +232,21 @@ int orc_chain_add_bearing_range(orc_chain *c, int count, const int32_t *idx, con
   }
   return 0;
 }
+int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
+                                    const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                    const double *K, const double *sensor) {
+  if (c->kind != ORC_POSE3 || c->ld != 3 || c->vw) return -2;
+  for (int k = 0; k < count; k++) {
+    orc_factor *f = new_factor(c, F_INTERP_PROJ);
+    f->idx = left[k]; f->lm = landmark[k];
+    f->meas[0] = measured[2 * (size_t)k]; f->meas[1] = measured[2 * (size_t)k + 1];
+    f->sig[0] = sigmas[2 * (size_t)k]; f->sig[1] = sigmas[2 * (size_t)k + 1];
+    f->dt = dt[k]; f->tau = tau[k];
+    orc_copy(5, K, f->aux);                       /* fx, fy, s, u0, v0 */
+    if (sensor) { f->has_sensor = 1; orc_copy(12, sensor, f->sensor); }
+  }
+  return 0;
+}
 
 /* ------------------------------------------------------------------ factor evaluation */
 
@@ -376,6 +391,15 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
       orc_range_bearing_2dlinear(f->meas[0], f->meas[1], p1, pt, e, H1, H5);
       *uses_lm = 1;
       if (want_jac) { PUT(JL, H1, 0, d); PUT(Jm, H5, 0, ld); }
+      break;
+    case F_INTERP_PROJ:
+      rows = 2;
+      if (orc_calcLambda(d, c->Qc, f->dt, f->tau, Lam) || orc_calcPsi(d, c->Qc, f->dt, f->tau, Psi)) return -1;
+      orc_interp_projection_pose3(Lam, Psi, f->meas, f->aux, f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt, e,
+                                  H1, H2, H3, H4, H5);
+      *uses_right = 1;
+      *uses_lm = 1;
+      if (want_jac) { PUT(JL, H1, 0, d); PUT(JL, H2, d, d); PUT(JR, H3, 0, d); PUT(JR, H4, d, d); PUT(Jm, H5, 0, ld); }
       break;
     default: return -2;
   }

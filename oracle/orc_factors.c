@@ -151,6 +151,69 @@ double orc_interp_range_pose3vw(const double *Lambda, const double *Psi, double 
   return hx - measured;
 }
 
+/* PinholeCamera<Cal3_S2>::project(point, Dpose, Dpoint) (GTSAM CalibratedCamera.cpp / Cal3_S2.cpp; call site
+ * GPInterpolatedProjectionFactorPose3.h:106-118):  q = R^T (p - t) must have q.z > 0 (else CheiralityException),
+ * pn = (q.x, q.y) / q.z, uv = (fx pn.x + s pn.y + u0, fy pn.y + v0), K = [fx, fy, s, u0, v0].
+ * Dpn_pose = [uv', -1-u^2, v, -d, 0, d u; 1+v^2, -uv', -u, 0, -d, d v] with (u, v) = pn, d = 1/q.z (PinholeBase::Dpose),
+ * Dpn_point = d [Rt_0 - u Rt_2; Rt_1 - v Rt_2], Rt = R^T (PinholeBase::Dpoint), Duv_pn = [fx, s; 0, fy].
+ * Returns 0, or 1 on a cheirality violation (outputs untouched). */
+int orc_pinhole_project(const double cam[12], const double K[5], const double point[3], double uv[2], double *Dpose,
+                        double *Dpoint) {
+  double q[3];
+  orc_pose3_transform_to(cam, point, q, NULL, NULL);
+  if (q[2] <= 0.0) return 1;
+  const double d = 1.0 / q[2], u = q[0] * d, v = q[1] * d;
+  uv[0] = K[0] * u + K[2] * v + K[3];
+  uv[1] = K[1] * v + K[4];
+  const double Dk[4] = {K[0], K[2], 0.0, K[1]};
+  if (Dpose) {
+    const double Dp[12] = {u * v, -1.0 - u * u, v, -d, 0.0, d * u,
+                           1.0 + v * v, -u * v, -u, 0.0, -d, d * v};
+    orc_mm(2, 2, 6, Dk, Dp, Dpose);
+  }
+  if (Dpoint) {
+    double Dp[6];
+    for (int j = 0; j < 3; j++) {   /* Rt(i, j) = R(j, i) = cam[3 * j + i] */
+      Dp[j] = d * (cam[3 * j + 0] - u * cam[3 * j + 2]);
+      Dp[3 + j] = d * (cam[3 * j + 1] - v * cam[3 * j + 2]);
+    }
+    orc_mm(2, 2, 3, Dk, Dp, Dpoint);
+  }
+  return 0;
+}
+
+/* GPInterpolatedProjectionFactorPose3<Cal3_S2>::evaluateError -- GPInterpolatedProjectionFactorPose3.h:82-139.
+ * A landmark behind the camera does not throw (throwCheirality = false, the default): the error is 2 fx in both
+ * components and every Jacobian is zero (:122-138).  H1..H4: 2x6, H5: 2x3.  Returns 1 in that case, else 0. */
+int orc_interp_projection_pose3(const double *Lambda, const double *Psi, const double measured[2], const double K[5],
+                                const double *sensor, const double *p1, const double *v1, const double *p2,
+                                const double *v2, const double *point, double *e, double *H1, double *H2, double *H3,
+                                double *H4, double *H5) {
+  double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], cam[12], H0[36], Hcam[12], Hpose[12], uv[2];
+  int want = H1 || H2 || H3 || H4;
+  orc_interp_pose3(Lambda, Psi, p1, v1, p2, v2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
+                   want ? Hi4 : NULL);
+  if (sensor) orc_pose3_compose(pose, sensor, cam, H0, NULL);
+  else orc_copy(12, pose, cam);
+  if (orc_pinhole_project(cam, K, point, uv, Hcam, H5)) {
+    e[0] = e[1] = 2.0 * K[0];
+    if (H1) orc_zero(12, H1);
+    if (H2) orc_zero(12, H2);
+    if (H3) orc_zero(12, H3);
+    if (H4) orc_zero(12, H4);
+    if (H5) orc_zero(6, H5);
+    return 1;
+  }
+  e[0] = uv[0] - measured[0];
+  e[1] = uv[1] - measured[1];
+  if (want) {
+    if (sensor) orc_mm(2, 6, 6, Hcam, H0, Hpose);
+    else orc_copy(12, Hcam, Hpose);
+    update_pose_jacobians(2, 6, Hpose, Hi1, Hi2, Hi3, Hi4, H1, H2, H3, H4);
+  }
+  return 0;
+}
+
 /* RangeFactor2DLinear::evaluateError -- RangeFactor2DLinear.h:43-56 */
 double orc_range_2dlinear(double measured, const double *pose, const double *point, double *H1, double *H2) {
   double d[2] = {point[0] - pose[0], point[1] - pose[1]};

@@ -64,6 +64,35 @@ interpolator_vw = [
          v2=[0, 0, 0], w2=[0, 0, 1], expect=None, fd=1e-6, tol_H=[1e-8] * 6),
 ]
 
+# ---- GPInterpolatedProjectionFactorPose3<Cal3_S2> (dt = 0.1, tau = 0.04, Qc = 0.001 I6, sigma = 0.1;
+# K1 = Cal3_S2() = (fx, fy, s, u0, v0) = (1, 1, 0, 0, 0), K2 = Cal3_S2(50, 50, 0, 40, 30);
+# testGPInterpolatedProjectionFactorPose3.cpp:39-47).  meas given as a dict = "project `land` through the camera at
+# true_pose * sensor", as the reference builds it (:131-134).
+PROJ = SL + "testGPInterpolatedProjectionFactorPose3.cpp"
+K1, K2 = [1, 1, 0, 0, 0], [50, 50, 0, 40, 30]
+PSENS = P3(1.0, 0.4, 0.5, 0.3, 0.6, -0.7)
+interp_projection = [
+    dict(src=PROJ + ":58-83", dt=0.1, tau=0.04, qc=0.001, K=K1, sensor=None, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6,
+         p2=P3(0, 0, 0, 0, 0, 0), v2=Z6, land=[0, 0, 10], meas=[0, 0], expect=[0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=PROJ + ":87-112", dt=0.1, tau=0.04, qc=0.001, K=K1, sensor=None, p1=P3(0, 0, 0, -0.04, 0, 0),
+         v1=[0, 0, 0, 1, 0, 0], p2=P3(0, 0, 0, 0.06, 0, 0), v2=[0, 0, 0, 1, 0, 0], land=[0, 0, 10], meas=[0, 0],
+         expect=[0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=PROJ + ":116-141", dt=0.1, tau=0.04, qc=0.001, K=K1, sensor=None, p1=P3(-0.04, 0, 0, 0, 0, 0),
+         v1=[0, 0, 1, 0, 0, 0], p2=P3(0.06, 0, 0, 0, 0, 0), v2=[0, 0, 1, 0, 0, 0], land=[0, 0, 10], meas=[0, 0],
+         expect=[0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+    dict(src=PROJ + ":146-176", dt=0.1, tau=0.04, qc=0.001, K=K2, sensor=PSENS, p1=P3(0, 0, 0, 0, 0, 0),
+         v1=[0, 0, 0, 15, 0, 0], p2=P3(0, 0, 0, 1.5, 0, 0), v2=[0, 0, 0, 15, 0, 0], land=[3.4, 1.2, 10],
+         meas=dict(true_pose=P3(0, 0, 0, 0.6, 0, 0)), expect=[0, 0], tol_e=1e-6, fd=1e-6, tol_H=[1e-6] * 5),
+]
+# optimisation (:180-262): two poses with priors, GP prior (dt 0.1, Qc 0.01 I6), three projections of one landmark at
+# tau = 0.02 / 0.06 / 0.09 generated from cameras at x = 0.2 / 0.6 / 0.9; Gauss-Newton must recover everything to 1e-6
+projection_optimization = dict(
+    src=PROJ + ":180-262", dt=0.1, qc=0.01, K=K2, prior_sigma=0.01, cam_sigma=0.1, taus=[0.02, 0.06, 0.09],
+    cam_poses=[P3(0, 0, 0, 0.2, 0, 0), P3(0, 0, 0, 0.6, 0, 0), P3(0, 0, 0, 0.9, 0, 0)],
+    p1=P3(0, 0, 0, 0, 0, 0), p2=P3(0, 0, 0, 1, 0, 0), v1=[0, 0, 0, 10, 0, 0], v2=[0, 0, 0, 10, 0, 0], land=[3.4, 1.2, 20],
+    p1_init=P3(0.1, 0.2, 0.4, 0.2, 0.3, -0.2), p2_init=P3(-0.1, -0.2, -0.4, 1.2, -0.3, 0.2),
+    v1_init=[-0.3, 0, 0, 0.7, 0, 0.2], v2_init=[0, 0, 0.4, 1.2, 0, -0.1], land_init=[3.3, 1.3, 18], tol=1e-6)
+
 gp_prior = [
     # ---- GaussianProcessPriorPose3 (dt = 0.1, Qc = 0.01 I6: testGaussianProcessPriorPose3.cpp:29-30)
     dict(src=GP + "testGaussianProcessPriorPose3.cpp:43-65", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6,
@@ -330,7 +359,8 @@ optimization = [
 
 out = dict(
     _about="Inputs/expected values transcribed from gtrll/gpslam's own unit tests; see transcribe_reference_tests.py",
-    gp_prior=gp_prior, gp_prior_vw=gp_prior_vw, interpolator_vw=interpolator_vw, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
+    gp_prior=gp_prior, interp_projection=interp_projection, projection_optimization=projection_optimization,
+    gp_prior_vw=gp_prior_vw, interpolator_vw=interpolator_vw, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
     bearing_range2d=bearing_range2d, odometry2d=odometry2d, body_centric_velocity=body_centric_velocity,
     lie_jacobians=lie_jacobians, se3_velocity=se3_velocity, optimization=optimization)
 

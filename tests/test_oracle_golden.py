@@ -342,3 +342,76 @@ def test_vw_equals_body_velocity_factor_under_change_of_variables():
     assert np.abs(e_vw - e_b).max() <= 1e-14
     R = p1[:9].reshape(3, 3)
     assert np.allclose(vb1, np.concatenate([R.T @ s1[3:], R.T @ s1[:3]]), atol=1e-15)
+
+
+def _proj_meas(c):
+    if isinstance(c["meas"], dict):       # cam.project(land) with cam at true_pose * body_T_sensor
+        cam = dec_pose(O.POSE3, c["meas"]["true_pose"])
+        if c["sensor"] is not None:
+            out = np.zeros(12)
+            O.call("orc_pose3_compose", cam, dec_pose(O.POSE3, c["sensor"]), out, None, None)
+            cam = out
+        return O.pinhole_project(cam, c["K"], c["land"])
+    return O.A(c["meas"])
+
+
+def test_interp_projection_cases(golden):
+    """GPInterpolatedProjectionFactorPose3<Cal3_S2> (testGPInterpolatedProjectionFactorPose3.cpp:37-177)."""
+    for c in golden["interp_projection"]:
+        Lam, Psi = O.lambda_psi(6, c["qc"] * np.eye(6), c["dt"], c["tau"])
+        p1, p2 = dec_pose(O.POSE3, c["p1"]), dec_pose(O.POSE3, c["p2"])
+        v1, v2, land = O.A(c["v1"]), O.A(c["v2"]), O.A(c["land"])
+        sensor = None if c["sensor"] is None else dec_pose(O.POSE3, c["sensor"])
+        meas = _proj_meas(c)
+        e, H, behind = O.interp_projection(Lam, Psi, meas, c["K"], sensor, p1, v1, p2, v2, land)
+        assert not behind and np.abs(e - np.array(c["expect"])).max() <= c["tol_e"], c["src"]
+        f = lambda a, b, cc, dd, ll: O.interp_projection(Lam, Psi, meas, c["K"], sensor, a, b, cc, dd, ll, jac=False)[0]
+        num = [lambda h: numdiff_manifold(O.POSE3, lambda x: f(x, v1, p2, v2, land), p1, h),
+               lambda h: numdiff_vector(lambda x: f(p1, x, p2, v2, land), v1, h),
+               lambda h: numdiff_manifold(O.POSE3, lambda x: f(p1, v1, x, v2, land), p2, h),
+               lambda h: numdiff_vector(lambda x: f(p1, v1, p2, x, land), v2, h),
+               lambda h: numdiff_vector(lambda x: f(p1, v1, p2, v2, x), land, h)]
+        for k in range(5):
+            ok, err = _jac_ok(H[k], num[k], c["fd"], c["tol_H"][k])
+            assert ok, (c["src"], k, err)
+
+
+def test_projection_cheirality_is_masked_not_thrown():
+    """GPInterpolatedProjectionFactorPose3.h:122-138 with throwCheirality = false: error = 2 fx, zero Jacobians."""
+    Lam, Psi = O.lambda_psi(6, 0.001 * np.eye(6), 0.1, 0.04)
+    p = O.pose3((0, 0, 0), (0, 0, 0))
+    e, H, behind = O.interp_projection(Lam, Psi, [0, 0], [50, 50, 0, 40, 30], None, p, np.zeros(6), p, np.zeros(6), [0, 0, -5])
+    assert behind and np.all(e == 100.0) and all(np.all(h == 0) for h in H)
+
+
+def build_projection_problem(c, chain):
+    """testGPInterpolatedProjectionFactorPose3.cpp:180-262 on a ChainSolver-like object (landmark_dim = 3)."""
+    p1, p2 = dec_pose(O.POSE3, c["p1"]), dec_pose(O.POSE3, c["p2"])
+    meas = np.stack([O.pinhole_project(dec_pose(O.POSE3, cp), c["K"], c["land"]) for cp in c["cam_poses"]])
+    chain.set_qc(c["qc"] * np.eye(6))
+    chain.set_states(np.stack([dec_pose(O.POSE3, c["p1_init"]), dec_pose(O.POSE3, c["p2_init"])]),
+                     np.stack([O.A(c["v1_init"]), O.A(c["v2_init"])]))
+    chain.set_landmarks(np.array([c["land_init"]], dtype=float))
+    chain.add_pose_priors([0, 1], np.stack([p1, p2]), np.full((2, 6), c["prior_sigma"]))
+    chain.add_gp_priors([0], [c["dt"]])
+    n = len(c["taus"])
+    chain.add_interp_projection([0] * n, [0] * n, meas, np.full((n, 2), c["cam_sigma"]), [c["dt"]] * n, c["taus"], c["K"])
+    chain.compile()
+    return chain
+
+
+def check_projection_result(c, chain):
+    pose, vel = chain.get_states()
+    assert pose_close(O.POSE3, dec_pose(O.POSE3, c["p1"]), pose[0], c["tol"])
+    assert pose_close(O.POSE3, dec_pose(O.POSE3, c["p2"]), pose[1], c["tol"])
+    assert np.abs(vel[0] - np.array(c["v1"])).max() <= c["tol"] and np.abs(vel[1] - np.array(c["v2"])).max() <= c["tol"]
+    assert np.abs(chain.get_landmarks()[0] - np.array(c["land"])).max() <= c["tol"]
+    assert chain.error() <= c["tol"]
+
+
+def test_projection_optimisation_fixed_point(golden):
+    c = golden["projection_optimization"]
+    chain = build_projection_problem(c, O.Chain(O.POSE3, landmark_dim=3))
+    rc, st = chain.optimize()
+    assert rc == 0
+    check_projection_result(c, chain)
