@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_get_rows", "gpslam_hip_block_tridiag_solve",
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
-    "gpslam_hip_interpolate_poses",
+    "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection",
 ]
 
 
@@ -196,6 +196,14 @@ class ChainSolver:
         sensor = None if sensor is None else _f64(sensor)
         return self._chk(self.lib.gpslam_hip_add_interp_gps(self._h, len(left), _p(left), _p(measured), _p(sigmas),
                                                             _p(dt), _p(tau), _p(sensor)), "add_interp_gps")
+
+    def add_interp_projection(self, left, landmark, measured, sigmas, dt, tau, K, sensor=None):
+        left, landmark = _i32(left), _i32(landmark)
+        measured, sigmas, dt, tau, K = _f64(measured), _f64(sigmas), _f64(dt), _f64(tau), _f64(K)
+        sensor = None if sensor is None else _f64(sensor)
+        return self._chk(self.lib.gpslam_hip_add_interp_projection(
+            self._h, len(left), _p(left), _p(landmark), _p(measured), _p(sigmas), _p(dt), _p(tau), _p(K),
+            None if sensor is None else _p(sensor)), "add_interp_projection")
 
     def add_odometry2d(self, left, measured, sigmas):
         left, measured, sigmas = _i32(left), _f64(measured), _f64(sigmas)

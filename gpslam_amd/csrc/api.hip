@@ -62,6 +62,7 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
   std::vector<double> meas, sig, dt, tau;
   bool has_sensor = false;
   double sensor[12] = {0};
+  double calib[5] = {1, 1, 0, 0, 0};   // Cal3_S2 of the projection factor
   DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0;
   int count() const { return (int)idx.size(); }
   void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); }
@@ -85,7 +86,7 @@ struct gpslam_hip_handle {
   std::vector<double> gp_dt;
   DevBuf d_gp_left, d_gp_dt, d_gp_row0;
   SimpleSet pri, vpri, btw, lpri;
-  MeasSet ms[6];
+  MeasSet ms[kNumMeasKinds];
   // row table
   int M = 0;
   DevBuf rowLR, rowE, rowM, rowLm, rowptr;
@@ -216,6 +217,7 @@ template <typename F> void dispatch_fk(int fk, F &&f) {
     case 3: f(std::integral_constant<int, 3>{}); break;
     case 4: f(std::integral_constant<int, 4>{}); break;
     case 5: f(std::integral_constant<int, 5>{}); break;
+    case 6: f(std::integral_constant<int, 6>{}); break;
   }
 }
 
@@ -300,7 +302,7 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     });
     off += nb;
   }
-  for (int fk = 0; fk < 6; fk++) {
+  for (int fk = 0; fk < kNumMeasKinds; fk++) {
     MeasSet &s = h->ms[fk];
     if (s.count() == 0) continue;
     MeasArgs<Real> a;
@@ -310,6 +312,7 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     a.sig = s.d_sig.as<Real>(); a.coef = s.d_coef.as<Real>();
     for (int k = 0; k < 12; k++) a.sensor[k] = (Real)s.sensor[k];
     a.has_sensor = s.has_sensor ? 1 : 0;
+    for (int k = 0; k < 5; k++) a.calib[k] = (Real)s.calib[k];
     a.vw = h->vw;
     a.row0 = s.d_row0.as<int>();
     a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>(); a.rowLm = h->rowLm.as<int>();
@@ -831,6 +834,17 @@ int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t
   if (!h) return GPSLAM_E_INVALID;
   return add_meas(h, FK_INTERP_GPS, 3, 3, true, false, true, h->mf == POSE3, count, left, nullptr, measured, sigmas, dt, tau, sensor);
 }
+int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                     const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                     const double *K, const double *sensor) {
+  if (!h || !K) return GPSLAM_E_INVALID;
+  if (h->vw) return fail(h, GPSLAM_E_UNSUPPORTED, "the reference has no projection factor for the VW velocity family");
+  MeasSet &s = h->ms[FK_INTERP_PROJ];
+  if (s.count() > 0 && std::memcmp(s.calib, K, sizeof(s.calib)) != 0) return fail(h, GPSLAM_E_UNSUPPORTED, "one calibration per handle");
+  int rc = add_meas(h, FK_INTERP_PROJ, 2, 2, true, true, true, h->mf == POSE3 && h->ld == 3, count, left, landmark, measured, sigmas, dt, tau, sensor);
+  if (rc == 0) std::memcpy(s.calib, K, sizeof(s.calib));
+  return rc;
+}
 int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas) {
   if (!h) return GPSLAM_E_INVALID;
@@ -871,11 +885,11 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     row0.resize(idx.size());
     for (size_t f = 0; f < idx.size(); f++) { row0[f] = cursor[idx[f]]; cursor[idx[f]] += rows; }
   };
-  std::vector<int> r_pri, r_vpri, r_btw, r_ms[6];
+  std::vector<int> r_pri, r_vpri, r_btw, r_ms[kNumMeasKinds];
   place(h->pri.idx, d, r_pri);
   place(h->vpri.idx, d, r_vpri);
   place(h->btw.idx, d, r_btw);
-  for (int fk = 0; fk < 6; fk++) place(h->ms[fk].idx, h->ms[fk].rows, r_ms[fk]);
+  for (int fk = 0; fk < kNumMeasKinds; fk++) place(h->ms[fk].idx, h->ms[fk].rows, r_ms[fk]);
   int rc;
   if ((rc = upload(h, h->rowptr, rowptr))) return rc;
   if ((rc = upload(h, h->d_gp_left, h->gp_left))) return rc;
@@ -894,7 +908,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   { std::vector<int> none; if ((rc = up_set(h->lpri, none))) return rc; }
   int npart = nblocks((int)h->gp_left.size(), 128) + nblocks(h->pri.count(), 128) + nblocks(h->vpri.count(), 128) +
               nblocks(h->btw.count(), 128) + 1;
-  for (int fk = 0; fk < 6; fk++) {
+  for (int fk = 0; fk < kNumMeasKinds; fk++) {
     MeasSet &s = h->ms[fk];
     if ((rc = upload(h, s.d_idx, s.idx))) return rc;
     if ((rc = upload(h, s.d_lm, s.lm))) return rc;
@@ -917,7 +931,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     HIPCHK(hipMemsetAsync(h->rowM.p, 0, Mrows * h->ld * sizeof(Real), h->stream));
     HIPCHK(hipMemsetAsync(h->rowLm.p, 0xFF, Mrows * sizeof(int), h->stream));  // -1: row touches no landmark
     std::vector<std::vector<std::pair<int, int>>> per_lm(h->L);              // (row, state)
-    for (int fk = 0; fk < 6; fk++) {
+    for (int fk = 0; fk < kNumMeasKinds; fk++) {
       MeasSet &s = h->ms[fk];
       if (!s.haslm) continue;
       for (int f = 0; f < s.count(); f++)

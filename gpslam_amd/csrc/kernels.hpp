@@ -452,8 +452,9 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
 
 // ------------------------------------------------------------------ K2: measurement factors
 
-enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5 };
-template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE) ? 2 : 3); };
+enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5, FK_INTERP_PROJ = 6 };
+constexpr int kNumMeasKinds = 7;
+template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
 template <typename T> struct MeasArgs {
   const T *pose, *vel;
@@ -468,6 +469,7 @@ template <typename T> struct MeasArgs {
   const T *coef;       // count x 4: l11, l12, p11, p12 (interpolated kinds)
   T sensor[12];
   int has_sensor;
+  T calib[5];          // Cal3_S2: fx, fy, s, u0, v0 (projection factor)
   int vw;              // Pose3 only: velocities are world-frame [v; w]
   const int *row0;
   T *rowLR, *rowE, *rowM;
@@ -478,7 +480,7 @@ template <typename T> struct MeasArgs {
 // valid (manifold, kind) pairs; everything else is rejected on the host and compiles to an empty kernel
 template <int MF, int FK> struct MeasValid {
   static constexpr bool v = ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && (MF == POSE2 || MF == POSE3 || MF == LINEAR3)) ||
-                            (FK == FK_INTERP_ATT && MF == ROT3) || (FK == FK_INTERP_GPS && MF == POSE3) ||
+                            (FK == FK_INTERP_ATT && MF == ROT3) || ((FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ) && MF == POSE3) ||
                             ((FK == FK_ODOM2D || FK == FK_BEARING_RANGE) && MF == LINEAR3);
 };
 
@@ -496,8 +498,8 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
   if constexpr (MeasValid<MF, FK>::v) {
     if (f < a.count) {
       const int i = a.idx[f];
-      constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D);
-      constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE);
+      constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ);
+      constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ);
       T p1[pd], v1[d], p2[pd], v2[d];
 #pragma unroll
       for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = two ? a.pose[(size_t)k * a.stride + i + 1] : T(0); }
@@ -519,7 +521,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         for (int q = 0; q < a.ld; q++) pt[q] = a.lmk[(size_t)lm * a.ld + q];
       }
       ICoef<T> kc = {T(0), T(0), T(0), T(0)};
-      if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS)
+      if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ)
         kc = {a.coef[4 * (size_t)f], a.coef[4 * (size_t)f + 1], a.coef[4 * (size_t)f + 2], a.coef[4 * (size_t)f + 3]};
       const T *ms = a.meas + (size_t)f * a.mw;
       T e[rows];
@@ -628,6 +630,42 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
             if (a.has_sensor) Hp = rowmul(Hp, AdS);
             put_v6(rowmul(Hp, o.H1), JL + r * b); put_v6(rowmul(Hp, o.H2), JL + r * b + 6);
             put_v6(rowmul(Hp, o.H3), JR + r * b); put_v6(rowmul(Hp, o.H4), JR + r * b + 6);
+          }
+        }
+      } else if constexpr (FK == FK_INTERP_PROJ) {
+        // GPInterpolatedProjectionFactorPose3<Cal3_S2>::evaluateError, GPInterpolatedProjectionFactorPose3.h:82-139:
+        // PinholeCamera(pose * body_P_sensor, K).project(point); a landmark behind the camera is masked, not thrown
+        // (throwCheirality = false): error = 2 fx, all Jacobians zero (:122-138)
+        Interp6Out<T, JAC> o;
+        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
+        const SE3<T> S = as_se3(a.sensor);
+        const SE3<T> cam = a.has_sensor ? se3_compose(pose, S) : pose;
+        const V3<T> pw = {pt[0], pt[1], pt[2]};
+        const V3<T> q = tmul(cam.R, pw - cam.t);
+        const T fx = a.calib[0], fy = a.calib[1], sk = a.calib[2];
+        if (!(q.z > T(0))) {
+          e[0] = T(2) * fx; e[1] = T(2) * fx;
+        } else {
+          const T dz = T(1) / q.z, u = q.x * dz, v = q.y * dz;
+          e[0] = fx * u + sk * v + a.calib[3] - ms[0];
+          e[1] = fy * v + a.calib[4] - ms[1];
+          if (JAC) {
+            // PinholeBase::Dpose / Dpoint, then Cal3_S2::uncalibrate's [[fx, s], [0, fy]]
+            const V6<T> r0 = {{u * v, T(-1) - u * u, v}, {-dz, T(0), dz * u}};
+            const V6<T> r1 = {{T(1) + v * v, -u * v, -u}, {T(0), -dz, dz * v}};
+            V6<T> h0 = fx * r0 + sk * r1, h1 = fy * r1;
+            if (a.has_sensor) {
+              const BL6<T> AdS = se3_adjoint(se3_inverse(S));
+              h0 = rowmul(h0, AdS);
+              h1 = rowmul(h1, AdS);
+            }
+            const M3<T> &R = cam.R;
+            const V3<T> c0 = {R.m[0], R.m[3], R.m[6]}, c1 = {R.m[1], R.m[4], R.m[7]}, c2 = {R.m[2], R.m[5], R.m[8]};
+            const V3<T> d0 = dz * (c0 - u * c2), d1 = dz * (c1 - v * c2);
+            put_v3(fx * d0 + sk * d1, Jm);
+            put_v3(fy * d1, Jm + 3);
+            put_v6(rowmul(h0, o.H1), JL); put_v6(rowmul(h0, o.H2), JL + 6); put_v6(rowmul(h0, o.H3), JR); put_v6(rowmul(h0, o.H4), JR + 6);
+            put_v6(rowmul(h1, o.H1), JL + b); put_v6(rowmul(h1, o.H2), JL + b + 6); put_v6(rowmul(h1, o.H3), JR + b); put_v6(rowmul(h1, o.H4), JR + b + 6);
           }
         }
       } else if constexpr (FK == FK_ODOM2D) {

@@ -146,6 +146,14 @@ int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t count, const in
 /* GPInterpolatedGPSFactorPose3 -- gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54 */
 int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas, const double *dt, const double *tau, const double *sensor);
+/* GPInterpolatedProjectionFactorPose3<Cal3_S2>(measured, cam_model, Qc_model, x_i, v_i, x_i+1, v_i+1, l, delta_t, tau, K,
+ * body_P_sensor) -- gpslam/slam/GPInterpolatedProjectionFactorPose3.h:64-139: reprojection error of 3-D landmark l
+ * through a pinhole camera riding on the GP-interpolated pose.  measured: count x 2 pixels, sigmas: count x 2,
+ * K = {fx, fy, s, u0, v0} (gtsam::Cal3_S2; one calibration per handle), sensor = body_P_sensor (12 doubles) or NULL.
+ * throwCheirality = false semantics: a landmark behind the camera contributes error 2 fx and zero Jacobians. */
+int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                     const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                     const double *K, const double *sensor);
 /* OdometryFactor2DLinear(x_left, x_left+1, measured) -- gpslam/slam/OdometryFactor2DLinear.h:38-40 */
 int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas);
