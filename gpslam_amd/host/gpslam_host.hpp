@@ -108,6 +108,38 @@ struct Unit3 {
 };
 
 // ---------------------------------------------------------------- noise models
+/// gtsam::Cal3_S2: fx, fy, skew, principal point (default = identity calibration)
+class Cal3_S2 {
+ public:
+  Cal3_S2() {}
+  Cal3_S2(double fx, double fy, double s, double u0, double v0) : fx_(fx), fy_(fy), s_(s), u0_(u0), v0_(v0) {}
+  double fx() const { return fx_; }
+  double fy() const { return fy_; }
+  double skew() const { return s_; }
+  double px() const { return u0_; }
+  double py() const { return v0_; }
+ private:
+  double fx_ = 1, fy_ = 1, s_ = 0, u0_ = 0, v0_ = 0;
+};
+
+/// gtsam::PinholeCamera<CALIBRATION>::project -- host-side helper for building measurements (as the reference's
+/// tests do with cam.project(land), testGPInterpolatedProjectionFactorPose3.cpp:131-134); not part of the device path.
+template <class CALIBRATION> class PinholeCamera {
+ public:
+  PinholeCamera(const Pose3 &pose, const CALIBRATION &K) : pose_(pose), K_(K) {}
+  Point2 project(const Point3 &p) const {
+    const double dx = p.x - pose_.t.x, dy = p.y - pose_.t.y, dz = p.z - pose_.t.z;
+    const double *R = pose_.R.R;
+    const double qx = R[0] * dx + R[3] * dy + R[6] * dz, qy = R[1] * dx + R[4] * dy + R[7] * dz, qz = R[2] * dx + R[5] * dy + R[8] * dz;
+    if (!(qz > 0.0)) throw std::domain_error("CheiralityException: point behind the camera");
+    const double u = qx / qz, v = qy / qz;
+    return Point2(K_.fx() * u + K_.skew() * v + K_.px(), K_.fy() * v + K_.py());
+  }
+ private:
+  Pose3 pose_;
+  CALIBRATION K_;
+};
+
 namespace noiseModel {
 struct Base {
   int dim_ = 0;
@@ -176,11 +208,13 @@ class Values {
 
 // ---------------------------------------------------------------- factors
 namespace detail {
-enum FType { F_GP, F_POSE_PRIOR, F_VEL_PRIOR, F_LM_PRIOR, F_BETWEEN, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT, F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE };
+enum FType { F_GP, F_POSE_PRIOR, F_VEL_PRIOR, F_LM_PRIOR, F_BETWEEN, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT, F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ };
 struct Desc {   // what a factor hands to the graph compiler
   FType type;
   int manifold = -1;                 // GPSLAM_* the factor requires, -1 = any
   Key k[5] = {0, 0, 0, 0, 0};        // pose1, vel1, pose2, vel2, landmark (as applicable)
+  Key kw[2] = {0, 0};                // omega1, omega2 of the *Pose3VW factors
+  bool vw = false;                   // world-frame (v, w) velocity family
   std::vector<double> meas, sig, sensor, aux;
   double dt = 0, tau = 0;
   Matrix Qc;
@@ -276,6 +310,7 @@ struct Session {
   std::vector<uint64_t> state_index;        // sorted symbol indices of the states
   std::vector<uint64_t> lm_index;
   std::vector<bool> has_vel;                // velocity key present in the user's Values
+  bool vw = false;                          // Pose3VW family: 'v' and 'w' keys hold world-frame 3-vectors
   Values values;
   ~Session() { if (h) gpslam_hip_destroy(h); }
 
@@ -297,11 +332,20 @@ struct Session {
   // classify the variables, map keys to chain positions, create the handle, upload states
   void build(const NonlinearFactorGraph &graph, const Values &init, int device = 0) {
     values = init;
-    std::map<uint64_t, const Value *> poses, vels, lms;
+    std::map<uint64_t, const Value *> poses, vels, omegas, lms;
+    bool any_vw = false, any_body = false;
+    for (auto &fp : graph.factors()) {
+      const Desc f = fp->describe();
+      if (f.vw) any_vw = true;
+      else if (f.type == F_GP || f.type == F_INTERP_RANGE || f.type == F_INTERP_GPS || f.type == F_INTERP_PROJ || f.type == F_INTERP_ATT) any_body = true;
+    }
+    if (any_vw && any_body) throw std::invalid_argument("Pose3VW factors cannot be mixed with body-velocity GP factors in one graph");
+    vw = any_vw;
     for (auto &kv : init.raw()) {
       const unsigned char c = symbolChr(kv.first);
       if (kv.second.type == T_POINT2 || kv.second.type == T_POINT3) lms[symbolIndex(kv.first)] = &kv.second;
       else if (c == 'v') vels[symbolIndex(kv.first)] = &kv.second;
+      else if (vw && c == 'w') omegas[symbolIndex(kv.first)] = &kv.second;
       else poses[symbolIndex(kv.first)] = &kv.second;
     }
     if (poses.empty()) throw std::invalid_argument("no pose variables (keys other than 'v' / landmarks) in the Values");
@@ -320,8 +364,16 @@ struct Session {
       auto vi = vels.find(kv.first);
       has_vel.push_back(vi != vels.end());
       if (vi != vels.end()) {
-        if ((int)vi->second->d.size() != d) throw std::invalid_argument("velocity dimension does not match the pose manifold");
-        std::memcpy(&V[(size_t)i * d], vi->second->d.data(), sizeof(double) * d);
+        const int want = vw ? 3 : d;
+        if ((int)vi->second->d.size() != want) throw std::invalid_argument("velocity dimension does not match the pose manifold");
+        std::memcpy(&V[(size_t)i * d], vi->second->d.data(), sizeof(double) * want);
+      }
+      if (vw) {   // state velocity slot = [v; w] (include/gpslam_hip.h, GPSLAM_VELOCITY_WORLD_VW)
+        auto wi = omegas.find(kv.first);
+        if (wi != omegas.end()) {
+          if (wi->second->d.size() != 3) throw std::invalid_argument("omega variables are Vector3");
+          std::memcpy(&V[(size_t)i * d + 3], wi->second->d.data(), sizeof(double) * 3);
+        }
       }
       i++;
     }
@@ -332,6 +384,10 @@ struct Session {
     cfg.manifold = manifold; cfg.precision = GPSLAM_FP64; cfg.device = device;
     cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;   // GTSAM's default charts
     cfg.landmark_dim = ld; cfg.nranks = 1;
+    if (vw) {
+      if (manifold != GPSLAM_POSE3) throw std::invalid_argument("Pose3VW factors need Pose3 states");
+      cfg.reserved[3] = GPSLAM_VELOCITY_WORLD_VW;
+    }
     int rc = gpslam_hip_create(&cfg, &h);
     if (rc < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
     check(gpslam_hip_set_states(h, N, P.data(), V.data()), h, "set_states");
@@ -354,13 +410,15 @@ struct Session {
       switch (f.type) {
         case F_GP: {
           set_qc(f.Qc);
-          if (symbolIndex(f.k[0]) != symbolIndex(f.k[1]) || symbolIndex(f.k[2]) != symbolIndex(f.k[3]))
+          if (symbolIndex(f.k[0]) != symbolIndex(f.k[1]) || symbolIndex(f.k[2]) != symbolIndex(f.k[3]) ||
+              (f.vw && (symbolIndex(f.kw[0]) != symbolIndex(f.k[0]) || symbolIndex(f.kw[1]) != symbolIndex(f.k[2]))))
             throw std::invalid_argument("GP prior: pose and velocity keys of a state must share their index");
           int32_t l = adjacent(f.k[0], f.k[2]);
           check(gpslam_hip_add_gp_priors(h, 1, &l, &f.dt), h, "add_gp_priors");
         } break;
         case F_POSE_PRIOR: { int32_t s = state_of(f.k[0]); check(gpslam_hip_add_pose_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_pose_priors"); } break;
-        case F_VEL_PRIOR: { int32_t s = state_of(f.k[0]); check(gpslam_hip_add_vel_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_vel_priors"); } break;
+        case F_VEL_PRIOR: { if (vw) throw std::invalid_argument("PriorFactor<Vector3> on a 'v' / 'w' key of a Pose3VW graph is not supported yet");
+          int32_t s = state_of(f.k[0]); check(gpslam_hip_add_vel_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_vel_priors"); } break;
         case F_LM_PRIOR: { int32_t s = lm_of(f.k[0]); check(gpslam_hip_add_landmark_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_landmark_priors"); } break;
         case F_BETWEEN: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_between(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_between"); } break;
         case F_INTERP_RANGE: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
@@ -373,6 +431,9 @@ struct Session {
         case F_ODOM2D: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_odometry2d(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_odometry2d"); } break;
         case F_BEARING_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]);
           check(gpslam_hip_add_bearing_range(h, 1, &s, &m, &f.meas[0], &f.meas[1], f.sig.data()), h, "add_bearing_range"); } break;
+        case F_INTERP_PROJ: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
+          check(gpslam_hip_add_interp_projection(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), h,
+                "add_interp_projection"); } break;
       }
     }
     // states whose velocity is not a variable of the user's graph: pin a zero velocity (decoupled, zero error)
@@ -397,7 +458,10 @@ struct Session {
         kv.second.d.assign(LM.begin() + (size_t)j * ld, LM.begin() + (size_t)(j + 1) * ld);
       } else if (c == 'v') {
         const int s = state_of(kv.first);
-        kv.second.d.assign(V.begin() + (size_t)s * d, V.begin() + (size_t)(s + 1) * d);
+        kv.second.d.assign(V.begin() + (size_t)s * d, V.begin() + (size_t)s * d + (vw ? 3 : d));
+      } else if (vw && c == 'w') {
+        const int s = state_of(kv.first);
+        kv.second.d.assign(V.begin() + (size_t)s * d + 3, V.begin() + (size_t)(s + 1) * d);
       } else {
         const int s = state_of(kv.first);
         kv.second.d.assign(P.begin() + (size_t)s * pd, P.begin() + (size_t)(s + 1) * pd);
@@ -436,6 +500,21 @@ class NonlinearOptimizer {
   }
   virtual void iterate() = 0;
   virtual ~NonlinearOptimizer() {}
+  /// Dense trajectory output: GaussianProcessInterpolator*::interpolatePose (gpslam.h:57-86) of the current estimate
+  /// at time tau[q] after the state with pose key left[q] (interval length dt[q]), all queries in one launch.
+  template <typename POSE> std::vector<POSE> interpolatePoses(const std::vector<Key> &left, const std::vector<double> &dt,
+                                                              const std::vector<double> &tau) {
+    if (left.size() != dt.size() || left.size() != tau.size()) throw std::invalid_argument("interpolatePoses: size mismatch");
+    std::vector<int32_t> idx(left.size());
+    for (size_t q = 0; q < left.size(); q++) idx[q] = s_.state_of(left[q]);
+    std::vector<double> out(left.size() * (size_t)s_.pd);
+    detail::check(gpslam_hip_interpolate_poses(s_.h, (int32_t)left.size(), idx.data(), dt.data(), tau.data(), out.data()), s_.h,
+                  "interpolate_poses");
+    std::vector<POSE> r;
+    for (size_t q = 0; q < left.size(); q++)
+      r.push_back(detail::VT<POSE>::un(std::vector<double>(out.begin() + q * s_.pd, out.begin() + (q + 1) * s_.pd)));
+    return r;
+  }
  protected:
   NonlinearOptimizer(const NonlinearFactorGraph &g, const Values &v, const NonlinearOptimizerParams &p) : params_(p) {
     s_.build(g, v);
@@ -589,6 +668,51 @@ class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3, 4)
+};
+
+/// gpslam/gp/GaussianProcessPriorPose3VW.h:43-51 -- world-frame translational (v) and rotational (w) velocity keys
+class GaussianProcessPriorPose3VW : public gtsam::NonlinearFactor {
+ public:
+  GaussianProcessPriorPose3VW(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key omegaKey1, gtsam::Key poseKey2,
+                              gtsam::Key velKey2, gtsam::Key omegaKey2, double delta_t, const gtsam::SharedNoiseModel &Qc_model) {
+    d_ = detail_g::gp(GPSLAM_POSE3, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model);
+    d_.kw[0] = omegaKey1; d_.kw[1] = omegaKey2; d_.vw = true;
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GaussianProcessPriorPose3VW, 6)
+};
+
+/// gpslam/slam/GPInterpolatedGPSFactorPose3VW.h:50-60
+class GPInterpolatedGPSFactorPose3VW : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedGPSFactorPose3VW(const gtsam::Point3 &measured, const gtsam::SharedNoiseModel &meas_model,
+                                 const gtsam::SharedNoiseModel &Qc_model, gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key omegaKey1,
+                                 gtsam::Key poseKey2, gtsam::Key velKey2, gtsam::Key omegaKey2, double delta_t, double tau,
+                                 const gtsam::Pose3 *body_P_sensor = nullptr) {
+    d_.type = gtsam::detail::F_INTERP_GPS; d_.manifold = GPSLAM_POSE3; d_.vw = true;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.kw[0] = omegaKey1; d_.kw[1] = omegaKey2;
+    d_.meas = {measured.x, measured.y, measured.z}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance();
+    d_.dt = delta_t; d_.tau = tau;
+    if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3VW, 6)
+};
+
+/// gpslam/slam/GPInterpolatedProjectionFactorPose3.h:64-76 (CALIBRATION = gtsam::Cal3_S2).  throwCheirality /
+/// verboseCheirality keep their defaults (false): a landmark behind the camera is masked on the device.
+template <class CALIBRATION = gtsam::Cal3_S2>
+class GPInterpolatedProjectionFactorPose3 : public gtsam::NonlinearFactor {
+ public:
+  GPInterpolatedProjectionFactorPose3(const gtsam::Point2 &measured, const gtsam::SharedNoiseModel &cam_model,
+                                      const gtsam::SharedNoiseModel &Qc_model, gtsam::Key poseKey1, gtsam::Key velKey1,
+                                      gtsam::Key poseKey2, gtsam::Key velKey2, gtsam::Key pointKey, double delta_t, double tau,
+                                      const std::shared_ptr<CALIBRATION> &K, const gtsam::Pose3 *body_P_sensor = nullptr) {
+    d_.type = gtsam::detail::F_INTERP_PROJ; d_.manifold = GPSLAM_POSE3;
+    d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
+    d_.meas = {measured.x, measured.y}; d_.sig = gtsam::sigmas_of(cam_model); d_.Qc = Qc_model->covariance();
+    d_.dt = delta_t; d_.tau = tau; d_.aux = {K->fx(), K->fy(), K->skew(), K->px(), K->py()};
+    if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedProjectionFactorPose3<CALIBRATION>, 5)
 };
 
 /// gpslam/slam/RangeFactor2DLinear.h:30-37

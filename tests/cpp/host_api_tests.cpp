@@ -3,7 +3,8 @@
 // GaussNewtonOptimizer / LevenbergMarquardtOptimizer, compare with the ground truth.  Scenarios and numbers are those
 // of gpslam/gp/tests/testGaussianProcessPrior{Pose3,Pose2,Rot3,Linear}.cpp (Optimization),
 // gpslam/slam/tests/testGPInterpolatedRangeFactorPose{2,3}.cpp (optimization) and
-// gpslam/slam/tests/testRangeBearingFactor2DLinear.cpp (optimization).
+// gpslam/slam/tests/testRangeBearingFactor2DLinear.cpp (optimization), gpslam/gp/tests/testGaussianProcessPriorPose3VW.cpp
+// (Optimization) and gpslam/slam/tests/testGPInterpolatedProjectionFactorPose3.cpp (optimization).
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -221,6 +222,84 @@ static void test_range_bearing_2dlinear_optimization() {
   EXPECT_NEAR(values.at<Point2>(key_lnd).y, 2.0, 1e-6);
 }
 
+static void test_gp_prior_pose3vw_optimization() {
+  // testGaussianProcessPriorPose3VW.cpp:142-188 (the reference only checks that the optimisation runs; the optimum is
+  // the initial configuration: both poses fixed one metre apart, dt = 1, world velocity (1, 0, 0))
+  auto model_prior = noiseModel::Isotropic::Sigma(6, 0.001);
+  double delta_t = 1;
+  auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+  Pose3 pose1(Rot3(), Point3(0, 0, 0)), pose2(Rot3(), Point3(1, 0, 0));
+  Vector3 v1 = {1, 0, 0}, w1 = {0, 0, 0}, v2 = {1, 0, 0}, w2 = {0, 0, 0};
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Pose3>(Symbol('x', 1), pose1, model_prior));
+  graph.add(PriorFactor<Pose3>(Symbol('x', 2), pose2, model_prior));
+  graph.add(GaussianProcessPriorPose3VW(Symbol('x', 1), Symbol('v', 1), Symbol('w', 1), Symbol('x', 2), Symbol('v', 2), Symbol('w', 2),
+                                        delta_t, Qc_model));
+  Values init_values;
+  init_values.insert(Symbol('x', 1), pose1);
+  init_values.insert(Symbol('v', 1), v1);
+  init_values.insert(Symbol('w', 1), w1);
+  init_values.insert(Symbol('x', 2), pose2);
+  init_values.insert(Symbol('v', 2), Vector3{0.7, 0.2, -0.1});   // perturbed: the prior must pull it back to (1, 0, 0)
+  init_values.insert(Symbol('w', 2), Vector3{0.05, -0.02, 0.03});
+  GaussNewtonParams parameters;
+  GaussNewtonOptimizer optimizer(graph, init_values, parameters);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-6);
+  EXPECT(nearV(v1, values.at<Vector3>(Symbol('v', 1)), 1e-6) && nearV(w1, values.at<Vector3>(Symbol('w', 1)), 1e-6));
+  EXPECT(nearV(v2, values.at<Vector3>(Symbol('v', 2)), 1e-6) && nearV(w2, values.at<Vector3>(Symbol('w', 2)), 1e-6));
+  EXPECT(near3(pose2.t, values.at<Pose3>(Symbol('x', 2)).t, 1e-6));
+}
+
+static void test_projection_optimization_and_trajectory_query() {
+  // testGPInterpolatedProjectionFactorPose3.cpp:180-262
+  typedef GPInterpolatedProjectionFactorPose3<Cal3_S2> ProjectionFactor;
+  auto model_prior = noiseModel::Isotropic::Sigma(6, 0.01);
+  auto model_cam = noiseModel::Isotropic::Sigma(2, 0.1);
+  double delta_t = 0.1, tau1 = 0.02, tau2 = 0.06, tau3 = 0.09;
+  auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+  Pose3 p1(Rot3(), Point3(0, 0, 0)), p2(Rot3(), Point3(1, 0, 0));
+  Pose3 pcam1(Rot3(), Point3(0.2, 0, 0)), pcam2(Rot3(), Point3(0.6, 0, 0)), pcam3(Rot3(), Point3(0.9, 0, 0));
+  Vector6 v1 = {0, 0, 0, 10, 0, 0}, v2 = {0, 0, 0, 10, 0, 0};
+  Pose3 p1i(Rot3::Ypr(0.1, 0.2, 0.4), Point3(0.2, 0.3, -0.2));
+  Pose3 p2i(Rot3::Ypr(-0.1, -0.2, -0.4), Point3(1.2, -0.3, 0.2));
+  Vector6 v1i = {-0.3, 0, 0, 0.7, 0, 0.2}, v2i = {0, 0, 0.4, 1.2, 0, -0.1};
+  auto K = std::make_shared<Cal3_S2>(50, 50, 0, 40, 30);
+  Point3 land(3.4, 1.2, 20), landi(3.3, 1.3, 18);
+  Point2 meas1 = PinholeCamera<Cal3_S2>(pcam1, *K).project(land);
+  Point2 meas2 = PinholeCamera<Cal3_S2>(pcam2, *K).project(land);
+  Point2 meas3 = PinholeCamera<Cal3_S2>(pcam3, *K).project(land);
+  NonlinearFactorGraph graph;
+  graph.add(PriorFactor<Pose3>(Symbol('x', 1), p1, model_prior));
+  graph.add(PriorFactor<Pose3>(Symbol('x', 2), p2, model_prior));
+  graph.add(GaussianProcessPriorPose3(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), delta_t, Qc_model));
+  graph.add(ProjectionFactor(meas1, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau1, K));
+  graph.add(ProjectionFactor(meas2, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau2, K));
+  graph.add(ProjectionFactor(meas3, model_cam, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), delta_t, tau3, K));
+  Values init_values;
+  init_values.insert(Symbol('x', 1), p1i);
+  init_values.insert(Symbol('v', 1), v1i);
+  init_values.insert(Symbol('x', 2), p2i);
+  init_values.insert(Symbol('v', 2), v2i);
+  init_values.insert(Symbol('l', 1), landi);
+  GaussNewtonParams parameters;
+  GaussNewtonOptimizer optimizer(graph, init_values, parameters);
+  optimizer.optimize();
+  Values values = optimizer.values();
+  EXPECT_NEAR(0, graph.error(values), 1e-6);
+  EXPECT(near3(p1.t, values.at<Pose3>(Symbol('x', 1)).t, 1e-6) && nearR(p1.R, values.at<Pose3>(Symbol('x', 1)).R, 1e-6));
+  EXPECT(near3(p2.t, values.at<Pose3>(Symbol('x', 2)).t, 1e-6) && nearR(p2.R, values.at<Pose3>(Symbol('x', 2)).R, 1e-6));
+  EXPECT(nearV(v1, values.at<Vector6>(Symbol('v', 1)), 1e-6));
+  EXPECT(nearV(v2, values.at<Vector6>(Symbol('v', 2)), 1e-6));
+  EXPECT(near3(land, values.at<Point3>(Symbol('l', 1)), 1e-6));
+  // dense trajectory output: the camera poses the measurements were generated from (GaussianProcessInterpolatorPose3,
+  // gpslam.h:72-77, as one batched query)
+  std::vector<Pose3> q = optimizer.interpolatePoses<Pose3>({Symbol('x', 1), Symbol('x', 1), Symbol('x', 1)},
+                                                           {delta_t, delta_t, delta_t}, {tau1, tau2, tau3});
+  EXPECT(q.size() == 3 && near3(pcam1.t, q[0].t, 1e-6) && near3(pcam2.t, q[1].t, 1e-6) && near3(pcam3.t, q[2].t, 1e-6));
+}
+
 static void test_error_conventions() {
   auto model = noiseModel::Isotropic::Sigma(3, 0.1);
   auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
@@ -249,6 +328,8 @@ int main() {
   test_interp_range_pose2_optimization();
   test_interp_range_pose3_optimization_with_extrapolation();
   test_range_bearing_2dlinear_optimization();
+  test_gp_prior_pose3vw_optimization();
+  test_projection_optimization_and_trajectory_query();
   test_error_conventions();
   if (failures == 0) std::printf("host_api_tests: all tests passed\n");
   return failures == 0 ? 0 : 1;
