@@ -27,7 +27,8 @@ ABI_SYMBOLS = [
     "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_get_rows", "gpslam_hip_block_tridiag_solve",
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
-    "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection",
+    "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
+    "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer",
 ]
 
 
@@ -331,6 +332,20 @@ class ChainSolver:
 
     def iterate_phase1(self, lam=0.0):
         return self._chk(self.lib.gpslam_hip_iterate_phase1(self._h, C.c_double(lam)), "iterate_phase1")
+
+    def iterate_phase2a(self):
+        return self._chk(self.lib.gpslam_hip_iterate_phase2a(self._h), "iterate_phase2a")
+
+    def iterate_phase2b(self, want_stats=True):
+        st = Stats()
+        self._chk(self.lib.gpslam_hip_iterate_phase2b(self._h, C.byref(st) if want_stats else None), "iterate_phase2b")
+        return st
+
+    def landmark_reduce_buffer(self):
+        """(device pointer, bytes) of this rank's landmark Schur complement [S | gL]; (None, 0) without landmarks."""
+        ptr, nb = C.c_void_p(), C.c_size_t()
+        self._chk(self.lib.gpslam_hip_landmark_reduce_buffer(self._h, C.byref(ptr), C.byref(nb)), "landmark_reduce_buffer")
+        return ptr.value, nb.value
 
     def iterate_phase2(self, want_stats=True):
         st = Stats()

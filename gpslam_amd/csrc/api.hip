@@ -247,6 +247,7 @@ GpArgs<Real> gp_args(gpslam_hip_handle *h, Real *partial) {
 LmArgs<Real> lm_args(gpslam_hip_handle *h, double lambda) {
   LmArgs<Real> a;
   a.N = h->N; a.R = h->R; a.B = h->b; a.L = h->L; a.ld = h->ld; a.nl = h->nl;
+  a.Nx = h->N + (has_right_rank(h) ? 1 : 0);
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>();
   a.lmrow = h->lmrow.as<int>(); a.lmrow_state = h->lmrow_state.as<int>(); a.lmrow_ptr = h->lmrow_ptr.as<int>();
   a.nlmrows = h->nlmrows;
@@ -254,7 +255,7 @@ LmArgs<Real> lm_args(gpslam_hip_handle *h, double lambda) {
   a.t = h->lm_t.as<Real>();
   a.npri = h->lpri.count(); a.pri_lm = h->lpri.d_idx.as<int>(); a.pri_meas = h->lpri.d_meas.as<Real>();
   a.pri_sig = h->lpri.d_sig.as<Real>();
-  a.lmk = h->lmk.as<Real>(); a.S = h->lm_S.as<Real>(); a.gL = h->lm_gL.as<Real>(); a.dL = h->lm_dL.as<Real>();
+  a.lmk = h->lmk.as<Real>(); a.S = h->lm_S.as<Real>(); a.gL = h->lm_S.as<Real>() + (size_t)h->nl * h->R; a.dL = h->lm_dL.as<Real>();
   a.lambda = (Real)lambda; a.flag = h->flag.as<int>(); a.partial = nullptr;
   return a;
 }
@@ -439,15 +440,27 @@ int launch_backward(gpslam_hip_handle *h, const Real *xtop) {
 }
 
 // landmark Schur complement, landmark solve, pose correction (nl > 0)
-int launch_landmarks(gpslam_hip_handle *h, double lambda) {
+// Landmark border in two halves: (a) this handle's contribution to the Schur complement [S | gL] -- summed over the
+// ranks by the caller when the chain is sharded -- and (b) the landmark solve and the correction of the chain update.
+int launch_landmarks_reduce(gpslam_hip_handle *h, double lambda) {
   if (h->nl <= 0) return 0;
   LmArgs<Real> a = lm_args(h, lambda);
   if (h->nlmrows > 0) k_lm_t<Real><<<dim3(nblocks(h->nlmrows * h->R, 128)), dim3(128), 0, h->stream>>>(a);
   k_lm_reduce<Real><<<dim3(nblocks(h->nl * h->R, 128)), dim3(128), 0, h->stream>>>(a);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int launch_landmarks_solve(gpslam_hip_handle *h, double lambda) {
+  if (h->nl <= 0) return 0;
+  LmArgs<Real> a = lm_args(h, lambda);
   k_lm_solve<Real><<<dim3(1), dim3(64), 0, h->stream>>>(a);
   k_lm_correct<Real><<<dim3(nblocks(h->N * h->b, 256)), dim3(256), 0, h->stream>>>(a);
   HIPCHK(hipGetLastError());
   return 0;
+}
+int launch_landmarks(gpslam_hip_handle *h, double lambda) {
+  int rc = launch_landmarks_reduce(h, lambda);
+  return rc ? rc : launch_landmarks_solve(h, lambda);
 }
 
 int launch_solve(gpslam_hip_handle *h, double lambda) {
@@ -867,7 +880,6 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   h->R = 1 + h->nl;
   if (3 * b + h->R > 64 || h->R > kMaxRhs)
     return fail(h, GPSLAM_E_UNSUPPORTED, "too many landmark columns for the dense border (3*2d + 1 + L*landmark_dim must be <= 64)");
-  if (sharded(h) && h->nl > 0) return fail(h, GPSLAM_E_UNSUPPORTED, "landmarks with segment sharding: not supported yet");
   // ---- row layout: rows grouped by left state; inside a state: GP, pose prior, velocity prior, between, measurements
   std::vector<int> rows_in(N + 1, 0);
   for (int32_t l : h->gp_left) rows_in[l] += b;
@@ -947,8 +959,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     if ((rc = upload(h, h->lmrow_state, lmstate))) return rc;
     if ((rc = upload(h, h->lmrow_ptr, lmptr))) return rc;
     HIPCHK(h->lm_t.reserve((size_t)std::max(h->nlmrows, 1) * h->R * sizeof(Real)));
-    HIPCHK(h->lm_S.reserve((size_t)h->nl * h->R * sizeof(Real)));
-    HIPCHK(h->lm_gL.reserve((size_t)h->nl * sizeof(Real)));
+    HIPCHK(h->lm_S.reserve(((size_t)h->nl * h->R + h->nl) * sizeof(Real)));   // [S (nl x R) | gL (nl)]: one buffer, one all-reduce
     HIPCHK(h->lm_dL.reserve((size_t)h->nl * sizeof(Real)));
     if (!h->lmk.p) return fail(h, GPSLAM_E_INVALID, "set_landmarks() before compile()");
   }
@@ -1139,7 +1150,7 @@ int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *lambda, const gpslam_hip
     if ((rc = launch_dot(h, h->dvec.as<Real>(), h->gsave.as<Real>(), nx, 3))) return rc;   // delta . g
     if ((rc = launch_dot(h, h->dvec.as<Real>(), h->dvec.as<Real>(), nx, 4))) return rc;    // |delta|^2
     if (h->nl > 0) {
-      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_gL.as<Real>(), h->nl, 5))) return rc;
+      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), (h->lm_S.as<Real>() + (size_t)h->nl * h->R), h->nl, 5))) return rc;
       if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_dL.as<Real>(), h->nl, 6))) return rc;
     }
     if ((rc = launch_retract(h, 2))) return rc;
@@ -1428,9 +1439,12 @@ int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double lambda) {
 }
 
 // phase 2 (after the all-gather of the records into interface_recv): every rank solves the P-block reduced
-// system redundantly, back-substitutes its segment, retracts its states and its copy of the halo state.
-// st (optional) returns THIS RANK's error terms and |delta|_inf; the caller reduces them across ranks.
-int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
+// system redundantly and back-substitutes its segment (2a); with landmarks it then forms its share of the landmark
+// Schur complement, which the caller sums over the ranks (one all-reduce of gpslam_hip_landmark_reduce_buffer);
+// 2b solves the landmark system (redundantly), corrects the chain update, retracts the states, the landmarks and
+// the local copy of the halo state.  st (optional) returns THIS RANK's error terms and |delta|_inf; the caller
+// reduces them across ranks.
+int gpslam_hip_iterate_phase2a(gpslam_hip_handle *h) {
   int rc = need_compiled(h);
   if (rc) return rc;
   if (!sharded(h)) return GPSLAM_E_INVALID;
@@ -1451,8 +1465,31 @@ int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
   }
   const Real *xtop = h->top_x.as<Real>() + (size_t)h->cfg.rank * b * R;   // [x_sep(rank), x_sep(rank + 1)]
   if ((rc = launch_backward(h, xtop))) return rc;
+  return launch_landmarks_reduce(h, h->ph_lambda);
+}
+
+int gpslam_hip_landmark_reduce_buffer(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes) {
+  if (!h || !dev_ptr || !bytes) return GPSLAM_E_INVALID;
+  *dev_ptr = h->nl > 0 ? h->lm_S.p : nullptr;
+  *bytes = h->nl > 0 ? ((size_t)h->nl * h->R + h->nl) * sizeof(Real) : 0;
+  return 0;
+}
+
+int gpslam_hip_iterate_phase2b(gpslam_hip_handle *h, gpslam_hip_stats *st) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  const int b = h->b, R = h->R;
+  Real *xtop = h->top_x.as<Real>() + (size_t)h->cfg.rank * b * R;
+  if ((rc = launch_landmarks_solve(h, h->ph_lambda))) return rc;
   if ((rc = launch_retract(h, 2))) return rc;
   if (has_right_rank(h)) {  // keep the local copy of the neighbour's first state in step with its owner
+    if (h->nl > 0) {        // its update needs the landmark correction too: delta = x0 - Z dL on that one block
+      LmArgs<Real> la = lm_args(h, 0.0);
+      la.N = 1; la.x = xtop + (size_t)b * R;
+      k_lm_correct<Real><<<dim3(nblocks(b, 256)), dim3(256), 0, h->stream>>>(la);
+    }
     RetractArgs<Real> a;
     a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = 1; a.R = R;
     a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4;
@@ -1461,7 +1498,9 @@ int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
       k_retract<Real, MF><<<dim3(1), dim3(128), 0, h->stream>>>(a);
     });
   }
-  if ((rc = launch_factors(h, 1, 1))) return rc;
+  // the error of the new state: only when the caller wants statistics (inside a fixed-count run the next
+  // iteration's linearisation evaluates it anyway)
+  if (st && (rc = launch_factors(h, 1, 1))) return rc;
   HIPCHK(hipGetLastError());
   if (st) {
     double s[4];
@@ -1477,6 +1516,14 @@ int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
     if (flag) return fail(h, GPSLAM_E_NOT_SPD, "non-positive pivot in the block elimination");
   }
   return 0;
+}
+
+// 2a + 2b for chains without landmarks (or a single rank): nothing to reduce in between
+int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
+  if (h && h->nl > 0 && h->cfg.nranks > 1)
+    return fail(h, GPSLAM_E_INVALID, "landmarks on a sharded chain: phase2a, all-reduce of the landmark buffer, phase2b");
+  int rc = gpslam_hip_iterate_phase2a(h);
+  return rc ? rc : gpslam_hip_iterate_phase2b(h, st);
 }
 
 }  // extern "C"

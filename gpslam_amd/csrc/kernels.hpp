@@ -735,6 +735,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
 
 template <typename T> struct LmArgs {
   int N, R, B, L, ld, nl;   // R = 1 + nl
+  int Nx;                   // solution slots in x: N, or N + 1 when a halo state follows the segment
   const T *rowLR, *rowE, *rowM;
   const int *lmrow;         // row ids of rows that touch a landmark, grouped by landmark
   const int *lmrow_state;   // left state of each such row
@@ -765,7 +766,7 @@ template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a)
   const T *x0 = a.x + ((size_t)s * a.R + c) * a.B;
   T acc = T(0);
   for (int k = 0; k < a.B; k++) acc += row[k] * x0[k];
-  if (s + 1 < a.N) {
+  if (s + 1 < a.Nx) {
     const T *x1 = a.x + ((size_t)(s + 1) * a.R + c) * a.B;
     for (int k = 0; k < a.B; k++) acc += row[a.B + k] * x1[k];
   }

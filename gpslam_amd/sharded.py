@@ -8,6 +8,8 @@ Rank r owns states [lo_r, hi_r) and every factor whose LEFT state lies in that r
     exchange (RCCL):       ONE all-gather of the records over xGMI -- the only collective on the data path
     phase 2 (local, HIP):  every rank solves the tiny P-block reduced system redundantly, back-substitutes,
                            retracts its states and its halo copy (so the halo never needs another exchange)
+    with landmarks (replicated on every rank; each rank owns the measurement factors of its segment) phase 2 is
+    split around ONE all-reduce of the landmark Schur complement [S | gL] ((L ld)(L ld + 2) doubles: 80 for Plaza)
 
 Scalars (error, |delta|_inf) are reduced only when the caller asks for them.
 
@@ -50,6 +52,14 @@ def local_problem(problem, rank, nranks):
     cut("prior_idx", ["prior_pose", "prior_sig"])
     cut("vprior_idx", ["vprior", "vprior_sig"])
     cut("between_left", ["between_meas", "between_sig"])
+    cut("range_left", ["range_lm", "range_z", "range_sigma", "range_dt", "range_tau"])
+    if "landmarks" in p:                      # landmarks are replicated; their priors live on rank 0
+        out["landmarks"] = np.asarray(p["landmarks"]).copy()
+        out["linear"] = p.get("linear", False)
+        if rank == 0:
+            for k in ("lprior_idx", "lprior", "lprior_sig"):
+                if k in p:
+                    out[k] = np.asarray(p[k]).copy()
     return out
 
 
@@ -59,6 +69,13 @@ def apply_local(lp, solver):
     solver.set_states(lp["pose"], lp["vel"])
     if "halo_pose" in lp:
         solver.set_halo_state(lp["halo_pose"], lp["halo_vel"])
+    if "landmarks" in lp:
+        solver.set_landmarks(lp["landmarks"])
+        if "lprior_idx" in lp:
+            solver.add_landmark_priors(lp["lprior_idx"], lp["lprior"], lp["lprior_sig"])
+        if "range_left" in lp and len(lp["range_left"]):
+            solver.add_interp_range(lp["range_left"], lp["range_lm"], lp["range_z"], lp["range_sigma"], lp["range_dt"],
+                                    lp["range_tau"])
     if "gp_left" in lp and len(lp["gp_left"]):
         solver.add_gp_priors(lp["gp_left"], lp["gp_dt"])
     if "prior_idx" in lp and len(lp["prior_idx"]):
@@ -66,7 +83,10 @@ def apply_local(lp, solver):
     if "vprior_idx" in lp and len(lp["vprior_idx"]):
         solver.add_vel_priors(lp["vprior_idx"], lp["vprior"], lp["vprior_sig"])
     if "between_left" in lp and len(lp["between_left"]):
-        solver.add_between(lp["between_left"], lp["between_meas"], lp["between_sig"])
+        if lp.get("linear", False):
+            solver.add_odometry2d(lp["between_left"], lp["between_meas"], lp["between_sig"])
+        else:
+            solver.add_between(lp["between_left"], lp["between_meas"], lp["between_sig"])
     solver.compile()
     return solver
 
@@ -86,6 +106,13 @@ def device_tensors(solver):
     return (torch.as_tensor(_DevView(sp, sb), device="cuda"), torch.as_tensor(_DevView(rp, rb), device="cuda"))
 
 
+def landmark_tensor(solver):
+    """torch view of a GPU backend's landmark Schur-complement buffer [S | gL], or None without landmarks."""
+    import torch
+    ptr, nb = solver.landmark_reduce_buffer()
+    return torch.as_tensor(_DevView(ptr, nb), device="cuda") if nb else None
+
+
 class ShardedSolver:
     """One rank of a segment-sharded Gauss-Newton solve.
 
@@ -95,9 +122,10 @@ class ShardedSolver:
     group : torch.distributed process group handle or None for the default group
     """
 
-    def __init__(self, backend, send, recv, rank, nranks, dist=None, group=None):
+    def __init__(self, backend, send, recv, rank, nranks, dist=None, group=None, landmark_buf=None):
         self.backend, self.send, self.recv = backend, send, recv
         self.rank, self.nranks, self.dist, self.group = rank, nranks, dist, group
+        self.landmark_buf = landmark_buf      # [S | gL] of this rank (torch tensor) when the chain has landmarks
 
     def exchange(self):
         if self.dist is None:
@@ -109,7 +137,13 @@ class ShardedSolver:
     def iterate(self, lam=0.0, want_stats=True):
         self.backend.iterate_phase1(lam)
         self.exchange()
-        st = self.backend.iterate_phase2(want_stats)
+        if self.landmark_buf is None:
+            st = self.backend.iterate_phase2(want_stats)
+        else:
+            self.backend.iterate_phase2a()
+            if self.dist is not None and self.nranks > 1:
+                self.dist.all_reduce(self.landmark_buf, group=self.group)     # sum of the ranks' Schur complements
+            st = self.backend.iterate_phase2b(want_stats)
         if not want_stats:
             return None
         vals = np.array([st.error_before, st.error_after, st.delta_inf_norm], dtype=np.float64)

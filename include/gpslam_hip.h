@@ -222,8 +222,16 @@ int gpslam_hip_interface_send(gpslam_hip_handle *h, void **dev_ptr, size_t *byte
 int gpslam_hip_interface_recv(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes);
 /* phase 1: linearize + assemble + local elimination down to the rank separator -> interface record */
 int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double lambda);
-/* phase 2 (after the all-gather): reduced solve, back-substitution, retract, local error */
+/* phase 2 (after the all-gather): reduced solve, back-substitution, retract, local error (st may be NULL: no error
+ * pass, no host synchronisation).  Chains with landmarks on more than one rank run it in two halves with one
+ * all-reduce (sum) of the landmark buffer in between -- SURVEY.md section 8(e) collective (3):
+ *   phase2a: reduced solve + back-substitution + this rank's share of the landmark Schur complement [S | gL]
+ *   all-reduce of gpslam_hip_landmark_reduce_buffer (doubles)
+ *   phase2b: landmark solve (redundant on every rank), chain correction, retract of states / halo / landmarks */
 int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
+int gpslam_hip_iterate_phase2a(gpslam_hip_handle *h);
+int gpslam_hip_iterate_phase2b(gpslam_hip_handle *h, gpslam_hip_stats *st);
+int gpslam_hip_landmark_reduce_buffer(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes);
 /* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
 int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
 
