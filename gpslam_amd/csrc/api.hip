@@ -372,7 +372,9 @@ void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
 void launch_bwd(gpslam_hip_handle *h, const BwdArgs<Real> &a, int grid) {
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
-    k_chunk_backward<Real, BB><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+    // 16-byte pieces per lane per record: 3 wave loads cover 2 b^2 + b R <= 384 doubles, 5 cover every admissible R
+    if (2 * BB * BB + BB * h->R <= 384) k_chunk_backward<Real, BB, 3><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
+    else k_chunk_backward<Real, BB, 5><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
   });
 }
 

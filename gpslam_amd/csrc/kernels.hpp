@@ -1367,8 +1367,11 @@ template <typename T> struct BwdArgs {
 };
 
 // x_j = Y_j - U_j x_{j+1} - V_j x_sep, right to left through the chunk.  Lane (k, rr) owns component k of the rhs
-// columns rr, rr + RG, ...; the factors of block j-1 are fetched while block j is being substituted.
-template <typename T, int B>
+// columns rr, rr + RG, ...  The pass is pure streaming (2400 B of factors per 24 FMAs on 12 lanes for Pose3), so it
+// lives or dies by how the factors arrive: the wave fetches each record [V | U | Y] as contiguous 16-byte pieces
+// (NP wave loads of 1 KiB instead of 25 loads of 96 useful bytes), PFB records ahead in a register ring, and hands
+// them to the consuming lanes through LDS.  NP = 16-byte pieces per lane per record: 3 covers R <= 8 for B = 12.
+template <typename T, int B, int NP>
 __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   const int R = a.R;
   const int BS = 2 * B * B + B * R;
@@ -1379,11 +1382,14 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   const bool has_sep = !a.no_sep;
   const bool right_exists = has_sep && ((e < a.n) || (a.last_has_right != 0));
   constexpr int RG = 64 / B;
+  constexpr int PFB = 3;
   const int rr = lane / B, k = lane - rr * B;
   const bool active = rr < RG;
+  typedef T V2 __attribute__((ext_vector_type(2)));
   __shared__ T xs[kMaxRhs * B];
   __shared__ T xa[kMaxRhs * B];
   __shared__ T xb[kMaxRhs * B];
+  __shared__ __attribute__((aligned(16))) T rec[NP * 128];      // one record [V | U | Y]
   for (int idx = lane; idx < R * B; idx += 64) {
     xs[idx] = has_sep ? a.xup[(size_t)c * R * B + idx] : T(0);
     xa[idx] = right_exists ? a.xup[(size_t)(c + 1) * R * B + idx] : T(0);
@@ -1396,37 +1402,48 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   if (right_exists && e == a.n)
     for (int idx = lane; idx < R * B; idx += 64) a.x[(size_t)a.n * R * B + idx] = xa[idx];
   const int j0 = has_sep ? s + 1 : s;
-  int ping = 0;
-  T Ur[B], Vr[B], Un[B], Vn[B];
+  const int pieces = BS / 2;                                      // BS is even (B is)
+  V2 ring[PFB][NP];
+  auto arm = [&](int u, int j) {
+    if (j >= j0) {
+      const V2 *src = reinterpret_cast<const V2 *>(a.blk + (size_t)j * BS);
 #pragma unroll
-  for (int q = 0; q < B; q++) { Ur[q] = T(0); Vr[q] = T(0); Un[q] = T(0); Vn[q] = T(0); }
-  if (active && e - 1 >= j0) {
-    const T *bp = a.blk + (size_t)(e - 1) * BS;
-#pragma unroll
-    for (int q = 0; q < B; q++) { Ur[q] = bp[B * B + q * B + k]; Vr[q] = has_sep ? bp[q * B + k] : T(0); }
-  }
-  for (int j = e - 1; j >= j0; --j) {
-    const T *bp = a.blk + (size_t)j * BS;
-    const T *cur = ping ? xb : xa;
-    T *nx = ping ? xa : xb;
-    if (active && j - 1 >= j0) {   // prefetch the factors of block j-1
-      const T *bq = a.blk + (size_t)(j - 1) * BS;
-#pragma unroll
-      for (int q = 0; q < B; q++) { Un[q] = bq[B * B + q * B + k]; Vn[q] = has_sep ? bq[q * B + k] : T(0); }
+      for (int p = 0; p < NP; p++)
+        if (lane + 64 * p < pieces) ring[u][p] = src[lane + 64 * p];
     }
-    if (active) {
-      for (int r = rr; r < R; r += RG) {
-        T v = bp[2 * B * B + r * B + k];
+  };
 #pragma unroll
-        for (int q = 0; q < B; q++) v -= Ur[q] * cur[r * B + q] + Vr[q] * xs[r * B + q];
-        nx[r * B + k] = v;
-        a.x[(size_t)j * R * B + r * B + k] = v;
+  for (int u = 0; u < PFB; u++) arm(u, e - 1 - u);
+  int ping = 0;
+  for (int base = e - 1; base >= j0; base -= PFB) {
+#pragma unroll
+    for (int u = 0; u < PFB; u++) {
+      const int j = base - u;
+      if (j >= j0) {                                              // wave-uniform
+        V2 *rv = reinterpret_cast<V2 *>(rec);
+#pragma unroll
+        for (int p = 0; p < NP; p++)
+          if (lane + 64 * p < pieces) rv[lane + 64 * p] = ring[u][p];
+        arm(u, j - PFB);
+        wave_lds_sync();
+        const T *cur = ping ? xb : xa;
+        T *nx = ping ? xa : xb;
+        if (active) {
+          T Ur[B], Vr[B];
+#pragma unroll
+          for (int q = 0; q < B; q++) { Ur[q] = rec[B * B + q * B + k]; Vr[q] = has_sep ? rec[q * B + k] : T(0); }
+          for (int r = rr; r < R; r += RG) {
+            T v = rec[2 * B * B + r * B + k];
+#pragma unroll
+            for (int q = 0; q < B; q++) v -= Ur[q] * cur[r * B + q] + Vr[q] * xs[r * B + q];
+            nx[r * B + k] = v;
+            a.x[(size_t)j * R * B + r * B + k] = v;
+          }
+        }
+        wave_lds_sync();
+        ping ^= 1;
       }
     }
-#pragma unroll
-    for (int q = 0; q < B; q++) { Ur[q] = Un[q]; Vr[q] = Vn[q]; }
-    wave_lds_sync();
-    ping ^= 1;
   }
 }
 
