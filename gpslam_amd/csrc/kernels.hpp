@@ -1130,10 +1130,16 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
   const int lane = threadIdx.x;
   const bool has_sep = !a.no_sep;
   const bool right_exists = (e < a.n) || (a.last_has_right != 0);
-  constexpr int kVCols = FAST ? B + (64 - 4 * B) / 2 : 1;
+  // FAST: the eliminated record [V_j | U_j | Y_j] is laid out in LDS exactly as it goes to memory: the A lanes take their
+  // V / Y operands from there, and the wave writes it back as contiguous 16-byte pieces (3 wave stores per Pose3 block
+  // instead of 6 stores of 16-byte fragments at a 96-byte stride)
+  constexpr int kRecLen = FAST ? 2 * B * B + B * ((64 - 4 * B) / 2) : 2;
   __shared__ __attribute__((aligned(16))) T ldsM[2 * B * B];   // [O_j | F_j]: one array, so that Mat below is an offset
   T *const ldsO = ldsM, *const ldsF = ldsM + B * B;
-  __shared__ __attribute__((aligned(16))) T ldsV[kVCols * B];
+  __shared__ __attribute__((aligned(16))) T ldsRec[kRecLen];
+  if (FAST && a.no_sep) {   // no spike columns at the top level: keep the V part of the stored records defined
+    for (int q = threadIdx.x; q < B * B; q += 64) ldsRec[q] = T(0);
+  }
   int dbase = 0, obase = B;
   const int cF = lane - 2 * B;
   const bool isF = has_sep && cF >= 0 && cF < B;
@@ -1228,25 +1234,24 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
       col[k] = rowk;
     }
     T *bp = a.blk + (size_t)j * BS;
+    T *rp = FAST ? ldsRec : bp;                                       // where this block's factors are assembled
     if (isO) {
 #pragma unroll
-      for (int k = 0; k < B; k++) bp[B * B + cO * B + k] = col[k];  // U_j, column cO
+      for (int k = 0; k < B; k++) rp[B * B + cO * B + k] = col[k];  // U_j, column cO
     } else if (isF) {
 #pragma unroll
-      for (int k = 0; k < B; k++) bp[cF * B + k] = col[k];          // V_j, column cF
-      if (FAST) {
-#pragma unroll
-        for (int k = 0; k < B; k++) ldsV[cF * B + k] = col[k];
-      }
+      for (int k = 0; k < B; k++) rp[cF * B + k] = col[k];          // V_j, column cF
     } else if (isR) {
 #pragma unroll
-      for (int k = 0; k < B; k++) bp[2 * B * B + cR * B + k] = col[k];  // Y_j
-      if (FAST && has_sep) {
-#pragma unroll
-        for (int k = 0; k < B; k++) ldsV[(B + cR) * B + k] = col[k];
-      }
+      for (int k = 0; k < B; k++) rp[2 * B * B + cR * B + k] = col[k];  // Y_j
     }
     wave_lds_sync();
+    if (FAST) {
+      typedef T V2 __attribute__((ext_vector_type(2)));
+      const V2 *src = reinterpret_cast<const V2 *>(ldsRec);
+      V2 *dst = reinterpret_cast<V2 *>(bp);
+      for (int q = lane; q < BS / 2; q += 64) dst[q] = src[q];
+    }
     if (!FAST && has_sep && (isF || isR)) {   // wide borders: separator sums in a pass of their own
 #pragma unroll
       for (int q = 0; q < B; q++) {
@@ -1259,8 +1264,9 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
     // one B x B product per lane:  nxt -= Mat * col
     const int moff = isA ? B * B : 0;
     if (isA) {
+      const T *vp = ldsRec + (cA < B ? cA * B : 2 * B * B + (cA - B) * B);   // column of V_j, or of Y_j
 #pragma unroll
-      for (int k = 0; k < B; k++) col[k] = ldsV[cA * B + k];
+      for (int k = 0; k < B; k++) col[k] = vp[k];
     } else if (!(isO || isF || isR)) {
 #pragma unroll
       for (int k = 0; k < B; k++) col[k] = T(0);     // D lanes (and spare lanes) take the operand unchanged
