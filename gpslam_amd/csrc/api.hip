@@ -93,7 +93,7 @@ struct gpslam_hip_handle {
   DevBuf partial;
   // landmark border
   int nlmrows = 0;
-  DevBuf lmrow, lmrow_state, lmrow_ptr, lm_t, lm_S, lm_gL, lm_dL;
+  DevBuf lmrow, lmrow_state, lmrow_ptr, lm_t, lm_S, lm_dL;   // lm_S = [S (nl x R) | gL (nl)]
   // solver
   std::vector<Level> lv;
   DevBuf gsave, dvec;
@@ -681,7 +681,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->pose, &h->vel, &h->lmk, &h->pose_bak, &h->vel_bak, &h->lmk_bak, &h->d_gp_left, &h->d_gp_dt,
                     &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
-                    &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_gL, &h->lm_dL, &h->gsave, &h->dvec,
+                    &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
                     &h->api_e, &h->api_H};
   for (DevBuf *b : bufs) b->release();
