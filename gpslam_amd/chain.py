@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
-    "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer",
+    "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
+    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject",
 ]
 
 
@@ -340,6 +341,21 @@ class ChainSolver:
         st = Stats()
         self._chk(self.lib.gpslam_hip_iterate_phase2b(self._h, C.byref(st) if want_stats else None), "iterate_phase2b")
         return st
+
+    def lm_begin(self):
+        return self._chk(self.lib.gpslam_hip_lm_begin(self._h), "lm_begin")
+
+    def lm_trial_phase1(self, lam):
+        return self._chk(self.lib.gpslam_hip_lm_trial_phase1(self._h, C.c_double(lam)), "lm_trial_phase1")
+
+    def lm_trial_phase2(self):
+        """[error, trial error, |delta|_inf, delta.g, |delta|^2, indefinite flag] of this rank."""
+        out = np.zeros(6)
+        self._chk(self.lib.gpslam_hip_lm_trial_phase2(self._h, _p(out)), "lm_trial_phase2")
+        return out
+
+    def lm_reject(self):
+        return self._chk(self.lib.gpslam_hip_lm_reject(self._h), "lm_reject")
 
     def landmark_reduce_buffer(self):
         """(device pointer, bytes) of this rank's landmark Schur complement [S | gL]; (None, 0) without landmarks."""

@@ -1467,7 +1467,8 @@ int gpslam_hip_iterate_phase2a(gpslam_hip_handle *h) {
   }
   const Real *xtop = h->top_x.as<Real>() + (size_t)h->cfg.rank * b * R;   // [x_sep(rank), x_sep(rank + 1)]
   if ((rc = launch_backward(h, xtop))) return rc;
-  return launch_landmarks_reduce(h, h->ph_lambda);
+  // the ranks' Schur complements are summed: the LM damping of the landmark block goes in exactly once
+  return launch_landmarks_reduce(h, (h->cfg.nranks > 1 && h->cfg.rank != 0) ? 0.0 : h->ph_lambda);
 }
 
 int gpslam_hip_landmark_reduce_buffer(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes) {
@@ -1518,6 +1519,92 @@ int gpslam_hip_iterate_phase2b(gpslam_hip_handle *h, gpslam_hip_stats *st) {
     if (flag) return fail(h, GPSLAM_E_NOT_SPD, "non-positive pivot in the block elimination");
   }
   return 0;
+}
+
+// ---- Levenberg-Marquardt on a sharded chain.  The decisions of gpslam_hip_iterate_lm need three global sums (error,
+// delta . g, |delta|^2), so the loop lives with the caller (gpslam_amd/sharded.py: ShardedSolver.iterate_lm) and the
+// library provides its device-side steps:
+//   lm_begin            linearise once at the current estimate, remember it
+//   lm_trial_phase1     damp with lambda, eliminate the segment            -> all-gather of the interface records
+//   iterate_phase2a     reduced solve, back-substitution, landmark share   -> all-reduce of the landmark buffer
+//   lm_trial_phase2     landmark solve, trial update, this rank's scalars  -> all-reduce of the scalars, decision
+//   lm_reject           back to the linearisation point (an accepted trial needs nothing)
+int gpslam_hip_lm_begin(gpslam_hip_handle *h) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  if ((rc = launch_factors(h, 0, 0))) return rc;        // rows + scal[0] = this rank's error
+  return backup_state(h, false);
+}
+
+int gpslam_hip_lm_trial_phase1(gpslam_hip_handle *h, double lambda) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  h->ph_lambda = lambda;
+  HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
+  if ((rc = launch_assemble(h, true))) return rc;       // rows are still those of the linearisation point
+  return launch_forward(h, lambda);
+}
+
+// out6 = {error at the linearisation point, trial error, |delta|_inf, delta . g, |delta|^2, indefinite-pivot flag},
+// all for THIS rank's states (landmark terms on rank 0 only); sums / maxima over the ranks give the global values
+int gpslam_hip_lm_trial_phase2(gpslam_hip_handle *h, double *out6) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h) || !out6) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  const int b = h->b, R = h->R, nx = h->N * h->b;
+  Real *xtop = h->top_x.as<Real>() + (size_t)h->cfg.rank * b * R;
+  if ((rc = launch_landmarks_solve(h, h->ph_lambda))) return rc;
+  if (has_right_rank(h) && h->nl > 0) {
+    LmArgs<Real> la = lm_args(h, 0.0);
+    la.N = 1; la.x = xtop + (size_t)b * R;
+    k_lm_correct<Real><<<dim3(nblocks(b, 256)), dim3(256), 0, h->stream>>>(la);
+  }
+  k_gather_delta<Real><<<dim3(nblocks(nx, 256)), dim3(256), 0, h->stream>>>(h->lv[0].x.as<Real>(), h->N, h->R, h->b, h->dvec.as<Real>());
+  if ((rc = launch_dot(h, h->dvec.as<Real>(), h->gsave.as<Real>(), nx, 3))) return rc;   // delta . g
+  if ((rc = launch_dot(h, h->dvec.as<Real>(), h->dvec.as<Real>(), nx, 4))) return rc;    // |delta|^2
+  const bool lm_here = h->nl > 0 && h->cfg.rank == 0;    // replicated landmark update: counted once
+  if (lm_here) {
+    if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_S.as<Real>() + (size_t)h->nl * h->R, h->nl, 5))) return rc;
+    if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_dL.as<Real>(), h->nl, 6))) return rc;
+  }
+  // the rows of the last local state also feed the gradient of the neighbour's first state (halo_add = [RD | Rg]):
+  // that share of delta . g is only known here
+  if (has_right_rank(h)) {
+    if ((rc = launch_dot(h, xtop + (size_t)b * R, h->halo_add.as<Real>() + (size_t)b * b, b, 7))) return rc;
+  }
+  if ((rc = launch_retract(h, 2))) return rc;
+  if (has_right_rank(h)) {
+    RetractArgs<Real> a;
+    a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = 1; a.R = R;
+    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4;
+    dispatch_mf(h->mf, [&](auto tag) {
+      constexpr int MF = decltype(tag)::value;
+      k_retract<Real, MF><<<dim3(1), dim3(128), 0, h->stream>>>(a);
+    });
+  }
+  if ((rc = launch_factors(h, 1, 1))) return rc;         // scal[1] = trial error
+  double s[8];
+  int flag = 0;
+  if ((rc = read_scal(h, s, 8, &flag))) return rc;
+  out6[0] = s[0]; out6[1] = s[1]; out6[2] = s[2];
+  out6[3] = s[3] + (has_right_rank(h) ? s[7] : 0.0) + (lm_here ? s[5] : 0.0);
+  out6[4] = s[4] + (lm_here ? s[6] : 0.0);
+  out6[5] = flag ? 1.0 : 0.0;
+  return 0;
+}
+
+int gpslam_hip_lm_reject(gpslam_hip_handle *h) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!sharded(h)) return GPSLAM_E_INVALID;
+  (void)hipSetDevice(h->cfg.device);
+  return backup_state(h, true);
 }
 
 // 2a + 2b for chains without landmarks (or a single rank): nothing to reduce in between

@@ -937,7 +937,10 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   const int BS = 2 * B * B + B * a.R;
   T *bp = a.blk + (size_t)sc * BS;
   const bool isblk = out && sc < a.N;
-  if (isblk) for (int r = 1; r < a.R; r++) bp[2 * B * B + r * B + c] = T(0);
+  // rhs columns: of this state's record, or -- for the virtual state behind the segment -- of the addend owed to the
+  // next rank's first state (the rows of the last interval carry landmark columns too)
+  T *gcol = isblk ? bp + 2 * B * B : ((out && a.halo_add) ? a.halo_add + B * B : nullptr);
+  if (gcol) for (int r = 1; r < a.R; r++) gcol[r * B + c] = T(0);
   auto ld = [&](int i, T &Lc, T &Rc, T &e) {
     Lc = T(0); Rc = T(0); e = T(0);
     if (i < n_own) {
@@ -974,18 +977,18 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
     }
     gsum -= Lc * e;
     gsum -= Pc * ep;
-    if (a.rowM && isblk) {
+    if (a.rowM && gcol) {
       if (i < n_own) {
         const int rho = rp_s + i;
         const int lm = a.rowLm[rho];
         if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+          for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
       }
       if (i < n_prev) {
         const int rho = rp_prev + i;
         const int lm = a.rowLm[rho];
         if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) bp[2 * B * B + (1 + lm * a.ld + q) * B + c] += Pc * a.rowM[(size_t)rho * a.ld + q];
+          for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Pc * a.rowM[(size_t)rho * a.ld + q];
       }
     }
   }
@@ -994,7 +997,6 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
 #pragma unroll
     for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
     a.halo_add[B * B + c] = gsum;
-    for (int r = 1; r < a.R; r++) a.halo_add[B * B + r * B + c] = T(0);
     return;
   }
 #pragma unroll

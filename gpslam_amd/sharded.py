@@ -158,6 +158,53 @@ class ShardedSolver:
             vals = np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max()])
         return dict(error_before=float(vals[0]), error_after=float(vals[1]), delta_inf_norm=float(vals[2]))
 
+    def _reduce_lm_scalars(self, loc):
+        """sum of (error, trial error, delta.g, |delta|^2), max of (|delta|_inf, indefinite flag) over the ranks"""
+        if self.dist is None or self.nranks == 1:
+            return loc
+        import torch
+        t = torch.from_numpy(np.asarray(loc, dtype=np.float64).copy())
+        if self.send.is_cuda:
+            t = t.cuda()
+        allv = [torch.empty_like(t) for _ in range(self.nranks)]
+        self.dist.all_gather(allv, t, group=self.group)
+        m = torch.stack(allv).cpu().numpy()
+        return np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
+
+    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+        """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the ranks: the loop of gpslam_hip_iterate_lm
+        with its three global sums made collective.  Every rank takes the same decisions (identical reduced scalars).
+        Returns (stats dict, new lambda)."""
+        be = self.backend
+        be.lm_begin()
+        accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
+        while True:
+            be.lm_trial_phase1(lam)
+            self.exchange()
+            be.iterate_phase2a()
+            if self.landmark_buf is not None and self.dist is not None and self.nranks > 1:
+                self.dist.all_reduce(self.landmark_buf, group=self.group)
+            s = self._reduce_lm_scalars(be.lm_trial_phase2())
+            err0 = float(s[0])
+            ok = False
+            if s[5] == 0.0:
+                lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
+                if lin_change >= 0.0:
+                    cost_change = s[0] - s[1]
+                    fidelity = cost_change / lin_change if lin_change > 1e-20 else 0.0
+                    if fidelity > min_model_fidelity:
+                        ok, new_err, dinf = True, float(s[1]), float(s[2])
+            if ok:
+                lam = max(lam / lambda_factor, lambda_lower_bound)
+                accepted = True
+                break
+            be.lm_reject()
+            if lam >= lambda_upper_bound:
+                break
+            lam *= lambda_factor
+        return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
+                    accepted=accepted), lam
+
     def run(self, iters, lam=0.0):
         """`iters` iterations back to back; statistics only for the last one."""
         out = None

@@ -232,6 +232,15 @@ int gpslam_hip_iterate_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
 int gpslam_hip_iterate_phase2a(gpslam_hip_handle *h);
 int gpslam_hip_iterate_phase2b(gpslam_hip_handle *h, gpslam_hip_stats *st);
 int gpslam_hip_landmark_reduce_buffer(gpslam_hip_handle *h, void **dev_ptr, size_t *bytes);
+/* LevenbergMarquardtOptimizer::iterate on a sharded chain: the accept / reject decisions need global sums, so the
+ * loop is the caller's (gpslam_amd/sharded.py: ShardedSolver.iterate_lm mirrors gpslam_hip_iterate_lm line by line):
+ *   lm_begin;  repeat { lm_trial_phase1(lambda); all-gather records; iterate_phase2a; [all-reduce landmark buffer];
+ *   lm_trial_phase2(out6); all-reduce out6 (sum of [0], [1], [3], [4]; max of [2], [5]); accept, or lm_reject and a
+ *   larger lambda }.  out6 = {error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag} of this rank. */
+int gpslam_hip_lm_begin(gpslam_hip_handle *h);
+int gpslam_hip_lm_trial_phase1(gpslam_hip_handle *h, double lambda);
+int gpslam_hip_lm_trial_phase2(gpslam_hip_handle *h, double *out6);
+int gpslam_hip_lm_reject(gpslam_hip_handle *h);
 /* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
 int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
 

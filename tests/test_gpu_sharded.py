@@ -137,7 +137,7 @@ def test_sharded_chain_with_landmarks_matches_unsharded():
     problem = plaza.build_problem(data, init_ground_truth=True)
     kind, chart = gpslam_amd.POSE2, gpslam_amd.CHART_FIRST_ORDER
     single = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
-    for P in (2, 5):
+    for P in (2, 3, 5):      # P = 3 puts range measurements into the intervals that straddle the cuts
         stream = torch.cuda.current_stream().cuda_stream
         ranks = []
         for r in range(P):
@@ -175,3 +175,79 @@ def test_sharded_chain_with_landmarks_matches_unsharded():
         for r in ranks:
             r[0].close()
     single.close()
+
+
+def _lm_iterate_emulated(ranks, lam, factor=10.0, upper=1e5, lower=0.0, fidelity_min=1e-3):
+    """ShardedSolver.iterate_lm with the collectives done by hand across P handles that share one GPU."""
+    P = len(ranks)
+    for r in ranks:
+        r[0].lm_begin()
+    accepted, err0, new_err = False, 0.0, 0.0
+    while True:
+        for r in ranks:
+            r[0].lm_trial_phase1(lam)
+        for r in ranks:
+            rv = r[2].view(P, -1)
+            for k in range(P):
+                rv[k].copy_(ranks[k][1])
+        for r in ranks:
+            r[0].iterate_phase2a()
+        if ranks[0][3] is not None:
+            total = sum(r[3].clone() for r in ranks)
+            for r in ranks:
+                r[3].copy_(total)
+        m = np.stack([r[0].lm_trial_phase2() for r in ranks])
+        s = np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
+        err0 = s[0]
+        ok = False
+        if s[5] == 0.0:
+            lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
+            if lin_change >= 0.0:
+                fid = (s[0] - s[1]) / lin_change if lin_change > 1e-20 else 0.0
+                if fid > fidelity_min:
+                    ok, new_err = True, s[1]
+        if ok:
+            lam = max(lam / factor, lower)
+            accepted = True
+            break
+        for r in ranks:
+            r[0].lm_reject()
+        if lam >= upper:
+            break
+        lam *= factor
+    return err0, (new_err if accepted else err0), lam, accepted
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_sharded_levenberg_marquardt_matches_unsharded(P):
+    """LevenbergMarquardtOptimizer::iterate across ranks on the Plaza2 graph from the dead-reckoned initial values (the
+    reference's own scenario, matlab/PlazaPose2.m:208-228): same lambda schedule and errors as the unsharded solver."""
+    import os
+    import torch
+    import gpslam_amd
+    from gpslam_amd import plaza, sharded
+    data = plaza.load(os.path.join(os.path.dirname(__file__), "golden", "plaza2.npz"))
+    problem = plaza.build_problem(data)
+    kind, chart = gpslam_amd.POSE2, gpslam_amd.CHART_FIRST_ORDER
+    ref = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
+    stream = torch.cuda.current_stream().cuda_stream
+    ranks = []
+    for r in range(P):
+        s = gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2, device=0, rank=r, nranks=P)
+        s.set_stream(stream)
+        sharded.apply_local(sharded.local_problem(problem, r, P), s)
+        send, recv = sharded.device_tensors(s)
+        ranks.append((s, send, recv, sharded.landmark_tensor(s)))
+    lam_s = lam_r = 1e-5
+    for it in range(6):
+        e0, e1, lam_s, acc = _lm_iterate_emulated(ranks, lam_s)
+        out = ref.iterate_lm(lam_r)
+        rc, st, lam_r = out[0], out[1], out[2]
+        assert rc == 0 and acc == bool(st.accepted)
+        assert lam_s == lam_r, (it, lam_s, lam_r)
+        assert abs(e0 - st.error_before) <= 1e-7 * st.error_before
+        assert abs(e1 - st.error_after) <= 1e-6 * st.error_after, (it, e1, st.error_after)
+    pose = np.vstack([r[0].get_states()[0] for r in ranks])
+    assert np.abs(pose - ref.get_states()[0]).max() <= 1e-5
+    for r in ranks:
+        r[0].close()
