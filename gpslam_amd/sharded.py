@@ -141,7 +141,7 @@ class ShardedSolver:
             st = self.backend.iterate_phase2(want_stats)
         else:
             self.backend.iterate_phase2a()
-            if self.dist is not None and self.nranks > 1:
+            if self.dist is not None:
                 self.dist.all_reduce(self.landmark_buf, group=self.group)     # sum of the ranks' Schur complements
             st = self.backend.iterate_phase2b(want_stats)
         if not want_stats:
@@ -160,7 +160,7 @@ class ShardedSolver:
 
     def _reduce_lm_scalars(self, loc):
         """sum of (error, trial error, delta.g, |delta|^2), max of (|delta|_inf, indefinite flag) over the ranks"""
-        if self.dist is None or self.nranks == 1:
+        if self.dist is None:
             return loc
         import torch
         t = torch.from_numpy(np.asarray(loc, dtype=np.float64).copy())
@@ -182,7 +182,7 @@ class ShardedSolver:
             be.lm_trial_phase1(lam)
             self.exchange()
             be.iterate_phase2a()
-            if self.landmark_buf is not None and self.dist is not None and self.nranks > 1:
+            if self.landmark_buf is not None and self.dist is not None:
                 self.dist.all_reduce(self.landmark_buf, group=self.group)
             s = self._reduce_lm_scalars(be.lm_trial_phase2())
             err0 = float(s[0])

@@ -121,6 +121,25 @@ def test_rccl_exchange_plumbing_world_size_one():
         p0, v0 = single.get_states()
         p1, v1 = s.get_states()
         assert np.abs(p0 - p1).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+        # landmarks + Levenberg-Marquardt through the same orchestration class: all-gather of the records, all-reduce
+        # of the landmark Schur complement, all-gather of the decision scalars -- the collectives really run (RCCL)
+        from gpslam_amd import plaza
+        data = plaza.load(os.path.join(os.path.dirname(__file__), "golden", "plaza2.npz"))
+        problem = plaza.build_problem(data)
+        kind, chart = gpslam_amd.POSE2, gpslam_amd.CHART_FIRST_ORDER
+        sp = gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2, device=0, rank=0, nranks=1, force_sharded=True)
+        sp.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharded.apply_local(sharded.local_problem(problem, 0, 1), sp)
+        send, recv = sharded.device_tensors(sp)
+        svp = sharded.ShardedSolver(sp, send, recv, 0, 1, dist=dist, landmark_buf=sharded.landmark_tensor(sp))
+        ref = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
+        lam_s = lam_r = 1e-5
+        for _ in range(7):
+            st_s, lam_s = svp.iterate_lm(lam_s)
+            rc, st_r, lam_r = ref.iterate_lm(lam_r)[:3]
+            assert lam_s == lam_r and abs(st_s["error_after"] - st_r.error_after) <= 1e-6 * st_r.error_after
+        m = plaza.metrics(problem, sp.get_states()[0], sp.get_landmarks())
+        assert m["position_m"] < 0.25
     finally:
         dist.destroy_process_group()
 
