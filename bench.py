@@ -204,6 +204,12 @@ def main():
             "phase_ms_per_iter_1gpu": {k: float(v) / 3 for k, v in
                                        zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
             "kernel_ms": {n: float(v) for n, v in zip(names, kms)},
+            # every hot kernel against the same roof: algorithmic GB/s (SURVEY 8(d) bytes per unit) and, where the
+            # committed counter passes cover it, the HBM bytes it really moved per launch
+            "kernel_roofline": {n: {"algorithmic_GBps": alg[i] / (kms[i] * 1e-3) / 1e9,
+                                    "frac_of_peak": alg[i] / (kms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "moved_GBps": (pmc_traffic(i, N) / (kms[i] * 1e-3) / 1e9) if pmc_traffic(i, N) else None}
+                                for i, n in enumerate(names)},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N),
                          "traffic_source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum, "

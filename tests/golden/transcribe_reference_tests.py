@@ -93,6 +93,67 @@ projection_optimization = dict(
     p1_init=P3(0.1, 0.2, 0.4, 0.2, 0.3, -0.2), p2_init=P3(-0.1, -0.2, -0.4, 1.2, -0.3, 0.2),
     v1_init=[-0.3, 0, 0, 0.7, 0, 0.2], v2_init=[0, 0, 0.4, 1.2, 0, -0.1], land_init=[3.3, 1.3, 18], tol=1e-6)
 
+# ---- GPInterpolatedGPSFactorPose3 (dt = 0.1, tau = 0.04, Qc = 0.001 I6, sigma 0.1, body_T_sensor = Ypr(1.0, 0.4, 0.5),
+# (0.3, 0.6, -0.7): testGPInterpolatedGPSFactorPose3.cpp:40-46).  meas as a dict = translation of true_pose * sensor.
+GPSF = SL + "testGPInterpolatedGPSFactorPose3.cpp"
+GSENS = P3(1.0, 0.4, 0.5, 0.3, 0.6, -0.7)
+interp_gps = [
+    dict(src=GPSF + ":55-78", dt=0.1, tau=0.04, qc=0.001, sensor=None, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6, p2=P3(0, 0, 0, 0, 0, 0),
+         v2=Z6, meas=[0, 0, 0], expect=[0, 0, 0], tol_e=1e-6, fd=1e-4, tol_H=[1e-6] * 4),
+    dict(src=GPSF + ":82-105", dt=0.1, tau=0.04, qc=0.001, sensor=None, p1=P3(0, 0, 0, -0.04, 0, 0), v1=[0, 0, 0, 1, 0, 0],
+         p2=P3(0, 0, 0, 0.06, 0, 0), v2=[0, 0, 0, 1, 0, 0], meas=[0, 0, 0], expect=[0, 0, 0], tol_e=1e-6, fd=1e-4,
+         tol_H=[1e-6] * 4),
+    dict(src=GPSF + ":109-132", dt=0.1, tau=0.04, qc=0.001, sensor=None, p1=P3(-0.04, 0, 0, 0, 0, 0), v1=[0, 0, 1, 0, 0, 0],
+         p2=P3(0.06, 0, 0, 0, 0, 0), v2=[0, 0, 1, 0, 0, 0], meas=[0, 0, 0], expect=[0, 0, 0], tol_e=1e-6, fd=1e-4,
+         tol_H=[1e-6] * 4),
+    dict(src=GPSF + ":136-162", dt=0.1, tau=0.04, qc=0.001, sensor=GSENS, p1=P3(0, 0, 0, 0, 0, 0), v1=[0, 0, 0, 15, 0, 0],
+         p2=P3(0, 0, 0, 1.5, 0, 0), v2=[0, 0, 0, 15, 0, 0], meas=dict(true_pose=P3(0, 0, 0, 0.6, 0, 0)), expect=[0, 0, 0],
+         tol_e=1e-6, fd=1e-4, tol_H=[1e-6] * 4),
+    dict(src=GPSF + ":166-188", dt=0.1, tau=0.04, qc=0.001, sensor=GSENS, p1=P3(1.3, 2.4, 1.2, 0.2, 0.3, 0.4),
+         v1=[1.0, 2.0, 0.4, 15, 0.3, 0.2], p2=P3(0.5, 6.5, 1.1, 1.5, 0.7, 0.5), v2=[2.0, 0.2, 0.1, 17, 0.4, 0.7],
+         meas=[0, 0, 0], expect=None, fd=1e-4, tol_H=[1e-6] * 4),
+]
+# optimisation (:193-262): loose prior on x1 (sigma 100), tight velocity priors, GP prior (dt 0.1, Qc 0.01 I6), three GPS
+# fixes at tau = -0.1 / 0.05 / 0.2 (two of them extrapolate) on the line the true trajectory follows
+gps_optimization = dict(
+    src=GPSF + ":193-262", dt=0.1, qc=0.01, prior_sigma=0.01, loose_sigma=100.0, gps_sigma=0.1, taus=[-0.1, 0.05, 0.2],
+    meas=[[-1, 0, 0], [0.5, 0, 0], [2, 0, 0]], p1=P3(0, 0, 0, 0, 0, 0), p2=P3(0, 0, 0, 1, 0, 0), v1=[0, 0, 0, 10, 0, 0],
+    v2=[0, 0, 0, 10, 0, 0], p1_init=P3(0.1, 0.1, -0.1, 0.04, 0.1, -0.06), p2_init=P3(-0.1, 0.1, -0.1, 1.05, -0.1, 0.1),
+    v1_init=[-0.1, 0, 0, 9.8, 0, 0.2], v2_init=[0, 0, 0.2, 9.7, 0, -0.1], tol=1e-6)
+
+# ---- GPInterpolatedGPSFactorPose3VW (same dt / tau / Qc; body_T_sensor = Ypr(1.4, 4.4, -0.5), (0.3, 0.6, -0.7) and a
+# rotation-only variant: testGPInterpolatedGPSFactorPose3VW.cpp:40-46).  Last case literal (v1 / w1 assigned twice, v2 / w2
+# left from the previous case, :249-250).
+GPSV = SL + "testGPInterpolatedGPSFactorPose3VW.cpp"
+VSENS, VSENS_ROT = P3(1.4, 4.4, -0.5, 0.3, 0.6, -0.7), P3(1.4, 4.4, -0.5, 0, 0, 0)
+interp_gps_vw = [
+    dict(src=GPSV + ":56-83", sensor=None, p1=P3(0, 0, 0, 0, 0, 0), v1=Z3, w1=Z3, p2=P3(0, 0, 0, 0, 0, 0), v2=Z3, w2=Z3,
+         meas=[0, 0, 0], expect=[0, 0, 0]),
+    dict(src=GPSV + ":87-114", sensor=None, p1=P3(0, 0, 0, -0.04, 0.04, 0), v1=[1, -1, 0], w1=Z3, p2=P3(0, 0, 0, 0.06, -0.06, 0),
+         v2=[1, -1, 0], w2=Z3, meas=[0, 0, 0], expect=[0, 0, 0]),
+    dict(src=GPSV + ":118-145", sensor=None, p1=P3(-0.04, 0, 0, 0, 0, 0), v1=Z3, w1=[0, 0, 1], p2=P3(0.06, 0, 0, 0, 0, 0), v2=Z3,
+         w2=[0, 0, 1], meas=[0, 0, 0], expect=[0, 0, 0]),
+    dict(src=GPSV + ":149-178", sensor=VSENS, p1=P3(0, 0, 0, 1, 0, 0), v1=[15, 5, 0], w1=Z3, p2=P3(0, 0, 0, 2.5, 0.5, 0),
+         v2=[15, 5, 0], w2=Z3, meas=dict(true_pose=P3(0, 0, 0, 1.6, 0.2, 0)), expect=[0, 0, 0]),
+    dict(src=GPSV + ":180-210", sensor=VSENS_ROT, p1=P3(0, 0, 0, 1, 0, 0), v1=[15, 5, 0], w1=Z3, p2=P3(0, 0, 0, 2.5, 0.5, 0),
+         v2=[15, 5, 0], w2=Z3, meas=[0, 0, 0], expect=[1.6, 0.2, 0]),
+    dict(src=GPSV + ":213-243", sensor=VSENS, p1=P3(0, 0, 0, 0, 0, 0), v1=Z3, w1=[0, 0, 10], p2=P3(1.0, 0, 0, 0, 0, 0), v2=Z3,
+         w2=[0, 0, 10], meas=dict(true_pose=P3(0.4, 0, 0, 0, 0, 0)), expect=[0, 0, 0]),
+    dict(src=GPSV + ":246-270", sensor=VSENS, p1=P3(0.4, -0.8, 0.2, 3, -8, 2), v1=[0.6, 0.3, -0.9], w1=[0.4, -0.2, 0.8],
+         p2=P3(0.1, 0.3, -0.5, -9, 3, 4), v2=Z3, w2=[0, 0, 10], meas=[0, 0, 0], expect=None),
+]
+for _c in interp_gps_vw:
+    _c.update(dt=0.1, tau=0.04, qc=0.001, tol_e=1e-6, fd=1e-4, tol_H=[1e-6] * 6)
+
+# ---- convertVWtoVb known answers (testPose3Utils.cpp:345-420): body 6-velocity [w_b; v_b] of world (v, w) at `pose`;
+# the Jacobians are checked against central differences of the same function (:359-367)
+vw_conversion = [
+    dict(src=GP + "testPose3Utils.cpp:355-368", pose=P3(0, 0, 0, 0, 0, 0), v=[1, 0, 0], w=[1, 0, 0], v6=[1, 0, 0, 1, 0, 0]),
+    dict(src=GP + "testPose3Utils.cpp:371-384", pose=P3(0, 0, 0, 3, 4, 5), v=[1, 2, 3], w=[1, -2, -3], v6=[1, -2, -3, 1, 2, 3]),
+    dict(src=GP + "testPose3Utils.cpp:388-401", pose=P3(PI / 2, 0, 0, 0, 0, 0), v=[1, 0, 0], w=[0, 0, 1], v6=[0, 0, 1, 0, -1, 0]),
+    dict(src=GP + "testPose3Utils.cpp:404-417", pose=P3(PI / 2, 0, 0, 0, 0, 0), v=[-3, 4, 0], w=[0, 0, 1], v6=[0, 0, 1, 4, 3, 0]),
+]
+
 gp_prior = [
     # ---- GaussianProcessPriorPose3 (dt = 0.1, Qc = 0.01 I6: testGaussianProcessPriorPose3.cpp:29-30)
     dict(src=GP + "testGaussianProcessPriorPose3.cpp:43-65", kind="pose3", dt=0.1, p1=P3(0, 0, 0, 0, 0, 0), v1=Z6,
@@ -359,7 +420,8 @@ optimization = [
 
 out = dict(
     _about="Inputs/expected values transcribed from gtrll/gpslam's own unit tests; see transcribe_reference_tests.py",
-    gp_prior=gp_prior, interp_projection=interp_projection, projection_optimization=projection_optimization,
+    gp_prior=gp_prior, vw_conversion=vw_conversion, interp_gps=interp_gps, gps_optimization=gps_optimization, interp_gps_vw=interp_gps_vw,
+    interp_projection=interp_projection, projection_optimization=projection_optimization,
     gp_prior_vw=gp_prior_vw, interpolator_vw=interpolator_vw, interpolator=interpolator, interp_range=interp_range, range2d=range2d,
     bearing_range2d=bearing_range2d, odometry2d=odometry2d, body_centric_velocity=body_centric_velocity,
     lie_jacobians=lie_jacobians, se3_velocity=se3_velocity, optimization=optimization)

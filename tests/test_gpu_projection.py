@@ -101,3 +101,16 @@ def test_projection_reference_optimisation(golden):
     orc = build_projection_problem(c, O.Chain(O.POSE3, landmark_dim=3))
     rc0, st0 = orc.optimize()
     assert st0.iterations == st.iterations
+
+
+def test_gps_reference_optimisation(golden):
+    """testGPInterpolatedGPSFactorPose3.cpp:193-262 through the C ABI (two of the three fixes extrapolate)."""
+    from test_oracle_golden import build_gps_problem, check_gps_result
+    c = golden["gps_optimization"]
+    dev = build_gps_problem(c, gpu().ChainSolver(O.POSE3))
+    rc, st = dev.optimize()
+    assert rc == 0
+    check_gps_result(c, dev)
+    orc = build_gps_problem(c, O.Chain(O.POSE3))
+    rc0, st0 = orc.optimize()
+    assert st0.iterations == st.iterations

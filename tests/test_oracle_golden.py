@@ -415,3 +415,91 @@ def test_projection_optimisation_fixed_point(golden):
     rc, st = chain.optimize()
     assert rc == 0
     check_projection_result(c, chain)
+
+
+def _gps_meas(c):
+    if isinstance(c["meas"], dict):       # (true_pose * body_T_sensor).translation()
+        out = np.zeros(12)
+        O.call("orc_pose3_compose", dec_pose(O.POSE3, c["meas"]["true_pose"]), dec_pose(O.POSE3, c["sensor"]), out, None, None)
+        return out[9:12].copy()
+    return O.A(c["meas"])
+
+
+def _interp_gps(Lam, Psi, meas, sensor, p1, s1, p2, s2, vw, jac=True):
+    e = np.zeros(3)
+    H = [np.zeros((3, 6)) for _ in range(4)] if jac else [None] * 4
+    O.call("orc_interp_gps_pose3vw" if vw else "orc_interp_gps_pose3", O.A(Lam), O.A(Psi), O.A(meas),
+           None if sensor is None else O.A(sensor), O.A(p1), O.A(s1), O.A(p2), O.A(s2), e, *H)
+    return e, H
+
+
+def test_interp_gps_cases(golden):
+    """GPInterpolatedGPSFactorPose3 and ...Pose3VW (testGPInterpolatedGPSFactorPose3.cpp, ...Pose3VW.cpp): zero-error
+    configurations, the literal (1.6, 0.2, 0) of the rotation-only sensor case, Jacobians vs central differences."""
+    for key, vw in (("interp_gps", False), ("interp_gps_vw", True)):
+        for c in golden[key]:
+            Lam, Psi = O.lambda_psi(6, c["qc"] * np.eye(6), c["dt"], c["tau"])
+            p1, p2 = dec_pose(O.POSE3, c["p1"]), dec_pose(O.POSE3, c["p2"])
+            s1 = O.A(c["v1"] + c["w1"]) if vw else O.A(c["v1"])
+            s2 = O.A(c["v2"] + c["w2"]) if vw else O.A(c["v2"])
+            sensor = None if c["sensor"] is None else dec_pose(O.POSE3, c["sensor"])
+            meas = _gps_meas(c)
+            e, H = _interp_gps(Lam, Psi, meas, sensor, p1, s1, p2, s2, vw)
+            if c["expect"] is not None:
+                assert np.abs(e - np.array(c["expect"])).max() <= c["tol_e"], c["src"]
+            f = lambda a, b, cc, dd: _interp_gps(Lam, Psi, meas, sensor, a, b, cc, dd, vw, jac=False)[0]
+            num = [lambda h: numdiff_manifold(O.POSE3, lambda x: f(x, s1, p2, s2), p1, h),
+                   lambda h: numdiff_vector(lambda x: f(p1, x, p2, s2), s1, h),
+                   lambda h: numdiff_manifold(O.POSE3, lambda x: f(p1, s1, x, s2), p2, h),
+                   lambda h: numdiff_vector(lambda x: f(p1, s1, p2, x), s2, h)]
+            for k in range(4):      # VW: [H_v | H_w] packed side by side = the reference's H2|H3 and H5|H6
+                ok, err = _jac_ok(H[k], num[k], c["fd"], c["tol_H"][k])
+                assert ok, (c["src"], k, err)
+
+
+def build_gps_problem(c, chain):
+    """testGPInterpolatedGPSFactorPose3.cpp:193-262 on a ChainSolver-like object."""
+    p1 = dec_pose(O.POSE3, c["p1"])
+    chain.set_qc(c["qc"] * np.eye(6))
+    chain.set_states(np.stack([dec_pose(O.POSE3, c["p1_init"]), dec_pose(O.POSE3, c["p2_init"])]),
+                     np.stack([O.A(c["v1_init"]), O.A(c["v2_init"])]))
+    chain.add_pose_priors([0], p1[None, :], np.full((1, 6), c["loose_sigma"]))
+    chain.add_vel_priors([0, 1], np.stack([O.A(c["v1"]), O.A(c["v2"])]), np.full((2, 6), c["prior_sigma"]))
+    chain.add_gp_priors([0], [c["dt"]])
+    n = len(c["taus"])
+    chain.add_interp_gps([0] * n, np.array(c["meas"], dtype=float), np.full((n, 3), c["gps_sigma"]), [c["dt"]] * n, c["taus"])
+    chain.compile()
+    return chain
+
+
+def check_gps_result(c, chain):
+    pose, vel = chain.get_states()
+    assert pose_close(O.POSE3, dec_pose(O.POSE3, c["p1"]), pose[0], c["tol"])
+    assert pose_close(O.POSE3, dec_pose(O.POSE3, c["p2"]), pose[1], c["tol"])
+    assert np.abs(vel[0] - np.array(c["v1"])).max() <= c["tol"] and np.abs(vel[1] - np.array(c["v2"])).max() <= c["tol"]
+    assert chain.error() <= c["tol"]
+
+
+def test_gps_optimisation_fixed_point(golden):
+    c = golden["gps_optimization"]
+    chain = build_gps_problem(c, O.Chain(O.POSE3))
+    rc, st = chain.optimize()
+    assert rc == 0
+    check_gps_result(c, chain)
+
+
+def test_vw_conversion_known_answers(golden):
+    """convertVWtoVb (testPose3Utils.cpp:345-420): values to 1e-9, the three Jacobians against central differences."""
+    for c in golden["vw_conversion"]:
+        pose, v, w = dec_pose(O.POSE3, c["pose"]), O.A(c["v"]), O.A(c["w"])
+        v6, Hv, Hw, Hp = np.zeros(6), np.zeros((6, 3)), np.zeros((6, 3)), np.zeros((6, 6))
+        O.call("orc_convertVWtoVb", v, w, pose, v6, Hv, Hw, Hp)
+        assert np.abs(v6 - np.array(c["v6"])).max() <= 1e-9, c["src"]
+
+        def f(a, b, p):
+            out = np.zeros(6)
+            O.call("orc_convertVWtoVb", O.A(a), O.A(b), O.A(p), out, None, None, None)
+            return out
+        assert np.abs(Hv - numdiff_vector(lambda x: f(x, w, pose), v, 1e-6)).max() <= 1e-6
+        assert np.abs(Hw - numdiff_vector(lambda x: f(v, x, pose), w, 1e-6)).max() <= 1e-6
+        assert np.abs(Hp - numdiff_manifold(O.POSE3, lambda x: f(v, w, x), pose, 1e-6)).max() <= 1e-6
