@@ -94,6 +94,8 @@ struct gpslam_hip_handle {
   // landmark border
   int nlmrows = 0;
   DevBuf lmrow, lmrow_state, lmrow_ptr, lm_t, lm_S, lm_dL;   // lm_S = [S (nl x R) | gL (nl)]
+  DevBuf lm_chunk_lm, lm_chunk_j0, lm_chunk_j1, lm_chunk_ptr, lm_part;   // chunked reduction of the landmark rows
+  int nlmchunks = 0;
   // solver
   std::vector<Level> lv;
   DevBuf gsave, dvec;
@@ -251,6 +253,8 @@ LmArgs<Real> lm_args(gpslam_hip_handle *h, double lambda) {
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>();
   a.lmrow = h->lmrow.as<int>(); a.lmrow_state = h->lmrow_state.as<int>(); a.lmrow_ptr = h->lmrow_ptr.as<int>();
   a.nlmrows = h->nlmrows;
+  a.chunk_lm = h->lm_chunk_lm.as<int>(); a.chunk_j0 = h->lm_chunk_j0.as<int>(); a.chunk_j1 = h->lm_chunk_j1.as<int>();
+  a.chunk_ptr = h->lm_chunk_ptr.as<int>(); a.nchunks = h->nlmchunks; a.part = h->lm_part.as<Real>();
   a.x = h->lv.empty() ? nullptr : h->lv[0].x.as<Real>();
   a.t = h->lm_t.as<Real>();
   a.npri = h->lpri.count(); a.pri_lm = h->lpri.d_idx.as<int>(); a.pri_meas = h->lpri.d_meas.as<Real>();
@@ -448,6 +452,7 @@ int launch_landmarks_reduce(gpslam_hip_handle *h, double lambda) {
   if (h->nl <= 0) return 0;
   LmArgs<Real> a = lm_args(h, lambda);
   if (h->nlmrows > 0) k_lm_t<Real><<<dim3(nblocks(h->nlmrows * h->R, 128)), dim3(128), 0, h->stream>>>(a);
+  if (h->nlmchunks > 0) k_lm_reduce_part<Real><<<dim3(h->nlmchunks), dim3(128), 0, h->stream>>>(a);   // ld * R <= 3 * 28 threads
   k_lm_reduce<Real><<<dim3(nblocks(h->nl * h->R, 128)), dim3(128), 0, h->stream>>>(a);
   HIPCHK(hipGetLastError());
   return 0;
@@ -681,7 +686,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->pose, &h->vel, &h->lmk, &h->pose_bak, &h->vel_bak, &h->lmk_bak, &h->d_gp_left, &h->d_gp_dt,
                     &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
-                    &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->gsave, &h->dvec,
+                    &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
                     &h->api_e, &h->api_H};
   for (DevBuf *b : bufs) b->release();
@@ -957,6 +962,21 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
       lmptr[l + 1] = (int)lmrow.size();
     }
     h->nlmrows = (int)lmrow.size();
+    {   // chunks of at most kLmChunk consecutive rows of one landmark
+      std::vector<int> clm, cj0, cj1, cptr(h->L + 1, 0);
+      for (int l = 0; l < h->L; l++) {
+        for (int j = lmptr[l]; j < lmptr[l + 1]; j += kLmChunk) {
+          clm.push_back(l); cj0.push_back(j); cj1.push_back(std::min(j + kLmChunk, lmptr[l + 1]));
+        }
+        cptr[l + 1] = (int)clm.size();
+      }
+      h->nlmchunks = (int)clm.size();
+      if ((rc = upload(h, h->lm_chunk_lm, clm))) return rc;
+      if ((rc = upload(h, h->lm_chunk_j0, cj0))) return rc;
+      if ((rc = upload(h, h->lm_chunk_j1, cj1))) return rc;
+      if ((rc = upload(h, h->lm_chunk_ptr, cptr))) return rc;
+      HIPCHK(h->lm_part.reserve((size_t)std::max(h->nlmchunks, 1) * 2 * h->ld * h->R * sizeof(Real)));
+    }
     if ((rc = upload(h, h->lmrow, lmrow))) return rc;
     if ((rc = upload(h, h->lmrow_state, lmstate))) return rc;
     if ((rc = upload(h, h->lmrow_ptr, lmptr))) return rc;

@@ -70,6 +70,16 @@ template <typename T> __global__ void __launch_bounds__(256) k_final_reduce(cons
   if (threadIdx.x == 0) *out = (double)r;
 }
 
+// Kernels that run one wave per workgroup (the solver, the landmark solve) exchange data between lanes through LDS.  DS operations of one
+// wave execute in order, so a compiler-level ordering point is all that is needed; __syncthreads() would add an
+// s_barrier and, worse, drain vmcnt to zero, i.e. wait for the prefetched next-block operands and for the factor
+// stores of the current block at every step.
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ------------------------------------------------------------------ K1: GP prior rows
 
 template <typename T> struct GpArgs {
@@ -741,6 +751,10 @@ template <typename T> struct LmArgs {
   const int *lmrow_state;   // left state of each such row
   const int *lmrow_ptr;     // L + 1
   int nlmrows;
+  const int *chunk_lm, *chunk_j0, *chunk_j1;   // row chunks of the landmark rows (each inside one landmark)
+  const int *chunk_ptr;     // L + 1: chunks of landmark l are chunk_ptr[l] .. chunk_ptr[l + 1]
+  int nchunks;
+  T *part;                  // nchunks x ld x R partial sums of the Schur complement
   T *x;                     // level-0 solutions, N x R x B (column 0 is corrected in place)
   T *t;                     // nlmrows x R
   // landmark priors
@@ -773,62 +787,106 @@ template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a)
   a.t[(size_t)j * a.R + c] = acc;
 }
 
-// S[al][c]: c = 0 -> rhs gL - B^T x0; c >= 1 -> (H_LL + lambda I - B^T Z)[al][c-1].  Fixed summation order.
+// Landmark Schur complement S[al][c]: c = 0 -> rhs gL - B^T x0; c >= 1 -> (H_LL + lambda I - B^T Z)[al][c-1], in two
+// stages with a fixed summation order: a landmark may be seen from tens of thousands of rows (Plaza-rate ranges on a
+// 1e6-state chain: 55k rows per landmark), so the rows are cut into chunks that one workgroup each reduces, thread
+// (q, c) = (component of the landmark, column) running down the chunk; a second kernel adds the chunks of a landmark
+// in order, the priors and the damping.
+constexpr int kLmChunk = 64;
+template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce_part(LmArgs<T> a) {
+  const int ch = blockIdx.x;
+  const int q = threadIdx.x / a.R, c = threadIdx.x - q * a.R;
+  if (q >= a.ld) return;
+  const int lm = a.chunk_lm[ch];
+  const int cl = c - 1;
+  const bool same = (c >= 1) && (cl / a.ld == lm);
+  const int q2 = same ? cl - lm * a.ld : 0;
+  T acc = T(0);
+  for (int j = a.chunk_j0[ch]; j < a.chunk_j1[ch]; j++) {
+    const int rho = a.lmrow[j];
+    const T m = a.rowM[(size_t)rho * a.ld + q];
+    if (c == 0) acc -= m * a.rowE[rho];                    // gL part; the -B^T x0 part follows
+    else if (same) acc += m * a.rowM[(size_t)rho * a.ld + q2];
+    acc -= m * a.t[(size_t)j * a.R + c];
+  }
+  // for c = 0 the two parts are needed separately (gL feeds the LM model): keep gL in a second slot
+  a.part[((size_t)ch * a.ld + q) * a.R + c] = acc;
+  if (c == 0) {
+    T g = T(0);
+    for (int j = a.chunk_j0[ch]; j < a.chunk_j1[ch]; j++) {
+      const int rho = a.lmrow[j];
+      g -= a.rowM[(size_t)rho * a.ld + q] * a.rowE[rho];
+    }
+    a.part[((size_t)a.nchunks * a.ld + (size_t)ch * a.ld + q) * a.R] = g;
+  }
+}
 template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce(LmArgs<T> a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int al = tid / a.R, c = tid - al * a.R;
   if (al >= a.nl) return;
   const int lm = al / a.ld, q = al - lm * a.ld;
-  const int cl = c - 1;                                   // landmark column
-  const bool same = (c >= 1) && (cl / a.ld == lm);
-  const int q2 = same ? cl - lm * a.ld : 0;
+  const int cl = c - 1;
   T acc = T(0), g = T(0);
-  const int j_lo = a.lmrow_ptr[lm], j_hi = a.lmrow_ptr[lm + 1];
-  for (int j = j_lo; j < j_hi; j++) {
-    const int rho = a.lmrow[j];
-    const T m = a.rowM[(size_t)rho * a.ld + q];
-    if (c == 0) { g -= m * a.rowE[rho]; }
-    else if (same) acc += m * a.rowM[(size_t)rho * a.ld + q2];
-    acc -= m * a.t[(size_t)j * a.R + c];
+  for (int ch = a.chunk_ptr[lm]; ch < a.chunk_ptr[lm + 1]; ch++) {
+    acc += a.part[((size_t)ch * a.ld + q) * a.R + c];
+    if (c == 0) g += a.part[((size_t)a.nchunks * a.ld + (size_t)ch * a.ld + q) * a.R];
   }
   for (int k = 0; k < a.npri; k++) {
     if (a.pri_lm[k] != lm) continue;
     const T w = T(1) / a.pri_sig[(size_t)k * a.ld + q];
-    if (c == 0) g -= w * w * (a.lmk[(size_t)lm * a.ld + q] - a.pri_meas[(size_t)k * a.ld + q]);
+    if (c == 0) { const T gp = -w * w * (a.lmk[(size_t)lm * a.ld + q] - a.pri_meas[(size_t)k * a.ld + q]); g += gp; acc += gp; }
     else if (cl == al) acc += w * w;
   }
-  if (c == 0) { a.gL[al] = g; acc += g; }
+  if (c == 0) a.gL[al] = g;
   else if (cl == al) acc += a.lambda;
   a.S[(size_t)al * a.R + c] = acc;
 }
 
-// dense SPD solve of the (tiny) landmark system in one thread, then dL; nl <= 27
-template <typename T> __global__ void k_lm_solve(LmArgs<T> a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int n = a.nl, R = a.R;
-  T *S = a.S;
-  // in-place Cholesky on columns 1..n (upper part used), rhs in column 0
+// Dense SPD solve of the (small) landmark system, S = columns 1..nl of a.S (upper part), rhs = column 0 -> dL.
+// One wave, right-looking Cholesky in LDS: step j scales column j (lane per row) and applies the rank-1 update to the
+// trailing block and to the rhs (lane per entry); then the back-substitution.  nl <= 27.
+template <typename T> __global__ void __launch_bounds__(64) k_lm_solve(LmArgs<T> a) {
+  constexpr int NM = kMaxRhs - 1;
+  __shared__ T M[NM][NM + 1];      // lower triangle becomes L; +1: no bank conflicts down a column
+  __shared__ T y[NM];
+  const int n = a.nl, R = a.R, lane = threadIdx.x;
+  for (int idx = lane; idx < n * n; idx += 64) {
+    const int i = idx / n, j = idx - i * n;
+    M[i][j] = (j <= i) ? a.S[(size_t)j * R + 1 + i] : T(0);         // S is stored by its upper part: S[j][i], j <= i
+  }
+  for (int i = lane; i < n; i += 64) y[i] = a.S[(size_t)i * R];
+  wave_lds_sync();
   for (int j = 0; j < n; j++) {
-    T dd = S[(size_t)j * R + 1 + j];
-    for (int k = 0; k < j; k++) dd -= S[(size_t)k * R + 1 + j] * S[(size_t)k * R + 1 + j];
-    if (!(dd > T(0))) { *a.flag = 1; dd = T(1); }
-    dd = sqrt(dd);
-    S[(size_t)j * R + 1 + j] = dd;
-    for (int i = j + 1; i < n; i++) {
-      T sv = S[(size_t)j * R + 1 + i];
-      for (int k = 0; k < j; k++) sv -= S[(size_t)k * R + 1 + j] * S[(size_t)k * R + 1 + i];
-      S[(size_t)j * R + 1 + i] = sv / dd;
+    T dd = M[j][j];
+    if (!(dd > T(0))) { if (lane == 0) *a.flag = 1; dd = T(1); }
+    const T l = sqrt(dd), linv = T(1) / l;
+    wave_lds_sync();
+    for (int i = j + lane; i < n; i += 64) M[i][j] = (i == j) ? l : M[i][j] * linv;
+    if (lane == 0) y[j] *= linv;
+    wave_lds_sync();
+    const int m = n - j - 1;                                        // trailing block (j+1 .. n-1)^2, lower part, + rhs
+    for (int idx = lane; idx < m * m + m; idx += 64) {
+      if (idx < m * m) {
+        const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+        if (k <= i) M[i][k] -= M[i][j] * M[k][j];
+      } else {
+        const int i = j + 1 + (idx - m * m);
+        y[i] -= M[i][j] * y[j];
+      }
     }
+    wave_lds_sync();
   }
-  for (int i = 0; i < n; i++) {
-    T sv = S[(size_t)i * R];
-    for (int k = 0; k < i; k++) sv -= S[(size_t)k * R + 1 + i] * a.dL[k];
-    a.dL[i] = sv / S[(size_t)i * R + 1 + i];
-  }
+  // L^T dL = y
   for (int i = n - 1; i >= 0; i--) {
-    T sv = a.dL[i];
-    for (int k = i + 1; k < n; k++) sv -= S[(size_t)i * R + 1 + k] * a.dL[k];
-    a.dL[i] = sv / S[(size_t)i * R + 1 + i];
+    if (lane == 0) {
+      const T v = y[i] / M[i][i];
+      y[i] = v;
+      a.dL[i] = v;
+    }
+    wave_lds_sync();
+    const T v = y[i];
+    for (int k = lane; k < i; k += 64) y[k] -= M[i][k] * v;
+    wave_lds_sync();
   }
 }
 
@@ -1064,15 +1122,6 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
 
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan
 
-// The solver kernels run one wave per workgroup and exchange data between lanes through LDS.  DS operations of one
-// wave execute in order, so a compiler-level ordering point is all that is needed; __syncthreads() would add an
-// s_barrier and, worse, drain vmcnt to zero, i.e. wait for the prefetched next-block operands and for the factor
-// stores of the current block at every step.
-__device__ __forceinline__ void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 
 __device__ __forceinline__ double lane_bcast(double v, int lane) {

@@ -9,6 +9,11 @@ the tests and in bench.py's cpu_baseline leg), so both sides see bit-identical i
   C3  GaussianProcessPriorPose3 chain, N = 1e5, dt = 0.1, Qc = 0.01 I6 (testGaussianProcessPriorPose3.cpp:29-31),
       BetweenFactor<Pose3> odometry from truth + noise, prior on x0, dead-reckoned initial values with zero
       velocity (the recipe of matlab/PlazaPose2.m:125,:196-202 lifted to SE(3))
+  C4' SE(2) chain with GPInterpolatedRangeFactorPose2 at the Plaza2 rate (0.44 ranges per interval, tau ~ U(0, dt),
+      sigma 0.5, Qc sigma 0.1, odometry sigma [1, 1, pi] 1e-3, landmark priors sigma 1: matlab/PlazaPose2.m:40-46)
+      to a handful of landmarks -- config 4's factor mix with the dense landmark border this build supports (L <= 13)
+  C5  SO(3) chain: GaussianProcessPriorRot3 + GPInterpolatedAttitudeFactorRot3 at 4x the state rate
+      (matlab/GPAHRSexample.m:21,:28,:38-39: Qc sigma, accelerometer sigma 0.1), the reference-faithful variant of config 5
 """
 import numpy as np
 
@@ -108,6 +113,84 @@ def linear_chain(N, D=3, seed=0, dt=0.1, qc=0.01, sigma_fix=0.1, every=10):
                 vprior_idx=np.array([0], dtype=np.int32), vprior=vel[:1].copy(), vprior_sig=np.full((1, D), 1e-3))
 
 
+def se2_exp(xi):
+    """Pose2::Expmap, batched: (..., 3) [vx, vy, w] -> (..., 3) [x, y, theta]"""
+    vx, vy, w = xi[..., 0], xi[..., 1], xi[..., 2]
+    small = np.abs(w) < 1e-10
+    ws = np.where(small, 1.0, w)
+    a = np.where(small, 1.0 - w * w / 6.0, np.sin(w) / ws)
+    b = np.where(small, 0.5 * w, (1.0 - np.cos(w)) / ws)
+    return np.stack([a * vx - b * vy, b * vx + a * vy, w], -1)
+
+
+def se2_compose(a, b):
+    c, s = np.cos(a[..., 2]), np.sin(a[..., 2])
+    return np.stack([a[..., 0] + c * b[..., 0] - s * b[..., 1], a[..., 1] + s * b[..., 0] + c * b[..., 1],
+                     a[..., 2] + b[..., 2]], -1)
+
+
+def pose2_range_chain(N, L=8, seed=0, dt=0.1, rate=0.44):
+    """C4': SE(2) trajectory on a large figure of eight, odometry, interpolated ranges to L landmarks."""
+    rng = np.random.default_rng(SEED_BASE + 4 + seed)
+    i = np.arange(N - 1)
+    twist = np.stack([1.0 + 0.2 * np.sin(0.003 * i), 0.05 * np.cos(0.007 * i), 0.15 * np.sin(0.0011 * i)], -1)
+    rel = se2_exp(dt * twist)                              # true relative motions
+    truth = np.zeros((N, 3))
+    for k in range(N - 1):                                 # sequential composition (cheap: N 3-vectors)
+        truth[k + 1] = se2_compose(truth[k], rel[k])
+    sig_odo = np.array([1e-3, 1e-3, np.pi * 1e-3])
+    odo = rel + sig_odo * rng.standard_normal((N - 1, 3))  # measured = true + noise (first-order chart)
+    dead = np.zeros((N, 3))
+    for k in range(N - 1):
+        dead[k + 1] = se2_compose(dead[k], odo[k])
+    centre, span = truth[:, :2].mean(0), np.ptp(truth[:, :2], axis=0).max() + 10.0
+    lmk = centre + span * (rng.random((L, 2)) - 0.5)
+    has = rng.random(N - 1) < rate
+    left = np.nonzero(has)[0].astype(np.int32)
+    tau = dt * rng.random(len(left))
+    lm = rng.integers(0, L, len(left)).astype(np.int32)
+    # pose at the measurement time on the true (constant-twist per interval) trajectory
+    at = se2_compose(truth[left], se2_exp(tau[:, None] * twist[left]))
+    z = np.linalg.norm(lmk[lm] - at[:, :2], axis=1) + 0.5 * rng.standard_normal(len(left))
+    return dict(kind=POSE2, name="C4' pose2 GP prior + odometry + interpolated ranges", N=N, qc=0.01 * np.eye(3),
+                pose=dead, vel=np.zeros((N, 3)), truth=truth, landmarks=lmk + 0.5 * rng.standard_normal((L, 2)),
+                landmark_truth=lmk, linear=False,
+                gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),
+                between_left=np.arange(N - 1, dtype=np.int32), between_meas=odo, between_sig=np.tile(sig_odo, (N - 1, 1)),
+                prior_idx=np.array([0], dtype=np.int32), prior_pose=truth[:1].copy(), prior_sig=np.array([[1.0, 1.0, np.pi]]),
+                lprior_idx=np.arange(L, dtype=np.int32), lprior=lmk.copy(), lprior_sig=np.full((L, 2), 1.0),
+                range_left=left, range_lm=lm, range_z=z, range_sigma=np.full(len(left), 0.5),
+                range_dt=np.full(len(left), dt), range_tau=tau)
+
+
+def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sigma=0.1):
+    """C5 (reference-faithful variant): SO(3) GP chain with interpolated attitude (accelerometer) factors."""
+    rng = np.random.default_rng(SEED_BASE + 5 + seed)
+    i = np.arange(N - 1)
+    omega = np.stack([0.3 * np.sin(0.004 * i), 0.2 * np.cos(0.006 * i + 0.5), 0.4 + 0.1 * np.sin(0.002 * i)], -1)
+    dR = so3_exp(dt * omega)
+    R = np.zeros((N, 3, 3))
+    R[0] = np.eye(3)
+    # inclusive prefix product by doubling, as for SE(3)
+    P, _ = se3_prefix(dR, np.zeros((N - 1, 3)))
+    R[1:] = P
+    M = (N - 1) * per_interval
+    left = np.repeat(np.arange(N - 1), per_interval).astype(np.int32)
+    tau = dt * (np.tile(np.arange(per_interval), N - 1) + rng.random(M)) / per_interval
+    Rm = R[left] @ so3_exp(tau[:, None] * omega[left])     # true attitude at the measurement times
+    bref = np.array([0.0, 0.0, 1.0])                       # body reference axis (Unit3(0, 0, 1), AttitudeFactorRot3.h:48)
+    nz = Rm @ bref + acc_sigma * rng.standard_normal((M, 3))
+    nz /= np.linalg.norm(nz, axis=1, keepdims=True)        # measured nav-frame direction of the body axis
+    init = R @ so3_exp(0.05 * rng.standard_normal((N, 3)))
+    return dict(kind=ROT3, name="C5 rot3 GP prior + interpolated attitude", N=N, qc=qc_sigma ** 2 * np.eye(3),
+                pose=init.reshape(N, 9), vel=np.zeros((N, 3)), truth=R.reshape(N, 9),
+                gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),
+                prior_idx=np.array([0], dtype=np.int32), prior_pose=R[:1].reshape(1, 9), prior_sig=np.full((1, 3), 1e-2),
+                vprior_idx=np.array([0], dtype=np.int32), vprior=omega[:1].copy(), vprior_sig=np.full((1, 3), 0.1),
+                att_left=left, att_nz=nz, att_bref=np.tile(bref, (M, 1)), att_sigma=np.full((M, 2), acc_sigma),
+                att_dt=np.full(M, dt), att_tau=tau)
+
+
 def apply(problem, solver):
     """Feed a problem description to a solver (ChainSolver or oracle.Chain) and compile it."""
     p = problem
@@ -120,6 +203,14 @@ def apply(problem, solver):
         solver.add_vel_priors(p["vprior_idx"], p["vprior"], p["vprior_sig"])
     if "between_left" in p:
         solver.add_between(p["between_left"], p["between_meas"], p["between_sig"])
+    if "landmarks" in p:
+        solver.set_landmarks(p["landmarks"])
+        if "lprior_idx" in p:
+            solver.add_landmark_priors(p["lprior_idx"], p["lprior"], p["lprior_sig"])
+        if "range_left" in p:
+            solver.add_interp_range(p["range_left"], p["range_lm"], p["range_z"], p["range_sigma"], p["range_dt"], p["range_tau"])
+    if "att_left" in p:
+        solver.add_interp_attitude(p["att_left"], p["att_nz"], p["att_bref"], p["att_sigma"], p["att_dt"], p["att_tau"])
     solver.compile()
     return solver
 
