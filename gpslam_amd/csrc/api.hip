@@ -452,8 +452,8 @@ int launch_landmarks_reduce(gpslam_hip_handle *h, double lambda) {
   if (h->nl <= 0) return 0;
   LmArgs<Real> a = lm_args(h, lambda);
   if (h->nlmrows > 0) k_lm_t<Real><<<dim3(nblocks(h->nlmrows * h->R, 128)), dim3(128), 0, h->stream>>>(a);
-  if (h->nlmchunks > 0) k_lm_reduce_part<Real><<<dim3(h->nlmchunks), dim3(128), 0, h->stream>>>(a);   // ld * R <= 3 * 28 threads
-  k_lm_reduce<Real><<<dim3(nblocks(h->nl * h->R, 128)), dim3(128), 0, h->stream>>>(a);
+  if (h->nlmchunks > 0) k_lm_reduce_part<Real><<<dim3(h->nlmchunks), dim3(256), 0, h->stream>>>(a);
+  k_lm_reduce<Real><<<dim3(h->nl * h->R), dim3(64), 0, h->stream>>>(a);
   HIPCHK(hipGetLastError());
   return 0;
 }

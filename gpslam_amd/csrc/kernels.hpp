@@ -793,44 +793,50 @@ template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a)
 // (q, c) = (component of the landmark, column) running down the chunk; a second kernel adds the chunks of a landmark
 // in order, the priors and the damping.
 constexpr int kLmChunk = 64;
-template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce_part(LmArgs<T> a) {
+template <typename T> __global__ void __launch_bounds__(256) k_lm_reduce_part(LmArgs<T> a) {
   const int ch = blockIdx.x;
-  const int q = threadIdx.x / a.R, c = threadIdx.x - q * a.R;
-  if (q >= a.ld) return;
-  const int lm = a.chunk_lm[ch];
-  const int cl = c - 1;
-  const bool same = (c >= 1) && (cl / a.ld == lm);
-  const int q2 = same ? cl - lm * a.ld : 0;
-  T acc = T(0);
-  for (int j = a.chunk_j0[ch]; j < a.chunk_j1[ch]; j++) {
-    const int rho = a.lmrow[j];
-    const T m = a.rowM[(size_t)rho * a.ld + q];
-    if (c == 0) acc -= m * a.rowE[rho];                    // gL part; the -B^T x0 part follows
-    else if (same) acc += m * a.rowM[(size_t)rho * a.ld + q2];
-    acc -= m * a.t[(size_t)j * a.R + c];
-  }
-  // for c = 0 the two parts are needed separately (gL feeds the LM model): keep gL in a second slot
-  a.part[((size_t)ch * a.ld + q) * a.R + c] = acc;
-  if (c == 0) {
-    T g = T(0);
-    for (int j = a.chunk_j0[ch]; j < a.chunk_j1[ch]; j++) {
+  const int W = a.ld * a.R;                       // (q, c) pairs, <= 84
+  const int nsub = 256 / W;                       // row phases per pair (the loop is a chain of dependent loads)
+  const int sub = threadIdx.x / W, qc = threadIdx.x - sub * W;
+  const int q = qc / a.R, c = qc - q * a.R;
+  __shared__ T red[2][256];
+  T acc = T(0), g = T(0);
+  if (sub < nsub) {
+    const int lm = a.chunk_lm[ch];
+    const int cl = c - 1;
+    const bool same = (c >= 1) && (cl / a.ld == lm);
+    const int q2 = same ? cl - lm * a.ld : 0;
+    for (int j = a.chunk_j0[ch] + sub; j < a.chunk_j1[ch]; j += nsub) {
       const int rho = a.lmrow[j];
-      g -= a.rowM[(size_t)rho * a.ld + q] * a.rowE[rho];
+      const T m = a.rowM[(size_t)rho * a.ld + q];
+      if (c == 0) g -= m * a.rowE[rho];
+      else if (same) acc += m * a.rowM[(size_t)rho * a.ld + q2];
+      acc -= m * a.t[(size_t)j * a.R + c];
     }
-    a.part[((size_t)a.nchunks * a.ld + (size_t)ch * a.ld + q) * a.R] = g;
+    red[0][threadIdx.x] = acc;
+    red[1][threadIdx.x] = g;
+  }
+  __syncthreads();
+  if (sub == 0) {                                  // fixed order over the phases
+    T sa = T(0), sg = T(0);
+    for (int u = 0; u < nsub; u++) { sa += red[0][u * W + qc]; sg += red[1][u * W + qc]; }
+    a.part[((size_t)ch * a.ld + q) * a.R + c] = sa + sg;          // c = 0: gL - B^T x0
+    if (c == 0) a.part[((size_t)a.nchunks * a.ld + (size_t)ch * a.ld + q) * a.R] = sg;   // gL alone feeds the LM model
   }
 }
-template <typename T> __global__ void __launch_bounds__(128) k_lm_reduce(LmArgs<T> a) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int al = tid / a.R, c = tid - al * a.R;
-  if (al >= a.nl) return;
+// one wave per (al, c): lanes stride over the chunks of the landmark, then a fixed-order wave sum
+template <typename T> __global__ void __launch_bounds__(64) k_lm_reduce(LmArgs<T> a) {
+  const int al = blockIdx.x / a.R, c = blockIdx.x - al * a.R;
   const int lm = al / a.ld, q = al - lm * a.ld;
   const int cl = c - 1;
   T acc = T(0), g = T(0);
-  for (int ch = a.chunk_ptr[lm]; ch < a.chunk_ptr[lm + 1]; ch++) {
+  for (int ch = a.chunk_ptr[lm] + (int)threadIdx.x; ch < a.chunk_ptr[lm + 1]; ch += 64) {
     acc += a.part[((size_t)ch * a.ld + q) * a.R + c];
     if (c == 0) g += a.part[((size_t)a.nchunks * a.ld + (size_t)ch * a.ld + q) * a.R];
   }
+  acc = wave_sum(acc);
+  g = wave_sum(g);
+  if (threadIdx.x != 0) return;
   for (int k = 0; k < a.npri; k++) {
     if (a.pri_lm[k] != lm) continue;
     const T w = T(1) / a.pri_sig[(size_t)k * a.ld + q];
