@@ -506,6 +506,11 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   T err = T(0);
   if constexpr (MeasValid<MF, FK>::v) {
+    // whitened Jacobian rows leave through the per-wave staging buffer (wave_store_rows), like the GP prior's
+    T JL[JAC ? rows * b : 1], JR[JAC ? rows * b : 1], wgt[rows];
+    int row0v = -1;
+#pragma unroll
+    for (int r = 0; r < rows; r++) wgt[r] = T(0);
     if (f < a.count) {
       const int i = a.idx[f];
       constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ);
@@ -535,7 +540,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         kc = {a.coef[4 * (size_t)f], a.coef[4 * (size_t)f + 1], a.coef[4 * (size_t)f + 2], a.coef[4 * (size_t)f + 3]};
       const T *ms = a.meas + (size_t)f * a.mw;
       T e[rows];
-      T JL[JAC ? rows * b : 1], JR[JAC ? rows * b : 1], Jm[JAC ? rows * 3 : 1];
+      T Jm[JAC ? rows * 3 : 1];
       if (JAC) {
 #pragma unroll
         for (int k = 0; k < rows * b; k++) { JL[k] = T(0); JR[k] = T(0); }
@@ -719,21 +724,34 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         }
       }
       const int row0 = JAC ? a.row0[f] : 0;
+      row0v = row0;
 #pragma unroll
       for (int r = 0; r < rows; r++) {
         const T w = T(1) / a.sig[(size_t)f * rows + r];
         const T we = e[r] * w;
         err += we * we;
+        wgt[r] = w;
         if (JAC) {
           a.rowE[row0 + r] = we;
-          T *row = a.rowLR + (size_t)(row0 + r) * 2 * b;
-#pragma unroll
-          for (int c = 0; c < b; c++) { row[c] = w * JL[r * b + c]; row[b + c] = w * JR[r * b + c]; }
           if (a.ld > 0) {
             a.rowLm[row0 + r] = lm;
             for (int q = 0; q < a.ld; q++) a.rowM[(size_t)(row0 + r) * a.ld + q] = w * Jm[r * 3 + q];
           }
         }
+      }
+    }
+    if constexpr (JAC) {
+      constexpr int LS = 2 * b + 2;
+      __shared__ T stage[2 * 64 * LS];
+      __shared__ int srow[128];
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      T *st = stage + wv * 64 * LS, *mine = st + lane * LS;
+      srow[threadIdx.x] = row0v;
+#pragma unroll
+      for (int r = 0; r < rows; r++) {
+#pragma unroll
+        for (int c = 0; c < b; c++) { mine[c] = wgt[r] * JL[r * b + c]; mine[b + c] = wgt[r] * JR[r * b + c]; }
+        wave_store_rows<T, 2 * b>(st, srow + wv * 64, lane, r, a.rowLR);
       }
     }
   }
