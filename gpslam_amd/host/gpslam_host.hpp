@@ -394,12 +394,14 @@ struct Session {
     if (L > 0) check(gpslam_hip_set_landmarks(h, L, LM.data()), h, "set_landmarks");
     // ---- factors
     bool qc_set = false;
+    std::vector<double> qc_used;
     for (auto &fp : graph.factors()) {
       const Desc f = fp->describe();
       if (f.manifold >= 0 && f.manifold != manifold) throw std::invalid_argument("factor type does not match the pose type in the Values");
       auto set_qc = [&](const Matrix &Qc) {
         if (Qc.rows != d) throw std::invalid_argument("Qc_model dimension does not match the manifold");
-        if (!qc_set) { check(gpslam_hip_set_qc(h, Qc.a.data()), h, "set_qc"); qc_set = true; }
+        if (!qc_set) { check(gpslam_hip_set_qc(h, Qc.a.data()), h, "set_qc"); qc_set = true; qc_used = Qc.a; }
+        else if (Qc.a != qc_used) throw std::invalid_argument("all GP factors of one graph must share one Qc_model (one Qc per handle)");
       };
       auto adjacent = [&](Key k1, Key k2) {
         const int s1 = state_of(k1), s2 = state_of(k2);
