@@ -77,6 +77,8 @@ struct gpslam_hip_handle {
   int N = 0, L = 0, stride = 0, R = 1, nl = 0;
   bool own_stream = true;
   hipStream_t stream = nullptr;
+  hipStream_t aux_stream = nullptr;   // side stream for the light factor kernels (launch_factors)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   double Qc[36], U[36];
   std::vector<double> h_lmk;
@@ -268,6 +270,15 @@ LmArgs<Real> lm_args(gpslam_hip_handle *h, double lambda) {
 int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
   Real *part = h->partial.as<Real>();
   int off = 0;
+  // The factor kernels are independent of one another (disjoint rows, disjoint partial sums).  The GP-prior kernel
+  // runs one register-heavy wave per SIMD and leaves most issue slots empty, the others are light streaming kernels:
+  // they go to a second stream and run underneath it (fork / join with events; joined before the reduction).
+  const bool fork = (mode == 0) && !h->gp_left.empty() && h->aux_stream != nullptr;
+  hipStream_t side = fork ? h->aux_stream : h->stream;
+  if (fork) {
+    HIPCHK(hipEventRecord(h->ev_fork, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->aux_stream, h->ev_fork, 0));
+  }
   if (!h->gp_left.empty()) {
     GpArgs<Real> a = gp_args(h, part + off);
     const int nb = nblocks(a.count, 128);
@@ -296,13 +307,13 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
       constexpr int MF = decltype(tag)::value;
       const dim3 g(nb), t(128);
       if (mode == 0) {
-        if (kind == 0) k_simple<Real, MF, 0, true><<<g, t, 0, h->stream>>>(a);
-        else if (kind == 1) k_simple<Real, MF, 1, true><<<g, t, 0, h->stream>>>(a);
-        else k_simple<Real, MF, 2, true><<<g, t, 0, h->stream>>>(a);
+        if (kind == 0) k_simple<Real, MF, 0, true><<<g, t, 0, side>>>(a);
+        else if (kind == 1) k_simple<Real, MF, 1, true><<<g, t, 0, side>>>(a);
+        else k_simple<Real, MF, 2, true><<<g, t, 0, side>>>(a);
       } else {
-        if (kind == 0) k_simple<Real, MF, 0, false><<<g, t, 0, h->stream>>>(a);
-        else if (kind == 1) k_simple<Real, MF, 1, false><<<g, t, 0, h->stream>>>(a);
-        else k_simple<Real, MF, 2, false><<<g, t, 0, h->stream>>>(a);
+        if (kind == 0) k_simple<Real, MF, 0, false><<<g, t, 0, side>>>(a);
+        else if (kind == 1) k_simple<Real, MF, 1, false><<<g, t, 0, side>>>(a);
+        else k_simple<Real, MF, 2, false><<<g, t, 0, side>>>(a);
       }
     });
     off += nb;
@@ -327,8 +338,8 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
       constexpr int MF = decltype(tag)::value;
       dispatch_fk(fk, [&](auto ftag) {
         constexpr int FK = decltype(ftag)::value;
-        if (mode == 0) k_meas<Real, MF, FK, true><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
-        else k_meas<Real, MF, FK, false><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
+        if (mode == 0) k_meas<Real, MF, FK, true><<<dim3(nb), dim3(128), 0, side>>>(a);
+        else k_meas<Real, MF, FK, false><<<dim3(nb), dim3(128), 0, side>>>(a);
       });
     });
     off += nb;
@@ -336,8 +347,12 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
   if (h->lpri.count() > 0) {
     LmArgs<Real> a = lm_args(h, 0.0);
     a.partial = part + off;
-    k_lmprior_err<Real><<<dim3(1), dim3(128), 0, h->stream>>>(a);
+    k_lmprior_err<Real><<<dim3(1), dim3(128), 0, side>>>(a);
     off += 1;
+  }
+  if (fork) {
+    HIPCHK(hipEventRecord(h->ev_join, h->aux_stream));
+    HIPCHK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
   }
   k_final_reduce<Real><<<dim3(1), dim3(256), 0, h->stream>>>(part, off, h->scal.as<double>() + slot, 0);
   HIPCHK(hipGetLastError());
@@ -667,6 +682,9 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   std::memset(h->U, 0, sizeof(h->U));
   for (int i = 0; i < h->d; i++) h->Qc[i * h->d + i] = h->U[i * h->d + i] = 1.0;
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
+  if (hipStreamCreateWithFlags(&h->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
   for (int i = 0; i < 6; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
   if (h->scal.reserve(16 * sizeof(double)) != hipSuccess || h->flag.reserve(sizeof(int)) != hipSuccess) {
@@ -694,6 +712,9 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   for (MeasSet &s : h->ms) s.release();
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   if (h->stream && h->own_stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return 0;
