@@ -91,6 +91,71 @@ def apply_local(lp, solver):
     return solver
 
 
+class GraphRecorder:
+    """Records the ChainSolver calls that describe a graph, so that the same description can be replayed onto the
+    unsharded solver, the oracle, or -- cut at the segment boundaries -- onto the ranks of a sharded solve.
+
+    Every factor call of the ChainSolver surface starts with the index array of the factors' (left) states; the other
+    array arguments with one entry per factor are cut with it, everything else (body_P_sensor, calibration) is shared."""
+
+    FACTOR_CALLS = ("add_gp_priors", "add_pose_priors", "add_vel_priors", "add_between", "add_interp_range", "add_range",
+                    "add_interp_attitude", "add_interp_gps", "add_odometry2d", "add_bearing_range", "add_interp_projection")
+    # positions of the arguments that are NOT one-per-factor: body_P_sensor, camera calibration
+    SHARED_ARGS = {"add_interp_range": (6,), "add_interp_gps": (5,), "add_interp_projection": (6, 7)}
+
+    def __init__(self):
+        self.calls = []          # (method name, args)
+        self.qc = self.pose = self.vel = self.landmarks = None
+        self.lm_priors = []
+
+    def set_qc(self, Qc):
+        self.qc = np.array(Qc, dtype=np.float64)
+
+    def set_states(self, pose, vel):
+        self.pose, self.vel = np.array(pose, dtype=np.float64), np.array(vel, dtype=np.float64)
+
+    def set_landmarks(self, pts):
+        self.landmarks = np.array(pts, dtype=np.float64)
+
+    def add_landmark_priors(self, idx, prior, sigmas):
+        self.lm_priors.append((np.asarray(idx), np.asarray(prior), np.asarray(sigmas)))
+
+    def compile(self):
+        pass
+
+    def __getattr__(self, name):
+        if name in GraphRecorder.FACTOR_CALLS:
+            return lambda *args: self.calls.append((name, args))
+        raise AttributeError(name)
+
+    def replay(self, solver, rank=0, nranks=1):
+        """Feed rank `rank`'s segment of the recorded graph to `solver` (a whole-chain solver for nranks = 1)."""
+        N = len(self.pose)
+        b = partition(N, nranks)
+        lo, hi = b[rank], b[rank + 1]
+        solver.set_qc(self.qc)
+        solver.set_states(self.pose[lo:hi], self.vel[lo:hi])
+        if rank < nranks - 1:
+            solver.set_halo_state(self.pose[hi], self.vel[hi])
+        if self.landmarks is not None:
+            solver.set_landmarks(self.landmarks)
+            if rank == 0:                       # replicated landmarks: their priors are counted once
+                for idx, prior, sig in self.lm_priors:
+                    solver.add_landmark_priors(idx, prior, sig)
+        for name, args in self.calls:
+            idx = np.asarray(args[0])
+            keep = (idx >= lo) & (idx < hi)
+            if not keep.any():
+                continue
+            cut = [(idx[keep] - lo).astype(np.int32)]
+            for pos, a in enumerate(args[1:], start=1):
+                shared = a is None or pos in GraphRecorder.SHARED_ARGS.get(name, ())
+                cut.append(a if shared else np.asarray(a)[keep])
+            getattr(solver, name)(*cut)
+        solver.compile()
+        return solver
+
+
 class _DevView:
     """Wrap a raw device pointer as something torch.as_tensor understands (no copy)."""
 

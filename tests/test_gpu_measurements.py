@@ -41,7 +41,7 @@ def true_range(kind, pose, land, sensor=None):
     return float(np.hypot(land[0] - pose[0], land[1] - pose[1]))
 
 
-def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None):
+def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=()):
     rng = np.random.default_rng(seed + 1000)
     d, ld = O.TANGENT_DIM[kind], LD[kind]
     if chart is None:
@@ -71,7 +71,7 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None):
         uz = np.array([true_range(kind, c["truth_pose"][i], lands_true[l]) for i, l in zip(uidx, ulm)])
         specs.update(uidx=uidx, ulm=ulm, uz=uz + 0.01 * rng.standard_normal(len(uz)))
     solvers = []
-    for make in (lambda: O.Chain(kind, chart, ld), lambda: gpu().ChainSolver(kind, chart, ld)):
+    for make in (lambda: O.Chain(kind, chart, ld), lambda: gpu().ChainSolver(kind, chart, ld)) + tuple(extra_makers):
         s = make()
         s.set_qc(Qc)
         s.set_states(c["pose"], c["vel"])
@@ -126,6 +126,8 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None):
             s.add_bearing_range(specs["bidx"], specs["blm"], specs["bear"], specs["brng"], np.full((len(specs["bidx"]), 2), 0.05))
         s.compile()
         solvers.append(s)
+    if extra_makers:
+        return solvers[0], solvers[1], c, solvers[2:]
     return solvers[0], solvers[1], c
 
 

@@ -270,3 +270,55 @@ def test_sharded_levenberg_marquardt_matches_unsharded(P):
     assert np.abs(pose - ref.get_states()[0]).max() <= 1e-5
     for r in ranks:
         r[0].close()
+
+
+@pytest.mark.parametrize("kind,sensor,P", [(O.POSE2, True, 3), (O.POSE3, True, 2), (O.POSE3, False, 5), (O.LINEAR3, False, 4),
+                                           (O.ROT3, False, 3)],
+                         ids=["pose2+sensor/3", "pose3+sensor/2", "pose3/5", "linear3/4", "rot3-attitude/3"])
+def test_every_measurement_mix_sharded(kind, sensor, P):
+    """Every measurement factor kind (interpolated range / attitude / GPS, range, odometry, bearing-range; with and
+    without body_P_sensor; with a landmark border) on a chain cut into P segments: the recorded graph is replayed per
+    rank (GraphRecorder) and iterated next to the unsharded solver.  Several factors sit in the intervals that straddle
+    the cuts (two measurements per interval)."""
+    import torch
+    import gpslam_amd
+    from gpslam_amd import sharded
+    from test_gpu_measurements import build_meas_pair, LD
+    orc, ref, c, (rec,) = build_meas_pair(kind, N=61, seed=7, sensor=sensor, extra_makers=(sharded.GraphRecorder,))
+    chart = O.CHART_FIRST_ORDER if kind == O.POSE2 else O.CHART_EXPMAP
+    stream = torch.cuda.current_stream().cuda_stream
+    ranks = []
+    for r in range(P):
+        s = gpslam_amd.ChainSolver(kind, chart, LD[kind], device=0, rank=r, nranks=P)
+        s.set_stream(stream)
+        rec.replay(s, r, P)
+        send, recv = sharded.device_tensors(s)
+        ranks.append((s, send, recv, sharded.landmark_tensor(s)))
+    for it in range(4):
+        for r in ranks:
+            r[0].iterate_phase1(0.0)
+        for r in ranks:
+            rv = r[2].view(P, -1)
+            for k in range(P):
+                rv[k].copy_(ranks[k][1])
+        for r in ranks:
+            r[0].iterate_phase2a()
+        if ranks[0][3] is not None:
+            total = sum(r[3].clone() for r in ranks)
+            for r in ranks:
+                r[3].copy_(total)
+        sts = [r[0].iterate_phase2b(True) for r in ranks]
+        rc, st = ref.iterate_gn()
+        assert rc == 0
+        eb, ea = sum(x.error_before for x in sts), sum(x.error_after for x in sts)
+        assert abs(eb - st.error_before) <= 1e-8 * max(1.0, st.error_before), it
+        assert abs(ea - st.error_after) <= 1e-6 * max(1.0, st.error_after), it
+    pose = np.vstack([r[0].get_states()[0] for r in ranks])
+    vel = np.vstack([r[0].get_states()[1] for r in ranks])
+    p1, v1 = ref.get_states()
+    assert np.abs(pose - p1).max() <= 1e-8 * max(1.0, np.abs(p1).max())
+    assert np.abs(vel - v1).max() <= 1e-8 * max(1.0, np.abs(v1).max())
+    if LD[kind]:
+        assert np.abs(ranks[0][0].get_landmarks() - ref.get_landmarks()).max() <= 1e-8
+    for r in ranks:
+        r[0].close()
