@@ -13,7 +13,9 @@
  *   gpslam/gp/GaussianProcessInterpolator{Linear,Pose2,Pose3,Rot3}.h,
  *   gpslam/slam/GPInterpolatedRangeFactor{Pose2,Pose3,2DLinear}.h,
  *   gpslam/slam/GPInterpolatedAttitudeFactorRot3.h, GPInterpolatedGPSFactorPose3.h,
- *   gpslam/slam/{Range,RangeBearing,Odometry}Factor2DLinear.h
+ *   gpslam/slam/{Range,RangeBearing,Odometry}Factor2DLinear.h,
+ *   gpslam/gp/GaussianProcessPriorPose3VW.h, GaussianProcessInterpolatorPose3VW.h,
+ *   gpslam/slam/GPInterpolatedGPSFactorPose3VW.h, GPInterpolatedProjectionFactorPose3.h
  * plus the GTSAM pieces those call.  GTSAM (">= 4.0 alpha", unpinned: README.md:12,
  * CMakeLists.txt:15) is a third-party dependency that is NOT in /root/reference and NOT in
  * this image (no Eigen, no Boost either), so the reference itself is unbuildable here and
