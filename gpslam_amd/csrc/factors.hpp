@@ -556,13 +556,14 @@ GD SE3<T> interp_pose3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef
   const SE3<T> a = as_se3(p1), b = as_se3(p2);
   const SE3<T> h = se3_between(a, b);
   const V6<T> r = se3_log(h);                                          // :68
-  const BL6<T> Jinv = se3_jrinv(r);                                    // :72
+  const JrK<T> k0 = jr_coefs(r.w);                                     // trig coefficients shared by Jinv and the FD block
+  const BL6<T> Jinv = se3_jrinv_k(k0, r);                              // :72
   const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
   const V6<T> xi = k.l12 * u1 + k.p11 * r + k.p12 * (Jinv * u2);       // Lambda_1 r1 + Psi_1 r2, r1 = [0; v1], r2 = [r; Jinv v2]
   const SE3<T> ex = se3_exp(xi);
   if (JAC) {
     const BL6<T> He = se3_jr(xi);                                      // Hcomp22 * Hexp (:80)
-    const BL6<T> FD = se3_jrinv_times_x_fd(r, u2);                     // (:84, :93) computed once
+    const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);               // (:84, :93) computed once
     const BL6<T> tmp1 = neg(Jinv * se3_adjoint(se3_inverse(h)));       // Hlogmap Hcomp11 Hinv
     const BL6<T> s1 = k.p11 * tmp1 + k.p12 * (FD * tmp1);              // Psi_1 * dr2_dT1
     o.H1 = se3_adjoint(se3_inverse(ex)) + He * s1;                     // Hcomp21 + ... (:87)

@@ -191,6 +191,23 @@ def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sig
                 att_dt=np.full(M, dt), att_tau=tau)
 
 
+def pose3_gps_chain(N, per_interval=4, seed=0, dt=0.1):
+    """C5 (SE(3) variant): the C3 chain without odometry but with GPInterpolatedGPSFactorPose3 at 4x the state rate."""
+    p = pose3_chain(N, seed=seed, dt=dt)
+    rng = np.random.default_rng(SEED_BASE + 55 + seed)
+    for k in ("between_left", "between_meas", "between_sig"):
+        p.pop(k)
+    M = (N - 1) * per_interval
+    left = np.repeat(np.arange(N - 1), per_interval).astype(np.int32)
+    tau = dt * (np.tile(np.arange(per_interval), N - 1) + rng.random(M)) / per_interval
+    # positions along the dead-reckoned path (close to the truth: odometry noise 1e-3) + GPS noise
+    t0, t1 = p["pose"][left, 9:12], p["pose"][left + 1, 9:12]
+    w = (tau / dt)[:, None]
+    p.update(name="C5b pose3 GP prior + interpolated GPS", gps_left=left, gps_meas=(1 - w) * t0 + w * t1 + 0.05 * rng.standard_normal((M, 3)),
+             gps_sigma=np.full((M, 3), 0.05), gps_dt=np.full(M, dt), gps_tau=tau)
+    return p
+
+
 def apply(problem, solver):
     """Feed a problem description to a solver (ChainSolver or oracle.Chain) and compile it."""
     p = problem
@@ -209,6 +226,8 @@ def apply(problem, solver):
             solver.add_landmark_priors(p["lprior_idx"], p["lprior"], p["lprior_sig"])
         if "range_left" in p:
             solver.add_interp_range(p["range_left"], p["range_lm"], p["range_z"], p["range_sigma"], p["range_dt"], p["range_tau"])
+    if "gps_left" in p:
+        solver.add_interp_gps(p["gps_left"], p["gps_meas"], p["gps_sigma"], p["gps_dt"], p["gps_tau"])
     if "att_left" in p:
         solver.add_interp_attitude(p["att_left"], p["att_nz"], p["att_bref"], p["att_sigma"], p["att_dt"], p["att_tau"])
     solver.compile()

@@ -11,7 +11,8 @@ from gpslam_amd import synthetic as S
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 for name, make, kw in (("C2 linear3", lambda: S.linear_chain(N), {}),
                        ("C4' pose2+ranges (L=8)", lambda: S.pose2_range_chain(N, L=8), dict(chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2)),
-                       ("C5 rot3+attitude x4", lambda: S.rot3_attitude_chain(N), {})):
+                       ("C5 rot3+attitude x4", lambda: S.rot3_attitude_chain(N), {}),
+                       ("C5b pose3+gps x4", lambda: S.pose3_gps_chain(N), {})):
     t0 = time.time()
     p = make()
     s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], **kw))
@@ -21,7 +22,7 @@ for name, make, kw in (("C2 linear3", lambda: S.linear_chain(N), {}),
         s.set_landmarks(p["landmarks"])
     st, ph = s.run_gn(3, timed=True)
     ph = ph / 3
-    nf = len(p.get("range_left", [])) + len(p.get("att_left", []))
+    nf = len(p.get("range_left", [])) + len(p.get("att_left", [])) + len(p.get("gps_left", []))
     print("%-26s N=%d meas=%d  ms/iter: lin %.3f asm %.3f solve %.3f retract+err %.3f total %.3f  -> %.3g state-iter/s  (setup %.1fs)"
           % (name, N, nf, ph[0], ph[1], ph[2], ph[3], ph[4], N / (ph[4] * 1e-3), time.time() - t0))
     s.close()
