@@ -95,6 +95,8 @@ struct gpslam_hip_handle {
   DevBuf partial;
   // landmark border
   int nlmrows = 0;
+  DevBuf rowC, rowCE, crowptr;   // compact row table (pose priors, between factors) and its row pointers
+  int Mc = 0;
   DevBuf lmrow, lmrow_state, lmrow_ptr, lm_t, lm_S, lm_dL;   // lm_S = [S (nl x R) | gL (nl)]
   DevBuf lm_chunk_lm, lm_chunk_j0, lm_chunk_j1, lm_chunk_ptr, lm_part;   // chunked reduction of the landmark rows
   int nlmchunks = 0;
@@ -301,7 +303,9 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride;
     a.count = s.count(); a.chart = h->cfg.chart;
     a.idx = s.d_idx.as<int>(); a.meas = s.d_meas.as<Real>(); a.sig = s.d_sig.as<Real>(); a.row0 = s.d_row0.as<int>();
-    a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.partial = part + off;
+    const bool compact = (kind != 1);   // pose priors and between factors: velocity-free rows
+    a.rowLR = compact ? h->rowC.as<Real>() : h->rowLR.as<Real>(); a.rowE = compact ? h->rowCE.as<Real>() : h->rowE.as<Real>();
+    a.partial = part + off;
     const int nb = nblocks(a.count, 128);
     dispatch_mf(h->mf, [&](auto tag) {
       constexpr int MF = decltype(tag)::value;
@@ -364,6 +368,7 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   a.N = h->N; a.R = h->R;
   a.rowptr = h->rowptr.as<int>();
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
+  a.crowptr = h->crowptr.as<int>(); a.rowC = h->rowC.as<Real>(); a.rowCE = h->rowCE.as<Real>();
   a.rowM = h->nl > 0 ? h->rowM.as<Real>() : nullptr;
   a.rowLm = h->nl > 0 ? h->rowLm.as<int>() : nullptr;
   a.ld = h->ld;
@@ -703,7 +708,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   (void)hipSetDevice(h->cfg.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf *bufs[] = {&h->pose, &h->vel, &h->lmk, &h->pose_bak, &h->vel_bak, &h->lmk_bak, &h->d_gp_left, &h->d_gp_dt,
-                    &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
+                    &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowC, &h->rowCE, &h->crowptr, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
                     &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
                     &h->api_e, &h->api_H};
@@ -911,9 +916,10 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   // ---- row layout: rows grouped by left state; inside a state: GP, pose prior, velocity prior, between, measurements
   std::vector<int> rows_in(N + 1, 0);
   for (int32_t l : h->gp_left) rows_in[l] += b;
-  for (int32_t i : h->pri.idx) rows_in[i] += d;
   for (int32_t i : h->vpri.idx) rows_in[i] += d;
-  for (int32_t i : h->btw.idx) rows_in[i] += d;
+  std::vector<int> crows_in(N + 1, 0);       // compact rows: pose priors, between factors
+  for (int32_t i : h->pri.idx) crows_in[i] += d;
+  for (int32_t i : h->btw.idx) crows_in[i] += d;
   for (MeasSet &s : h->ms) for (int32_t i : s.idx) rows_in[i] += s.rows;
   std::vector<int> rowptr(N + 2, 0);
   for (int s = 0; s <= N; s++) rowptr[s + 1] = rowptr[s] + rows_in[s];
@@ -925,10 +931,18 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     row0.resize(idx.size());
     for (size_t f = 0; f < idx.size(); f++) { row0[f] = cursor[idx[f]]; cursor[idx[f]] += rows; }
   };
+  std::vector<int> crowptr(N + 2, 0);
+  for (int s = 0; s <= N; s++) crowptr[s + 1] = crowptr[s] + crows_in[s];
+  h->Mc = crowptr[N + 1];
+  std::vector<int> ccursor(crowptr.begin(), crowptr.end() - 1);
+  auto cplace = [&](const std::vector<int32_t> &idx, int rows, std::vector<int> &row0) {
+    row0.resize(idx.size());
+    for (size_t f = 0; f < idx.size(); f++) { row0[f] = ccursor[idx[f]]; ccursor[idx[f]] += rows; }
+  };
   std::vector<int> r_pri, r_vpri, r_btw, r_ms[kNumMeasKinds];
-  place(h->pri.idx, d, r_pri);
+  cplace(h->pri.idx, d, r_pri);
   place(h->vpri.idx, d, r_vpri);
-  place(h->btw.idx, d, r_btw);
+  cplace(h->btw.idx, d, r_btw);
   for (int fk = 0; fk < kNumMeasKinds; fk++) place(h->ms[fk].idx, h->ms[fk].rows, r_ms[fk]);
   int rc;
   if ((rc = upload(h, h->rowptr, rowptr))) return rc;
@@ -963,6 +977,9 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   const size_t Mrows = (size_t)std::max(h->M, 1);
   HIPCHK(h->rowLR.reserve(Mrows * 2 * b * sizeof(Real)));
   HIPCHK(h->rowE.reserve(Mrows * sizeof(Real)));
+  HIPCHK(h->rowC.reserve((size_t)std::max(h->Mc, 1) * b * sizeof(Real)));
+  HIPCHK(h->rowCE.reserve((size_t)std::max(h->Mc, 1) * sizeof(Real)));
+  if ((rc = upload(h, h->crowptr, crowptr))) return rc;
   // ---- landmark border bookkeeping
   h->nlmrows = 0;
   if (h->nl > 0) {
@@ -1301,18 +1318,36 @@ int gpslam_hip_get_rows(gpslam_hip_handle *h, int32_t *n_rows, double *rowLR, do
   int rc = need_compiled(h);
   if (rc) return rc;
   (void)hipSetDevice(h->cfg.device);
-  if (n_rows) *n_rows = h->M;
+  // the M rows of the full-width table, then the Mc compact rows (pose priors, between factors) expanded to full width
+  const size_t M = (size_t)h->M, Mc = (size_t)h->Mc, b = (size_t)h->b, d = (size_t)h->d;
+  if (n_rows) *n_rows = (int32_t)(M + Mc);
   if (!rowLR && !rowE && !rowM && !rowLm) return 0;
   if ((rc = launch_factors(h, 0, 0))) return rc;
-  const size_t M = (size_t)h->M;
-  if (M == 0) return 0;
-  if (rowLR) HIPCHK(hipMemcpyAsync(rowLR, h->rowLR.p, M * 2 * h->b * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
-  if (rowE) HIPCHK(hipMemcpyAsync(rowE, h->rowE.p, M * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
-  if (h->nl > 0) {
-    if (rowM) HIPCHK(hipMemcpyAsync(rowM, h->rowM.p, M * h->ld * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
-    if (rowLm) HIPCHK(hipMemcpyAsync(rowLm, h->rowLm.p, M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  if (M + Mc == 0) return 0;
+  std::vector<Real> cLR(Mc * b), cE(Mc);
+  if (M > 0) {
+    if (rowLR) HIPCHK(hipMemcpyAsync(rowLR, h->rowLR.p, M * 2 * b * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    if (rowE) HIPCHK(hipMemcpyAsync(rowE, h->rowE.p, M * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    if (h->nl > 0) {
+      if (rowM) HIPCHK(hipMemcpyAsync(rowM, h->rowM.p, M * h->ld * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+      if (rowLm) HIPCHK(hipMemcpyAsync(rowLm, h->rowLm.p, M * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    }
+  }
+  if (Mc > 0) {
+    HIPCHK(hipMemcpyAsync(cLR.data(), h->rowC.p, Mc * b * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(cE.data(), h->rowCE.p, Mc * sizeof(Real), hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  for (size_t r = 0; r < Mc; r++) {
+    if (rowLR) {
+      double *dst = rowLR + (M + r) * 2 * b;
+      for (size_t k = 0; k < 2 * b; k++) dst[k] = 0.0;
+      for (size_t k = 0; k < d; k++) { dst[k] = cLR[r * b + k]; dst[b + k] = cLR[r * b + d + k]; }
+    }
+    if (rowE) rowE[M + r] = cE[r];
+    if (rowM) for (int q = 0; q < h->ld; q++) rowM[(M + r) * h->ld + q] = 0.0;
+    if (rowLm) rowLm[M + r] = -1;
+  }
   return 0;
 }
 

@@ -397,7 +397,10 @@ template <typename T> struct FacArgs {
 template <typename T, int MF, int KIND, bool JAC>
 __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
-  constexpr int LS = 2 * b + 2;
+  // PriorFactor<Pose> and BetweenFactor<Pose> have no velocity columns: they go to the compact row table,
+  // [d/dpose_left (d) | d/dpose_right (d)] per row, which halves what K3 has to read for them
+  constexpr int W = (KIND == 1) ? 2 * b : 2 * d;
+  constexpr int LS = W + 2;
   __shared__ T stage[JAC ? 2 * 64 * LS : 1];
   __shared__ int srow[JAC ? 128 : 1];
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,7 +445,7 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
     if (JAC) {
       if (valid) a.rowE[row0 + r] = we;
 #pragma unroll
-      for (int c = 0; c < 2 * b; c++) mine[c] = T(0);
+      for (int c = 0; c < W; c++) mine[c] = T(0);
       if (KIND == 1) {
         mine[d + r] = w;
       } else {
@@ -450,10 +453,10 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
         for (int c = 0; c < d; c++) mine[c] = w * H1[r * d + c];
         if (KIND == 2) {
 #pragma unroll
-          for (int c = 0; c < d; c++) mine[b + c] = w * H2[r * d + c];
+          for (int c = 0; c < d; c++) mine[d + c] = w * H2[r * d + c];
         }
       }
-      wave_store_rows<T, 2 * b>(st, srow + wv * 64, lane, r, a.rowLR);
+      wave_store_rows<T, W>(st, srow + wv * 64, lane, r, a.rowLR);
     }
   }
   const T tot = block_sum(T(0.5) * err);
@@ -970,6 +973,8 @@ template <typename T> struct AsmArgs {
   int N, R;               // states, rhs columns (1 + border)
   const int *rowptr;      // N + 2 entries; rows of left state s: [rowptr[s], rowptr[s+1]); rowptr[-1] handled by s > 0
   const T *rowLR, *rowE;
+  const int *crowptr;     // compact rows (velocity-free Jacobians) of left state s: [crowptr[s], crowptr[s+1])
+  const T *rowC, *rowCE;  // Mc x B = [d/dpose_left (B/2) | d/dpose_right (B/2)], Mc
   const T *rowM;          // M x ld (border) or null
   const int *rowLm;       // landmark id per row or -1
   int ld;
@@ -1007,6 +1012,7 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   int n_max = n_own;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) n_max = max(n_max, __shfl_xor(n_max, o, 64));
+  n_max = __builtin_amdgcn_readfirstlane(n_max);
   const int rp_prev = __shfl(rp_s, gp, 64);       // first row of state s - 1 (landmark columns of its rows)
   const int n_prev = __shfl(n_own, gp, 64);
   T D[B], O[B];
@@ -1023,35 +1029,45 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   // next rank's first state (the rows of the last interval carry landmark columns too)
   T *gcol = isblk ? bp + 2 * B * B : ((out && a.halo_add) ? a.halo_add + B * B : nullptr);
   if (gcol) for (int r = 1; r < a.R; r++) gcol[r * B + c] = T(0);
+  // loads are unconditional (row index clamped to the state's last row, the ghost group re-reads its R element
+  // instead of an L element); validity is applied when the values are consumed.  A predicated load would make the
+  // loaded value a phi with zero, and the copy that implements the phi waits for the load.
+  const int n_last = max(n_own - 1, 0);
   auto ld = [&](int i, T &Lc, T &Rc, T &e) {
-    Lc = T(0); Rc = T(0); e = T(0);
-    if (i < n_own) {
-      const T *row = a.rowLR + (size_t)(rp_s + i) * 2 * B;
-      if (g >= 1) Lc = row[c];
-      Rc = row[B + c];
-      e = a.rowE[rp_s + i];
-    }
+    const int rho = rp_s + min(i, n_last);
+    const T *row = a.rowLR + (size_t)rho * 2 * B;
+    Lc = row[g >= 1 ? c : B + c];
+    Rc = row[B + c];
+    e = a.rowE[rho];
   };
-  T Lc0, Rc0, e0, Lc1, Rc1, e1;
-  ld(0, Lc0, Rc0, e0);
-  ld(1, Lc1, Rc1, e1);
-  for (int i = 0; i < n_max; i++) {
-    const T Lc = Lc0, Rc = Rc0, e = e0;
-    Lc0 = Lc1; Rc0 = Rc1; e0 = e1;
-    ld(i + 2, Lc1, Rc1, e1);
+  // PF register sets rotate by full unrolling (no register copies: a copy of a set whose load is still in flight
+  // would wait for it and cut the prefetch distance to one iteration -- measured 1000-2400 cycles of exposed
+  // latency per row before this change)
+  constexpr int PF = 3;
+  T rL[PF], rR[PF], rE[PF];
+  if (n_max > 0) {                                // (an empty row table may be a null pointer)
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+      ld(j, rL[j], rR[j], rE[j]);
+      __builtin_amdgcn_sched_barrier(0);          // issue order = consumption order (vmcnt counts in order)
+    }
+  }
+  auto step = [&](int i, const T Lraw, const T Rraw, const T eraw) {
+    const bool valid = i < n_own;
+    const T Lc = (valid && g >= 1) ? Lraw : T(0), Rc = valid ? Rraw : T(0), e = valid ? eraw : T(0);
     T *buf = xw + (i & 1) * XS;
     buf[lane] = Lc;
     buf[64 + lane] = Rc;
-    if (c == 0 && g < G) buf[128 + g] = e;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     const T *Lrow = buf + gb;
     const T *Prow = buf + 64 + gp;                // right half of the current row of state s - 1
     const T Pc = Prow[c];
-    const T ep = buf[128 + (g >= 1 ? g - 1 : 0)];
+    const T ep = __shfl(e, gp, 64);               // e of state s - 1's current row (no branch: keeps the step one block)
 #pragma unroll
     for (int k = 0; k < B; k++) {
+      if (B > 8 && k == B / 2) __builtin_amdgcn_sched_barrier(0);   // halves the LDS read-back registers live at once
       const T Lk = Lrow[k];
       D[k] += Lc * Lk;
       O[k] += Rc * Lk;
@@ -1059,32 +1075,125 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
     }
     gsum -= Lc * e;
     gsum -= Pc * ep;
-    if (a.rowM && gcol) {
-      if (i < n_own) {
-        const int rho = rp_s + i;
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+  };
+  for (int i0 = 0; i0 < n_max; i0 += PF) {
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+      step(i0 + j, rL[j], rR[j], rE[j]);          // steps past n_max exchange zeros
+      ld(i0 + j + PF, rL[j], rR[j], rE[j]);
+      __builtin_amdgcn_sched_barrier(0);          // keeps the next step's LDS reads from being hoisted (VGPRs)
+    }
+  }
+  // compact rows: the same exchange with half-width rows; only the pose rows / columns of D_s and O_s are touched
+  {
+    constexpr int Dh = B / 2;
+    int crp = 0, cn = 0;
+    if (owner) {
+      crp = a.crowptr[s];
+      cn = a.crowptr[s + 1] - crp;
+    }
+    int cmax = cn;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cmax = max(cmax, __shfl_xor(cmax, o, 64));
+    cmax = __builtin_amdgcn_readfirstlane(cmax);
+    const int cn_last = max(cn - 1, 0);
+    const int cc = c < Dh ? c : 0;
+    auto ldc = [&](int i, T &Lc, T &Rc, T &e) {
+      const int rho = crp + min(i, cn_last);
+      const T *row = a.rowC + (size_t)rho * B;
+      Lc = row[g >= 1 ? cc : Dh + cc];
+      Rc = row[Dh + cc];
+      e = a.rowCE[rho];
+    };
+    T cL[PF], cR[PF], cE[PF];
+    if (cmax > 0) {
+#pragma unroll
+      for (int j = 0; j < PF; j++) {
+        ldc(j, cL[j], cR[j], cE[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      if (i < n_prev) {
-        const int rho = rp_prev + i;
-        const int lm = a.rowLm[rho];
-        if (lm >= 0)
-          for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Pc * a.rowM[(size_t)rho * a.ld + q];
+    }
+    auto cstep = [&](int i, const T Lraw, const T Rraw, const T eraw) {
+      const bool valid = i < cn;
+      const T Lc = (valid && g >= 1 && c < Dh) ? Lraw : T(0), Rc = (valid && c < Dh) ? Rraw : T(0), e = valid ? eraw : T(0);
+      T *buf = xw + (i & 1) * XS;
+      buf[lane] = Lc;
+      buf[64 + lane] = Rc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const T *Lrow = buf + gb;
+      const T *Prow = buf + 64 + gp;
+      const T Pc = Prow[c];
+      const T ep = __shfl(e, gp, 64);               // e of state s - 1's current row (no branch: keeps the step one block)
+#pragma unroll
+      for (int k = 0; k < Dh; k++) {
+        const T Lk = Lrow[k];
+        D[k] += Lc * Lk;
+        O[k] += Rc * Lk;
+        D[k] += Pc * Prow[k];
+      }
+      gsum -= Lc * e;
+      gsum -= Pc * ep;
+    };
+    for (int i0 = 0; i0 < cmax; i0 += PF) {
+#pragma unroll
+      for (int j = 0; j < PF; j++) {
+        cstep(i0 + j, cL[j], cR[j], cE[j]);
+        ldc(i0 + j + PF, cL[j], cR[j], cE[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
-  if (!out) return;
-  if (sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
+  // landmark columns of the rows that have one (range / projection factors; a small minority of the rows): a second
+  // pass that re-reads just those rows, own rows first, then the rows of state s - 1 -- kept out of the exchange
+  // loop so that its steps stay branch-free
+  if (a.rowM && gcol) {
+    for (int i = 0; i < n_own; i++) {
+      const int rho = rp_s + i;
+      const int lm = a.rowLm[rho];
+      if (lm < 0) continue;
+      const T Lc = a.rowLR[(size_t)rho * 2 * B + c];
+      for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Lc * a.rowM[(size_t)rho * a.ld + q];
+    }
+    for (int i = 0; i < n_prev; i++) {
+      const int rho = rp_prev + i;
+      const int lm = a.rowLm[rho];
+      if (lm < 0) continue;
+      const T Pc = a.rowLR[(size_t)rho * 2 * B + B + c];
+      for (int q = 0; q < a.ld; q++) gcol[(1 + lm * a.ld + q) * B + c] += Pc * a.rowM[(size_t)rho * a.ld + q];
+    }
+  }
+  if (out && sc == a.N) {   // halo: what the rows of state N-1 owe the neighbour's first state
 #pragma unroll
     for (int k = 0; k < B; k++) a.halo_add[c * B + k] = D[k];
     a.halo_add[B * B + c] = gsum;
-    return;
   }
+  // [D | O | g] leave through a per-wave LDS image of the G - 1 records, then as 16-byte-per-lane stores that are
+  // contiguous within a record.  Writing a lane's row of D directly (16-byte pieces at a B * 8 byte stride, one write
+  // request per lane) cost 0.085 of the kernel's 0.20 ms on the benchmark chain.
+  constexpr int RS = 2 * B * B + B;
+  __shared__ T stg[WPB][(G - 1) * RS];
+  T *sw = &stg[threadIdx.x >> 6][0];
+  if (isblk) {
+    T *r = sw + (g - 1) * RS;
 #pragma unroll
-  for (int k = 0; k < B; k++) { bp[c * B + k] = D[k]; bp[B * B + c * B + k] = O[k]; }
-  bp[2 * B * B + c] = gsum;
-  if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
+    for (int k = 0; k < B; k++) { r[c * B + k] = D[k]; r[B * B + c * B + k] = O[k]; }
+    r[2 * B * B + c] = gsum;
+    if (a.gsave) a.gsave[(size_t)sc * B + c] = gsum;
+  }
+  wave_lds_sync();
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const int s_first = wave * (G - 1);
+  constexpr int NPAIR = (G - 1) * RS / 2;
+  static_assert(RS % 2 == 0, "records are copied in pairs");
+#pragma unroll
+  for (int t = 0; t < (NPAIR + 63) / 64; t++) {
+    const int q = t * 64 + lane;
+    const int j = (2 * q) / RS, off = 2 * q - j * RS;
+    if (q < NPAIR && s_first + j < a.N)
+      *reinterpret_cast<V2 *>(a.blk + (size_t)(s_first + j) * BS + off) = *reinterpret_cast<const V2 *>(sw + 2 * q);
+  }
 }
 
 // ------------------------------------------------------------------ trajectory queries

@@ -185,9 +185,10 @@ int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam
 int gpslam_hip_normal_equations(gpslam_hip_handle *h, double *D, double *O, double *g, double *B);
 /* whitened Jacobian rows of the current linearisation (what NoiseModelFactor::linearize produces after
  * WhitenSystem): rowLR M x 4d = [d/dx_left | d/dx_right], rowE M, rowM M x landmark_dim, rowLm M (landmark id or -1).
- * Row order: grouped by left state; inside a state GP priors, pose priors, velocity priors, between, then
- * interpolated range, range, attitude, GPS, odometry2d, bearing-range, each in the order they were added.
- * Any output pointer may be NULL; n_rows receives M. */
+ * Row order: first the rows with velocity columns, grouped by left state (inside a state: GP priors, velocity priors,
+ * then interpolated range, range, attitude, GPS, odometry2d, bearing-range, projection, each in the order they were
+ * added); then the velocity-free rows (pose priors, between factors; the device keeps them in a half-width table),
+ * again grouped by left state, expanded to full width.  Any output pointer may be NULL; n_rows receives M. */
 int gpslam_hip_get_rows(gpslam_hip_handle *h, int32_t *n_rows, double *rowLR, double *rowE, double *rowM,
                         int32_t *rowLm);
 /* solve the block-tridiagonal SPD system D/O/g (host arrays as above, N x b) with the device solver; x: N x b */
