@@ -1369,6 +1369,12 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
   };
 
   const int j0 = has_sep ? s + 1 : s;
+  if (isA) {
+    // the A lanes start from the separator's own row of D (or rhs column) and subtract the sums from it: the loads
+    // fly with the first block's instead of being an exposed round trip at the end (one per hierarchy level)
+    if (cA < B) load_D_row(s, cA, nxt);
+    else load_G_col(s, cA - B, nxt);
+  }
   if (j0 < e) {
     if (lane < B) load_D_row(j0, lane, col);
     else if (lane < 2 * B) load_O_row(j0, lane - B, col);
@@ -1512,14 +1518,14 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
     const int rD = FAST ? cA : cF, rG = FAST ? cA - B : cR;
     if (wD) {
       T dr[B];
-      load_D_row(s, rD, dr);
+      if (!FAST) load_D_row(s, rD, dr);
 #pragma unroll
-      for (int k = 0; k < B; k++) ub[rD * B + k] = FAST ? dr[k] + nxt[k] : dr[k] - acc[FAST ? 0 : k];
+      for (int k = 0; k < B; k++) ub[rD * B + k] = FAST ? nxt[k] : dr[k] - acc[FAST ? 0 : k];
     } else if (wG) {
       T gr[B];
-      load_G_col(s, rG, gr);
+      if (!FAST) load_G_col(s, rG, gr);
 #pragma unroll
-      for (int k = 0; k < B; k++) ub[2 * B * B + rG * B + k] = FAST ? gr[k] + nxt[k] : gr[k] - acc[FAST ? 0 : k];
+      for (int k = 0; k < B; k++) ub[2 * B * B + rG * B + k] = FAST ? nxt[k] : gr[k] - acc[FAST ? 0 : k];
     }
     if (j0 >= e) {  // chunk without interior: the separator keeps its original coupling
       if (lane < B) {
