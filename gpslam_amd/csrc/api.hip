@@ -385,8 +385,19 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   return 0;
 }
 
+// k_chunk_forward_rows covers block size 12 with a single right-hand side (GPSLAM_FWD_ROWS=0 keeps the column-layout
+// kernel, for A/B measurements)
+bool rows_kernel_applies(const gpslam_hip_handle *h) {
+  static const bool off = getenv("GPSLAM_FWD_ROWS") && atoi(getenv("GPSLAM_FWD_ROWS")) == 0;
+  return h->b == 12 && h->R == 1 && !off;
+}
 void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
   const bool fast = (4 * h->b + 2 * h->R <= 64);   // room for the separator sums in spare lanes
+  // level 0 of a Pose3 chain without landmark columns: four chunks per wave, panel rows in lanes
+  if (rows_kernel_applies(h) && !a.no_sep && !a.add) {
+    k_chunk_forward_rows<<<dim3(nblocks(grid, 4)), dim3(64), 0, h->stream>>>(a);
+    return;
+  }
   dispatch_b(h->b, [&](auto tag) {
     constexpr int BB = decltype(tag)::value;
     if (fast) k_chunk_forward<Real, BB, true><<<dim3(grid), dim3(64), 0, h->stream>>>(a);
@@ -1030,9 +1041,9 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   // ---- solver hierarchy: chunks of m0 states at level 0, m1 above.  Unsharded: a single-wave sequential top
   // level of <= `top` blocks.  Sharded: reduce down to one block per rank (the rank separator).
   // reserved[1] / reserved[2] override the upper-level chunk length and the size of the sequential top level
-  // Level-0 chunk length: the forward kernel keeps 4 waves per SIMD resident, i.e. `slots` chunks run at once and a
-  // launch costs (rounds of slots) x (block steps per chunk); pick the length in [16, 32] that minimises that
-  // product (1e5 states on 256 CUs: 25 -> 4000 chunks, one round of 24 steps instead of two rounds of 15).
+  // Level-0 chunk length: `slots` chunks run at once and a launch costs (rounds of slots) x (block steps per chunk);
+  // pick the length that minimises that product (1e5 Pose3 states on 256 CUs: 13 -> 7693 chunks, one round of 12 steps
+  // of the row-layout kernel; the column-layout kernel gets 25 -> 4000 chunks, one round of 24 steps).
   int m0 = 16;
   if (h->cfg.chunk > 1) {
     m0 = h->cfg.chunk;
@@ -1040,9 +1051,11 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     hipDeviceProp_t prop;
     const int cus = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0)
                         ? prop.multiProcessorCount : 256;
-    const long slots = (long)cus * 16;
+    // column-layout kernel: one chunk per wave, 4 waves per SIMD; row-layout kernel: four chunks per wave, 2 waves per SIMD
+    const bool rows = rows_kernel_applies(h);
+    const long slots = (long)cus * (rows ? 32 : 16);
     long best = -1;
-    for (int m = 16; m <= 32; m++) {
+    for (int m = rows ? 8 : 16; m <= 32; m++) {
       const long chunks = (N + m - 1) / m;
       const long cost = ((chunks + slots - 1) / slots) * (m - 1);
       if (best < 0 || cost < best) { best = cost; m0 = m; }

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "factors.hpp"
+#include <type_traits>
 
 namespace gps {
 
@@ -1552,6 +1553,280 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
         for (int k = 0; k < B; k++) ub[B * B + lane * B + k] = T(0);
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------- row-layout forward elimination (Pose3, R = 1)
+//
+// Same elimination as k_chunk_forward, same records in and out, different mapping: FOUR chunks per wave, one per
+// 16-lane DPP row, lane r < 12 of a row holding ROW r of the panel [ D~_j | O_j^T | F_j | g~_j ].  The multipliers
+// D~[r][k] of a Gauss-Jordan step are then lane-local and only the pivot row travels -- by `v_mov_b32_dpp
+// row_newbcast:k` (full VALU rate, no SGPR round trip) instead of a v_readlane per multiplier.  The updates
+//   D~_{j+1} = D_{j+1} - O_j U_j,  F_{j+1} = -O_j V_j,  g~_{j+1} = g_{j+1} - O_j Y_j
+// take row r of O_j as local scalars against broadcast rows of U_j / V_j / Y_j; the separator sums need F_j^T,
+// which is carried alongside as G_j = F_j^T with  G_{j+1} = -G_j U_j  (V_j^T = G_j D~_j^-1 by symmetry):
+//   D_sep -= G_j V_j,  g_sep -= G_j Y_j.
+// Records enter and leave as contiguous 16-byte pieces through a per-row LDS image (which also provides the
+// transposed reads of O).  ~660 VALU instructions per chunk-step against ~830 (288 of them v_readlane) before.
+template <int I, int N, typename F> __device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+// v_mov_b64 is one of the few 64-bit DPP instructions (row_newbcast only); the compiler splits a broadcast double into
+// two v_mov_b32_dpp, so the 64-bit form is written out.  A DPP read of a VGPR needs two wait states after the VALU
+// write of that VGPR, which the compiler cannot insert for inline asm: every block starts with s_nop 1 (the block
+// itself only reads its sources).
+template <int K> __device__ __forceinline__ double row_bcast(double v) {
+  double o;
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=&v"(o) : "v"(v), "n"(K));
+  return o;
+}
+template <int K> __device__ __forceinline__ void row_bcast12(const double *s, double *d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b64_dpp %0, %12 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %1, %13 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %2, %14 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %3, %15 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %4, %16 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %5, %17 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %6, %18 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %7, %19 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %8, %20 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %9, %21 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %10, %22 row_newbcast:%24 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %11, %23 row_newbcast:%24 row_mask:0xf bank_mask:0xf"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),
+        "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]),
+        "v"(s[10]), "v"(s[11]), "n"(K));
+}
+
+__global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a) {
+  constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
+  constexpr int NPC = BS / 2;                                  // 16-byte pieces of a record
+  constexpr int NV = (NPC + 15) / 16;                          // pieces per lane of a 16-lane row
+  typedef double V2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
+  const int c = blockIdx.x * 4 + grp;
+  const int nch = (a.n + a.m - 1) / a.m;
+  const bool valid = c < nch;
+  const int s = valid ? c * a.m : 0;
+  const int e = valid ? min(s + a.m, a.n) : 0;
+  const int j0 = s + 1;
+  const bool rowlane = r < B;
+  const int rr = rowlane ? r : 0;                              // idle lanes shadow row 0 (they never store)
+  const bool right_exists = (e < a.n) || (a.last_has_right != 0);
+  const bool has_int = valid && j0 < e;
+  const double lambda = a.lambda;
+  __shared__ __attribute__((aligned(16))) double L[4 * BS];   // one record image per 16-lane row
+  // Every LDS access below is  L[opaque per-lane offset + compile-time constant]: left to itself the compiler derives the
+  // row / column / piece addresses from one another by strength reduction and ends up with a dozen VGPRs holding the
+  // same address (40 VGPRs, which spilled -- and every scratch reload drains vmcnt, i.e. waits for the factor stores)
+  int ro = grp * BS + rr * B;     // row r:      L[ro + k]
+  int co = grp * BS + rr;         // column r:   L[co + k * B]
+  int po = grp * BS + 2 * r;      // 16-byte piece q * 16 + r of the image: L[po + 32 * q]
+  int dg = grp * BS + rr * B + rr;
+  asm volatile("" : "+v"(ro), "+v"(co), "+v"(po), "+v"(dg));
+
+  // record j as 16-byte pieces, unconditionally (clamped): whether it exists is applied when it is consumed
+  auto load_rec = [&](int j, V2 *v) {
+    const V2 *src = reinterpret_cast<const V2 *>(a.blk + (size_t)min(max(j, 0), a.n - 1) * BS);
+#pragma unroll
+    for (int t = 0; t < NV; t++) v[t] = src[min(t * 16 + r, NPC - 1)];
+  };
+  auto put_rec = [&](const V2 *v, bool ok) {
+#pragma unroll
+    for (int t = 0; t < NV; t++) {
+      const int idx = t * 16 + r;
+      V2 w = v[t];
+      if (!ok) { w.x = 0.0; w.y = 0.0; }
+      if (idx < NPC) *reinterpret_cast<V2 *>(&L[po + 32 * t]) = w;
+    }
+  };
+  auto add_lambda = [&](bool ok) {
+    if (lambda != 0.0) {
+      if (rowlane && ok) L[dg] += lambda;
+      wave_lds_sync();
+    }
+  };
+
+  V2 pa[NV], pb[NV];
+  load_rec(s, pa);
+  load_rec(j0, pb);
+  double Dr[B], Or[B], Fr[B], Gr[B], Ar[B];
+  double gr, as_;
+  put_rec(pa, valid);
+  wave_lds_sync();
+  add_lambda(valid);
+#pragma unroll
+  for (int k = 0; k < B; k++) {
+    Ar[k] = L[ro + k];                       // row r of D_sep
+    Fr[k] = L[ro + B * B + k];               // F_{s+1} = O_s: row r
+    Gr[k] = L[co + B * B + k * B];           // G_{s+1} = O_s^T: row r
+  }
+  as_ = L[co + 2 * B * B];
+  wave_lds_sync();
+  put_rec(pb, has_int);
+  wave_lds_sync();
+  add_lambda(has_int);
+#pragma unroll
+  for (int k = 0; k < B; k++) {
+    Dr[k] = L[ro + k];                       // row r of D_j
+    Or[k] = L[co + B * B + k * B];           // row r of O_j^T
+  }
+  gr = L[co + 2 * B * B];
+  // (the image of record j stays in LDS through the elimination: row r of O_j is fetched from it afterwards, which
+  //  keeps 24 VGPRs free while the prefetched record j + 1 occupies 40)
+
+  if (valid && !has_int && rowlane) {        // chunk without interior: the separator keeps its original coupling
+    double *ub = a.up_blk + (size_t)c * BS;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      ub[r * B + k] = Ar[k];
+      ub[B * B + r * B + k] = right_exists ? Fr[k] : 0.0;
+    }
+    ub[2 * B * B + r] = as_;
+    if (right_exists) {
+      double *ua = a.up_add + (size_t)(c + 1) * AS;
+      const double *ra = (e == a.n) ? a.remote_add : nullptr;
+#pragma unroll
+      for (int k = 0; k < B; k++) ua[r * B + k] = ra ? ra[r * B + k] : 0.0;
+      ua[B * B + r] = ra ? ra[B * B + r] : 0.0;
+    }
+  }
+
+  // lane 0 belongs to the wave's first chunk, which is never shorter than the others
+  const int steps = __builtin_amdgcn_readfirstlane(max(e - j0, 0));
+  for (int t = 0; t < steps; t++) {
+    const int j = j0 + t;
+    const bool live = j < e, lastb = (j == e - 1), nextlive = (j + 1 < e);
+    V2 pf[NV];
+    load_rec(j + 1, pf);                     // record j + 1 flies under the elimination of block j
+    __builtin_amdgcn_sched_barrier(0);
+    // Gauss-Jordan on D~_j by row operations; the pivot row stays unscaled until the end (scaling commutes)
+    double invs = 1.0;
+    bool bad = false;
+    static_for<0, B>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const double piv = row_bcast<k>(Dr[k]);
+      bad = bad || !(piv > 0.0);
+      const double inv = fast_rcp(piv);
+      const bool isk = (r == k);
+      invs = isk ? inv : invs;
+      const double mp = isk ? 0.0 : Dr[k] * inv;
+      double tb[B];
+      row_bcast12<k>(Dr, tb);
+#pragma unroll
+      for (int q = k + 1; q < B; q++) Dr[q] = fma(-mp, tb[q], Dr[q]);
+      row_bcast12<k>(Or, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) Or[q] = fma(-mp, tb[q], Or[q]);
+      row_bcast12<k>(Fr, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) Fr[q] = fma(-mp, tb[q], Fr[q]);
+      gr = fma(-mp, row_bcast<k>(gr), gr);
+    });
+    if (bad && live && r == 0) *a.flag = 1;
+    __builtin_amdgcn_sched_barrier(0);
+    double Ol[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) Ol[k] = L[ro + B * B + k];          // row r of O_j, from the image of record j
+#pragma unroll
+    for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }   // U_j, V_j: row r
+    gr *= invs;                                                      // Y_j
+    wave_lds_sync();
+    if (rowlane) {
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        L[co + k * B] = Fr[k];               // the stored record is column-major [V | U | Y]
+        L[co + B * B + k * B] = Or[k];
+      }
+      L[co + 2 * B * B] = gr;
+    }
+    wave_lds_sync();
+    if (live) {
+      V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
+#pragma unroll
+      for (int q = 0; q < NV; q++) {
+        const int idx = q * 16 + r;
+        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&L[po + 32 * q]);
+      }
+    }
+    wave_lds_sync();
+    put_rec(pf, nextlive);                   // zeros after the chunk's last block: the products then are the addends
+    wave_lds_sync();
+    add_lambda(nextlive);
+    double Dn[B], Fn[B], Gn[B], gn;
+#pragma unroll
+    for (int k = 0; k < B; k++) { Dn[k] = L[ro + k]; Gn[k] = 0.0; }
+    gn = L[co + 2 * B * B];
+    __builtin_amdgcn_sched_barrier(0);
+    // two passes, so that at most seven 12-vectors are live: rows of U_j first (O_j^T is dead afterwards) ...
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const double ol = Ol[i], gg = Gr[i];
+      double tb[B];
+      row_bcast12<i>(Or, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) {
+        Dn[q] = fma(-ol, tb[q], Dn[q]);
+        Gn[q] = fma(-gg, tb[q], Gn[q]);
+      }
+      const double yb = row_bcast<i>(gr);
+      gn = fma(-ol, yb, gn);
+      as_ = fma(-gg, yb, as_);
+      __builtin_amdgcn_sched_barrier(0);   // one source row at a time (the scheduler otherwise batches all 144 broadcasts)
+    });
+    // (pinned here: the compiler otherwise sinks the G_{j+1} sums below the output branch at the end of the step and
+    //  spills all 144 broadcast values to feed them there)
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Gn[k]), "+v"(Dn[k]));
+    __builtin_amdgcn_sched_barrier(0);
+    // ... then rows of V_j
+#pragma unroll
+    for (int k = 0; k < B; k++) Fn[k] = 0.0;
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const double ol = Ol[i], gg = Gr[i];
+      double tb[B];
+      row_bcast12<i>(Fr, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) {
+        Fn[q] = fma(-ol, tb[q], Fn[q]);
+        Ar[q] = fma(-gg, tb[q], Ar[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = Gn[k];
+      Or[k] = L[co + B * B + k * B];
+    }
+    gr = gn;
+    __builtin_amdgcn_sched_barrier(0);
+    if (live && lastb && rowlane) {          // after the chunk's last block the "next block" operands are the addends
+      double *ub = a.up_blk + (size_t)c * BS;
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        ub[r * B + k] = Ar[k];                                 // D_sep - sum G V
+        ub[B * B + r * B + k] = right_exists ? Fr[k] : 0.0;   // C = -O V couples separator c to separator c + 1
+      }
+      ub[2 * B * B + r] = as_;
+      if (right_exists) {
+        double *ua = a.up_add + (size_t)(c + 1) * AS;
+        const double *ra = (e == a.n) ? a.remote_add : nullptr;   // what is already owed to the outside separator
+#pragma unroll
+        for (int k = 0; k < B; k++) ua[r * B + k] = (ra ? ra[r * B + k] : 0.0) + Dr[k];   // -O U
+        ua[B * B + r] = (ra ? ra[B * B + r] : 0.0) + gr;                                    // -O Y
+      }
+    }
+    wave_lds_sync();
   }
 }
 
