@@ -997,7 +997,9 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   constexpr int G = 64 / B;                       // lane groups per wave (the first one is the ghost)
   static_assert(G >= 2, "needs at least one real state per wave");
   const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  // blocks walk the chain from its END: the rows written last by the linearisation are the ones still in the
+  // memory-side cache
+  const int wave = (int)(((gridDim.x - 1 - blockIdx.x) * blockDim.x + threadIdx.x) >> 6);
   const int g = lane / B, c = lane - g * B;
   const int nstates = a.N + (a.halo_add ? 1 : 0);
   const int s = wave * (G - 1) + g - 1;           // ghost: the state before the wave's first
