@@ -1195,7 +1195,9 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
     const int q = t * 64 + lane;
     const int j = (2 * q) / RS, off = 2 * q - j * RS;
     if (q < NPAIR && s_first + j < a.N)
-      *reinterpret_cast<V2 *>(a.blk + (size_t)(s_first + j) * BS + off) = *reinterpret_cast<const V2 *>(sw + 2 * q);
+      // non-temporal: the records are next touched by another kernel, and kept out of the caches they leave the rows
+      // this kernel still has to read where the linearisation left them (0.150 -> 0.133 ms; the elimination pays 10 us)
+      __builtin_nontemporal_store(*reinterpret_cast<const V2 *>(sw + 2 * q), reinterpret_cast<V2 *>(a.blk + (size_t)(s_first + j) * BS + off));
   }
 }
 
