@@ -31,7 +31,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # same kernels on the same workload comes from the committed PMC passes (scripts/collect_profiles.sh ->
 # profiles/<round>_pmc.json; explicit-size L2->fabric request counters TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ{,_64B}).
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
-PMC_KEYS = [("k_gp<double, 3, 0>",), ("k_assemble",), ("k_chunk_forward_rows", "k_chunk_forward<double, 12, true>"),
+PMC_KEYS = [("k_gp<double, 3, 0>",), ("k_assemble",), ("k_fused_level0", "k_chunk_forward_rows", "k_chunk_forward<double, 12, true>"),
             ("k_chunk_backward<double, 12>",), ("k_retract<double, 3>",)]
 
 
@@ -168,9 +168,15 @@ def main():
         kms = [probe.time_kernel(w, reps=5) for w in range(5)]
         ab = S.algorithmic_bytes_per_state(S.POSE3)
         blocks = ab["linearize"] - (18 * 8 + 8)
+        fused = (kms[1] == 0.0)                    # the assembly runs inside the level-0 elimination (k_fused_level0)
+        if fused:
+            names[1] = "k_assemble (K3): fused into the level-0 elimination, no launch"
+            names[2] = "k_fused_level0 (K3 + K4 level 0: assembly + elimination)"
+            kms[1] = 1e-9
         alg = [ab["linearize"] * (N - 1),          # K1: read state + dt, write e + H1..H4 (whitened rows)
                (blocks + blocks) * N,              # K3: read rows, write blocks
-               ab["solve"] * N,                    # K4 forward: SURVEY 8(d) single-pass solve figure (conservative)
+               # K4 forward: SURVEY 8(d) single-pass solve figure (conservative); fused: read the rows, write the factors
+               (blocks + blocks if fused else ab["solve"]) * N,
                (blocks + 12 * 8) * N,              # back-substitution: read factors, write delta
                ab["retract"] * N]
         dom = int(np.argmax(kms))

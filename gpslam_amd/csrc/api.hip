@@ -106,6 +106,8 @@ struct gpslam_hip_handle {
   // segment sharding
   DevBuf halo_add, iface_send, iface_recv, top_blk, top_x;
   DevBuf scal, flag, api_e, api_H;
+  bool fuse_ok = false;     // k_fused_level0 applies to this graph (compile())
+  bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   double ph_lambda = 0.0;
@@ -391,9 +393,23 @@ bool rows_kernel_applies(const gpslam_hip_handle *h) {
   static const bool off = getenv("GPSLAM_FWD_ROWS") && atoi(getenv("GPSLAM_FWD_ROWS")) == 0;
   return h->b == 12 && h->R == 1 && !off;
 }
+// k_fused_level0 (assembly inside the level-0 elimination): unsharded Pose3 chains without landmark columns
+// (GPSLAM_FUSE_K3=0 keeps k_assemble_ghost + k_chunk_forward_rows, for A/B measurements)
+bool fused_kernel_applies(const gpslam_hip_handle *h) {
+  static const bool off = getenv("GPSLAM_FUSE_K3") && atoi(getenv("GPSLAM_FUSE_K3")) == 0;
+  return rows_kernel_applies(h) && !sharded(h) && h->nl == 0 && !off;
+}
 void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
   const bool fast = (4 * h->b + 2 * h->R <= 64);   // room for the separator sums in spare lanes
   // level 0 of a Pose3 chain without landmark columns: four chunks per wave, panel rows in lanes
+  if (h->fuse_now && !a.no_sep && !a.add) {
+    FusedArgs<Real> u;
+    u.f = a;
+    u.rowptr = h->rowptr.as<int>(); u.rowLR = h->rowLR.as<Real>(); u.rowE = h->rowE.as<Real>();
+    u.crowptr = h->crowptr.as<int>(); u.rowC = h->rowC.as<Real>(); u.rowCE = h->rowCE.as<Real>();
+    k_fused_level0<<<dim3(nblocks(grid, 4)), dim3(128), 0, h->stream>>>(u);
+    return;
+  }
   if (rows_kernel_applies(h) && !a.no_sep && !a.add) {
     k_chunk_forward_rows<<<dim3(nblocks(grid, 4)), dim3(64), 0, h->stream>>>(a);
     return;
@@ -542,9 +558,13 @@ int enqueue_gn(gpslam_hip_handle *h, double lambda, bool timed, bool eval_after 
   if (timed) HIPCHK(hipEventRecord(h->ev[0], h->stream));
   if ((rc = launch_factors(h, 0, 0))) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[1], h->stream));
-  if ((rc = launch_assemble(h, false))) return rc;
+  const bool fused = h->fuse_ok && h->lv.size() >= 2;   // the assembly happens inside the level-0 elimination
+  if (!fused && (rc = launch_assemble(h, false))) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[2], h->stream));
-  if ((rc = launch_solve(h, lambda))) return rc;
+  h->fuse_now = fused;
+  rc = launch_solve(h, lambda);
+  h->fuse_now = false;
+  if (rc) return rc;
   if (timed) HIPCHK(hipEventRecord(h->ev[3], h->stream));
   if ((rc = launch_retract(h, 2))) return rc;
   if (eval_after && (rc = launch_factors(h, 1, 1))) return rc;
@@ -1053,12 +1073,13 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
                         ? prop.multiProcessorCount : 256;
     // column-layout kernel: one chunk per wave, 4 waves per SIMD; row-layout kernel: four chunks per wave, 2 waves per SIMD
     const bool rows = rows_kernel_applies(h);
-    const long slots = (long)cus * (rows ? 32 : 16);
+    // (the fused kernel: four two-wave workgroups of four chunks per CU)
+    const long slots = (long)cus * (fused_kernel_applies(h) ? 16 : rows ? 32 : 16);
     long best = -1;
     for (int m = rows ? 8 : 16; m <= 32; m++) {
       const long chunks = (N + m - 1) / m;
       const long cost = ((chunks + slots - 1) / slots) * (m - 1);
-      if (best < 0 || cost < best) { best = cost; m0 = m; }
+      if (best < 0 || cost <= best) { best = cost; m0 = m; }   // ties: the longer chunk leaves fewer separators
     }
   }
   const int m1 = h->cfg.reserved[1] > 1 ? h->cfg.reserved[1] : 4;
@@ -1097,6 +1118,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     HIPCHK(hipMemsetAsync(h->iface_recv.p, 0, (size_t)P * (BS + AS) * sizeof(Real), h->stream));
     HIPCHK(hipMemsetAsync(h->top_x.p, 0, (size_t)(P + 1) * b * h->R * sizeof(Real), h->stream));
   }
+  h->fuse_ok = fused_kernel_applies(h);
   HIPCHK(hipStreamSynchronize(h->stream));
   h->compiled = true;
   return 0;
@@ -1455,6 +1477,7 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
         else k_gp<Real, MF, 0><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
       });
     } else if (which == 1) {
+      if (h->fuse_ok && h->lv.size() >= 2) { *avg_ms = 0.0; return 0; }   // no such launch: see the header
       if ((rc = launch_assemble(h, false))) return rc;
     } else if (which == 2 || which == 3) {
       Level &v = h->lv[0];
@@ -1466,7 +1489,9 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
       a.n = v.n; a.m = top ? v.n : v.m; a.R = h->R; a.no_sep = top ? 1 : 0; a.last_has_right = 0;
       a.remote_add = nullptr; a.lambda = Real(0); a.flag = h->flag.as<int>();
       const int grid = top ? 1 : v.nch;
+      h->fuse_now = h->fuse_ok && !top;
       launch_fwd(h, a, grid);
+      h->fuse_now = false;
       if (which == 3) {  // time the level-0 back-substitution instead (separator solutions = whatever lv[1].x holds)
         HIPCHK(hipEventRecord(h->ev[0], h->stream));
         BwdArgs<Real> bw;

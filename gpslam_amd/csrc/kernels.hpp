@@ -1859,6 +1859,357 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
   }
 }
 
+// ---------------------------------------------------------------- assembly fused into the level-0 elimination
+//
+// k_fused_level0: a workgroup is TWO waves that share four chunks.  Wave 1 (ASM) forms the records [D_j | O_j | g_j]
+// of the chunks' states straight from the row tables -- what k_assemble_ghost does, but chunk by chunk, state after
+// state, in the row layout of the elimination: lane r of a 16-lane row accumulates row r of D and O; per Jacobian row
+// it loads its own L and R element, gathers the 12 L (then the 12 R) elements of the row with
+// `v_mov_b64_dpp row_newbcast:0..11` and adds L[r] L[k] -> D_j, R[r] L[k] -> O_j, R[r] R[k] -> the carry that opens
+// D_{j+1}.  Wave 0 (ELIM) is k_chunk_forward_rows with the record images coming from ASM through LDS (two rotating
+// images per chunk, one s_barrier per block step) instead of from memory.  The block records [D | O | g] never exist in
+// HBM: -240 MB written, -262 MB read per iteration, and k_assemble_ghost's launch is gone.
+// Conventions that differ from the unfused pair: a separator's own record holds only its rows' L^T L part -- the
+// R^T R of the rows of the state before it (the previous chunk's last state) reaches it as part of the addend that
+// chunk sends to the upper level anyway (the "virtual" record after a chunk's last state is [carry | 0 | carry_g]).
+template <typename T> struct FusedArgs {
+  FwdArgs<T> f;           // level-0 arguments of the elimination (blk: where the factors [V | U | Y] go)
+  const int *rowptr;      // full-width rows of left state s: [rowptr[s], rowptr[s+1])
+  const T *rowLR, *rowE;  // M x 24, M
+  const int *crowptr;     // compact rows
+  const T *rowC, *rowCE;  // Mc x 12, Mc
+};
+
+template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
+template <> __device__ __forceinline__ void lane_gather<12>(double v, double *d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b64_dpp %0, %12 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %1, %12 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %2, %12 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %3, %12 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %4, %12 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %5, %12 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %6, %12 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %7, %12 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %8, %12 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %9, %12 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %10, %12 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %11, %12 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]),
+        "=&v"(d[8]), "=&v"(d[9]), "=&v"(d[10]), "=&v"(d[11])
+      : "v"(v));
+}
+template <> __device__ __forceinline__ void lane_gather<6>(double v, double *d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b64_dpp %0, %6 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %1, %6 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %2, %6 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %3, %6 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %4, %6 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %5, %6 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5])
+      : "v"(v));
+}
+
+// LDS-only workgroup barrier: the two waves exchange nothing but LDS, so neither the factor stores nor the row loads
+// in flight are drained (which __syncthreads() would do)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
+  const FwdArgs<double> &a = u.f;
+  constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
+  constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
+  typedef double V2 __attribute__((ext_vector_type(2)));
+  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15;
+  const int c = blockIdx.x * 4 + grp;
+  const int nch = (a.n + a.m - 1) / a.m;
+  const bool valid = c < nch;
+  const int s = valid ? c * a.m : 0;
+  const int e = valid ? min(s + a.m, a.n) : 0;
+  const int j0 = s + 1;
+  const bool rowlane = r < B;
+  const int rr = rowlane ? r : 0;
+  const bool right_exists = (e < a.n) || (a.last_has_right != 0);
+  const bool has_int = valid && j0 < e;
+  const double lambda = a.lambda;
+  __shared__ __attribute__((aligned(16))) double IMG[2 * 4 * BS];    // two rotating record images per chunk
+  __shared__ __attribute__((aligned(16))) double OUTR[4 * BS];       // the factor record on its way out
+  int ro = grp * BS + rr * B;     // row r of an image:    IMG[buf * 4 BS + ro + k]
+  int co = grp * BS + rr;         // column r:             IMG[... + co + k * B]
+  int po = grp * BS + 2 * r;      // 16-byte piece q * 16 + r of OUTR
+  asm volatile("" : "+v"(ro), "+v"(co), "+v"(po));
+  const int steps = __builtin_amdgcn_readfirstlane(max(e - j0, 0));   // lane 0: the wave's first (never shorter) chunk
+
+  if (role == 1) {
+    // ================================================================ ASM: images 0 .. steps + 1
+    // Everything that has a memory latency is requested one state ahead: the row pointers of state t + 2 and the first
+    // PF rows (full-width and compact) of state t + 1 are in flight while state t is accumulated.
+    constexpr int PF = 6, Dh = B / 2;
+    const int rc = r < Dh ? r : 0;
+    const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
+    double carry[B], carry_g = 0.0;
+#pragma unroll
+    for (int k = 0; k < B; k++) carry[k] = 0.0;
+    double Dacc[B], Oacc[B], gacc;
+    double fL[PF], fR[PF], fE[PF], cL[PF], cR[PF], cE[PF];   // the two operand rings
+    int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
+    int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
+    int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
+    auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
+      const int rho = rp + min(i, max(nf - 1, 0));
+      const double *row = u.rowLR + (size_t)rho * 2 * B;
+      Lv = row[rr]; Rv = row[B + rr]; ev = u.rowE[rho];
+    };
+    auto ldc = [&](int i, double &Lv, double &Rv, double &ev) {
+      const int rho = cp + min(i, max(nc - 1, 0));
+      const double *row = u.rowC + (size_t)rho * B;
+      Lv = row[rc]; Rv = row[Dh + rc]; ev = u.rowCE[rho];
+    };
+    // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
+    auto open_state = [&](int kimg, int p0, int p1, int q0, int q1) {
+      const bool live = valid && (s + kimg) < e;
+      rp = live ? p0 : 0; nf = live ? p1 - p0 : 0;
+      cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
+#pragma unroll
+      for (int q = 0; q < PF; q++) { ldf(q, fL[q], fR[q], fE[q]); ldc(q, cL[q], cR[q], cE[q]); }
+    };
+    auto assemble = [&](int kimg) {
+      const bool live = valid && (s + kimg) < e;
+      int nfm = nf, ncm = nc;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { nfm = max(nfm, __shfl_xor(nfm, o, 64)); ncm = max(ncm, __shfl_xor(ncm, o, 64)); }
+      nfm = __builtin_amdgcn_readfirstlane(nfm);
+      ncm = __builtin_amdgcn_readfirstlane(ncm);
+      double RRacc[B], grr = 0.0;
+#pragma unroll
+      for (int k = 0; k < B; k++) { Dacc[k] = carry[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
+      gacc = carry_g;
+      for (int i0 = 0; i0 < nfm; i0 += PF) {             // full-width rows
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int i = i0 + q;
+          const bool ok = i < nf;
+          const double Lv = ok ? fL[q] : 0.0, Rv = ok ? fR[q] : 0.0, ev = ok ? fE[q] : 0.0;
+          double tb[B];
+          lane_gather<12>(Lv, tb);
+#pragma unroll
+          for (int k = 0; k < B; k++) { Dacc[k] = fma(Lv, tb[k], Dacc[k]); Oacc[k] = fma(Rv, tb[k], Oacc[k]); }
+          lane_gather<12>(Rv, tb);
+#pragma unroll
+          for (int k = 0; k < B; k++) RRacc[k] = fma(Rv, tb[k], RRacc[k]);
+          gacc = fma(-Lv, ev, gacc);
+          grr = fma(-Rv, ev, grr);
+          ldf(i + PF, fL[q], fR[q], fE[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      for (int i0 = 0; i0 < ncm; i0 += PF) {             // compact rows (velocity-free): six columns each side
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+          const int i = i0 + q;
+          const bool ok = (i < nc) && (r < Dh);
+          const double Lv = ok ? cL[q] : 0.0, Rv = ok ? cR[q] : 0.0, ev = (i < nc) ? cE[q] : 0.0;
+          double tb[Dh];
+          lane_gather<6>(Lv, tb);
+#pragma unroll
+          for (int k = 0; k < Dh; k++) { Dacc[k] = fma(Lv, tb[k], Dacc[k]); Oacc[k] = fma(Rv, tb[k], Oacc[k]); }
+          lane_gather<6>(Rv, tb);
+#pragma unroll
+          for (int k = 0; k < Dh; k++) RRacc[k] = fma(Rv, tb[k], RRacc[k]);
+          gacc = fma(-Lv, ev, gacc);
+          grr = fma(-Rv, ev, grr);
+          ldc(i + PF, cL[q], cR[q], cE[q]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (live) {   // Levenberg-Marquardt damping on the diagonal of a real state's D
+#pragma unroll
+        for (int k = 0; k < B; k++) Dacc[k] += (k == r) ? lambda : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < B; k++) carry[k] = RRacc[k];
+      carry_g = grr;
+      // the next state: its row range is known, open its rings; fetch the pointers of the state after it
+      open_state(kimg + 1, rpn, rpnn, cpn, cpnn);
+      rpn = rpnn; cpn = cpnn;
+      rpnn = u.rowptr[min(s + kimg + 3, ptr_max)];
+      cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
+    };
+    auto write_img = [&](int buf) {
+      if (rowlane) {
+        double *img = IMG + buf * 4 * BS;
+#pragma unroll
+        for (int k = 0; k < B; k++) { img[ro + k] = Dacc[k]; img[ro + B * B + k] = Oacc[k]; }
+        img[co + 2 * B * B] = gacc;
+      }
+    };
+    open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn);
+    assemble(0); write_img(0);
+    assemble(1); write_img(1);
+    lds_barrier();                       // P: images 0 and 1 are there
+    assemble(2);
+    lds_barrier();                       // Q: ELIM has taken what it needs from image 0
+    write_img(0);
+    for (int t = 0; t < steps; t++) {
+      lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
+      if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1); }
+    }
+    return;
+  }
+
+  // ================================================================== ELIM (k_chunk_forward_rows on LDS images)
+  double Dr[B], Or[B], Fr[B], Gr[B], Ar[B];
+  double gr, as_;
+  lds_barrier();                         // P
+#pragma unroll
+  for (int k = 0; k < B; k++) {
+    Ar[k] = IMG[ro + k];                           // image 0: the separator
+    Fr[k] = IMG[ro + B * B + k];
+    Gr[k] = IMG[co + B * B + k * B];
+    Dr[k] = IMG[4 * BS + ro + k];                  // image 1: the first interior state (or the virtual end record)
+    Or[k] = IMG[4 * BS + co + B * B + k * B];
+  }
+  as_ = IMG[co + 2 * B * B];
+  gr = IMG[4 * BS + co + 2 * B * B];
+  lds_barrier();                         // Q
+  if (valid && !has_int && rowlane) {    // chunk without interior: the separator keeps its coupling, its rows' R^T R is owed
+    double *ub = a.up_blk + (size_t)c * BS;
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      ub[r * B + k] = Ar[k];
+      ub[B * B + r * B + k] = right_exists ? Fr[k] : 0.0;
+    }
+    ub[2 * B * B + r] = as_;
+    if (right_exists) {
+      double *ua = a.up_add + (size_t)(c + 1) * AS;
+#pragma unroll
+      for (int k = 0; k < B; k++) ua[r * B + k] = Dr[k];
+      ua[B * B + r] = gr;
+    }
+  }
+  for (int t = 0; t < steps; t++) {
+    const int j = j0 + t;
+    const bool live = j < e, lastb = (j == e - 1);
+    const double *cur = IMG + ((t + 1) & 1) * 4 * BS, *nxt = IMG + (t & 1) * 4 * BS;   // images t + 1 and t + 2
+    double invs = 1.0;
+    bool bad = false;
+    static_for<0, B>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const double piv = row_bcast<k>(Dr[k]);
+      bad = bad || !(piv > 0.0);
+      const double inv = fast_rcp(piv);
+      const bool isk = (r == k);
+      invs = isk ? inv : invs;
+      const double mp = isk ? 0.0 : Dr[k] * inv;
+      double tb[B];
+      row_bcast12<k>(Dr, tb);
+#pragma unroll
+      for (int q = k + 1; q < B; q++) Dr[q] = fma(-mp, tb[q], Dr[q]);
+      row_bcast12<k>(Or, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) Or[q] = fma(-mp, tb[q], Or[q]);
+      row_bcast12<k>(Fr, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) Fr[q] = fma(-mp, tb[q], Fr[q]);
+      gr = fma(-mp, row_bcast<k>(gr), gr);
+    });
+    if (bad && live && r == 0) *a.flag = 1;
+    __builtin_amdgcn_sched_barrier(0);
+    double Ol[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) Ol[k] = cur[ro + B * B + k];          // row r of O_j
+#pragma unroll
+    for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
+    gr *= invs;
+    if (rowlane) {
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        OUTR[co + k * B] = Fr[k];
+        OUTR[co + B * B + k * B] = Or[k];
+      }
+      OUTR[co + 2 * B * B] = gr;
+    }
+    lds_barrier();                       // step t
+    if (live) {
+      V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
+#pragma unroll
+      for (int q = 0; q < NV; q++) {
+        const int idx = q * 16 + r;
+        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);
+      }
+    }
+    double Dn[B], Fn[B], Gn[B], gn;
+#pragma unroll
+    for (int k = 0; k < B; k++) { Dn[k] = nxt[ro + k]; Gn[k] = 0.0; }
+    gn = nxt[co + 2 * B * B];
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const double ol = Ol[i], gg = Gr[i];
+      double tb[B];
+      row_bcast12<i>(Or, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) {
+        Dn[q] = fma(-ol, tb[q], Dn[q]);
+        Gn[q] = fma(-gg, tb[q], Gn[q]);
+      }
+      const double yb = row_bcast<i>(gr);
+      gn = fma(-ol, yb, gn);
+      as_ = fma(-gg, yb, as_);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Gn[k]), "+v"(Dn[k]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) Fn[k] = 0.0;
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const double ol = Ol[i], gg = Gr[i];
+      double tb[B];
+      row_bcast12<i>(Fr, tb);
+#pragma unroll
+      for (int q = 0; q < B; q++) {
+        Fn[q] = fma(-ol, tb[q], Fn[q]);
+        Ar[q] = fma(-gg, tb[q], Ar[q]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
+#pragma unroll
+    for (int k = 0; k < B; k++) {
+      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = Gn[k];
+      Or[k] = nxt[co + B * B + k * B];
+    }
+    gr = gn;
+    __builtin_amdgcn_sched_barrier(0);
+    if (live && lastb && rowlane) {
+      double *ub = a.up_blk + (size_t)c * BS;
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        ub[r * B + k] = Ar[k];
+        ub[B * B + r * B + k] = right_exists ? Fr[k] : 0.0;
+      }
+      ub[2 * B * B + r] = as_;
+      if (right_exists) {
+        double *ua = a.up_add + (size_t)(c + 1) * AS;
+#pragma unroll
+        for (int k = 0; k < B; k++) ua[r * B + k] = Dr[k];   // -O U + R^T R of the chunk's last rows
+        ua[B * B + r] = gr;
+      }
+    }
+  }
+}
+
 template <typename T> struct BwdArgs {
   const T *blk;   // eliminated records of this level
   T *x;           // n x R x B solutions of this level (+ one slot for the neighbour rank's separator)
