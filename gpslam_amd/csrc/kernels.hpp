@@ -2255,45 +2255,47 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   const int j0 = has_sep ? s + 1 : s;
   const int pieces = BS / 2;                                      // BS is even (B is)
   V2 ring[PFB][NP];
+  // The record loads are UNCONDITIONAL (record index clamped into the chunk, piece index into the record): a load under
+  // a branch -- or a ring slot that is only sometimes refilled -- makes the compiler's wait-count bookkeeping give up
+  // and drain vmcnt to zero at every step, which turns the 3-deep prefetch into none at all and additionally waits
+  // for the x stores (2.6 us per block step measured, a full memory round trip).  Steps past the chunk's first
+  // interior record recompute harmlessly; only their x store is masked.
+  const int jlo = min(j0, e - 1);
   auto arm = [&](int u, int j) {
-    if (j >= j0) {
-      const V2 *src = reinterpret_cast<const V2 *>(a.blk + (size_t)j * BS);
+    const V2 *src = reinterpret_cast<const V2 *>(a.blk + (size_t)max(j, jlo) * BS);
 #pragma unroll
-      for (int p = 0; p < NP; p++)
-        if (lane + 64 * p < pieces) ring[u][p] = src[lane + 64 * p];
-    }
+    for (int p = 0; p < NP; p++) ring[u][p] = src[min(lane + 64 * p, pieces - 1)];
   };
+  if (j0 < e) {
 #pragma unroll
-  for (int u = 0; u < PFB; u++) arm(u, e - 1 - u);
+    for (int u = 0; u < PFB; u++) arm(u, e - 1 - u);
+  }
   int ping = 0;
   for (int base = e - 1; base >= j0; base -= PFB) {
 #pragma unroll
     for (int u = 0; u < PFB; u++) {
       const int j = base - u;
-      if (j >= j0) {                                              // wave-uniform
-        V2 *rv = reinterpret_cast<V2 *>(rec);
+      V2 *rv = reinterpret_cast<V2 *>(rec);
 #pragma unroll
-        for (int p = 0; p < NP; p++)
-          if (lane + 64 * p < pieces) rv[lane + 64 * p] = ring[u][p];
-        arm(u, j - PFB);
-        wave_lds_sync();
-        const T *cur = ping ? xb : xa;
-        T *nx = ping ? xa : xb;
-        if (active) {
-          T Ur[B], Vr[B];
+      for (int p = 0; p < NP; p++) rv[lane + 64 * p] = ring[u][p];
+      arm(u, j - PFB);
+      wave_lds_sync();
+      const T *cur = ping ? xb : xa;
+      T *nx = ping ? xa : xb;
+      if (active) {
+        T Ur[B], Vr[B];
 #pragma unroll
-          for (int q = 0; q < B; q++) { Ur[q] = rec[B * B + q * B + k]; Vr[q] = has_sep ? rec[q * B + k] : T(0); }
-          for (int r = rr; r < R; r += RG) {
-            T v = rec[2 * B * B + r * B + k];
+        for (int q = 0; q < B; q++) { Ur[q] = rec[B * B + q * B + k]; Vr[q] = has_sep ? rec[q * B + k] : T(0); }
+        for (int r = rr; r < R; r += RG) {
+          T v = rec[2 * B * B + r * B + k];
 #pragma unroll
-            for (int q = 0; q < B; q++) v -= Ur[q] * cur[r * B + q] + Vr[q] * xs[r * B + q];
-            nx[r * B + k] = v;
-            a.x[(size_t)j * R * B + r * B + k] = v;
-          }
+          for (int q = 0; q < B; q++) v -= Ur[q] * cur[r * B + q] + Vr[q] * xs[r * B + q];
+          nx[r * B + k] = v;
+          if (j >= j0) a.x[(size_t)j * R * B + r * B + k] = v;
         }
-        wave_lds_sync();
-        ping ^= 1;
       }
+      wave_lds_sync();
+      ping ^= 1;
     }
   }
 }
