@@ -393,11 +393,13 @@ bool rows_kernel_applies(const gpslam_hip_handle *h) {
   static const bool off = getenv("GPSLAM_FWD_ROWS") && atoi(getenv("GPSLAM_FWD_ROWS")) == 0;
   return h->b == 12 && h->R == 1 && !off;
 }
-// k_fused_level0 (assembly inside the level-0 elimination): unsharded Pose3 chains without landmark columns
+// k_fused_level0 (assembly inside the level-0 elimination): Pose3 chains without landmark columns; on a sharded handle
+// the rows of the last local state carry their R^T R to the next rank inside the addend the last chunk sends upward,
+// which is what k_assemble_ghost's halo addend used to hold
 // (GPSLAM_FUSE_K3=0 keeps k_assemble_ghost + k_chunk_forward_rows, for A/B measurements)
 bool fused_kernel_applies(const gpslam_hip_handle *h) {
   static const bool off = getenv("GPSLAM_FUSE_K3") && atoi(getenv("GPSLAM_FUSE_K3")) == 0;
-  return rows_kernel_applies(h) && !sharded(h) && h->nl == 0 && !off;
+  return rows_kernel_applies(h) && h->nl == 0 && !off;
 }
 void launch_fwd(gpslam_hip_handle *h, const FwdArgs<Real> &a, int grid) {
   const bool fast = (4 * h->b + 2 * h->R <= 64);   // room for the separator sums in spare lanes
@@ -1550,8 +1552,11 @@ int gpslam_hip_iterate_phase1(gpslam_hip_handle *h, double lambda) {
   h->ph_lambda = lambda;
   HIPCHK(hipMemsetAsync(h->flag.p, 0, sizeof(int), h->stream));
   if ((rc = launch_factors(h, 0, 0))) return rc;
-  if ((rc = launch_assemble(h, false))) return rc;
-  return launch_forward(h, lambda);
+  if (!h->fuse_ok && (rc = launch_assemble(h, false))) return rc;
+  h->fuse_now = h->fuse_ok;
+  rc = launch_forward(h, lambda);
+  h->fuse_now = false;
+  return rc;
 }
 
 // phase 2 (after the all-gather of the records into interface_recv): every rank solves the P-block reduced
