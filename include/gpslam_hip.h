@@ -214,7 +214,7 @@ int gpslam_hip_run_gn(gpslam_hip_handle *h, int32_t iters, gpslam_hip_stats *st,
 /* average device time (ms, hipEvents on the handle's stream) of ONE launch of a hot kernel over `reps` launches:
  * which = 0 GP-prior linearisation (K1), 1 normal-equation assembly (K3), 2 level-0 forward elimination (K4),
  * 3 level-0 back-substitution, 4 retract (K6).  Inputs are re-created (untimed) before every timed launch.
- * Unsharded Pose3 chains without landmarks run the assembly INSIDE the level-0 elimination (k_fused_level0): there
+ * Pose3 chains without landmarks run the assembly INSIDE the level-0 elimination (k_fused_level0): there
  * which = 1 reports 0.0 (no such launch in an iteration) and which = 2 times the fused kernel. */
 int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, double *avg_ms);
 
