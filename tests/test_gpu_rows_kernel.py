@@ -4,6 +4,7 @@ chunk without interior (n mod m == 1), chunks of 2 (one interior block), explici
 automatic one, and Levenberg-Marquardt damping (lambda added to the staged record images)."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  -- before the HIP library: torch ships its own HIP runtime, and whichever loads first must be it
 
 from oracle import oracle as O
 import test_gpu_parity as T
@@ -58,3 +59,32 @@ def test_rows_kernel_matches_block_tridiag_solve_api():
     r[1:] += np.einsum('sij,sj->si', Oo[:-1], x[:-1])
     r[:-1] += np.einsum('sji,sj->si', Oo[:-1], x[1:])
     assert np.abs(r).max() <= 1e-9 * np.abs(g).max() * 1e3
+
+
+def test_fused_level0_damped_step_matches_unfused_trial():
+    """A damped Gauss-Newton step two ways on a forced-sharded single segment: iterate(lambda) goes through
+    k_fused_level0 (the assembly wave adds lambda to the diagonals it forms), an accepted first Levenberg-Marquardt
+    trial with the same lambda goes through k_assemble_ghost + k_chunk_forward_rows (lambda added to the staged
+    records).  Same states afterwards."""
+    import torch
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose3_chain(700)
+    lam = 1e-2
+    out = []
+    for use_lm in (False, True):
+        s = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=0, rank=0, nranks=1, force_sharded=True)
+        s.set_stream(torch.cuda.current_stream().cuda_stream)
+        sharded.apply_local(sharded.local_problem(problem, 0, 1), s)
+        send, recv = sharded.device_tensors(s)
+        sv = sharded.ShardedSolver(s, send, recv, 0, 1, dist=None)
+        if use_lm:
+            st, lam_new = sv.iterate_lm(lam)
+            assert st["accepted"] and abs(lam_new - lam / 10.0) <= 1e-15      # the first trial was taken
+        else:
+            sv.iterate(lam)
+        torch.cuda.synchronize()
+        out.append(s.get_states())
+    (p0, v0), (p1, v1) = out
+    assert np.abs(p0 - p1).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+    assert np.abs(v0 - v1).max() <= 1e-9 * max(1.0, np.abs(v0).max())
