@@ -220,7 +220,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N),
                          "traffic_source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum, "
                                            "profiles/latest_pmc.json (bytes per launch, same workload)",
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom]},
+                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom],
+                         # what actually limits the kernel the HBM fraction is quoted for
+                         "note": ("VALU-issue bound, not HBM bound: two-wave workgroups (assembly + elimination), ~3200 fp64 "
+                                  "VALU instructions per workgroup block step, one fat wave of each kind per SIMD"
+                                  if fused and dom == 2 else None)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem)
