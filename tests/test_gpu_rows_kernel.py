@@ -88,3 +88,31 @@ def test_fused_level0_damped_step_matches_unfused_trial():
     (p0, v0), (p1, v1) = out
     assert np.abs(p0 - p1).max() <= 1e-9 * max(1.0, np.abs(p0).max())
     assert np.abs(v0 - v1).max() <= 1e-9 * max(1.0, np.abs(v0).max())
+
+
+def test_fused_level0_with_measurement_rows_and_ragged_row_counts():
+    """Pose3 + GPInterpolatedGPSFactorPose3 at an irregular rate + scattered pose / velocity priors: the states of a
+    chunk have different numbers of full-width and compact rows, which the assembly wave of k_fused_level0 has to walk
+    in lock-step over four chunks.  Gauss-Newton against the oracle."""
+    gp = T.gpu()
+    from gpslam_amd import synthetic as S
+    N = 420
+    p = S.pose3_gps_chain(N, per_interval=3, seed=4)
+    rng = np.random.default_rng(11)
+    keep = rng.random(len(p["gps_left"])) < 0.6                 # 0 .. 3 GPS factors per interval
+    for k in ("gps_left", "gps_meas", "gps_sigma", "gps_dt", "gps_tau"):
+        p[k] = p[k][keep]
+    fix = np.sort(rng.choice(N, 25, replace=False)).astype(np.int32)
+    p.update(prior_idx=fix, prior_pose=p["pose"][fix].copy(), prior_sig=np.full((len(fix), 6), 0.05))
+    vfix = np.sort(rng.choice(N, 17, replace=False)).astype(np.int32)
+    p.update(vprior_idx=vfix, vprior=p["vel"][vfix].copy(), vprior_sig=np.full((len(vfix), 6), 0.1))
+    for chunk in (0, 7):
+        orc = S.apply(p, O.Chain(O.POSE3))
+        dev = S.apply(p, gp.ChainSolver(O.POSE3, chunk=chunk))
+        for it in range(4):
+            rc0, s0 = orc.iterate_gn()
+            rc1, s1 = dev.iterate_gn()
+            assert rc0 == 0 and rc1 == 0
+            assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), (chunk, it)
+        (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+        T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
