@@ -2145,9 +2145,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
         if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);
       }
     }
-    double Dn[B], Fn[B], Gn[B], gn;
+    double Dn[B], Fn[B], gn;
 #pragma unroll
-    for (int k = 0; k < B; k++) { Dn[k] = nxt[ro + k]; Gn[k] = 0.0; }
+    for (int k = 0; k < B; k++) Dn[k] = nxt[ro + k];
     gn = nxt[co + 2 * B * B];
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, B>([&](auto ii) {
@@ -2156,17 +2156,14 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       double tb[B];
       row_bcast12<i>(Or, tb);
 #pragma unroll
-      for (int q = 0; q < B; q++) {
-        Dn[q] = fma(-ol, tb[q], Dn[q]);
-        Gn[q] = fma(-gg, tb[q], Gn[q]);
-      }
+      for (int q = 0; q < B; q++) Dn[q] = fma(-ol, tb[q], Dn[q]);
       const double yb = row_bcast<i>(gr);
       gn = fma(-ol, yb, gn);
       as_ = fma(-gg, yb, as_);
       __builtin_amdgcn_sched_barrier(0);
     });
 #pragma unroll
-    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Gn[k]), "+v"(Dn[k]));
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Dn[k]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
@@ -2185,12 +2182,20 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
+    // G_{j+1} = F_{j+1}^T by a transpose through LDS (the V area of the factor image, copied out long ago) instead of
+    // the recurrence G_{j+1} = -G_j U_j: 24 LDS operations for 144 multiply-adds
+    if (rowlane) {
+#pragma unroll
+      for (int k = 0; k < B; k++) OUTR[ro + k] = Fn[k];
+    }
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < B; k++) {
-      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = Gn[k];
+      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = OUTR[co + k * B];
       Or[k] = nxt[co + B * B + k * B];
     }
     gr = gn;
+    wave_lds_sync();
     __builtin_amdgcn_sched_barrier(0);
     if (live && lastb && rowlane) {
       double *ub = a.up_blk + (size_t)c * BS;
