@@ -5,6 +5,7 @@
 //   row table   AoS   one record per whitened Jacobian row: rowLR[rho][2b] = [dL | dR], rowE[rho]
 //                     rows are grouped by the LEFT state of their factor; rowptr[s] .. rowptr[s+1]
 //   blocks      AoS   per state one record [D (b x b) | O (b x b) | G (R cols of b)], O_s = H[s+1, s]
+//                     (k_fused_level0 never writes them: it forms them in LDS)
 //   solver      the same records, overwritten in place by the elimination with [V | U | Y]
 //
 // Kernels:
@@ -15,6 +16,10 @@
 //   k_interp_query     batched interpolatePose of the current estimate
 //   k_chunk_forward / k_chunk_backward   partitioned block Gauss-Jordan, one wave per chunk,
 //                 one panel column per lane, pivot broadcast through v_readlane            [K4]
+//   k_chunk_forward_rows   level 0 for block size 12: four chunks per wave on 16-lane DPP rows, panel ROWS in lanes,
+//                 pivot rows by v_mov_b64_dpp row_newbcast                                  [K4]
+//   k_fused_level0     K3 inside K4 level 0: two-wave workgroups, one wave assembles the block records of four
+//                 chunks from the row tables, the other eliminates them (LDS hand-over)      [K3 + K4]
 //   k_retract     x <- x (+) delta, |delta|_inf                                            [K6]
 #pragma once
 
