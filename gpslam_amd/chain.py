@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
-    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject",
+    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors",
 ]
 
 
@@ -217,6 +217,10 @@ class ChainSolver:
         bearing, rng, sigmas = _f64(bearing), _f64(rng), _f64(sigmas)
         return self._chk(self.lib.gpslam_hip_add_bearing_range(self._h, len(idx), _p(idx), _p(landmark), _p(bearing),
                                                                _p(rng), _p(sigmas)), "add_bearing_range")
+
+    def clear_factors(self):
+        self.n_gp = 0
+        return self._chk(self.lib.gpslam_hip_clear_factors(self._h), "clear_factors")
 
     def compile(self):
         return self._chk(self.lib.gpslam_hip_compile(self._h), "compile")

@@ -60,12 +60,13 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
   bool two = false, haslm = false, interp = false;
   std::vector<int32_t> idx, lm;
   std::vector<double> meas, sig, dt, tau;
-  bool has_sensor = false;
-  double sensor[12] = {0};
-  double calib[5] = {1, 1, 0, 0, 0};   // Cal3_S2 of the projection factor
-  DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0;
+  // body_P_sensor / Cal3_S2 per factor: a table of distinct kMeasAux-wide entries and one index per factor
+  std::vector<double> aux;
+  std::vector<int32_t> aidx;
+  bool any_aux = false;                // some factor of this kind carries a sensor transform or a calibration
+  DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0, d_aux, d_aidx;
   int count() const { return (int)idx.size(); }
-  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); }
+  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); d_aux.release(); d_aidx.release(); }
 };
 
 }  // namespace
@@ -332,9 +333,7 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     a.lmk = h->lmk.as<Real>(); a.ld = h->ld; a.count = s.count(); a.chart = h->cfg.chart;
     a.idx = s.d_idx.as<int>(); a.lm = s.d_lm.as<int>(); a.meas = s.d_meas.as<Real>(); a.mw = s.mw;
     a.sig = s.d_sig.as<Real>(); a.coef = s.d_coef.as<Real>();
-    for (int k = 0; k < 12; k++) a.sensor[k] = (Real)s.sensor[k];
-    a.has_sensor = s.has_sensor ? 1 : 0;
-    for (int k = 0; k < 5; k++) a.calib[k] = (Real)s.calib[k];
+    a.aux = s.any_aux ? s.d_aux.as<Real>() : nullptr; a.aidx = s.any_aux ? s.d_aidx.as<int>() : nullptr;
     a.vw = h->vw;
     a.row0 = s.d_row0.as<int>();
     a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>(); a.rowLm = h->rowLm.as<int>();
@@ -530,7 +529,7 @@ int launch_solve(gpslam_hip_handle *h, double lambda) {
 int launch_retract(gpslam_hip_handle *h, int slot) {
   RetractArgs<Real> a;
   a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = h->N; a.R = h->R;
-  a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
+  a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>(); a.flag = h->flag.as<int>();
   const int nb = nblocks(h->N, 128);
   dispatch_mf(h->mf, [&](auto tag) {
     constexpr int MF = decltype(tag)::value;
@@ -611,12 +610,11 @@ int max_left(const gpslam_hip_handle *h) { return h->N - 2 + (has_right_rank(h) 
 
 int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool haslm, bool interp, bool ok_mf,
              int32_t count, const int32_t *idx, const int32_t *lm, const double *meas, const double *sig,
-             const double *dt, const double *tau, const double *sensor) {
+             const double *dt, const double *tau, const double *sensor, const double *calib = nullptr) {
   if (!h || count < 0) return GPSLAM_E_INVALID;
   if (!ok_mf) return fail(h, GPSLAM_E_INVALID, "this factor does not exist for the handle's manifold / landmark dimension");
   if (count > 0 && (!idx || !meas || !sig || (haslm && !lm) || (interp && (!dt || !tau)))) return GPSLAM_E_INVALID;
   MeasSet &s = h->ms[fk];
-  if (s.count() > 0 && ((sensor != nullptr) != s.has_sensor)) return fail(h, GPSLAM_E_UNSUPPORTED, "one body_P_sensor per factor kind");
   const int mx = two ? max_left(h) : h->N - 1;
   for (int k = 0; k < count; k++) {
     if (idx[k] < 0 || idx[k] > mx) return fail(h, GPSLAM_E_INVALID, "factor state index out of range");
@@ -631,7 +629,18 @@ int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool hasl
   s.meas.insert(s.meas.end(), meas, meas + (size_t)count * mw);
   s.sig.insert(s.sig.end(), sig, sig + (size_t)count * rows);
   if (interp) { s.dt.insert(s.dt.end(), dt, dt + count); s.tau.insert(s.tau.end(), tau, tau + count); }
-  if (sensor) { s.has_sensor = true; std::memcpy(s.sensor, sensor, sizeof(double) * h->pd); }
+  {   // this call's body_P_sensor / calibration: find it in (or append it to) the kind's table
+    double ent[kMeasAux] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    if (sensor) { std::memcpy(ent, sensor, sizeof(double) * h->pd); ent[17] = 1.0; }
+    if (calib) std::memcpy(ent + 12, calib, sizeof(double) * 5);
+    int slot = -1;
+    const int nent = (int)(s.aux.size() / kMeasAux);
+    for (int q = 0; q < nent && slot < 0; q++)
+      if (std::memcmp(&s.aux[(size_t)q * kMeasAux], ent, sizeof(ent)) == 0) slot = q;
+    if (slot < 0) { slot = nent; s.aux.insert(s.aux.end(), ent, ent + kMeasAux); }
+    s.aidx.insert(s.aidx.end(), (size_t)count, slot);
+    if (sensor || calib) s.any_aux = true;
+  }
   h->compiled = false;
   return 0;
 }
@@ -918,11 +927,7 @@ int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const 
                                      const double *K, const double *sensor) {
   if (!h || !K) return GPSLAM_E_INVALID;
   if (h->vw) return fail(h, GPSLAM_E_UNSUPPORTED, "the reference has no projection factor for the VW velocity family");
-  MeasSet &s = h->ms[FK_INTERP_PROJ];
-  if (s.count() > 0 && std::memcmp(s.calib, K, sizeof(s.calib)) != 0) return fail(h, GPSLAM_E_UNSUPPORTED, "one calibration per handle");
-  int rc = add_meas(h, FK_INTERP_PROJ, 2, 2, true, true, true, h->mf == POSE3 && h->ld == 3, count, left, landmark, measured, sigmas, dt, tau, sensor);
-  if (rc == 0) std::memcpy(s.calib, K, sizeof(s.calib));
-  return rc;
+  return add_meas(h, FK_INTERP_PROJ, 2, 2, true, true, true, h->mf == POSE3 && h->ld == 3, count, left, landmark, measured, sigmas, dt, tau, sensor, K);
 }
 int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas) {
@@ -938,10 +943,32 @@ int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int3
   return add_meas(h, FK_BEARING_RANGE, 2, 2, false, true, false, h->mf == LINEAR3 && h->ld == 2, count, idx, landmark, m.data(), sigmas, nullptr, nullptr, nullptr);
 }
 
+int gpslam_hip_clear_factors(gpslam_hip_handle *h) {
+  if (!h) return GPSLAM_E_INVALID;
+  h->gp_left.clear(); h->gp_dt.clear();
+  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) { s->idx.clear(); s->meas.clear(); s->sig.clear(); }
+  for (MeasSet &s : h->ms) {
+    s.idx.clear(); s.lm.clear(); s.meas.clear(); s.sig.clear(); s.dt.clear(); s.tau.clear(); s.aux.clear(); s.aidx.clear();
+    s.any_aux = false;
+  }
+  h->compiled = false;
+  return 0;
+}
+
 int gpslam_hip_compile(gpslam_hip_handle *h) {
   if (!h || h->N <= 0) return GPSLAM_E_INVALID;
   (void)hipSetDevice(h->cfg.device);
   const int N = h->N, d = h->d, b = h->b;
+  {   // factors were range-checked against the N and L of the moment they were added; set_states / set_landmarks may
+      // have shrunk either since: re-validate every stored index before it is used to size or index anything
+    const int ml = max_left(h);
+    auto bad = [](const std::vector<int32_t> &v, int hi) { for (int32_t i : v) if (i < 0 || i > hi) return true; return false; };
+    if (bad(h->gp_left, ml) || bad(h->btw.idx, ml) || bad(h->pri.idx, N - 1) || bad(h->vpri.idx, N - 1) || bad(h->lpri.idx, h->L - 1))
+      return fail(h, GPSLAM_E_INVALID, "a stored factor refers to a state / landmark that no longer exists (set_states / set_landmarks shrank the problem)");
+    for (const MeasSet &s : h->ms)
+      if (bad(s.idx, s.two ? ml : N - 1) || (s.haslm && bad(s.lm, h->L - 1)))
+        return fail(h, GPSLAM_E_INVALID, "a stored measurement factor refers to a state / landmark that no longer exists");
+  }
   h->nl = h->L * h->ld;
   h->R = 1 + h->nl;
   if (3 * b + h->R > 64 || h->R > kMaxRhs)
@@ -1005,6 +1032,8 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     std::vector<double> coef((size_t)(s.interp ? s.count() : 0) * 4);
     for (int k = 0; k < (s.interp ? s.count() : 0); k++) interp_coef(s.dt[k], s.tau[k], &coef[4 * (size_t)k]);
     if ((rc = upload_real(h, s.d_coef, coef))) return rc;
+    if ((rc = upload_real(h, s.d_aux, s.aux))) return rc;
+    if ((rc = upload(h, s.d_aidx, s.aidx))) return rc;
     npart += nblocks(s.count(), 128);
   }
   const size_t Mrows = (size_t)std::max(h->M, 1);
@@ -1506,7 +1535,7 @@ int gpslam_hip_time_kernel(gpslam_hip_handle *h, int32_t which, int32_t reps, do
       HIPCHK(hipEventRecord(h->ev[0], h->stream));
       RetractArgs<Real> a;
       a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = h->N; a.R = h->R;
-      a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>();
+      a.chart = h->cfg.chart; a.first = 0; a.x = h->lv[0].x.as<Real>(); a.partial = h->partial.as<Real>(); a.flag = h->flag.as<int>();
       dispatch_mf(h->mf, [&](auto tag) {
         constexpr int MF = decltype(tag)::value;
         k_retract<Real, MF><<<dim3(nblocks(h->N, 128)), dim3(128), 0, h->stream>>>(a);
@@ -1614,7 +1643,7 @@ int gpslam_hip_iterate_phase2b(gpslam_hip_handle *h, gpslam_hip_stats *st) {
     }
     RetractArgs<Real> a;
     a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = 1; a.R = R;
-    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4;
+    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4; a.flag = h->flag.as<int>();
     dispatch_mf(h->mf, [&](auto tag) {
       constexpr int MF = decltype(tag)::value;
       k_retract<Real, MF><<<dim3(1), dim3(128), 0, h->stream>>>(a);
@@ -1701,7 +1730,7 @@ int gpslam_hip_lm_trial_phase2(gpslam_hip_handle *h, double *out6) {
   if (has_right_rank(h)) {
     RetractArgs<Real> a;
     a.pose = h->pose.as<Real>(); a.vel = h->vel.as<Real>(); a.stride = h->stride; a.N = 1; a.R = R;
-    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4;
+    a.chart = h->cfg.chart; a.first = h->N; a.x = xtop + (size_t)b * R; a.partial = h->partial.as<Real>() + nblocks(h->N, 128) + 4; a.flag = h->flag.as<int>();
     dispatch_mf(h->mf, [&](auto tag) {
       constexpr int MF = decltype(tag)::value;
       k_retract<Real, MF><<<dim3(1), dim3(128), 0, h->stream>>>(a);

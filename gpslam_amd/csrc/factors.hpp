@@ -398,7 +398,7 @@ template <typename T, bool JAC> struct PoseFactors<T, POSE2, JAC> {
       v[0] = h.x; v[1] = h.y; v[2] = wrap_pi(h.th);
       if (JAC) {
         const T c = cos(h.th), s = sin(h.th);
-        HL = {{c, s, T(0), -s, c, T(0), T(0), T(0), T(1)}};
+        HL = {{c, -s, T(0), s, c, T(0), T(0), T(0), T(1)}};   // = h.rotation().matrix(): d(x, y, th)/d(delta) under h o (dx, dy, dth)
       }
     } else {
       const V3<T> xi = se2_log(h);

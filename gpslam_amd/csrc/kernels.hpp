@@ -39,6 +39,8 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
 }
+// |v| for a maximum that must not lose NaNs (fmax drops them): a NaN update reads as +inf
+template <typename T> __device__ __forceinline__ T abs_or_inf(T v) { return (v == v) ? fabs(v) : T(INFINITY); }
 template <typename T> __device__ __forceinline__ T wave_max(T v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_down(v, o, 64));
@@ -473,6 +475,7 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
 
 enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5, FK_INTERP_PROJ = 6 };
 constexpr int kNumMeasKinds = 7;
+constexpr int kMeasAux = 18;
 template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
 template <typename T> struct MeasArgs {
@@ -486,9 +489,9 @@ template <typename T> struct MeasArgs {
   int mw;
   const T *sig;        // count x rows
   const T *coef;       // count x 4: l11, l12, p11, p12 (interpolated kinds)
-  T sensor[12];
-  int has_sensor;
-  T calib[5];          // Cal3_S2: fx, fy, s, u0, v0 (projection factor)
+  const T *aux;        // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
+  const int *aidx;     // count: entry of each factor (one body_P_sensor / calibration PER FACTOR, as in the reference:
+                       // GPInterpolatedRangeFactorPose3.h:46-54), or null: no sensor transform anywhere
   int vw;              // Pose3 only: velocities are world-frame [v; w]
   const int *row0;
   T *rowLR, *rowE, *rowM;
@@ -548,6 +551,12 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ)
         kc = {a.coef[4 * (size_t)f], a.coef[4 * (size_t)f + 1], a.coef[4 * (size_t)f + 2], a.coef[4 * (size_t)f + 3]};
       const T *ms = a.meas + (size_t)f * a.mw;
+      // per-factor body_P_sensor / calibration (identical entries are shared through the table)
+      const T *ax = a.aidx ? a.aux + (size_t)a.aidx[f] * kMeasAux : nullptr;
+      const bool has_sensor = ax && ax[17] != T(0);
+      T sens[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) sens[k] = (has_sensor && k < pd) ? ax[k] : T(0);
       T e[rows];
       T Jm[JAC ? rows * 3 : 1];
       if (JAC) {
@@ -561,8 +570,8 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         // GPInterpolatedRangeFactorPose3::evaluateError, gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
         Interp6Out<T, JAC> o;
         SE3<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o) : as_se3(p1);
-        const SE3<T> S = as_se3(a.sensor);
-        const SE3<T> sp = a.has_sensor ? se3_compose(pose, S) : pose;
+        const SE3<T> S = as_se3(sens);
+        const SE3<T> sp = has_sensor ? se3_compose(pose, S) : pose;
         const V3<T> pw = {pt[0], pt[1], pt[2]};
         const V3<T> q = tmul(sp.R, pw - sp.t);                       // Pose3::transform_to
         const T r = sqrt(dot(q, q));
@@ -570,7 +579,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         e[0] = r - ms[0];
         if (JAC) {
           V6<T> Hr = {rowmul(qh, skew(q)), -qh};                     // D_r_local * [skew(q), -I]
-          if (a.has_sensor) Hr = rowmul(Hr, se3_adjoint(se3_inverse(S)));   // Hpose * H0 (:87)
+          if (has_sensor) Hr = rowmul(Hr, se3_adjoint(se3_inverse(S)));   // Hpose * H0 (:87)
           put_v3(sp.R * qh, Jm);                                     // D_r_local * R^T
           if (FK == FK_INTERP_RANGE) {
             put_v6(rowmul(Hr, o.H1), JL); put_v6(rowmul(Hr, o.H2), JL + 6);
@@ -583,8 +592,8 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         // GPInterpolatedRangeFactorPose2::evaluateError, gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98
         Interp3Out<T, JAC> o;
         SE2<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose2<T, JAC>(p1, v1, p2, v2, kc, o) : SE2<T>{p1[0], p1[1], p1[2]};
-        const SE2<T> S = {a.sensor[0], a.sensor[1], a.sensor[2]};
-        const SE2<T> sp = a.has_sensor ? se2_compose(pose, S) : pose;
+        const SE2<T> S = {sens[0], sens[1], sens[2]};
+        const SE2<T> sp = has_sensor ? se2_compose(pose, S) : pose;
         const T dx = pt[0] - sp.x, dy = pt[1] - sp.y;
         const T r = sqrt(dx * dx + dy * dy);
         const T hx = dx / r, hy = dy / r;
@@ -592,7 +601,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         if (JAC) {
           const T c = cos(sp.th), sn = sin(sp.th);
           V3<T> Hr = {-c * hx - sn * hy, sn * hx - c * hy, T(0)};   // D_r_d * [[-c, s, 0], [-s, -c, 0]]
-          if (a.has_sensor) Hr = rowmul(Hr, se2_adjoint(se2_inverse(S)));
+          if (has_sensor) Hr = rowmul(Hr, se2_adjoint(se2_inverse(S)));
           Jm[0] = hx; Jm[1] = hy;
           if (FK == FK_INTERP_RANGE) {
             put_v3(rowmul(Hr, o.H1), JL); put_v3(rowmul(Hr, o.H2), JL + 3);
@@ -643,15 +652,15 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         // GPInterpolatedGPSFactorPose3::evaluateError, gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
         Interp6Out<T, JAC> o;
         const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
-        const SE3<T> S = as_se3(a.sensor);
-        const SE3<T> sp = a.has_sensor ? se3_compose(pose, S) : pose;
+        const SE3<T> S = as_se3(sens);
+        const SE3<T> sp = has_sensor ? se3_compose(pose, S) : pose;
         e[0] = sp.t.x - ms[0]; e[1] = sp.t.y - ms[1]; e[2] = sp.t.z - ms[2];
         if (JAC) {
           const BL6<T> AdS = se3_adjoint(se3_inverse(S));
 #pragma unroll
           for (int r = 0; r < 3; r++) {
             V6<T> Hp = {{T(0), T(0), T(0)}, {sp.R.m[3 * r], sp.R.m[3 * r + 1], sp.R.m[3 * r + 2]}};   // translation(H) = [0, R]
-            if (a.has_sensor) Hp = rowmul(Hp, AdS);
+            if (has_sensor) Hp = rowmul(Hp, AdS);
             put_v6(rowmul(Hp, o.H1), JL + r * b); put_v6(rowmul(Hp, o.H2), JL + r * b + 6);
             put_v6(rowmul(Hp, o.H3), JR + r * b); put_v6(rowmul(Hp, o.H4), JR + r * b + 6);
           }
@@ -662,23 +671,23 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         // (throwCheirality = false): error = 2 fx, all Jacobians zero (:122-138)
         Interp6Out<T, JAC> o;
         const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
-        const SE3<T> S = as_se3(a.sensor);
-        const SE3<T> cam = a.has_sensor ? se3_compose(pose, S) : pose;
+        const SE3<T> S = as_se3(sens);
+        const SE3<T> cam = has_sensor ? se3_compose(pose, S) : pose;
         const V3<T> pw = {pt[0], pt[1], pt[2]};
         const V3<T> q = tmul(cam.R, pw - cam.t);
-        const T fx = a.calib[0], fy = a.calib[1], sk = a.calib[2];
+        const T fx = ax ? ax[12] : T(1), fy = ax ? ax[13] : T(1), sk = ax ? ax[14] : T(0), cu0 = ax ? ax[15] : T(0), cv0 = ax ? ax[16] : T(0);
         if (!(q.z > T(0))) {
           e[0] = T(2) * fx; e[1] = T(2) * fx;
         } else {
           const T dz = T(1) / q.z, u = q.x * dz, v = q.y * dz;
-          e[0] = fx * u + sk * v + a.calib[3] - ms[0];
-          e[1] = fy * v + a.calib[4] - ms[1];
+          e[0] = fx * u + sk * v + cu0 - ms[0];
+          e[1] = fy * v + cv0 - ms[1];
           if (JAC) {
             // PinholeBase::Dpose / Dpoint, then Cal3_S2::uncalibrate's [[fx, s], [0, fy]]
             const V6<T> r0 = {{u * v, T(-1) - u * u, v}, {-dz, T(0), dz * u}};
             const V6<T> r1 = {{T(1) + v * v, -u * v, -u}, {T(0), -dz, dz * v}};
             V6<T> h0 = fx * r0 + sk * r1, h1 = fy * r1;
-            if (a.has_sensor) {
+            if (has_sensor) {
               const BL6<T> AdS = se3_adjoint(se3_inverse(S));
               h0 = rowmul(h0, AdS);
               h1 = rowmul(h1, AdS);
@@ -937,9 +946,10 @@ template <typename T> __global__ void __launch_bounds__(256) k_lm_correct(LmArgs
 // landmarks += dL; out[0] = max |dL| (single block)
 template <typename T> __global__ void __launch_bounds__(64) k_lm_update(LmArgs<T> a, double *out_max) {
   T mx = T(0);
+  const bool bad = a.flag && *a.flag;          // indeterminate system: leave the landmarks where they are
   for (int i = threadIdx.x; i < a.nl; i += 64) {
-    a.lmk[i] += a.dL[i];
-    mx = fmax(mx, fabs(a.dL[i]));
+    if (!bad) a.lmk[i] += a.dL[i];
+    mx = fmax(mx, abs_or_inf(a.dL[i]));
   }
   mx = wave_max(mx);
   if (threadIdx.x == 0) *out_max = fmax(*out_max, (double)mx);
@@ -2338,6 +2348,8 @@ template <typename T> struct RetractArgs {
   int first;        // first state to update (the halo state of a segment is updated by its own launch)
   const T *x;       // N x R x b, column 0 = delta (indexed from `first`)
   T *partial;       // per-block max |delta|
+  const int *flag;  // non-SPD flag of the elimination: when set the states are left untouched (GTSAM throws
+                    // IndeterminantLinearSystemException before Values::retract), only |delta|_inf is reported
 };
 
 template <typename T, int MF>
@@ -2350,14 +2362,16 @@ __global__ void __launch_bounds__(128) k_retract(RetractArgs<T> a) {
     const T *dl = a.x + (size_t)li * a.R * b;
     T dlt[b], x[pd], out[pd];
 #pragma unroll
-    for (int k = 0; k < b; k++) { dlt[k] = dl[k]; mx = fmax(mx, fabs(dlt[k])); }
+    for (int k = 0; k < b; k++) { dlt[k] = dl[k]; mx = fmax(mx, abs_or_inf(dlt[k])); }
+    if (!(a.flag && *a.flag)) {
 #pragma unroll
-    for (int k = 0; k < pd; k++) x[k] = a.pose[(size_t)k * a.stride + i];
-    PoseFactors<T, MF, false>::retract(x, dlt, a.chart, out);
+      for (int k = 0; k < pd; k++) x[k] = a.pose[(size_t)k * a.stride + i];
+      PoseFactors<T, MF, false>::retract(x, dlt, a.chart, out);
 #pragma unroll
-    for (int k = 0; k < pd; k++) a.pose[(size_t)k * a.stride + i] = out[k];
+      for (int k = 0; k < pd; k++) a.pose[(size_t)k * a.stride + i] = out[k];
 #pragma unroll
-    for (int k = 0; k < d; k++) a.vel[(size_t)k * a.stride + i] += dlt[d + k];
+      for (int k = 0; k < d; k++) a.vel[(size_t)k * a.stride + i] += dlt[d + k];
+    }
   }
   const T r = block_max(mx);
   if (threadIdx.x == 0) a.partial[blockIdx.x] = r;

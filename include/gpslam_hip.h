@@ -133,7 +133,9 @@ int gpslam_hip_add_between(gpslam_hip_handle *h, int32_t count, const int32_t *l
 int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                                    const double *sigmas);
 /* GPInterpolatedRangeFactor{Pose2,Pose3,2DLinear}(z, model, Qc, x_i, v_i, x_i+1, v_i+1, l, dt, tau[, body_P_sensor])
- * gpslam/slam/GPInterpolatedRangeFactorPose2.h:46-54; sensor: one pose for all `count` factors or NULL */
+ * gpslam/slam/GPInterpolatedRangeFactorPose2.h:46-54; sensor: body_P_sensor of THIS call's `count` factors or NULL.
+ * Every factor keeps its own body_P_sensor as in the reference (GPInterpolatedRangeFactorPose3.h:46-54): calls with
+ * different sensor poses may be mixed freely on one handle. */
 int gpslam_hip_add_interp_range(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
                                 const double *z, const double *sigma, const double *dt, const double *tau,
                                 const double *sensor);
@@ -149,7 +151,7 @@ int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t
 /* GPInterpolatedProjectionFactorPose3<Cal3_S2>(measured, cam_model, Qc_model, x_i, v_i, x_i+1, v_i+1, l, delta_t, tau, K,
  * body_P_sensor) -- gpslam/slam/GPInterpolatedProjectionFactorPose3.h:64-139: reprojection error of 3-D landmark l
  * through a pinhole camera riding on the GP-interpolated pose.  measured: count x 2 pixels, sigmas: count x 2,
- * K = {fx, fy, s, u0, v0} (gtsam::Cal3_S2; one calibration per handle), sensor = body_P_sensor (12 doubles) or NULL.
+ * K = {fx, fy, s, u0, v0} (gtsam::Cal3_S2, kept per factor: calls may differ), sensor = body_P_sensor (12 doubles) or NULL.
  * throwCheirality = false semantics: a landmark behind the camera contributes error 2 fx and zero Jacobians. */
 int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
                                      const double *measured, const double *sigmas, const double *dt, const double *tau,
@@ -161,8 +163,13 @@ int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t
 int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
                                  const double *bearing, const double *range, const double *sigmas);
 
+/* drop every factor added so far (states, landmarks and Qc stay); the handle needs a new compile() */
+int gpslam_hip_clear_factors(gpslam_hip_handle *h);
+
 /* Graph compile: classify, sort by left state, pack SoA parameter arrays, size the solver hierarchy.
- * Must be called after the last add_* / set_states and before any of the calls below. */
+ * Must be called after the last add_* / set_states and before any of the calls below.  Every stored factor index is
+ * re-validated against the CURRENT number of states / landmarks (GPSLAM_E_INVALID if set_states / set_landmarks
+ * shrank the problem under factors that still refer to the removed variables). */
 int gpslam_hip_compile(gpslam_hip_handle *h);
 
 /* ---- the hot path ---- */

@@ -322,7 +322,7 @@ static void chart_local(int kind, int chart, const double *h, double *v, double 
         v[0] = h[0]; v[1] = h[1]; v[2] = atan2(sin(h[2]), cos(h[2]));
         if (H) {
           double c = cos(h[2]), s = sin(h[2]);
-          double A[9] = {c, s, 0.0, -s, c, 0.0, 0.0, 0.0, 1.0};   /* topLeft = R^T */
+          double A[9] = {c, -s, 0.0, s, c, 0.0, 0.0, 0.0, 1.0};   /* topLeft = h.rotation().matrix() (GTSAM Pose2::ChartAtOrigin::Local) */
           orc_copy(9, A, H);
         }
       } else {

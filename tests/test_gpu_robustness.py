@@ -1,0 +1,128 @@
+"""Round-2 boundary / robustness fixes, each through the C ABI on the GPU and against the oracle:
+per-factor body_P_sensor, index re-validation in compile(), clear_factors(), an indeterminate Gauss-Newton step
+leaves the states untouched, the Pose2 first-order chart Jacobian of PriorFactor / BetweenFactor."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_gpu_parity import gpu, random_chain, states_close
+from test_gpu_measurements import interp_truth, true_range
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("kind", [O.POSE2, O.POSE3], ids=["pose2", "pose3"])
+def test_two_different_sensor_extrinsics_on_one_handle(kind):
+    """The reference keeps body_P_sensor_ per factor (GPInterpolatedRangeFactorPose3.h:46-54): factors with two
+    different extrinsics and some without any, added in separate calls, must each use their own."""
+    rng = np.random.default_rng(5)
+    N, d, ld = 40, O.TANGENT_DIM[kind], (2 if kind == O.POSE2 else 3)
+    chart = O.CHART_FIRST_ORDER if kind == O.POSE2 else O.CHART_EXPMAP
+    c = random_chain(kind, N, 21, noise=0.02)
+    Qc = np.diag(0.01 + 0.02 * rng.random(d))
+    L = 3
+    lands = rng.uniform(-6, 6, (L, ld))
+    if kind == O.POSE3:
+        sensors = [O.pose3((0.3, -0.2, 0.1), (0.2, -0.1, 0.3)), O.pose3((-0.5, 0.1, 0.4), (-0.3, 0.4, 0.1)), None]
+    else:
+        sensors = [np.array([0.2, -0.1, 0.3]), np.array([-0.4, 0.3, -0.7]), None]
+    groups = []
+    for S in sensors:
+        left = np.sort(rng.integers(0, N - 1, size=N)).astype(np.int32)
+        tau = np.array([c["dt"][i] * rng.uniform(0.0, 1.0) for i in left])
+        lm = rng.integers(0, L, size=len(left)).astype(np.int32)
+        z = np.array([true_range(kind, interp_truth(kind, Qc, c, i, t), lands[l], S) for i, t, l in zip(left, tau, lm)])
+        groups.append((left, lm, z + 0.01 * rng.standard_normal(len(z)), tau, S))
+    fix = np.arange(0, N, 10)
+    solvers = []
+    for make in (lambda: O.Chain(kind, chart, ld), lambda: gpu().ChainSolver(kind, chart, ld)):
+        s = make()
+        s.set_qc(Qc)
+        s.set_states(c["pose"], c["vel"])
+        s.set_landmarks(lands + 0.05)
+        s.add_gp_priors(np.arange(N - 1), c["dt"])
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.02))
+        s.add_landmark_priors(np.arange(L), lands, np.full((L, ld), 0.3))
+        for left, lm, z, tau, S in groups:
+            s.add_interp_range(left, lm, z, np.full(len(left), 0.05), c["dt"][left], tau, S)
+        s.compile()
+        solvers.append(s)
+    orc, dev = solvers
+    assert abs(orc.error() - dev.error()) <= 1e-10 * max(1.0, orc.error())
+    D0, O0, g0, B0, _, _ = orc.normal_equations()
+    D1, O1, g1, B1 = dev.normal_equations()
+    for a, b in ((D0, D1), (O0, O1), (g0, g1), (B0, B1)):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max())
+    for _ in range(3):
+        orc.iterate_gn()
+        dev.iterate_gn()
+    states_close(kind, *orc.get_states(), *dev.get_states(), rel=1e-9)
+
+
+def test_compile_revalidates_indices_after_shrinking():
+    gp = gpu()
+    kind, N = O.POSE2, 32
+    c = random_chain(kind, N, 3)
+    s = gp.ChainSolver(kind, O.CHART_FIRST_ORDER, 2)
+    s.set_states(c["pose"], c["vel"])
+    s.set_landmarks(np.zeros((4, 2)))
+    s.add_gp_priors(np.arange(N - 1), c["dt"])
+    s.add_pose_priors([0, N - 1], c["truth_pose"][[0, N - 1]], np.full((2, 3), 0.1))
+    s.add_range([N - 1], [3], [1.0], [0.1])
+    s.compile()
+    s.set_states(c["pose"][:20], c["vel"][:20])          # factors still refer to states 20..31
+    with pytest.raises(gp.GpslamHipError, match="no longer exists"):
+        s.compile()
+    s.set_states(c["pose"], c["vel"])
+    s.set_landmarks(np.zeros((2, 2)))                    # the range factor refers to landmark 3
+    with pytest.raises(gp.GpslamHipError, match="no longer exists"):
+        s.compile()
+    s.clear_factors()                                    # a fresh, smaller graph on the same handle
+    s.set_states(c["pose"][:20], c["vel"][:20])
+    s.add_gp_priors(np.arange(19), c["dt"][:19])
+    s.add_pose_priors([0], c["truth_pose"][[0]], np.full((1, 3), 0.1))
+    s.compile()
+    rc, st = s.iterate_gn()
+    assert rc == 0 and np.isfinite(st.error_after)
+
+
+def test_indeterminate_gauss_newton_step_leaves_states_untouched():
+    """GTSAM throws IndeterminantLinearSystemException before Values::retract; here: GPSLAM_E_NOT_SPD and the states as
+    they were.  A chain with no absolute information at all (GP priors only pin differences) is singular."""
+    gp = gpu()
+    kind, N = O.LINEAR3, 64
+    c = random_chain(kind, N, 9)
+    s = gp.ChainSolver(kind)
+    s.set_states(c["pose"], c["vel"])
+    s.add_gp_priors(np.arange(N - 1), c["dt"])
+    s.compile()
+    p0, v0 = s.get_states()
+    with pytest.raises(gp.GpslamHipError):
+        s.iterate_gn()
+    p1, v1 = s.get_states()
+    assert np.array_equal(p0, p1) and np.array_equal(v0, v1)
+
+
+@pytest.mark.parametrize("chart", [O.CHART_FIRST_ORDER, O.CHART_EXPMAP])
+def test_pose2_prior_between_rows_match_oracle_at_large_residual(chart):
+    """Whitened rows of PriorFactor<Pose2> / BetweenFactor<Pose2> at residual headings far from zero (the oracle side is
+    pinned against central differences in tests/test_oracle_golden.py)."""
+    rng = np.random.default_rng(13)
+    kind, N = O.POSE2, 24
+    c = random_chain(kind, N, 17, noise=0.0)
+    pri = np.stack([O.retract(kind, c["pose"][i], [0.4, -0.3, 1.1], chart) for i in range(N)])
+    btw = rng.normal(size=(N - 1, 3))
+    solvers = []
+    for make in (lambda: O.Chain(kind, chart), lambda: gpu().ChainSolver(kind, chart)):
+        s = make()
+        s.set_states(c["pose"], c["vel"])
+        s.add_gp_priors(np.arange(N - 1), c["dt"])
+        s.add_pose_priors(np.arange(N), pri, np.full((N, 3), 0.3))
+        s.add_between(np.arange(N - 1), btw, np.full((N - 1, 3), 0.2))
+        s.compile()
+        solvers.append(s)
+    orc, dev = solvers
+    D0, O0, g0, _, _, _ = orc.normal_equations()
+    D1, O1, g1, _ = dev.normal_equations()
+    for a, b in ((D0, D1), (O0, O1), (g0, g1)):
+        assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(a).max())

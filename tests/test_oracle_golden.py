@@ -503,3 +503,57 @@ def test_vw_conversion_known_answers(golden):
         assert np.abs(Hv - numdiff_vector(lambda x: f(x, w, pose), v, 1e-6)).max() <= 1e-6
         assert np.abs(Hw - numdiff_vector(lambda x: f(v, x, pose), w, 1e-6)).max() <= 1e-6
         assert np.abs(Hp - numdiff_manifold(O.POSE3, lambda x: f(v, w, x), pose, 1e-6)).max() <= 1e-6
+
+
+def _fd_simple(kind, chart, fn, xs, which, h=1e-6):
+    """Central difference of a PriorFactor / BetweenFactor error w.r.t. argument `which` under the chart's retract
+    (numericalDerivative11 with traits::Retract, as the reference's Jacobian tests do)."""
+    d = O.TANGENT_DIM[kind]
+    cols = []
+    for k in range(d):
+        dl = np.zeros(d)
+        dl[k] = h
+        xp = list(xs); xm = list(xs)
+        xp[which] = O.retract(kind, xs[which], dl, chart)
+        xm[which] = O.retract(kind, xs[which], -dl, chart)
+        cols.append((fn(*xp) - fn(*xm)) / (2 * h))
+    return np.stack(cols, axis=1)
+
+
+@pytest.mark.parametrize("kind,chart", [(O.POSE2, O.CHART_FIRST_ORDER), (O.POSE2, O.CHART_EXPMAP),
+                                        (O.POSE3, O.CHART_EXPMAP), (O.ROT3, O.CHART_EXPMAP), (O.LINEAR3, O.CHART_EXPMAP)])
+def test_prior_between_jacobians_at_large_residual(kind, chart):
+    """PriorFactor<T> / BetweenFactor<T> Jacobians vs central differences under the SAME chart at a residual heading far
+    from zero (the Pose2 first-order chart had dLocal = R^T instead of R; nothing in the reference pins it)."""
+    rng = np.random.default_rng(11)
+    d, pd = O.TANGENT_DIM[kind], O.POSE_DIM[kind]
+
+    def rnd():
+        if kind == O.POSE2:
+            return np.array([rng.normal(), rng.normal(), rng.uniform(-2.5, 2.5)])
+        if kind == O.LINEAR3:
+            return rng.normal(size=3)
+        ident = np.concatenate([np.eye(3).ravel(), np.zeros(3)])[:pd]
+        return O.retract(kind, ident, rng.normal(size=d) * 0.9)
+
+    def prior_err(pr, x):
+        e = np.zeros(d)
+        O.call("orc_prior_factor", kind, chart, O.A(pr), O.A(x), e, None)
+        return e
+
+    def btw_err(m, x1, x2):
+        e = np.zeros(d)
+        O.call("orc_between_factor", kind, chart, O.A(m), O.A(x1), O.A(x2), e, None, None)
+        return e
+
+    for _ in range(5):
+        pr, x, x2, m = rnd(), rnd(), rnd(), rnd()
+        e, H = np.zeros(d), np.zeros((d, d))
+        O.call("orc_prior_factor", kind, chart, pr, x, e, H)
+        if kind == O.POSE2:
+            assert abs(e[2]) > 1e-3            # the residual heading is not ~0: R and R^T differ
+        np.testing.assert_allclose(H, _fd_simple(kind, chart, prior_err, [pr, x], 1), atol=2e-7)
+        H1, H2 = np.zeros((d, d)), np.zeros((d, d))
+        O.call("orc_between_factor", kind, chart, m, x, x2, e, H1, H2)
+        np.testing.assert_allclose(H1, _fd_simple(kind, chart, btw_err, [m, x, x2], 1), atol=2e-7)
+        np.testing.assert_allclose(H2, _fd_simple(kind, chart, btw_err, [m, x, x2], 2), atol=2e-7)
