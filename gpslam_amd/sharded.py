@@ -191,6 +191,14 @@ class ShardedSolver:
         self.backend, self.send, self.recv = backend, send, recv
         self.rank, self.nranks, self.dist, self.group = rank, nranks, dist, group
         self.landmark_buf = landmark_buf      # [S | gL] of this rank (torch tensor) when the chain has landmarks
+        # Stream ordering: the handle's kernels and torch.distributed's collectives must be ordered against
+        # one another.  A handle creates its own NON-BLOCKING stream, which torch knows nothing about, so a GPU backend
+        # is moved onto torch's current stream here: RCCL collectives launched through torch.distributed are ordered
+        # against that stream (they wait for work already enqueued on it, and later work on it waits for them), which
+        # makes phase1 -> all_gather -> phase2a -> all_reduce -> phase2b a correctly ordered sequence with no host sync.
+        if getattr(send, "is_cuda", False) and hasattr(backend, "set_stream"):
+            import torch
+            backend.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def exchange(self):
         if self.dist is None:
