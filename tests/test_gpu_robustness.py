@@ -81,6 +81,8 @@ def test_compile_revalidates_indices_after_shrinking():
     s.set_states(c["pose"][:20], c["vel"][:20])
     s.add_gp_priors(np.arange(19), c["dt"][:19])
     s.add_pose_priors([0], c["truth_pose"][[0]], np.full((1, 3), 0.1))
+    s.add_vel_priors([0], c["truth_vel"][[0]], np.full((1, 3), 0.1))
+    s.add_landmark_priors([0, 1], np.zeros((2, 2)), np.full((2, 2), 1.0))   # (an unconstrained landmark is singular)
     s.compile()
     rc, st = s.iterate_gn()
     assert rc == 0 and np.isfinite(st.error_after)
