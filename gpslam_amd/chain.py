@@ -87,7 +87,8 @@ def _p(a):
 
 class ChainSolver:
     def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, device=0, chunk=0, rank=0, nranks=1,
-                 force_sharded=False, upper_chunk=0, top_blocks=0, velocity_world=False):
+                 force_sharded=False, upper_chunk=0, top_blocks=0, velocity_world=False, segment_length=0,
+                 force_segmented=False):
         self.lib = load_library()
         self.kind, self.chart, self.ld = kind, chart, landmark_dim
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
@@ -99,6 +100,8 @@ class ChainSolver:
         cfg.reserved[1] = upper_chunk
         cfg.reserved[2] = top_blocks
         cfg.reserved[3] = 1 if velocity_world else 0   # GPSLAM_VELOCITY_WORLD_VW: the *Pose3VW factor family
+        cfg.reserved[4] = segment_length               # segmented landmark elimination: segment length (0 = automatic)
+        cfg.reserved[5] = 1 if force_segmented else 0  # ... for any landmark count (default: only beyond the dense border)
         self._h = C.c_void_p()
         rc = self.lib.gpslam_hip_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

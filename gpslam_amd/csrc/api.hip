@@ -14,32 +14,14 @@
 #include <type_traits>
 #include <vector>
 
+#include "devbuf.hpp"
 #include "kernels.hpp"
+#include "fatsep.hpp"
 
 using namespace gps;
 typedef double Real;  // GPSLAM_FP64; the kernels are templated on the scalar for the fp32 path
 
 namespace {
-
-struct DevBuf {
-  void *p = nullptr;
-  size_t bytes = 0;
-  hipError_t reserve(size_t n) {
-    if (n <= bytes) return hipSuccess;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-    hipError_t e = hipMalloc(&p, n ? n : 8);
-    if (e == hipSuccess) bytes = n ? n : 8;
-    return e;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    bytes = 0;
-  }
-  template <typename U> U *as() const { return reinterpret_cast<U *>(p); }
-};
 
 struct Level {
   int n = 0, m = 0, nch = 0;
@@ -107,6 +89,9 @@ struct gpslam_hip_handle {
   // segment sharding
   DevBuf halo_add, iface_send, iface_recv, top_blk, top_x;
   DevBuf scal, flag, api_e, api_H;
+  // landmark elimination at scale (fatsep.hpp): segments + fat separators instead of the dense border
+  FatSepPlan fs;
+  DevBuf lm_gL;             // undamped landmark gradient of the segmented path (the dense path keeps it behind lm_S)
   bool fuse_ok = false;     // k_fused_level0 applies to this graph (compile())
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool compiled = false;
@@ -349,7 +334,12 @@ int launch_factors(gpslam_hip_handle *h, int mode, int slot) {
     });
     off += nb;
   }
-  if (h->lpri.count() > 0) {
+  if (h->lpri.count() > 0 && h->fs.active) {   // tens of thousands of landmark priors: grid-stride, one partial per block
+    const int nbl = std::min(nblocks(h->lpri.count(), 256), 256);
+    k_fs_lmprior_err<Real><<<dim3(nbl), dim3(256), 0, side>>>(h->lmk.as<Real>(), h->lpri.d_idx.as<int>(), h->lpri.d_meas.as<Real>(),
+                                                               h->lpri.d_sig.as<Real>(), h->lpri.count(), h->ld, part + off);
+    off += nbl;
+  } else if (h->lpri.count() > 0) {
     LmArgs<Real> a = lm_args(h, 0.0);
     a.partial = part + off;
     k_lmprior_err<Real><<<dim3(1), dim3(128), 0, side>>>(a);
@@ -370,8 +360,9 @@ int launch_assemble(gpslam_hip_handle *h, bool save_g) {
   a.rowptr = h->rowptr.as<int>();
   a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>();
   a.crowptr = h->crowptr.as<int>(); a.rowC = h->rowC.as<Real>(); a.rowCE = h->rowCE.as<Real>();
-  a.rowM = h->nl > 0 ? h->rowM.as<Real>() : nullptr;
-  a.rowLm = h->nl > 0 ? h->rowLm.as<int>() : nullptr;
+  const bool border = h->nl > 0 && !h->fs.active;   // landmark columns ride in the records only with the dense border
+  a.rowM = border ? h->rowM.as<Real>() : nullptr;
+  a.rowLm = border ? h->rowLm.as<int>() : nullptr;
   a.ld = h->ld;
   a.blk = h->lv[0].blk.as<Real>();
   a.gsave = save_g ? h->gsave.as<Real>() : nullptr;
@@ -518,8 +509,161 @@ int launch_landmarks(gpslam_hip_handle *h, double lambda) {
   return rc ? rc : launch_landmarks_solve(h, lambda);
 }
 
+
+// ---- segmented landmark elimination (fatsep.hpp)
+FsArgs<Real> fs_args(gpslam_hip_handle *h, double lambda) {
+  FatSepPlan &p = h->fs;
+  FsArgs<Real> a;
+  a.N = h->N; a.B = h->b; a.ld = h->ld; a.L = h->L; a.K = p.K; a.NB = p.NB; a.NC = p.NC; a.NCP = p.NCP;
+  a.BS = 2 * h->b * h->b + h->b;
+  a.cuts = p.d_cuts.as<int>(); a.segid = p.d_segid.as<int>();
+  a.fat_lm_ptr = p.d_fat_lm_ptr.as<int>(); a.fat_lm = p.d_fat_lm.as<int>();
+  a.lm_fat = p.d_lm_fat.as<int>(); a.lm_slot = p.d_lm_slot.as<int>();
+  a.lmrow_ptr = h->lmrow_ptr.as<int>(); a.lmrow = h->lmrow.as<int>(); a.lmrow_state = h->lmrow_state.as<int>();
+  a.lmpri_ptr = p.d_lmpri_ptr.as<int>(); a.lmpri = p.d_lmpri.as<int>();
+  a.pri_meas = h->lpri.d_meas.as<Real>(); a.pri_sig = h->lpri.d_sig.as<Real>();
+  a.lmk = h->lmk.as<Real>();
+  a.rowptr = h->rowptr.as<int>(); a.rowLm = h->rowLm.as<int>();
+  a.rowLR = h->rowLR.as<Real>(); a.rowE = h->rowE.as<Real>(); a.rowM = h->rowM.as<Real>();
+  a.blk = h->lv[0].blk.as<Real>();
+  a.fac = p.fac.as<Real>(); a.Y = p.Y.as<Real>(); a.Aseg = p.Aseg.as<Real>();
+  a.Dfat = p.Dfat.as<Real>(); a.link = p.link.as<Real>(); a.gfat = p.gfat.as<Real>(); a.Qbuf = p.Qbuf.as<Real>();
+  a.S1 = p.S1.as<Real>(); a.S2 = p.S2.as<Real>(); a.sv = p.sv.as<Real>(); a.xfat = p.xfat.as<Real>();
+  a.gL = h->lm_gL.as<Real>(); a.dL = h->lm_dL.as<Real>();
+  a.x = h->lv[0].x.as<Real>(); a.rhs = p.rhs.as<Real>();
+  a.lambda = (Real)lambda; a.flag = h->flag.as<int>();
+  return a;
+}
+
+int fs_solve(gpslam_hip_handle *h, double lambda) {
+  FatSepPlan &p = h->fs;
+  FsArgs<Real> a = fs_args(h, lambda);
+  hipStream_t st = h->stream;
+  const int nseg = p.K - 1;
+  const size_t smem_elim = ((size_t)p.NB * (p.NB + 1) + (size_t)p.NB * (2 * p.NB + 1)) * sizeof(Real);
+  const size_t smem_top = ((size_t)p.NB * (p.NB + 1) + (size_t)p.NB) * sizeof(Real);
+  dispatch_b(h->b, [&](auto tag) {
+    constexpr int BB = decltype(tag)::value;
+    k_fs_factor<Real, BB><<<dim3(nseg), dim3(64), 0, st>>>(a);
+    k_fs_sweep<Real, BB><<<dim3(nseg), dim3(((p.NC + 63) / 64) * 64), 0, st>>>(a);
+  });
+  k_fs_syrk<9><<<dim3(nseg, p.NCP / 16), dim3(64), 0, st>>>(a);
+  k_fs_fat_assemble<Real><<<dim3(p.K), dim3(256), 0, st>>>(a);
+  for (const FatSepPlan::LevelHost &lv : p.levels) {
+    FatLevel fl;
+    fl.elim = p.d_elim.as<int>() + (size_t)6 * lv.elim_off; fl.nelim = lv.nelim;
+    fl.upd = p.d_upd.as<int>() + (size_t)3 * lv.upd_off; fl.nupd = lv.nupd;
+    k_fat_elim<Real><<<dim3(lv.nelim), dim3(256), smem_elim, st>>>(a, fl);
+    k_fat_update<Real><<<dim3(lv.nupd), dim3(256), 0, st>>>(a, fl);
+  }
+  k_fat_top<Real><<<dim3(1), dim3(256), smem_top, st>>>(a, p.top);
+  for (int li = (int)p.levels.size() - 1; li >= 0; li--) {
+    const FatSepPlan::LevelHost &lv = p.levels[li];
+    FatLevel fl;
+    fl.elim = p.d_elim.as<int>() + (size_t)6 * lv.elim_off; fl.nelim = lv.nelim;
+    fl.upd = nullptr; fl.nupd = 0;
+    k_fat_back<Real><<<dim3(lv.nelim), dim3(64), 0, st>>>(a, fl);
+  }
+  k_fs_scatter<Real><<<dim3(nblocks(std::max(p.K * h->b, h->L * h->ld), 256)), dim3(256), 0, st>>>(a);
+  dispatch_b(h->b, [&](auto tag) {
+    constexpr int BB = decltype(tag)::value;
+    k_fs_rhs<Real, BB><<<dim3(nblocks(h->N, 128)), dim3(128), 0, st>>>(a);
+    k_fs_solve1<Real, BB><<<dim3(nblocks(nseg, 64)), dim3(64), 0, st>>>(a);
+  });
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// compile(): segment plan, level sets of the cyclic reduction, buffers.  per_lm: rows touching each landmark (row, left
+// state), sorted by state; touch_hi: last state touched.
+int fs_build(gpslam_hip_handle *h, const std::vector<int> &touch_lo, const std::vector<int> &touch_hi) {
+  FatSepPlan &p = h->fs;
+  const int N = h->N, b = h->b, ld = h->ld, L = h->L;
+  std::vector<int> fat_of, slot_of, counts;
+  if (!p.choose(N, b, ld, L, touch_lo, touch_hi, h->cfg.reserved[4], fat_of, slot_of, counts)) return fail(h, GPSLAM_E_UNSUPPORTED, p.err.c_str());
+  const int K = p.K, NB = p.NB;
+  std::vector<int> segid(N, 0);
+  for (int k = 0; k + 1 < K; k++)
+    for (int s2 = p.cuts[k] + 1; s2 < p.cuts[k + 1]; s2++) segid[s2] = k;
+  for (int k = 0; k < K; k++) segid[p.cuts[k]] = -1 - k;
+  std::vector<int> fat_ptr(K + 1, 0), fat_lm(L, 0);
+  for (int k = 0; k < K; k++) fat_ptr[k + 1] = fat_ptr[k] + counts[k];
+  for (int l = 0; l < L; l++) fat_lm[fat_ptr[fat_of[l]] + slot_of[l]] = l;
+  std::vector<int> pri_ptr(L + 1, 0), pri_ids(h->lpri.idx.size());
+  for (int32_t i : h->lpri.idx) pri_ptr[i + 1]++;
+  for (int l = 0; l < L; l++) pri_ptr[l + 1] += pri_ptr[l];
+  { std::vector<int> cur(pri_ptr.begin(), pri_ptr.end() - 1);
+    for (size_t k = 0; k < h->lpri.idx.size(); k++) pri_ids[cur[h->lpri.idx[k]]++] = (int)k; }
+  // level sets of the block cyclic reduction
+  std::vector<int> elim, upd;
+  p.levels.clear();
+  std::vector<int> active(K), linkidx(K > 0 ? K - 1 : 0);
+  for (int k = 0; k < K; k++) active[k] = k;
+  for (int k = 0; k + 1 < K; k++) linkidx[k] = k;
+  int next_link = K - 1;
+  while (active.size() > 1) {
+    FatSepPlan::LevelHost lv;
+    lv.elim_off = (int)elim.size() / 6; lv.upd_off = (int)upd.size() / 3;
+    const int n = (int)active.size();
+    std::vector<int> nact, nlink;
+    for (int i = 0; i < n; i += 2) {
+      nact.push_back(active[i]);
+      upd.push_back(active[i]);
+      upd.push_back(i - 1 >= 0 ? active[i - 1] : -1);
+      upd.push_back(i + 1 < n ? active[i + 1] : -1);
+    }
+    for (int q = 1; q < n; q += 2) {
+      const int r = (q + 1 < n) ? active[q + 1] : -1;
+      const int lk_new = (r >= 0) ? next_link++ : -1;
+      elim.push_back(active[q]); elim.push_back(active[q - 1]); elim.push_back(r);
+      elim.push_back(linkidx[q - 1]); elim.push_back(r >= 0 ? linkidx[q] : -1); elim.push_back(lk_new);
+      if (r >= 0) nlink.push_back(lk_new);
+    }
+    lv.nelim = (int)elim.size() / 6 - lv.elim_off; lv.nupd = (int)upd.size() / 3 - lv.upd_off;
+    p.levels.push_back(lv);
+    active.swap(nact);
+    linkidx.swap(nlink);
+  }
+  p.top = active[0];
+  p.nlinks = std::max(next_link, 1);
+  hipStream_t st = h->stream;
+  HIPCHK(upload_vec(st, p.d_cuts, p.cuts));
+  HIPCHK(upload_vec(st, p.d_segid, segid));
+  HIPCHK(upload_vec(st, p.d_fat_lm_ptr, fat_ptr));
+  HIPCHK(upload_vec(st, p.d_fat_lm, fat_lm));
+  HIPCHK(upload_vec(st, p.d_lm_fat, fat_of));
+  HIPCHK(upload_vec(st, p.d_lm_slot, slot_of));
+  HIPCHK(upload_vec(st, p.d_lmpri_ptr, pri_ptr));
+  HIPCHK(upload_vec(st, p.d_lmpri, pri_ids));
+  HIPCHK(upload_vec(st, p.d_elim, elim));
+  HIPCHK(upload_vec(st, p.d_upd, upd));
+  const size_t NB2 = (size_t)NB * NB;
+  HIPCHK(p.fac.reserve((size_t)N * 2 * b * b * sizeof(Real)));
+  HIPCHK(p.Y.reserve((size_t)N * b * p.NCP * sizeof(Real)));
+  HIPCHK(hipMemsetAsync(p.Y.p, 0, (size_t)N * b * p.NCP * sizeof(Real), st));   // padding columns stay zero for good
+  HIPCHK(p.Aseg.reserve((size_t)(K - 1) * p.NCP * p.NCP * sizeof(Real)));
+  HIPCHK(p.Dfat.reserve((size_t)K * NB2 * sizeof(Real)));
+  HIPCHK(p.link.reserve((size_t)p.nlinks * NB2 * sizeof(Real)));
+  HIPCHK(p.gfat.reserve((size_t)K * NB * sizeof(Real)));
+  HIPCHK(p.Qbuf.reserve((size_t)K * NB2 * sizeof(Real)));
+  HIPCHK(p.S1.reserve((size_t)K * NB2 * sizeof(Real)));
+  HIPCHK(p.S2.reserve((size_t)K * NB2 * sizeof(Real)));
+  HIPCHK(p.sv.reserve((size_t)K * 2 * NB * sizeof(Real)));
+  HIPCHK(p.xfat.reserve((size_t)K * NB * sizeof(Real)));
+  HIPCHK(p.rhs.reserve((size_t)N * b * sizeof(Real)));
+  HIPCHK(p.partial.reserve(1024 * sizeof(Real)));
+  HIPCHK(h->lm_gL.reserve((size_t)std::max(h->nl, 1) * sizeof(Real)));
+  HIPCHK(h->lm_dL.reserve((size_t)std::max(h->nl, 1) * sizeof(Real)));
+  const size_t smem_elim = ((size_t)NB * (NB + 1) + (size_t)NB * (2 * NB + 1)) * sizeof(Real);
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fat_elim<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_elim));
+  HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fat_top<Real>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_elim));
+  p.active = true;
+  return 0;
+}
+
 int launch_solve(gpslam_hip_handle *h, double lambda) {
   int rc;
+  if (h->fs.active) return fs_solve(h, lambda);
   if ((rc = launch_forward(h, lambda))) return rc;
   if ((rc = launch_backward(h, nullptr))) return rc;
   return launch_landmarks(h, lambda);
@@ -536,7 +680,11 @@ int launch_retract(gpslam_hip_handle *h, int slot) {
     k_retract<Real, MF><<<dim3(nb), dim3(128), 0, h->stream>>>(a);
   });
   k_final_reduce<Real><<<dim3(1), dim3(256), 0, h->stream>>>(h->partial.as<Real>(), nb, h->scal.as<double>() + slot, 1);
-  if (h->nl > 0) {
+  if (h->nl > 0 && h->fs.active) {
+    const int nbl = std::min(nblocks(h->nl, 256), 1024);
+    k_fs_lm_update<Real><<<dim3(nbl), dim3(256), 0, h->stream>>>(h->lmk.as<Real>(), h->lm_dL.as<Real>(), h->nl, h->flag.as<int>(), h->fs.partial.as<Real>());
+    k_fs_max_into<Real><<<dim3(1), dim3(64), 0, h->stream>>>(h->fs.partial.as<Real>(), nbl, h->scal.as<double>() + slot);
+  } else if (h->nl > 0) {
     LmArgs<Real> la = lm_args(h, 0.0);
     k_lm_update<Real><<<dim3(1), dim3(64), 0, h->stream>>>(la, h->scal.as<double>() + slot);
   }
@@ -757,6 +905,8 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   for (DevBuf *b : bufs) b->release();
   for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
   for (MeasSet &s : h->ms) s.release();
+  h->fs.release();
+  h->lm_gL.release();
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
@@ -971,8 +1121,15 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   }
   h->nl = h->L * h->ld;
   h->R = 1 + h->nl;
-  if (3 * b + h->R > 64 || h->R > kMaxRhs)
-    return fail(h, GPSLAM_E_UNSUPPORTED, "too many landmark columns for the dense border (3*2d + 1 + L*landmark_dim must be <= 64)");
+  h->fs.active = false;
+  // Landmark columns: up to kMaxRhs - 1 of them ride through the whole chain solver as extra right-hand sides (the dense
+  // border, Plaza's handful of beacons).  More than that -- config 4's 5e4 locally visible landmarks -- go through the
+  // segmented elimination with fat separators (fatsep.hpp); reserved[5] = 1 forces that path for any landmark count.
+  const bool segmented = h->nl > 0 && (h->cfg.reserved[5] == 1 || 3 * b + h->R > 64 || h->R > kMaxRhs);
+  if (segmented) {
+    if (sharded(h)) return fail(h, GPSLAM_E_UNSUPPORTED, "the segmented landmark elimination runs on unsharded handles only (this round)");
+    h->R = 1;   // no landmark columns inside the chain solver
+  }
   // ---- row layout: rows grouped by left state; inside a state: GP, pose prior, velocity prior, between, measurements
   std::vector<int> rows_in(N + 1, 0);
   for (int32_t l : h->gp_left) rows_in[l] += b;
@@ -1021,7 +1178,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   if ((rc = up_set(h->btw, r_btw))) return rc;
   { std::vector<int> none; if ((rc = up_set(h->lpri, none))) return rc; }
   int npart = nblocks((int)h->gp_left.size(), 128) + nblocks(h->pri.count(), 128) + nblocks(h->vpri.count(), 128) +
-              nblocks(h->btw.count(), 128) + 1;
+              nblocks(h->btw.count(), 128) + 1 + 256;
   for (int fk = 0; fk < kNumMeasKinds; fk++) {
     MeasSet &s = h->ms[fk];
     if ((rc = upload(h, s.d_idx, s.idx))) return rc;
@@ -1044,6 +1201,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
   if ((rc = upload(h, h->crowptr, crowptr))) return rc;
   // ---- landmark border bookkeeping
   h->nlmrows = 0;
+  std::vector<int> touch_lo(h->L, -1), touch_hi(h->L, -1);   // first / last state the factors of each landmark touch
   if (h->nl > 0) {
     HIPCHK(h->rowM.reserve(Mrows * h->ld * sizeof(Real)));
     HIPCHK(h->rowLm.reserve(Mrows * sizeof(int)));
@@ -1053,16 +1211,24 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     for (int fk = 0; fk < kNumMeasKinds; fk++) {
       MeasSet &s = h->ms[fk];
       if (!s.haslm) continue;
-      for (int f = 0; f < s.count(); f++)
+      for (int f = 0; f < s.count(); f++) {
         for (int r = 0; r < s.rows; r++) per_lm[s.lm[f]].push_back({r_ms[fk][f] + r, s.idx[f]});
+        int &lo = touch_lo[s.lm[f]], &hi = touch_hi[s.lm[f]];
+        const int last = s.idx[f] + (s.two ? 1 : 0);
+        lo = (lo < 0) ? s.idx[f] : std::min(lo, (int)s.idx[f]);
+        hi = std::max(hi, last);
+      }
     }
     std::vector<int> lmrow, lmstate, lmptr(h->L + 1, 0);
     for (int l = 0; l < h->L; l++) {
+      // by left state (stable: equal states keep the order the factors were added in): the segmented path walks a
+      // landmark's rows along the chain, and the dense path's summation order is then independent of the call order
+      std::stable_sort(per_lm[l].begin(), per_lm[l].end(), [](const std::pair<int, int> &x, const std::pair<int, int> &y) { return x.second < y.second; });
       for (auto &pr : per_lm[l]) { lmrow.push_back(pr.first); lmstate.push_back(pr.second); }
       lmptr[l + 1] = (int)lmrow.size();
     }
     h->nlmrows = (int)lmrow.size();
-    {   // chunks of at most kLmChunk consecutive rows of one landmark
+    if (!segmented) {   // chunks of at most kLmChunk consecutive rows of one landmark
       std::vector<int> clm, cj0, cj1, cptr(h->L + 1, 0);
       for (int l = 0; l < h->L; l++) {
         for (int j = lmptr[l]; j < lmptr[l + 1]; j += kLmChunk) {
@@ -1080,8 +1246,10 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     if ((rc = upload(h, h->lmrow, lmrow))) return rc;
     if ((rc = upload(h, h->lmrow_state, lmstate))) return rc;
     if ((rc = upload(h, h->lmrow_ptr, lmptr))) return rc;
-    HIPCHK(h->lm_t.reserve((size_t)std::max(h->nlmrows, 1) * h->R * sizeof(Real)));
-    HIPCHK(h->lm_S.reserve(((size_t)h->nl * h->R + h->nl) * sizeof(Real)));   // [S (nl x R) | gL (nl)]: one buffer, one all-reduce
+    if (!segmented) {
+      HIPCHK(h->lm_t.reserve((size_t)std::max(h->nlmrows, 1) * h->R * sizeof(Real)));
+      HIPCHK(h->lm_S.reserve(((size_t)h->nl * h->R + h->nl) * sizeof(Real)));   // [S (nl x R) | gL (nl)]: one buffer, one all-reduce
+    }
     HIPCHK(h->lm_dL.reserve((size_t)h->nl * sizeof(Real)));
     if (!h->lmk.p) return fail(h, GPSLAM_E_INVALID, "set_landmarks() before compile()");
   }
@@ -1150,6 +1318,7 @@ int gpslam_hip_compile(gpslam_hip_handle *h) {
     HIPCHK(hipMemsetAsync(h->top_x.p, 0, (size_t)(P + 1) * b * h->R * sizeof(Real), h->stream));
   }
   h->fuse_ok = fused_kernel_applies(h);
+  if (segmented && (rc = fs_build(h, touch_lo, touch_hi))) return rc;
   HIPCHK(hipStreamSynchronize(h->stream));
   h->compiled = true;
   return 0;
@@ -1276,7 +1445,8 @@ int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *lambda, const gpslam_hip
     if ((rc = launch_dot(h, h->dvec.as<Real>(), h->gsave.as<Real>(), nx, 3))) return rc;   // delta . g
     if ((rc = launch_dot(h, h->dvec.as<Real>(), h->dvec.as<Real>(), nx, 4))) return rc;    // |delta|^2
     if (h->nl > 0) {
-      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), (h->lm_S.as<Real>() + (size_t)h->nl * h->R), h->nl, 5))) return rc;
+      const Real *gLp = h->fs.active ? h->lm_gL.as<Real>() : h->lm_S.as<Real>() + (size_t)h->nl * h->R;
+      if ((rc = launch_dot(h, h->lm_dL.as<Real>(), gLp, h->nl, 5))) return rc;
       if ((rc = launch_dot(h, h->lm_dL.as<Real>(), h->lm_dL.as<Real>(), h->nl, 6))) return rc;
     }
     if ((rc = launch_retract(h, 2))) return rc;
@@ -1359,6 +1529,7 @@ int gpslam_hip_normal_equations(gpslam_hip_handle *h, double *D, double *O, doub
   int rc = need_compiled(h);
   if (rc) return rc;
   (void)hipSetDevice(h->cfg.device);
+  if (B && h->fs.active) return fail(h, GPSLAM_E_UNSUPPORTED, "the dense landmark coupling B does not exist on the segmented landmark path");
   if ((rc = launch_factors(h, 0, 0))) return rc;
   if ((rc = launch_assemble(h, false))) return rc;
   const int N = h->N, b = h->b, R = h->R;

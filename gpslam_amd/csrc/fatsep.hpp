@@ -1,0 +1,709 @@
+// fatsep.hpp -- landmark elimination at scale (BASELINE config 4: 1e6 poses + 5e4 range landmarks with local
+// visibility; the graph is matlab/PlazaPose2.m:55-66, :147-178 scaled, factors gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98).
+//
+// A dense landmark border (kernels.hpp k_lm_*) carries every landmark column through the whole chain: R = 1 + L ld
+// right-hand sides, impossible for L = 5e4.  Here the chain is cut by nested dissection instead:
+//   * CUT states every C states; every landmark is attached to ONE cut such that all states its factors touch lie in the
+//     two segments next to that cut.  A cut state plus its landmarks is a FAT SEPARATOR (NB = 2d + ld * landmarks <= 64
+//     columns).  compile() picks the smallest C for which every landmark fits (a landmark seen from more than two
+//     segments does not; the segment length is doubled until all do).
+//   * every segment interior (a plain block-tridiagonal chain) is eliminated against its NC = 2 NB + 1 border columns
+//     [left fat | right fat | rhs]:  k_fs_factor (block Cholesky along the segment, one wave per segment),
+//     k_fs_sweep (forward substitution of the border columns, one thread per column: Y = L^-1 G),
+//     k_fs_syrk (the segment's Schur complement Y^T Y: a genuine dense GEMM with K = 2d * segment length, on
+//     v_mfma_f64_16x16x4_f64),  k_fs_fat_assemble (direct terms - Schur complements -> fat blocks).
+//   * the fat blocks form a block-tridiagonal system of K = N / C dense NB x NB blocks: block cyclic reduction over
+//     level sets (k_fat_elim / k_fat_update per level, k_fat_top, k_fat_back per level in reverse).
+//   * k_fs_rhs / k_fs_solve1: interior states by a single-rhs forward / backward sweep with the stored factors.
+// Everything is summed in a fixed order (no atomics): results are bit-reproducible from run to run.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "devbuf.hpp"
+
+namespace gps {
+
+constexpr int kFatMax = 64;   // largest fat block (cut state + landmark columns)
+
+template <typename T> struct FsArgs {
+  int N, B, ld, L, K, NB, NC, NCP;   // K cuts / fat blocks; NC = 2 NB + 1 border columns; NCP = NC rounded up to 16
+  int BS;                            // doubles per level-0 block record [D | O | g] (R = 1)
+  const int *cuts;                   // K
+  const int *segid;                  // N: segment of an interior state, -1 - k for cut k
+  const int *fat_lm_ptr, *fat_lm;    // K + 1, landmarks of each fat block in slot order
+  const int *lm_fat, *lm_slot;       // L
+  const int *lmrow_ptr, *lmrow, *lmrow_state;   // rows touching each landmark, sorted by left state
+  const int *lmpri_ptr, *lmpri;      // L + 1, prior ids per landmark
+  const T *pri_meas, *pri_sig;
+  const T *lmk;
+  const int *rowptr, *rowLm;
+  const T *rowLR, *rowE, *rowM;
+  const T *blk;                      // N records [D | O | g]
+  T *fac;                            // N x 2 B^2: [W = L^-1 (lower) | E = W O^T] of the interior states
+  T *Y;                              // N x B x NCP
+  T *Aseg;                           // (K - 1) x NCP x NCP
+  T *Dfat, *link, *gfat, *Qbuf, *S1, *S2, *sv;
+  T *xfat;                           // K x NB
+  T *gL, *dL;                        // L ld
+  T *x;                              // N x B solution (R = 1 layout of the level-0 solution array)
+  T *rhs;                            // N x B
+  T lambda;
+  int *flag;
+};
+
+__device__ __forceinline__ void fs_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- block Cholesky along every segment interior.  One wave per segment, matrices in LDS.
+// D~_j = D_j + lambda I - E_{j-1}^T E_{j-1} = L_j L_j^T;  W_j = L_j^-1;  E_j = W_j O_j^T  (O_j = H[j+1, j])
+template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_factor(FsArgs<T> a) {
+  const int seg = blockIdx.x, lane = threadIdx.x;
+  const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
+  __shared__ T A[B * B], E[B * B], W[B * B];
+  for (int jj = 0; jj < n; jj++) {
+    const int s = j0 + jj;
+    const T *bp = a.blk + (size_t)s * a.BS;
+    for (int idx = lane; idx < B * B; idx += 64) {
+      const int r = idx / B, c = idx - r * B;
+      T v = bp[idx] + (r == c ? a.lambda : T(0));
+      if (jj > 0)
+        for (int k = 0; k < B; k++) v -= E[k * B + r] * E[k * B + c];
+      A[idx] = v;
+    }
+    fs_wave_sync();
+    for (int p = 0; p < B; p++) {
+      T dd = A[p * B + p];
+      if (!(dd > T(0))) { if (lane == 0) *a.flag = 1; dd = T(1); }
+      const T l = sqrt(dd), inv = T(1) / l;
+      fs_wave_sync();
+      for (int r = p + lane; r < B; r += 64) A[r * B + p] = (r == p) ? l : A[r * B + p] * inv;
+      fs_wave_sync();
+      const int m2 = B - p - 1;
+      for (int idx = lane; idx < m2 * m2; idx += 64) {
+        const int r = p + 1 + idx / m2, c = p + 1 + idx % m2;
+        if (c <= r) A[r * B + c] -= A[r * B + p] * A[c * B + p];
+      }
+      fs_wave_sync();
+    }
+    if (lane < B) {          // column `lane` of W = L^-1
+      T w[B];
+#pragma unroll
+      for (int r = 0; r < B; r++) {
+        T sacc = (r == lane) ? T(1) : T(0);
+#pragma unroll
+        for (int k = 0; k < r; k++) sacc -= A[r * B + k] * w[k];
+        w[r] = (r >= lane) ? sacc / A[r * B + r] : T(0);
+      }
+#pragma unroll
+      for (int r = 0; r < B; r++) W[r * B + lane] = w[r];
+    }
+    fs_wave_sync();
+    T *fp = a.fac + (size_t)s * 2 * B * B;
+    for (int idx = lane; idx < B * B; idx += 64) {
+      const int r = idx / B, c = idx - r * B;
+      T e = T(0);
+      for (int k = 0; k <= r; k++) e += W[r * B + k] * bp[B * B + c * B + k];   // (W O^T)[r][c] = sum_k W[r][k] O[c][k]
+      fp[idx] = W[idx];
+      fp[B * B + idx] = e;
+      E[idx] = e;
+    }
+    fs_wave_sync();
+  }
+}
+
+// ---- forward substitution of the border columns.  One thread per (segment, column):
+// G~_j = G_j - E_{j-1}^T Y_{j-1},  Y_j = W_j G~_j.  Columns: [0, NB) left fat block, [NB, 2 NB) right fat block, 2 NB rhs.
+template <typename T, int B> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T> a) {
+  const int seg = blockIdx.x, c = threadIdx.x;
+  if (c >= a.NC) return;
+  const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
+  const int j0 = cutL + 1, n = cutR - cutL - 1;
+  const bool is_rhs = (c == 2 * a.NB);
+  const bool right = (!is_rhs && c >= a.NB);
+  const int cc = is_rhs ? 0 : (right ? c - a.NB : c);
+  const int kf = seg + (right ? 1 : 0);
+  const bool is_state = !is_rhs && cc < B;
+  int lm = -1, q = 0;
+  if (!is_rhs && !is_state) {
+    const int li = (cc - B) / a.ld;
+    q = (cc - B) - li * a.ld;
+    if (a.fat_lm_ptr[kf] + li < a.fat_lm_ptr[kf + 1]) lm = a.fat_lm[a.fat_lm_ptr[kf] + li];
+    if (lm < 0) return;     // padding column: Y stays zero (cleared once at compile time)
+  }
+  int cur = 0, end = 0;
+  if (lm >= 0) { cur = a.lmrow_ptr[lm]; end = a.lmrow_ptr[lm + 1]; }
+  T y[B];
+#pragma unroll
+  for (int r = 0; r < B; r++) y[r] = T(0);
+  for (int jj = 0; jj < n; jj++) {
+    const int s = j0 + jj;
+    T G[B];
+#pragma unroll
+    for (int r = 0; r < B; r++) G[r] = T(0);
+    if (is_rhs) {
+      const T *gp = a.blk + (size_t)s * a.BS + 2 * B * B;
+#pragma unroll
+      for (int r = 0; r < B; r++) G[r] = gp[r];
+    } else if (is_state) {
+      if (!right && jj == 0) {            // H[cutL + 1, cutL] = O_cutL
+        const T *op = a.blk + (size_t)cutL * a.BS + B * B;
+#pragma unroll
+        for (int r = 0; r < B; r++) G[r] = op[r * B + cc];
+      } else if (right && jj == n - 1) {  // H[cutR - 1, cutR] = O_{cutR-1}^T
+        const T *op = a.blk + (size_t)s * a.BS + B * B;
+#pragma unroll
+        for (int r = 0; r < B; r++) G[r] = op[cc * B + r];
+      }
+    } else {
+      while (cur < end && a.lmrow_state[cur] < s - 1) cur++;
+      for (int t = cur; t < end && a.lmrow_state[t] <= s; t++) {
+        const int rho = a.lmrow[t];
+        const T m = a.rowM[(size_t)rho * a.ld + q];
+        const T *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
+#pragma unroll
+        for (int r = 0; r < B; r++) G[r] += row[r] * m;
+      }
+    }
+    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    if (jj > 0) {
+      const T *ep = fp - 2 * B * B + B * B;    // E_{j-1}
+#pragma unroll
+      for (int k = 0; k < B; k++)
+#pragma unroll
+        for (int r = 0; r < B; r++) G[r] -= ep[k * B + r] * y[k];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k <= r; k++) acc += fp[r * B + k] * G[k];
+      y[r] = acc;
+    }
+    T *yp = a.Y + (size_t)s * B * a.NCP + c;
+#pragma unroll
+    for (int r = 0; r < B; r++) yp[(size_t)r * a.NCP] = y[r];
+  }
+}
+
+// ---- Schur complement of a segment: Aseg = Y^T Y (NCP x NCP, K dimension = B * interior states) on the fp64 matrix
+// cores.  One wave per (segment, 16-row tile): v_mfma_f64_16x16x4_f64, A[i][k] = Y[k][i0 + i], B[k][j] = Y[k][j0 + j]
+// (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
+typedef double fs_d4 __attribute__((ext_vector_type(4)));
+template <int TMAX> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<double> a) {
+  const int seg = blockIdx.x, ti = blockIdx.y, lane = threadIdx.x;
+  const int T16 = a.NCP / 16;
+  const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
+  const int kdim = n * a.B;
+  const double *Yb = a.Y + (size_t)j0 * a.B * a.NCP;
+  fs_d4 acc[TMAX];
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) acc[t] = fs_d4{0.0, 0.0, 0.0, 0.0};
+  const int kl = lane >> 4, cl = lane & 15;
+  for (int k0 = 0; k0 < kdim; k0 += 4) {
+    const int k = k0 + kl;
+    const bool ok = k < kdim;
+    const double *yr = Yb + (size_t)(ok ? k : 0) * a.NCP;
+    const double av = ok ? yr[ti * 16 + cl] : 0.0;
+#pragma unroll
+    for (int t = 0; t < TMAX; t++) {
+      if (t < T16) {
+        const double bv = ok ? yr[t * 16 + cl] : 0.0;
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  double *out = a.Aseg + (size_t)seg * a.NCP * a.NCP;
+#pragma unroll
+  for (int t = 0; t < TMAX; t++) {
+    if (t < T16) {
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) out[(size_t)(ti * 16 + kl + 4 * rg) * a.NCP + t * 16 + cl] = acc[t][rg];
+    }
+  }
+}
+
+// ---- fat blocks: direct terms minus the Schur complements of the two neighbouring segments.
+// variable v of fat block k: v < B -> component v of the cut state; else landmark fat_lm[ptr[k] + (v - B) / ld],
+// component (v - B) % ld, or padding (unit diagonal).
+template <typename T> struct FsVar { int kind, lm, q; };   // kind 0 state, 1 landmark, 2 padding
+template <typename T> __device__ __forceinline__ FsVar<T> fs_var(const FsArgs<T> &a, int k, int v) {
+  FsVar<T> o;
+  if (v < a.B) { o.kind = 0; o.lm = -1; o.q = v; return o; }
+  const int li = (v - a.B) / a.ld;
+  o.q = (v - a.B) - li * a.ld;
+  if (a.fat_lm_ptr[k] + li < a.fat_lm_ptr[k + 1]) { o.kind = 1; o.lm = a.fat_lm[a.fat_lm_ptr[k] + li]; }
+  else { o.kind = 2; o.lm = -1; }
+  return o;
+}
+// sum over the rows of landmark lm of (Jacobian entry of state `st`, component r) * m_q
+template <typename T> __device__ __forceinline__ T fs_state_lm(const FsArgs<T> &a, int st, int r, int lm, int q) {
+  T v = T(0);
+  for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
+    const int ls = a.lmrow_state[t];
+    if (ls != st && ls != st - 1) continue;
+    const int rho = a.lmrow[t];
+    v += a.rowLR[(size_t)rho * 2 * a.B + (ls == st ? 0 : a.B) + r] * a.rowM[(size_t)rho * a.ld + q];
+  }
+  return v;
+}
+template <typename T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(FsArgs<T> a) {
+  const int k = blockIdx.x, NB = a.NB, B = a.B;
+  const int cut = a.cuts[k];
+  const T *AL = (k > 0) ? a.Aseg + (size_t)(k - 1) * a.NCP * a.NCP : nullptr;   // segment on the left: this block is its RIGHT fat
+  const T *AR = (k < a.K - 1) ? a.Aseg + (size_t)k * a.NCP * a.NCP : nullptr;
+  const T *bp = a.blk + (size_t)cut * a.BS;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+    const int r = idx / NB, c = idx - r * NB;
+    const FsVar<T> vr = fs_var(a, k, r), vc = fs_var(a, k, c);
+    T v = T(0);
+    if (vr.kind == 2 || vc.kind == 2) {
+      v = (r == c) ? T(1) : T(0);
+    } else {
+      if (vr.kind == 0 && vc.kind == 0) v = bp[r * B + c];
+      else if (vr.kind == 0) v = fs_state_lm(a, cut, r, vc.lm, vc.q);
+      else if (vc.kind == 0) v = fs_state_lm(a, cut, c, vr.lm, vr.q);
+      else if (vr.lm == vc.lm) {
+        for (int t = a.lmrow_ptr[vr.lm]; t < a.lmrow_ptr[vr.lm + 1]; t++) {
+          const int rho = a.lmrow[t];
+          v += a.rowM[(size_t)rho * a.ld + vr.q] * a.rowM[(size_t)rho * a.ld + vc.q];
+        }
+        if (vr.q == vc.q)
+          for (int t = a.lmpri_ptr[vr.lm]; t < a.lmpri_ptr[vr.lm + 1]; t++) {
+            const T w = T(1) / a.pri_sig[(size_t)a.lmpri[t] * a.ld + vr.q];
+            v += w * w;
+          }
+      }
+      if (r == c) v += a.lambda;
+      if (AL) v -= AL[(size_t)(NB + r) * a.NCP + NB + c];
+      if (AR) v -= AR[(size_t)r * a.NCP + c];
+    }
+    a.Dfat[(size_t)k * NB * NB + idx] = v;
+    if (k < a.K - 1) {       // link k -> k + 1: H[fat k+1 variable r, fat k variable c]
+      const FsVar<T> wr = fs_var(a, k + 1, r);
+      const int cut1 = a.cuts[k + 1];
+      T o = T(0);
+      if (wr.kind != 2 && vc.kind != 2) {
+        if (wr.kind == 0 && vc.kind == 0) { if (cut1 == cut + 1) o = bp[B * B + r * B + c]; }
+        else if (wr.kind == 0 && vc.kind == 1) o = fs_state_lm(a, cut1, r, vc.lm, vc.q);
+        else if (wr.kind == 1 && vc.kind == 0) o = fs_state_lm(a, cut, c, wr.lm, wr.q);
+        o -= AR[(size_t)(NB + r) * a.NCP + c];
+      }
+      a.link[(size_t)k * NB * NB + idx] = o;
+    }
+  }
+  for (int r = threadIdx.x; r < NB; r += blockDim.x) {
+    const FsVar<T> vr = fs_var(a, k, r);
+    T g = T(0);
+    if (vr.kind == 0) g = bp[2 * B * B + r];
+    else if (vr.kind == 1) {
+      for (int t = a.lmrow_ptr[vr.lm]; t < a.lmrow_ptr[vr.lm + 1]; t++) {
+        const int rho = a.lmrow[t];
+        g -= a.rowM[(size_t)rho * a.ld + vr.q] * a.rowE[rho];
+      }
+      for (int t = a.lmpri_ptr[vr.lm]; t < a.lmpri_ptr[vr.lm + 1]; t++) {
+        const int pk = a.lmpri[t];
+        const T w = T(1) / a.pri_sig[(size_t)pk * a.ld + vr.q];
+        g -= w * w * (a.lmk[(size_t)vr.lm * a.ld + vr.q] - a.pri_meas[(size_t)pk * a.ld + vr.q]);
+      }
+      a.gL[(size_t)vr.lm * a.ld + vr.q] = g;   // undamped gradient (LM model)
+    }
+    if (vr.kind != 2) {
+      if (AL) g -= AL[(size_t)(NB + r) * a.NCP + 2 * NB];
+      if (AR) g -= AR[(size_t)r * a.NCP + 2 * NB];
+    }
+    a.gfat[(size_t)k * NB + r] = g;
+  }
+}
+
+// ---- block cyclic reduction over the fat blocks.  One level: eliminate every other active block m (left neighbour l,
+// right neighbour r or -1):  D_m = L L^T,  P = L^-1 H[m, l],  Q = L^-1 H[m, r],  z = L^-1 g_m;
+// S1 = P^T P -> D_l,  S2 = Q^T Q -> D_r,  new link H[r, l] = -Q^T P,  P^T z -> g_l,  Q^T z -> g_r.
+struct FatLevel {
+  const int *elim;     // 6 ints per eliminated block: m, l, r, link(l -> m), link(m -> r), new link(l -> r)
+  int nelim;
+  const int *upd;      // 3 ints per survivor: a, eliminated block on its left (or -1), on its right (or -1)
+  int nupd;
+};
+
+template <typename T> __device__ __forceinline__ void fat_chol_lds(T *Lm, int NB, int LS, int *flag) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int p = 0; p < NB; p++) {
+    T dd = Lm[p * LS + p];
+    if (!(dd > T(0))) { if (tid == 0) *flag = 1; dd = T(1); }
+    const T l = sqrt(dd), inv = T(1) / l;
+    __syncthreads();
+    for (int i = p + tid; i < NB; i += nt) Lm[i * LS + p] = (i == p) ? l : Lm[i * LS + p] * inv;
+    __syncthreads();
+    const int m2 = NB - p - 1;
+    for (int idx = tid; idx < m2 * m2; idx += nt) {
+      const int i = p + 1 + idx / m2, j = p + 1 + idx % m2;
+      if (j <= i) Lm[i * LS + j] -= Lm[i * LS + p] * Lm[j * LS + p];
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T> a, FatLevel lv) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
+  const int NB = a.NB, LS = NB + 1, XS = 2 * NB + 1, NB2 = NB * NB;
+  T *Lm = reinterpret_cast<T *>(fat_smem);
+  T *X = Lm + NB * LS;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int idx = tid; idx < NB2; idx += nt) {
+    const int i = idx / NB, j = idx - i * NB;
+    Lm[i * LS + j] = a.Dfat[(size_t)m * NB2 + idx];
+    X[i * XS + j] = a.link[(size_t)lk_lm * NB2 + idx];                               // H[m, l]
+    X[i * XS + NB + j] = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + j * NB + i] : T(0);    // H[m, r] = H[r, m]^T
+  }
+  for (int i = tid; i < NB; i += nt) X[i * XS + 2 * NB] = a.gfat[(size_t)m * NB + i];
+  __syncthreads();
+  fat_chol_lds(Lm, NB, LS, a.flag);
+  for (int c = tid; c < XS; c += nt) {      // forward substitution, one column per thread
+    for (int i = 0; i < NB; i++) {
+      T s = X[i * XS + c];
+      for (int k = 0; k < i; k++) s -= Lm[i * LS + k] * X[k * XS + c];
+      X[i * XS + c] = s / Lm[i * LS + i];
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < NB2; idx += nt) {
+    const int i = idx / NB, j = idx - i * NB;
+    a.Dfat[(size_t)m * NB2 + idx] = Lm[i * LS + j];
+    a.link[(size_t)lk_lm * NB2 + idx] = X[i * XS + j];           // P
+    a.Qbuf[(size_t)m * NB2 + idx] = X[i * XS + NB + j];          // Q
+    T s1 = T(0), s2 = T(0), s3 = T(0);
+    for (int k = 0; k < NB; k++) {
+      const T pi = X[k * XS + i], pj = X[k * XS + j], qi = X[k * XS + NB + i], qj = X[k * XS + NB + j];
+      s1 += pi * pj;
+      s2 += qi * qj;
+      s3 += qi * pj;
+    }
+    a.S1[(size_t)m * NB2 + idx] = s1;
+    a.S2[(size_t)m * NB2 + idx] = s2;
+    if (r >= 0) a.link[(size_t)lk_new * NB2 + idx] = -s3;         // H[r, l] = -(Q^T P)
+  }
+  for (int i = tid; i < NB; i += nt) {
+    T pz = T(0), qz = T(0);
+    for (int k = 0; k < NB; k++) { pz += X[k * XS + i] * X[k * XS + 2 * NB]; qz += X[k * XS + NB + i] * X[k * XS + 2 * NB]; }
+    a.gfat[(size_t)m * NB + i] = X[i * XS + 2 * NB];              // z
+    a.sv[(size_t)m * 2 * NB + i] = pz;
+    a.sv[(size_t)m * 2 * NB + NB + i] = qz;
+  }
+}
+
+template <typename T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T> a, FatLevel lv) {
+  const int NB = a.NB, NB2 = NB * NB;
+  const int *u = lv.upd + 3 * blockIdx.x;
+  const int blk = u[0], ml = u[1], mr = u[2];     // ml: eliminated block whose RIGHT neighbour this is; mr: ... LEFT ...
+  for (int idx = threadIdx.x; idx < NB2; idx += blockDim.x) {
+    T v = a.Dfat[(size_t)blk * NB2 + idx];
+    if (ml >= 0) v -= a.S2[(size_t)ml * NB2 + idx];
+    if (mr >= 0) v -= a.S1[(size_t)mr * NB2 + idx];
+    a.Dfat[(size_t)blk * NB2 + idx] = v;
+  }
+  for (int i = threadIdx.x; i < NB; i += blockDim.x) {
+    T v = a.gfat[(size_t)blk * NB + i];
+    if (ml >= 0) v -= a.sv[(size_t)ml * 2 * NB + NB + i];
+    if (mr >= 0) v -= a.sv[(size_t)mr * 2 * NB + i];
+    a.gfat[(size_t)blk * NB + i] = v;
+  }
+}
+
+// the last active block: dense Cholesky solve
+template <typename T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T> a, int top) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
+  const int NB = a.NB, LS = NB + 1;
+  T *Lm = reinterpret_cast<T *>(fat_smem);
+  T *y = Lm + NB * LS;
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lm[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)top * NB * NB + idx];
+  for (int i = threadIdx.x; i < NB; i += blockDim.x) y[i] = a.gfat[(size_t)top * NB + i];
+  __syncthreads();
+  fat_chol_lds(Lm, NB, LS, a.flag);
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < NB; i++) {
+      T s = y[i];
+      for (int k = 0; k < i; k++) s -= Lm[i * LS + k] * y[k];
+      y[i] = s / Lm[i * LS + i];
+    }
+    for (int i = NB - 1; i >= 0; i--) {
+      T s = y[i];
+      for (int k = i + 1; k < NB; k++) s -= Lm[k * LS + i] * y[k];
+      y[i] = s / Lm[i * LS + i];
+      a.xfat[(size_t)top * NB + i] = y[i];
+    }
+  }
+}
+
+// x_m = L^-T (z - P x_l - Q x_r)
+template <typename T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T> a, FatLevel lv) {
+  __shared__ T Ls[kFatMax * (kFatMax + 1)];
+  __shared__ T xs[2 * kFatMax], ts[kFatMax];
+  const int NB = a.NB, LS = NB + 1, NB2 = NB * NB, lane = threadIdx.x;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], l = e[1], r = e[2], lk_lm = e[3];
+  for (int idx = lane; idx < NB2; idx += 64) Ls[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)m * NB2 + idx];
+  for (int i = lane; i < NB; i += 64) {
+    xs[i] = a.xfat[(size_t)l * NB + i];
+    xs[NB + i] = (r >= 0) ? a.xfat[(size_t)r * NB + i] : T(0);
+  }
+  fs_wave_sync();
+  for (int i = lane; i < NB; i += 64) {
+    T t = a.gfat[(size_t)m * NB + i];
+    const T *P = a.link + (size_t)lk_lm * NB2 + (size_t)i * NB, *Q = a.Qbuf + (size_t)m * NB2 + (size_t)i * NB;
+    for (int j = 0; j < NB; j++) t -= P[j] * xs[j];
+    if (r >= 0) for (int j = 0; j < NB; j++) t -= Q[j] * xs[NB + j];
+    ts[i] = t;
+  }
+  fs_wave_sync();
+  for (int i = NB - 1; i >= 0; i--) {
+    const T xi = ts[i] / Ls[i * LS + i];
+    fs_wave_sync();
+    if (lane == 0) ts[i] = xi;
+    for (int k = lane; k < i; k += 64) ts[k] -= Ls[i * LS + k] * xi;
+    fs_wave_sync();
+  }
+  for (int i = lane; i < NB; i += 64) a.xfat[(size_t)m * NB + i] = ts[i];
+}
+
+// ---- scatter the fat solution: cut states -> x, landmarks -> dL
+template <typename T> __global__ void __launch_bounds__(256) k_fs_scatter(FsArgs<T> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid < a.K * a.B) {
+    const int k = tid / a.B, r = tid - k * a.B;
+    a.x[(size_t)a.cuts[k] * a.B + r] = a.xfat[(size_t)k * a.NB + r];
+  }
+  if (tid < a.L * a.ld) {
+    const int l = tid / a.ld, q = tid - l * a.ld;
+    a.dL[tid] = a.xfat[(size_t)a.lm_fat[l] * a.NB + a.B + a.lm_slot[l] * a.ld + q];
+  }
+}
+
+// ---- right-hand side of the interior states once the fat solution is known: rhs_s = g_s - G_s x_fat
+template <typename T, int B> __global__ void __launch_bounds__(128) k_fs_rhs(FsArgs<T> a) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.N || a.segid[s] < 0) return;
+  T r[B];
+  const T *bp = a.blk + (size_t)s * a.BS;
+#pragma unroll
+  for (int k = 0; k < B; k++) r[k] = bp[2 * B * B + k];
+  if (s > 0 && a.segid[s - 1] < 0) {            // left neighbour is a cut: H[s, s-1] = O_{s-1}
+    const T *op = a.blk + (size_t)(s - 1) * a.BS + B * B;
+    const T *xc = a.x + (size_t)(s - 1) * B;
+#pragma unroll
+    for (int k = 0; k < B; k++)
+#pragma unroll
+      for (int j = 0; j < B; j++) r[k] -= op[k * B + j] * xc[j];
+  }
+  if (s + 1 < a.N && a.segid[s + 1] < 0) {      // right neighbour is a cut: H[s, s+1] = O_s^T
+    const T *op = bp + B * B;
+    const T *xc = a.x + (size_t)(s + 1) * B;
+#pragma unroll
+    for (int k = 0; k < B; k++)
+#pragma unroll
+      for (int j = 0; j < B; j++) r[k] -= op[j * B + k] * xc[j];
+  }
+  for (int half = 0; half < 2; half++) {        // rows of state s (left halves), rows of state s - 1 (right halves)
+    const int st = s - half;
+    if (st < 0) continue;
+    for (int rho = a.rowptr[st]; rho < a.rowptr[st + 1]; rho++) {
+      const int lm = a.rowLm[rho];
+      if (lm < 0) continue;
+      T t = T(0);
+      for (int q = 0; q < a.ld; q++) t += a.rowM[(size_t)rho * a.ld + q] * a.dL[(size_t)lm * a.ld + q];
+      const T *row = a.rowLR + (size_t)rho * 2 * B + half * B;
+#pragma unroll
+      for (int k = 0; k < B; k++) r[k] -= row[k] * t;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < B; k++) a.rhs[(size_t)s * B + k] = r[k];
+}
+
+// ---- interior states: single right-hand side forward / backward sweep with the stored factors, one thread per segment
+template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_solve1(FsArgs<T> a) {
+  const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+  if (seg >= a.K - 1) return;
+  const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
+  T y[B];
+#pragma unroll
+  for (int k = 0; k < B; k++) y[k] = T(0);
+  for (int jj = 0; jj < n; jj++) {
+    const int s = j0 + jj;
+    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    T t[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) t[k] = a.rhs[(size_t)s * B + k];
+    if (jj > 0) {
+      const T *ep = fp - B * B;
+#pragma unroll
+      for (int k = 0; k < B; k++)
+#pragma unroll
+        for (int r = 0; r < B; r++) t[r] -= ep[k * B + r] * y[k];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {
+      T acc = T(0);
+#pragma unroll
+      for (int k = 0; k <= r; k++) acc += fp[r * B + k] * t[k];
+      y[r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) a.rhs[(size_t)s * B + k] = y[k];     // y~_s, read back by the backward sweep
+  }
+  T xn[B];
+#pragma unroll
+  for (int k = 0; k < B; k++) xn[k] = T(0);
+  for (int jj = n - 1; jj >= 0; jj--) {
+    const int s = j0 + jj;
+    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    T t[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) t[k] = a.rhs[(size_t)s * B + k];
+    if (jj < n - 1) {
+      const T *ep = fp + B * B;          // E_s couples s to s + 1
+#pragma unroll
+      for (int r = 0; r < B; r++)
+#pragma unroll
+        for (int k = 0; k < B; k++) t[r] -= ep[r * B + k] * xn[k];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) {        // x = W^T t
+      T acc = T(0);
+#pragma unroll
+      for (int k = r; k < B; k++) acc += fp[k * B + r] * t[k];
+      xn[r] = acc;
+    }
+#pragma unroll
+    for (int k = 0; k < B; k++) a.x[(size_t)s * B + k] = xn[k];
+  }
+}
+
+// landmarks += dL; *out_max = max(*out_max, |dL|_inf) -- L can be 5e4: a grid-stride kernel + one partial per block
+template <typename T> __global__ void __launch_bounds__(256) k_fs_lm_update(T *lmk, const T *dL, int nl, const int *flag, T *partial) {
+  __shared__ T red[256];
+  const bool bad = flag && *flag;
+  T mx = T(0);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += gridDim.x * blockDim.x) {
+    const T v = dL[i];
+    if (!bad) lmk[i] += v;
+    mx = fmax(mx, (v == v) ? fabs(v) : T(INFINITY));
+  }
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+template <typename T> __global__ void __launch_bounds__(64) k_fs_max_into(const T *partial, int n, double *out) {
+  T mx = T(0);
+  for (int i = threadIdx.x; i < n; i += 64) mx = fmax(mx, partial[i]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_down(mx, o, 64));
+  if (threadIdx.x == 0) *out = fmax(*out, (double)mx);
+}
+// error of the landmark priors, grid-stride
+template <typename T> __global__ void __launch_bounds__(256) k_fs_lmprior_err(const T *lmk, const int *pri_lm, const T *pri_meas, const T *pri_sig,
+                                                                             int npri, int ld, T *partial) {
+  __shared__ T red[256];
+  T err = T(0);
+  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npri; k += gridDim.x * blockDim.x)
+    for (int q = 0; q < ld; q++) {
+      const T we = (lmk[(size_t)pri_lm[k] * ld + q] - pri_meas[(size_t)k * ld + q]) / pri_sig[(size_t)k * ld + q];
+      err += we * we;
+    }
+  red[threadIdx.x] = T(0.5) * err;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+// =================================================================== host side
+
+struct FatSepPlan {
+  bool active = false;
+  int N = 0, B = 0, ld = 0, L = 0, K = 0, NB = 0, NC = 0, NCP = 0, C = 0, nlinks = 0, top = 0;
+  std::vector<int> cuts;
+  struct LevelHost { int elim_off, nelim, upd_off, nupd; };
+  std::vector<LevelHost> levels;
+  DevBuf d_cuts, d_segid, d_fat_lm_ptr, d_fat_lm, d_lm_fat, d_lm_slot, d_lmpri_ptr, d_lmpri, d_elim, d_upd;
+  DevBuf fac, Y, Aseg, Dfat, link, gfat, Qbuf, S1, S2, sv, xfat, gL, rhs, partial;
+  std::string err;
+
+  void release() {
+    for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
+                      &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial})
+      b->release();
+    active = false;
+  }
+
+  static std::vector<int> make_cuts(int N, int C) {
+    std::vector<int> c;
+    for (int s = 0; s < N - 1; s += C) c.push_back(s);
+    if (c.empty() || c.back() != N - 1) c.push_back(N - 1);
+    if (c.size() >= 3 && c[c.size() - 1] - c[c.size() - 2] < 2) c.erase(c.end() - 2);
+    return c;
+  }
+
+  // touch_lo / touch_hi: first / last state touched by the factors of each landmark (-1: none).
+  // Returns false (err set) when no segment length fits.
+  bool choose(int N_, int B_, int ld_, int L_, const std::vector<int> &touch_lo, const std::vector<int> &touch_hi, int c_forced,
+              std::vector<int> &fat_of, std::vector<int> &slot_of, std::vector<int> &counts) {
+    N = N_; B = B_; ld = ld_; L = L_;
+    if (N < 2) { err = "the segmented landmark elimination needs at least two states"; return false; }
+    for (int Ctry = (c_forced > 0 ? c_forced : 32);; Ctry *= 2) {
+      cuts = make_cuts(N, Ctry);
+      K = (int)cuts.size();
+      counts.assign(K, 0);
+      fat_of.assign(L, 0);
+      slot_of.assign(L, 0);
+      bool ok = true;
+      for (int l = 0; l < L && ok; l++) {
+        int lo, hi;
+        if (touch_lo[l] < 0) { lo = hi = l % K; }
+        else {
+          const int k_lo = (int)(std::upper_bound(cuts.begin(), cuts.end(), touch_lo[l]) - cuts.begin()) - 1;
+          const int k_hi = (int)(std::lower_bound(cuts.begin(), cuts.end(), touch_hi[l]) - cuts.begin());
+          if (k_hi - k_lo > 2) { ok = false; break; }
+          lo = std::max(k_hi - 1, 0);
+          hi = std::min(k_lo + 1, K - 1);
+        }
+        int best = lo;
+        for (int k = lo + 1; k <= hi; k++) if (counts[k] < counts[best]) best = k;
+        fat_of[l] = best;
+        slot_of[l] = counts[best]++;
+      }
+      int mx = 0;
+      for (int k = 0; k < K; k++) mx = std::max(mx, counts[k]);
+      const int nb = B + ld * mx;
+      if (ok && nb <= kFatMax) { C = Ctry; NB = (nb + 3) & ~3; if (NB > kFatMax) NB = kFatMax; break; }
+      if (c_forced > 0 || K <= 2) {
+        err = ok ? "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 64)"
+                 : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists";
+        return false;
+      }
+      if (ok && nb > kFatMax) {   // longer segments only add landmarks per cut
+        err = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 64)";
+        return false;
+      }
+    }
+    NC = 2 * NB + 1;
+    NCP = (NC + 15) & ~15;
+    return true;
+  }
+};
+
+}  // namespace gps

@@ -163,6 +163,60 @@ def pose2_range_chain(N, L=8, seed=0, dt=0.1, rate=0.44):
                 range_dt=np.full(len(left), dt), range_tau=tau)
 
 
+def se2_prefix(rel):
+    """Inclusive prefix composition of a batch of SE(2) elements (N x 3 [x, y, theta]) by doubling."""
+    x = rel.copy()
+    n, shift = len(x), 1
+    while shift < n:
+        x[shift:] = se2_compose(x[:-shift], x[shift:])
+        shift *= 2
+    return x
+
+
+def pose2_local_landmarks_chain(N, L=None, seed=0, dt=0.1, rate=0.44, window=200):
+    """Config C4 (BASELINE: 1e6 poses + 5e4 range landmarks, Plaza-scaled): the Plaza recipe (matlab/PlazaPose2.m:40-46,
+    :55-66, :147-178) on a long SE(2) drive past L = N / 20 landmarks, each visible only while the robot is within
+    `window` / 2 states of its closest approach, so that ~window / 20 landmarks are in view at any time and every
+    landmark collects about rate * 20 = 8.8 interpolated range factors."""
+    rng = np.random.default_rng(SEED_BASE + 44 + seed)
+    if L is None:
+        L = max(N // 20, 1)
+    i = np.arange(N - 1)
+    twist = np.stack([1.0 + 0.2 * np.sin(0.003 * i), 0.05 * np.cos(0.007 * i), 0.05 * np.sin(0.0011 * i)], -1)
+    rel = se2_exp(dt * twist)
+    truth = np.zeros((N, 3))
+    truth[1:] = se2_prefix(rel)
+    sig_odo = np.array([1e-3, 1e-3, np.pi * 1e-3])
+    odo = rel + sig_odo * rng.standard_normal((N - 1, 3))
+    dead = np.zeros((N, 3))
+    dead[1:] = se2_prefix(odo)
+    centre = np.minimum(((np.arange(L) + 0.5) * (N / L)).astype(np.int64), N - 1)     # closest-approach state
+    side = np.where(rng.random(L) < 0.5, -1.0, 1.0) * (3.0 + 5.0 * rng.random(L))
+    th = truth[centre, 2]
+    lmk = truth[centre, :2] + side[:, None] * np.stack([-np.sin(th), np.cos(th)], -1) + rng.standard_normal((L, 2))
+    has = rng.random(N - 1) < rate
+    left = np.nonzero(has)[0].astype(np.int32)
+    tau = dt * rng.random(len(left))
+    # a visible landmark: closest approach within window / 2 states of the interval
+    pos = (left + 0.5) * (L / N) - 0.5                       # fractional landmark index at this interval
+    half = 0.5 * window * (L / N)
+    lo = np.clip(np.ceil(pos - half), 0, L - 1).astype(np.int64)
+    hi = np.clip(np.floor(pos + half), 0, L - 1).astype(np.int64)
+    hi = np.maximum(hi, lo)
+    lm = (lo + (rng.random(len(left)) * (hi - lo + 1)).astype(np.int64)).astype(np.int32)
+    at = se2_compose(truth[left], se2_exp(tau[:, None] * twist[left]))
+    z = np.linalg.norm(lmk[lm] - at[:, :2], axis=1) + 0.5 * rng.standard_normal(len(left))
+    return dict(kind=POSE2, name="C4 pose2 GP prior + odometry + interpolated ranges to locally visible landmarks", N=N,
+                qc=0.01 * np.eye(3), pose=dead, vel=np.zeros((N, 3)), truth=truth,
+                landmarks=lmk + 0.5 * rng.standard_normal((L, 2)), landmark_truth=lmk, linear=False,
+                gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),
+                between_left=np.arange(N - 1, dtype=np.int32), between_meas=odo, between_sig=np.tile(sig_odo, (N - 1, 1)),
+                prior_idx=np.array([0], dtype=np.int32), prior_pose=truth[:1].copy(), prior_sig=np.array([[1.0, 1.0, np.pi]]),
+                lprior_idx=np.arange(L, dtype=np.int32), lprior=lmk.copy(), lprior_sig=np.full((L, 2), 1.0),
+                range_left=left, range_lm=lm, range_z=z, range_sigma=np.full(len(left), 0.5),
+                range_dt=np.full(len(left), dt), range_tau=tau)
+
+
 def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sigma=0.1):
     """C5 (reference-faithful variant): SO(3) GP chain with interpolated attitude (accelerometer) factors."""
     rng = np.random.default_rng(SEED_BASE + 5 + seed)

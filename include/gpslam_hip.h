@@ -66,7 +66,9 @@ typedef struct {
   int32_t chunk;         /* level-0 chunk length of the partitioned solver; 0 = default */
   int32_t rank, nranks;  /* contiguous-segment sharding: this handle owns segment `rank` of `nranks` */
   int32_t reserved[8];   /* [0] force the sharded code path, [1] upper-level chunk length, [2] sequential top size,
-                          * [3] GPSLAM_VELOCITY_* (POSE3 only); others must be 0 */
+                          * [3] GPSLAM_VELOCITY_* (POSE3 only), [4] segment length of the segmented landmark elimination
+                          * (0 = smallest that fits), [5] 1 = use the segmented landmark elimination for any landmark
+                          * count (default: only when the landmarks do not fit the dense border); others must be 0 */
 } gpslam_hip_config;
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */

@@ -1,0 +1,144 @@
+"""numpy model of the segmented landmark elimination with fat separators (test infrastructure).
+
+The HIP library solves chains with many locally visible landmarks (BASELINE config 4) by nested dissection along the
+chain: CUT states every C states, each landmark attached to one cut ("fat separator" = cut state + its landmarks), the
+interior of every segment eliminated against the two fat separators at its ends, and the resulting block-tridiagonal
+system of fat blocks solved by block cyclic reduction.  This file restates the same plan and the same algebra with dense
+numpy so that (a) the plan rules can be tested without a GPU, (b) the fat system the GPU assembles can be compared block
+by block, (c) the result can be checked against a dense solve of the whole bordered system.
+"""
+import bisect
+
+import numpy as np
+
+
+def make_cuts(N, C):
+    cuts = list(range(0, N - 1, C))
+    if cuts[-1] != N - 1:
+        cuts.append(N - 1)
+    if len(cuts) >= 3 and cuts[-1] - cuts[-2] < 2:      # keep at least one interior state in the last segment
+        cuts.pop(-2)
+    return cuts
+
+
+def plan(N, L, touch, C):
+    """touch[l] = (smin, smax) states touched by landmark l's factors, or None.  Returns (cuts, fat_of, slot_of, counts)
+    or None when some landmark spans more than two segments (C too small)."""
+    cuts = make_cuts(N, C)
+    K = len(cuts)
+    counts = [0] * K
+    fat_of, slot_of = [0] * L, [0] * L
+    for l in range(L):
+        if touch[l] is None:
+            lo = hi = l % K
+        else:
+            smin, smax = touch[l]
+            k_lo = bisect.bisect_right(cuts, smin) - 1
+            k_hi = bisect.bisect_left(cuts, smax)
+            if k_hi - k_lo > 2:
+                return None
+            lo, hi = max(k_hi - 1, 0), min(k_lo + 1, K - 1)
+        best = min(range(lo, hi + 1), key=lambda k: (counts[k], k))
+        fat_of[l], slot_of[l] = best, counts[best]
+        counts[best] += 1
+    return cuts, fat_of, slot_of, counts
+
+
+def fat_system(D, O, g, B, HLL, gL, ld, cuts, fat_of, slot_of, NB, lam=0.0):
+    """Dense elimination of every segment interior -> (Dfat K x NB x NB, Ofat (K-1) x NB x NB [H[k+1, k]], gfat K x NB).
+    Unused slots get a unit diagonal."""
+    N, b = g.shape
+    K = len(cuts)
+    L = len(fat_of)
+    nl = L * ld
+
+    def cols(k):
+        """global variable indices of fat block k, padded with -1: state cut_k then its landmarks"""
+        idx = [-1] * NB
+        for r in range(b):
+            idx[r] = cuts[k] * b + r
+        for l in range(L):
+            if fat_of[l] == k:
+                for q in range(ld):
+                    idx[b + slot_of[l] * ld + q] = N * b + l * ld + q
+        return idx
+
+    # dense full matrix (test sizes only)
+    n = N * b + nl
+    H = np.zeros((n, n))
+    rhs = np.zeros(n)
+    for i in range(N):
+        H[i * b:(i + 1) * b, i * b:(i + 1) * b] = D[i]
+        if i + 1 < N:
+            H[(i + 1) * b:(i + 2) * b, i * b:(i + 1) * b] = O[i]
+            H[i * b:(i + 1) * b, (i + 1) * b:(i + 2) * b] = O[i].T
+        rhs[i * b:(i + 1) * b] = g[i]
+    if nl:
+        H[:N * b, N * b:] = B.reshape(N * b, nl)
+        H[N * b:, :N * b] = B.reshape(N * b, nl).T
+        H[N * b:, N * b:] = HLL
+        rhs[N * b:] = gL
+    H += lam * np.eye(n)
+    top = sorted(set(i for k in range(K) for i in cols(k) if i >= 0))
+    top_set = set(top)
+    inner = [i for i in range(n) if i not in top_set]
+    Hti = H[np.ix_(top, inner)]
+    Hii = H[np.ix_(inner, inner)]
+    S = H[np.ix_(top, top)] - Hti @ np.linalg.solve(Hii, Hti.T)
+    sr = rhs[top] - Hti @ np.linalg.solve(Hii, rhs[inner])
+    pos = {v: p for p, v in enumerate(top)}
+    Dfat = np.zeros((K, NB, NB))
+    Ofat = np.zeros((max(K - 1, 0), NB, NB))
+    gfat = np.zeros((K, NB))
+    for k in range(K):
+        ck = cols(k)
+        for r, ir in enumerate(ck):
+            if ir < 0:
+                Dfat[k, r, r] = 1.0
+                continue
+            gfat[k, r] = sr[pos[ir]]
+            for c, ic in enumerate(ck):
+                if ic >= 0:
+                    Dfat[k, r, c] = S[pos[ir], pos[ic]]
+            if k + 1 < K:
+                for c2, ic2 in enumerate(cols(k + 1)):
+                    if ic2 >= 0:
+                        Ofat[k, c2, r] = S[pos[ic2], pos[ir]]
+    return Dfat, Ofat, gfat, (H, rhs)
+
+
+def cyclic_reduction(Dfat, Ofat, gfat):
+    """Block cyclic reduction over level sets (the order the HIP fat solver uses): returns x (K x NB)."""
+    K, NB = gfat.shape
+    Dm = {k: Dfat[k].copy() for k in range(K)}
+    gm = {k: gfat[k].copy() for k in range(K)}
+    link = {(k, k + 1): Ofat[k].copy() for k in range(K - 1)}    # link[(l, r)] = H[r, l]
+    active = list(range(K))
+    trail = []
+    while len(active) > 1:
+        nxt = active[0::2]
+        for p in range(1, len(active), 2):
+            m, l = active[p], active[p - 1]
+            r = active[p + 1] if p + 1 < len(active) else None
+            Lc = np.linalg.cholesky(Dm[m])
+            P = np.linalg.solve(Lc, link[(l, m)])                 # L^-1 H[m, l]
+            z = np.linalg.solve(Lc, gm[m])
+            Dm[l] -= P.T @ P
+            gm[l] -= P.T @ z
+            Q = None
+            if r is not None:
+                Q = np.linalg.solve(Lc, link[(m, r)].T)           # L^-1 H[m, r]
+                Dm[r] -= Q.T @ Q
+                gm[r] -= Q.T @ z
+                link[(l, r)] = -Q.T @ P
+            trail.append((m, l, r, Lc, P, Q, z))
+        active = nxt
+    x = {}
+    k0 = active[0]
+    x[k0] = np.linalg.solve(Dm[k0], gm[k0])
+    for m, l, r, Lc, P, Q, z in reversed(trail):
+        t = z - P @ x[l]
+        if r is not None:
+            t -= Q @ x[r]
+        x[m] = np.linalg.solve(Lc.T, t)
+    return np.stack([x[k] for k in range(K)])

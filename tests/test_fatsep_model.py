@@ -1,0 +1,63 @@
+"""The plan rules and the algebra of the segmented landmark elimination (numpy model, no GPU)."""
+import numpy as np
+
+import fatsep_model as FM
+
+
+def _random_problem(N, L, b, ld, window, seed):
+    rng = np.random.default_rng(seed)
+    rows = []                                            # (state, two, landmark, JL, JR, m, e)
+    centre = np.sort(rng.integers(0, N, L))
+    touch = [None] * L
+    for l in range(L):
+        for _ in range(rng.integers(2, 9)):
+            i = int(np.clip(centre[l] + rng.integers(-window // 2, window // 2 + 1), 0, N - 2))
+            rows.append((i, l, rng.normal(size=b), rng.normal(size=b), rng.normal(size=ld), rng.normal()))
+            lo, hi = (i, i + 1)
+            touch[l] = (lo, hi) if touch[l] is None else (min(touch[l][0], lo), max(touch[l][1], hi))
+    D = np.zeros((N, b, b)); O = np.zeros((N, b, b)); g = np.zeros((N, b))
+    B = np.zeros((N, b, L * ld)); HLL = np.zeros((L * ld, L * ld)); gL = np.zeros(L * ld)
+    for i in range(N - 1):                               # chain factors
+        J = rng.normal(size=(b + 2, 2 * b))
+        e = rng.normal(size=b + 2)
+        D[i] += J[:, :b].T @ J[:, :b]; D[i + 1] += J[:, b:].T @ J[:, b:]; O[i] += J[:, b:].T @ J[:, :b]
+        g[i] -= J[:, :b].T @ e; g[i + 1] -= J[:, b:].T @ e
+    D[0] += np.eye(b)
+    for i, l, JL, JR, m, e in rows:
+        D[i] += np.outer(JL, JL); D[i + 1] += np.outer(JR, JR); O[i] += np.outer(JR, JL)
+        g[i] -= JL * e; g[i + 1] -= JR * e
+        sl = slice(l * ld, (l + 1) * ld)
+        B[i, :, sl] += np.outer(JL, m); B[i + 1, :, sl] += np.outer(JR, m)
+        HLL[sl, sl] += np.outer(m, m); gL[sl] -= m * e
+    HLL += 0.1 * np.eye(L * ld)
+    return D, O, g, B, HLL, gL, touch
+
+
+def test_plan_rules():
+    assert FM.make_cuts(10, 4) == [0, 4, 9]               # 8 would leave no interior before 9
+    assert FM.make_cuts(2, 64) == [0, 1]
+    assert FM.make_cuts(130, 64) == [0, 64, 129]          # (128 dropped: it would leave an empty last segment)
+    touch = [(3, 4), (60, 70), (0, 140), None]
+    assert FM.plan(200, 4, touch, 64) is None            # landmark 2 spans three segments
+    cuts, fat_of, slot_of, counts = FM.plan(200, 4, [(3, 4), (60, 70), (100, 130), None], 64)
+    assert cuts == [0, 64, 128, 192, 199]
+    assert fat_of[1] == 1 and fat_of[2] == 2 and sum(counts) == 4
+
+
+def test_fat_elimination_and_cyclic_reduction_equal_dense_solve():
+    for seed, (N, L, C, window) in enumerate([(40, 6, 8, 6), (97, 20, 16, 12), (33, 5, 64, 30), (64, 9, 7, 5)]):
+        b, ld = 4, 2
+        D, O, g, B, HLL, gL, touch = _random_problem(N, L, b, ld, window, seed)
+        p = FM.plan(N, L, touch, C)
+        assert p is not None
+        cuts, fat_of, slot_of, counts = p
+        NB = b + ld * max(counts)
+        for lam in (0.0, 0.3):
+            Dfat, Ofat, gfat, (H, rhs) = FM.fat_system(D, O, g, B, HLL, gL, ld, cuts, fat_of, slot_of, NB, lam)
+            xfat = FM.cyclic_reduction(Dfat, Ofat, gfat)
+            xd = np.linalg.solve(H, rhs)
+            for k, c in enumerate(cuts):
+                np.testing.assert_allclose(xfat[k, :b], xd[c * b:(c + 1) * b], rtol=1e-8, atol=1e-10)
+            for l in range(L):
+                got = xfat[fat_of[l], b + slot_of[l] * ld: b + (slot_of[l] + 1) * ld]
+                np.testing.assert_allclose(got, xd[N * b + l * ld: N * b + (l + 1) * ld], rtol=1e-8, atol=1e-10)
