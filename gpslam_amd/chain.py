@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
-    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors",
+    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan",
 ]
 
 
@@ -307,6 +307,12 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_interpolate_poses(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out)),
                   "interpolate_poses")
         return out
+
+    def segment_plan(self):
+        """dict of the segmented landmark elimination's plan (active, C, K, NB, NC, NCP, levels, links)."""
+        out = np.zeros(8, dtype=np.int32)
+        self._chk(self.lib.gpslam_hip_segment_plan(self._h, _p(out)), "segment_plan")
+        return dict(zip(("active", "C", "K", "NB", "NC", "NCP", "levels", "links"), (int(v) for v in out)))
 
     def last_timing(self):
         t = np.zeros(5)

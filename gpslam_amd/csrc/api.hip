@@ -1653,6 +1653,16 @@ int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int3
   return 0;
 }
 
+int gpslam_hip_segment_plan(gpslam_hip_handle *h, int32_t out8[8]) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!out8) return GPSLAM_E_INVALID;
+  const FatSepPlan &p = h->fs;
+  const int32_t v[8] = {p.active ? 1 : 0, p.C, p.K, p.NB, p.NC, p.NCP, (int32_t)p.levels.size(), p.nlinks};
+  for (int i = 0; i < 8; i++) out8[i] = p.active ? v[i] : 0;
+  return 0;
+}
+
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5) {
   if (!h || !out5) return GPSLAM_E_INVALID;
   for (int i = 0; i < 5; i++) out5[i] = h->last_ms[i];

@@ -210,6 +210,10 @@ int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double
  * an optimisation is the use the MATLAB wrapper exports the interpolators for. */
 int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
                                  const double *tau, double *out_pose);
+/* the plan of the segmented landmark elimination chosen by compile(): out = {active (0 / 1), segment length C, fat
+ * blocks K, fat block size NB, border columns NC per segment, NC rounded up to MFMA tiles, cyclic-reduction levels,
+ * link blocks} */
+int gpslam_hip_segment_plan(gpslam_hip_handle *h, int32_t out8[8]);
 /* time (ms) of the last iterate call's phases measured with hipEvents on the handle's stream:
  * out[0] linearize, out[1] assemble, out[2] solve, out[3] retract+error, out[4] total */
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
