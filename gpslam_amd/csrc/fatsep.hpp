@@ -39,8 +39,8 @@ template <typename T> struct FsArgs {
   const int *lm_fat, *lm_slot;       // L
   const int *lmrow_ptr, *lmrow, *lmrow_state;   // rows touching each landmark, sorted by left state
   const int *lmpri_ptr, *lmpri;      // L + 1, prior ids per landmark
-  const T *pri_meas, *pri_sig;
-  const T *lmk;
+  const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
+  const double *lmk;
   const int *rowptr, *rowLm;
   const T *rowLR, *rowE, *rowM;
   const T *blk;                      // N records [D | O | g]
@@ -277,7 +277,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(F
         }
         if (vr.q == vc.q)
           for (int t = a.lmpri_ptr[vr.lm]; t < a.lmpri_ptr[vr.lm + 1]; t++) {
-            const T w = T(1) / a.pri_sig[(size_t)a.lmpri[t] * a.ld + vr.q];
+            const T w = T(1) / T(a.pri_sig[(size_t)a.lmpri[t] * a.ld + vr.q]);
             v += w * w;
           }
       }
@@ -310,8 +310,8 @@ template <typename T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(F
       }
       for (int t = a.lmpri_ptr[vr.lm]; t < a.lmpri_ptr[vr.lm + 1]; t++) {
         const int pk = a.lmpri[t];
-        const T w = T(1) / a.pri_sig[(size_t)pk * a.ld + vr.q];
-        g -= w * w * (a.lmk[(size_t)vr.lm * a.ld + vr.q] - a.pri_meas[(size_t)pk * a.ld + vr.q]);
+        const T w = T(1) / T(a.pri_sig[(size_t)pk * a.ld + vr.q]);
+        g -= w * w * T(a.lmk[(size_t)vr.lm * a.ld + vr.q] - a.pri_meas[(size_t)pk * a.ld + vr.q]);
       }
       a.gL[(size_t)vr.lm * a.ld + vr.q] = g;   // undamped gradient (LM model)
     }
@@ -589,7 +589,7 @@ template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_solve1(F
 }
 
 // landmarks += dL; *out_max = max(*out_max, |dL|_inf) -- L can be 5e4: a grid-stride kernel + one partial per block
-template <typename T> __global__ void __launch_bounds__(256) k_fs_lm_update(T *lmk, const T *dL, int nl, const int *flag, T *partial) {
+template <typename T> __global__ void __launch_bounds__(256) k_fs_lm_update(double *lmk, const T *dL, int nl, const int *flag, T *partial) {
   __shared__ T red[256];
   const bool bad = flag && *flag;
   T mx = T(0);
@@ -613,13 +613,13 @@ template <typename T> __global__ void __launch_bounds__(64) k_fs_max_into(const 
   if (threadIdx.x == 0) *out = fmax(*out, (double)mx);
 }
 // error of the landmark priors, grid-stride
-template <typename T> __global__ void __launch_bounds__(256) k_fs_lmprior_err(const T *lmk, const int *pri_lm, const T *pri_meas, const T *pri_sig,
+template <typename T> __global__ void __launch_bounds__(256) k_fs_lmprior_err(const double *lmk, const int *pri_lm, const double *pri_meas, const double *pri_sig,
                                                                              int npri, int ld, T *partial) {
   __shared__ T red[256];
   T err = T(0);
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < npri; k += gridDim.x * blockDim.x)
     for (int q = 0; q < ld; q++) {
-      const T we = (lmk[(size_t)pri_lm[k] * ld + q] - pri_meas[(size_t)k * ld + q]) / pri_sig[(size_t)k * ld + q];
+      const T we = T((lmk[(size_t)pri_lm[k] * ld + q] - pri_meas[(size_t)k * ld + q]) / pri_sig[(size_t)k * ld + q]);
       err += we * we;
     }
   red[threadIdx.x] = T(0.5) * err;

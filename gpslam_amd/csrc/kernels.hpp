@@ -90,13 +90,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // ------------------------------------------------------------------ K1: GP prior rows
 
+// Inputs (states, landmarks, factor parameters) are ALWAYS fp64 in HBM; T is the arithmetic / row-table type.  In the
+// fp32 mode (GPSLAM_FP32) the Jacobian rows, the normal equations and the solver run with T = float, while the residual
+// is evaluated by the T = double error pass of the same kernels, which then also deposits its whitened error as the
+// fp32 right-hand side (rowE32): fp32 linear algebra + fp64 residual = iterative refinement through the Gauss-Newton loop.
 template <typename T> struct GpArgs {
-  const T *pose, *vel;    // SoA
+  const double *pose, *vel;    // SoA
   int stride;             // SoA stride (>= N + 1)
   int count;
   const int *left;        // left state of factor f
-  const T *dt;
+  const double *dt;
   const int *row0;        // first row of factor f in the row table
+  float *rowE32;          // MODE 1 (error only, T = double): also store the whitened error here, or null
   T *rowLR, *rowE;        // MODE 0
   T *partial;             // per-block error partial sums
   T *out_e, *out_H;       // MODE 2: API layout
@@ -348,6 +353,7 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
       row0 = valid ? a.row0[f] : -1;
       srow[threadIdx.x] = row0;
     }
+    if (MODE == 1 && a.rowE32 && valid) row0 = a.row0[f];
 #pragma unroll
     for (int rho = 0; rho < d; rho++) {
       T wt = T(0), wb = T(0);
@@ -358,6 +364,10 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
       }
       wb *= sc;
       err += wt * wt + wb * wb;
+      if (MODE == 1 && a.rowE32 && valid) {
+        a.rowE32[row0 + rho] = (float)wt;
+        a.rowE32[row0 + d + rho] = (float)wb;
+      }
       if (MODE == 0) {
         if (valid) {
           a.rowE[row0 + rho] = wt;
@@ -391,12 +401,13 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
 // ------------------------------------------------------------------ unary / between rows
 
 template <typename T> struct FacArgs {
-  const T *pose, *vel;
+  const double *pose, *vel;
   int stride, count, chart;
   const int *idx;       // state (left state for between)
-  const T *meas;        // count x (pd or d)
-  const T *sig;         // count x d
+  const double *meas;   // count x (pd or d)
+  const double *sig;    // count x d
   const int *row0;
+  float *rowE32;        // error-only pass: fp32 copy of the whitened error (fp32 mode), or null
   T *rowLR, *rowE;
   T *partial;
 };
@@ -426,7 +437,7 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
     const int i = a.idx[f];
     if (KIND == 1) {
 #pragma unroll
-      for (int k = 0; k < d; k++) e[k] = a.vel[(size_t)k * a.stride + i] - a.meas[(size_t)f * d + k];
+      for (int k = 0; k < d; k++) e[k] = T(a.vel[(size_t)k * a.stride + i] - a.meas[(size_t)f * d + k]);
     } else {
       T x1[pd], m[pd];
 #pragma unroll
@@ -441,15 +452,16 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
       }
     }
   }
-  const int row0 = (JAC && valid) ? a.row0[f] : -1;
+  const int row0 = ((JAC || a.rowE32) && valid) ? a.row0[f] : -1;
   T *st = stage + (JAC ? wv * 64 * LS : 0);
   T *mine = st + (JAC ? lane * LS : 0);
   if (JAC) srow[threadIdx.x] = row0;
 #pragma unroll
   for (int r = 0; r < d; r++) {
-    const T w = valid ? T(1) / a.sig[(size_t)f * d + r] : T(0);
+    const T w = valid ? T(1) / T(a.sig[(size_t)f * d + r]) : T(0);
     const T we = e[r] * w;
     err += we * we;
+    if (!JAC && a.rowE32 && valid) a.rowE32[row0 + r] = (float)we;
     if (JAC) {
       if (valid) a.rowE[row0 + r] = we;
 #pragma unroll
@@ -479,17 +491,18 @@ constexpr int kMeasAux = 18;
 template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
 template <typename T> struct MeasArgs {
-  const T *pose, *vel;
+  const double *pose, *vel;
   int stride;
-  const T *lmk;        // L x ld (AoS)
+  const double *lmk;   // L x ld (AoS)
   int ld, count, chart;
   const int *idx;      // left (or only) state
   const int *lm;       // landmark or null
-  const T *meas;       // count x mw
+  const double *meas;  // count x mw
   int mw;
-  const T *sig;        // count x rows
-  const T *coef;       // count x 4: l11, l12, p11, p12 (interpolated kinds)
-  const T *aux;        // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
+  const double *sig;   // count x rows
+  const double *coef;  // count x 4: l11, l12, p11, p12 (interpolated kinds)
+  float *rowE32;       // error-only pass: fp32 copy of the whitened error (fp32 mode), or null
+  const double *aux;       // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
   const int *aidx;     // count: entry of each factor (one body_P_sensor / calibration PER FACTOR, as in the reference:
                        // GPInterpolatedRangeFactorPose3.h:46-54), or null: no sensor transform anywhere
   int vw;              // Pose3 only: velocities are world-frame [v; w]
@@ -549,14 +562,16 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       }
       ICoef<T> kc = {T(0), T(0), T(0), T(0)};
       if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ)
-        kc = {a.coef[4 * (size_t)f], a.coef[4 * (size_t)f + 1], a.coef[4 * (size_t)f + 2], a.coef[4 * (size_t)f + 3]};
-      const T *ms = a.meas + (size_t)f * a.mw;
+        kc = {T(a.coef[4 * (size_t)f]), T(a.coef[4 * (size_t)f + 1]), T(a.coef[4 * (size_t)f + 2]), T(a.coef[4 * (size_t)f + 3])};
+      T ms[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) ms[k] = (k < a.mw) ? T(a.meas[(size_t)f * a.mw + k]) : T(0);
       // per-factor body_P_sensor / calibration (identical entries are shared through the table)
-      const T *ax = a.aidx ? a.aux + (size_t)a.aidx[f] * kMeasAux : nullptr;
-      const bool has_sensor = ax && ax[17] != T(0);
+      const double *ax = a.aidx ? a.aux + (size_t)a.aidx[f] * kMeasAux : nullptr;
+      const bool has_sensor = ax && ax[17] != 0.0;
       T sens[12];
 #pragma unroll
-      for (int k = 0; k < 12; k++) sens[k] = (has_sensor && k < pd) ? ax[k] : T(0);
+      for (int k = 0; k < 12; k++) sens[k] = (has_sensor && k < pd) ? T(ax[k]) : T(0);
       T e[rows];
       T Jm[JAC ? rows * 3 : 1];
       if (JAC) {
@@ -675,7 +690,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         const SE3<T> cam = has_sensor ? se3_compose(pose, S) : pose;
         const V3<T> pw = {pt[0], pt[1], pt[2]};
         const V3<T> q = tmul(cam.R, pw - cam.t);
-        const T fx = ax ? ax[12] : T(1), fy = ax ? ax[13] : T(1), sk = ax ? ax[14] : T(0), cu0 = ax ? ax[15] : T(0), cv0 = ax ? ax[16] : T(0);
+        const T fx = ax ? T(ax[12]) : T(1), fy = ax ? T(ax[13]) : T(1), sk = ax ? T(ax[14]) : T(0), cu0 = ax ? T(ax[15]) : T(0), cv0 = ax ? T(ax[16]) : T(0);
         if (!(q.z > T(0))) {
           e[0] = T(2) * fx; e[1] = T(2) * fx;
         } else {
@@ -741,14 +756,15 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
           for (int r = 0; r < rows; r++) { vw_row_transform(p1, v1, JL + r * b); vw_row_transform(p2, v2, JR + r * b); }
         }
       }
-      const int row0 = JAC ? a.row0[f] : 0;
+      const int row0 = (JAC || a.rowE32) ? a.row0[f] : 0;
       row0v = row0;
 #pragma unroll
       for (int r = 0; r < rows; r++) {
-        const T w = T(1) / a.sig[(size_t)f * rows + r];
+        const T w = T(1) / T(a.sig[(size_t)f * rows + r]);
         const T we = e[r] * w;
         err += we * we;
         wgt[r] = w;
+        if (!JAC && a.rowE32) a.rowE32[row0 + r] = (float)we;
         if (JAC) {
           a.rowE[row0 + r] = we;
           if (a.ld > 0) {
@@ -796,8 +812,8 @@ template <typename T> struct LmArgs {
   // landmark priors
   int npri;
   const int *pri_lm;
-  const T *pri_meas, *pri_sig;
-  T *lmk;                   // L x ld
+  const double *pri_meas, *pri_sig;
+  double *lmk;              // L x ld (fp64 like the states)
   T *S;                     // nl x (nl + 1): column 0 = rhs, columns 1.. = Schur complement
   T *gL;                    // nl (undamped gradient, for LM)
   T *dL;                    // nl solution
@@ -1219,10 +1235,10 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
 // ------------------------------------------------------------------ trajectory queries
 
 template <typename T> struct QueryArgs {
-  const T *pose, *vel;   // SoA states
+  const double *pose, *vel;   // SoA states
   int stride, count;
   const int *left;       // query q lies in the interval (left[q], left[q] + 1)
-  const T *coef;         // count x 4: l11, l12, p11, p12 for (dt[q], tau[q])
+  const double *coef;        // count x 4: l11, l12, p11, p12 for (dt[q], tau[q])
   int vw;                // Pose3 only: velocities are world-frame [v; w]
   T *out;                // count x pose_dim (AoS, the layout of gpslam_hip_get_states' rows)
 };
@@ -1235,7 +1251,7 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.count) return;
   const int i = a.left[q];
-  const ICoef<T> k = {a.coef[4 * (size_t)q], a.coef[4 * (size_t)q + 1], a.coef[4 * (size_t)q + 2], a.coef[4 * (size_t)q + 3]};
+  const ICoef<T> k = {T(a.coef[4 * (size_t)q]), T(a.coef[4 * (size_t)q + 1]), T(a.coef[4 * (size_t)q + 2]), T(a.coef[4 * (size_t)q + 3])};
   T p1[pd], p2[pd], v1[d], v2[d];
 #pragma unroll
   for (int c = 0; c < pd; c++) { p1[c] = a.pose[(size_t)c * a.stride + i]; p2[c] = a.pose[(size_t)c * a.stride + i + 1]; }
@@ -2343,7 +2359,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_iface_build(const
 // ------------------------------------------------------------------ K6: retract
 
 template <typename T> struct RetractArgs {
-  T *pose, *vel;
+  double *pose, *vel;   // the state is fp64 whatever T is: the update is applied in fp64
   int stride, N, R, chart;
   int first;        // first state to update (the halo state of a segment is updated by its own launch)
   const T *x;       // N x R x b, column 0 = delta (indexed from `first`)
@@ -2360,13 +2376,13 @@ __global__ void __launch_bounds__(128) k_retract(RetractArgs<T> a) {
   T mx = T(0);
   if (li < a.N) {
     const T *dl = a.x + (size_t)li * a.R * b;
-    T dlt[b], x[pd], out[pd];
+    double dlt[b], x[pd], out[pd];
 #pragma unroll
-    for (int k = 0; k < b; k++) { dlt[k] = dl[k]; mx = fmax(mx, abs_or_inf(dlt[k])); }
+    for (int k = 0; k < b; k++) { dlt[k] = (double)dl[k]; mx = fmax(mx, abs_or_inf(dl[k])); }
     if (!(a.flag && *a.flag)) {
 #pragma unroll
       for (int k = 0; k < pd; k++) x[k] = a.pose[(size_t)k * a.stride + i];
-      PoseFactors<T, MF, false>::retract(x, dlt, a.chart, out);
+      PoseFactors<double, MF, false>::retract(x, dlt, a.chart, out);
 #pragma unroll
       for (int k = 0; k < pd; k++) a.pose[(size_t)k * a.stride + i] = out[k];
 #pragma unroll

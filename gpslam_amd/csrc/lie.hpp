@@ -16,6 +16,26 @@
 
 namespace gps {
 
+// <cmath> for both scalar types under the unqualified names the templates use.  In the HOST pass ::cos(float) is the
+// C function taking double (the fp32 instantiations would silently compute, and return, doubles); these overloads make
+// the float instantiations single precision in both passes.
+GD float sin(float x) { return ::sinf(x); }
+GD double sin(double x) { return ::sin(x); }
+GD float cos(float x) { return ::cosf(x); }
+GD double cos(double x) { return ::cos(x); }
+GD float tan(float x) { return ::tanf(x); }
+GD double tan(double x) { return ::tan(x); }
+GD float sqrt(float x) { return ::sqrtf(x); }
+GD double sqrt(double x) { return ::sqrt(x); }
+GD float acos(float x) { return ::acosf(x); }
+GD double acos(double x) { return ::acos(x); }
+GD float atan2(float y, float x) { return ::atan2f(y, x); }
+GD double atan2(double y, double x) { return ::atan2(y, x); }
+GD float fabs(float x) { return ::fabsf(x); }
+GD double fabs(double x) { return ::fabs(x); }
+GD float fmax(float a, float b) { return ::fmaxf(a, b); }
+GD double fmax(double a, double b) { return ::fmax(a, b); }
+
 template <typename T> struct Eps;
 template <> struct Eps<double> { static constexpr double v = 2.220446049250313e-16; };
 template <> struct Eps<float> { static constexpr float v = 1.1920929e-07f; };

@@ -34,9 +34,17 @@ def test_pose2_landmark_border_widths():
             assert rc0 == 0 and rc1 == 0
         assert np.abs(orc.get_states()[0] - dev.get_states()[0]).max() < 1e-7
         assert np.abs(orc.get_landmarks() - dev.get_landmarks()).max() < 1e-7
-    with pytest.raises(Exception):            # 14 landmarks: 29 right-hand-side columns do not fit the dense border
-        p = S.pose2_range_chain(100, L=14, rate=0.8)
-        S.apply(p, gp.ChainSolver(O.POSE2, chart=gp.CHART_FIRST_ORDER, landmark_dim=2))
+    # 14 landmarks: 29 right-hand-side columns do not fit the dense border -> the segmented elimination takes over (all 14
+    # are seen from the whole 100-state chain: one segment between two fat separators of 7 landmarks each)
+    p = S.pose2_range_chain(100, L=14, rate=0.8)
+    orc = S.apply(p, O.Chain(O.POSE2, chart=O.CHART_FIRST_ORDER, landmark_dim=2))
+    dev = S.apply(p, gp.ChainSolver(O.POSE2, chart=gp.CHART_FIRST_ORDER, landmark_dim=2))
+    assert dev.segment_plan()["active"] == 1
+    for _ in range(6):
+        orc.iterate_gn()
+        dev.iterate_gn()
+    assert np.abs(orc.get_states()[0] - dev.get_states()[0]).max() < 1e-7
+    assert np.abs(orc.get_landmarks() - dev.get_landmarks()).max() < 1e-7
 
 
 def test_pose3_landmark_border_widths():
