@@ -5,7 +5,7 @@ names lives in gpslam_amd/host/).  All compute happens in gpslam_amd/lib/libgpsl
 for gfx950); importing this package never falls back to a CPU implementation.
 """
 from .chain import (ChainSolver, GpslamHipError, LINEAR2, LINEAR3, POSE2, POSE3, ROT3, CHART_EXPMAP,
-                    CHART_FIRST_ORDER, POSE_DIM, TANGENT_DIM, Params, Stats, load_library)
+                    CHART_FIRST_ORDER, FP32, FP64, POSE_DIM, TANGENT_DIM, Params, Stats, load_library)
 
 __all__ = ["ChainSolver", "GpslamHipError", "LINEAR2", "LINEAR3", "POSE2", "POSE3", "ROT3", "CHART_EXPMAP",
-           "CHART_FIRST_ORDER", "POSE_DIM", "TANGENT_DIM", "Params", "Stats", "load_library"]
+           "CHART_FIRST_ORDER", "FP32", "FP64", "POSE_DIM", "TANGENT_DIM", "Params", "Stats", "load_library"]

@@ -12,6 +12,7 @@ from . import build as _build
 
 LINEAR2, LINEAR3, POSE2, POSE3, ROT3 = 0, 1, 2, 3, 4
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
+FP64, FP32 = 0, 1
 POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9}
 TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3}
 
@@ -88,13 +89,13 @@ def _p(a):
 class ChainSolver:
     def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, device=0, chunk=0, rank=0, nranks=1,
                  force_sharded=False, upper_chunk=0, top_blocks=0, velocity_world=False, segment_length=0,
-                 force_segmented=False):
+                 force_segmented=False, precision=0):
         self.lib = load_library()
         self.kind, self.chart, self.ld = kind, chart, landmark_dim
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
         self.b = 2 * self.d
         self.N = self.L = self.n_gp = 0
-        cfg = Config(manifold=kind, precision=0, device=device, chart=chart, landmark_dim=landmark_dim, chunk=chunk,
+        cfg = Config(manifold=kind, precision=precision, device=device, chart=chart, landmark_dim=landmark_dim, chunk=chunk,
                      rank=rank, nranks=nranks)
         cfg.reserved[0] = 1 if force_sharded else 0
         cfg.reserved[1] = upper_chunk

@@ -330,19 +330,19 @@ inline void launch_fused_k(const FusedArgs<double> &u, int grid, hipStream_t st)
 inline void launch_fused_k(const FusedArgs<float> &, int, hipStream_t) {}
 inline void launch_rows_k(const FwdArgs<double> &a, int grid, hipStream_t st) { k_chunk_forward_rows<<<dim3(grid), dim3(64), 0, st>>>(a); }
 inline void launch_rows_k(const FwdArgs<float> &, int, hipStream_t) {}
-inline void launch_syrk_k(const FsArgs<double> &a, int nseg, int tiles, hipStream_t st) { k_fs_syrk<9><<<dim3(nseg, tiles), dim3(64), 0, st>>>(a); }
-inline void launch_syrk_k(const FsArgs<float> &, int, int, hipStream_t) {}
 }  // namespace
 
 // =================================================================== the precision-dependent half, once per precision
 namespace impl64 {
 typedef double Real;
+typedef double RowT;
 #define IMPL_NS impl64
 #include "api_impl.inc"
 #undef IMPL_NS
 }  // namespace impl64
 namespace impl32 {
-typedef float Real;
+typedef double Real;
+typedef float RowT;
 #define IMPL_NS impl32
 #include "api_impl.inc"
 #undef IMPL_NS
@@ -370,7 +370,7 @@ void gpslam_hip_default_params(gpslam_hip_params *p) {
 int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (!cfg || !out) return GPSLAM_E_INVALID;
   if (cfg->manifold < 0 || cfg->manifold > 4) return GPSLAM_E_INVALID;
-  if (cfg->precision != GPSLAM_FP64) return GPSLAM_E_UNSUPPORTED;
+  if (cfg->precision != GPSLAM_FP64 && cfg->precision != GPSLAM_FP32) return GPSLAM_E_INVALID;
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
   if (cfg->reserved[3] != 0 && (cfg->reserved[3] != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;

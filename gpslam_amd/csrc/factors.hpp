@@ -10,6 +10,8 @@
 //   jacobianMethodNumercialDiff                    gpslam/gp/Pose3utils.cpp:167-179
 #pragma once
 
+#include <type_traits>
+
 #include "lie.hpp"
 
 namespace gps {
@@ -174,6 +176,93 @@ template <typename T> GD BL6<T> se3_jrinv_times_x_fd_k(const JrK<T> &k0, V6<T> x
   return D;
 }
 
+// =================================================================== fp32 arithmetic (GPSLAM_FP32)
+// The reference's formulas cannot simply be instantiated for float:
+//  * jacobianMethodNumercialDiff's step h = 1e-6 (Pose3utils.h:57, Pose3utils.cpp:167-179) is below float's resolution
+//    of the rotation vector (eps32 = 6e-8 relative): the central difference is noise.  The fp32 path takes the EXACT
+//    derivative d(Jr^-1(xi) x)/d xi instead: forward-mode differentiation (Dual3: value + 3 partials with respect to the
+//    rotation vector) through the very same nested-cross-product evaluation, and the closed form for the translational
+//    half (Q is linear in rho: column k of d/d rho is -Jw Q(w, e_k) Jw x_w).
+//  * the closed-form coefficients (th - sin th)/th^3, (1 - th^2/2 - cos th)/th^4, ... (Pose3utils.cpp:98-104, :219-223)
+//    cancel catastrophically at the th = 0.01 .. 0.1 rad of consecutive chain states: in fp32 the numerator of the th^-4
+//    coefficient is all rounding error.  Below th^2 = 0.25 they are evaluated by their Taylor series in th^2 (5 terms,
+//    truncation < 1e-9), above by the closed forms; the reference's thresholds 1e-5 / 1e-10 play no role in fp32.
+template <typename T> struct Dual3 {
+  T v, d[3];
+  GD Dual3() : v(T(0)), d{T(0), T(0), T(0)} {}
+  template <typename U, typename = typename std::enable_if<std::is_arithmetic<U>::value>::type>
+  GD Dual3(U x) : v(T(x)), d{T(0), T(0), T(0)} {}
+  GD Dual3(T x, int k) : v(x), d{k == 0 ? T(1) : T(0), k == 1 ? T(1) : T(0), k == 2 ? T(1) : T(0)} {}
+};
+template <typename T> GD Dual3<T> operator+(Dual3<T> a, Dual3<T> b) { Dual3<T> r; r.v = a.v + b.v; for (int i = 0; i < 3; i++) r.d[i] = a.d[i] + b.d[i]; return r; }
+template <typename T> GD Dual3<T> operator-(Dual3<T> a, Dual3<T> b) { Dual3<T> r; r.v = a.v - b.v; for (int i = 0; i < 3; i++) r.d[i] = a.d[i] - b.d[i]; return r; }
+template <typename T> GD Dual3<T> operator-(Dual3<T> a) { Dual3<T> r; r.v = -a.v; for (int i = 0; i < 3; i++) r.d[i] = -a.d[i]; return r; }
+template <typename T> GD Dual3<T> operator*(Dual3<T> a, Dual3<T> b) { Dual3<T> r; r.v = a.v * b.v; for (int i = 0; i < 3; i++) r.d[i] = a.d[i] * b.v + a.v * b.d[i]; return r; }
+template <typename T> GD Dual3<T> operator/(Dual3<T> a, Dual3<T> b) {
+  Dual3<T> r;
+  const T inv = T(1) / b.v;
+  r.v = a.v * inv;
+  for (int i = 0; i < 3; i++) r.d[i] = (a.d[i] - r.v * b.d[i]) * inv;
+  return r;
+}
+template <typename T> GD Dual3<T> sqrt(Dual3<T> a) { Dual3<T> r; r.v = sqrt(a.v); const T h = T(0.5) / r.v; for (int i = 0; i < 3; i++) r.d[i] = a.d[i] * h; return r; }
+template <typename T> GD Dual3<T> sin(Dual3<T> a) { Dual3<T> r; r.v = sin(a.v); const T c = cos(a.v); for (int i = 0; i < 3; i++) r.d[i] = a.d[i] * c; return r; }
+template <typename T> GD Dual3<T> cos(Dual3<T> a) { Dual3<T> r; r.v = cos(a.v); const T s = -sin(a.v); for (int i = 0; i < 3; i++) r.d[i] = a.d[i] * s; return r; }
+GD float dual_val(float x) { return x; }
+GD double dual_val(double x) { return x; }
+template <typename T> GD T dual_val(Dual3<T> x) { return x.v; }
+
+// coefficients of Jr^-1 and of Q as smooth functions of u = th^2 (S = float, double or a Dual3 of them)
+template <typename S> GD JrK<S> jr_coefs_smooth(V3<S> w) {
+  JrK<S> k;
+  k.ident = false;
+  const S u = dot(w, w);
+  if (dual_val(u) < 0.25) {
+    // (1 - (th/2) cot(th/2)) / th^2;  (th - sin th)/th^3;  (1 - th^2/2 - cos th)/th^4;  (th - sin th - th^3/6)/th^5
+    k.c = S(1.0 / 12) + u * (S(1.0 / 720) + u * (S(1.0 / 30240) + u * (S(1.0 / 1209600) + u * S(1.0 / 47900160))));
+    k.qa = S(1.0 / 6) - u * (S(1.0 / 120) - u * (S(1.0 / 5040) - u * (S(1.0 / 362880) - u * S(1.0 / 39916800))));
+    k.qb = S(-1.0 / 24) + u * (S(1.0 / 720) - u * (S(1.0 / 40320) - u * (S(1.0 / 3628800) - u * S(1.0 / 479001600))));
+    const S qd = S(-1.0 / 120) + u * (S(1.0 / 5040) - u * (S(1.0 / 362880) - u * (S(1.0 / 39916800) - u * S(1.0 / 6227020800.0))));
+    k.qc = S(-0.5) * (k.qb - S(3.0) * qd);
+  } else {
+    const S th = sqrt(u);
+    const S s = sin(th), co = cos(th);
+    const S t3 = u * th, t4 = u * u, t5 = t4 * th;
+    k.c = S(1.0) / u - (S(1.0) + co) / (S(2.0) * th * s);
+    k.qa = (th - s) / t3;
+    k.qb = (S(1.0) - S(0.5) * u - co) / t4;
+    k.qc = S(-0.5) * (k.qb - S(3.0) * (th - s - t3 / S(6.0)) / t5);
+  }
+  return k;
+}
+// fp32: the blended coefficients replace the reference's closed forms + thresholds
+GD JrK<float> jr_coefs(V3<float> w) { return jr_coefs_smooth<float>(w); }
+
+// d(Jr^-1(xi) x)/d xi, exact (fp32 path; the fp64 path keeps the reference's central difference below)
+GD BL6<float> se3_jrinv_times_x_fd_k(const JrK<float> &k0, V6<float> xi, V6<float> x) {
+  typedef Dual3<float> D;
+  const V3<D> w = {D(xi.w.x, 0), D(xi.w.y, 1), D(xi.w.z, 2)};
+  const V3<D> rho = {D(xi.v.x), D(xi.v.y), D(xi.v.z)};
+  const V3<D> xw = {D(x.w.x), D(x.w.y), D(x.w.z)}, xv = {D(x.v.x), D(x.v.y), D(x.v.z)};
+  const JrK<D> k = jr_coefs_smooth<D>(w);
+  const V3<D> top = so3_jrinv_apply_k(k, w, xw);
+  const V3<D> bot = so3_jrinv_apply_k(k, w, xv - se3_Q_apply_k(k, w, rho, top));
+  BL6<float> M;
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    M.A.m[0 + j] = top.x.d[j]; M.A.m[3 + j] = top.y.d[j]; M.A.m[6 + j] = top.z.d[j];
+    M.C.m[0 + j] = bot.x.d[j]; M.C.m[3 + j] = bot.y.d[j]; M.C.m[6 + j] = bot.z.d[j];
+  }
+  const V3<float> tv = {top.x.v, top.y.v, top.z.v};
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const V3<float> ej = {j == 0 ? 1.f : 0.f, j == 1 ? 1.f : 0.f, j == 2 ? 1.f : 0.f};
+    const V3<float> col = so3_jrinv_apply_k(k0, xi.w, -se3_Q_apply_k(k0, xi.w, ej, tv));
+    M.D.m[0 + j] = col.x; M.D.m[3 + j] = col.y; M.D.m[6 + j] = col.z;
+  }
+  return M;
+}
+
 // d( Jr^-1(xi) * x ) / d xi by central differences with h = 1e-6: the construction of
 // jacobianMethodNumercialDiff(rightJacobianPose3inv, xi, x) (Pose3utils.cpp:167-179, default dxi Pose3utils.h:57),
 // column i = (Jr^-1(xi + h e_i) x - Jr^-1(xi - h e_i) x) / (2h).  The reference subtracts the two 6x6 matrices
@@ -278,6 +367,8 @@ GD void gp3_tail(V3<T> r, const T *v1, const T *v2, T dt, const M3<T> &J1, const
     }
   }
 }
+
+GD BL6<float> se3_jrinv_times_x_fd(V6<float> xi, V6<float> x) { return se3_jrinv_times_x_fd_k(jr_coefs(xi.w), xi, x); }
 
 template <typename T, bool JAC> struct GpPrior<T, POSE2, JAC> {
   static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {

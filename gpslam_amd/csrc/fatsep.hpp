@@ -30,7 +30,7 @@ namespace gps {
 
 constexpr int kFatMax = 64;   // largest fat block (cut state + landmark columns)
 
-template <typename T> struct FsArgs {
+template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jacobian row tables (kernels.hpp, LmArgs)
   int N, B, ld, L, K, NB, NC, NCP;   // K cuts / fat blocks; NC = 2 NB + 1 border columns; NCP = NC rounded up to 16
   int BS;                            // doubles per level-0 block record [D | O | g] (R = 1)
   const int *cuts;                   // K
@@ -42,7 +42,7 @@ template <typename T> struct FsArgs {
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
   const int *rowptr, *rowLm;
-  const T *rowLR, *rowE, *rowM;
+  const TR *rowLR, *rowE, *rowM;
   const T *blk;                      // N records [D | O | g]
   T *fac;                            // N x 2 B^2: [W = L^-1 (lower) | E = W O^T] of the interior states
   T *Y;                              // N x B x NCP
@@ -64,7 +64,7 @@ __device__ __forceinline__ void fs_wave_sync() {
 
 // ---- block Cholesky along every segment interior.  One wave per segment, matrices in LDS.
 // D~_j = D_j + lambda I - E_{j-1}^T E_{j-1} = L_j L_j^T;  W_j = L_j^-1;  E_j = W_j O_j^T  (O_j = H[j+1, j])
-template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_factor(FsArgs<T> a) {
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(64) k_fs_factor(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, lane = threadIdx.x;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   __shared__ T A[B * B], E[B * B], W[B * B];
@@ -121,7 +121,7 @@ template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_factor(F
 
 // ---- forward substitution of the border columns.  One thread per (segment, column):
 // G~_j = G_j - E_{j-1}^T Y_{j-1},  Y_j = W_j G~_j.  Columns: [0, NB) left fat block, [NB, 2 NB) right fat block, 2 NB rhs.
-template <typename T, int B> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T> a) {
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, c = threadIdx.x;
   if (c >= a.NC) return;
   const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
@@ -167,7 +167,7 @@ template <typename T, int B> __global__ void __launch_bounds__(256) k_fs_sweep(F
       for (int t = cur; t < end && a.lmrow_state[t] <= s; t++) {
         const int rho = a.lmrow[t];
         const T m = a.rowM[(size_t)rho * a.ld + q];
-        const T *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
+        const TR *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
 #pragma unroll
         for (int r = 0; r < B; r++) G[r] += row[r] * m;
       }
@@ -197,7 +197,7 @@ template <typename T, int B> __global__ void __launch_bounds__(256) k_fs_sweep(F
 // cores.  One wave per (segment, 16-row tile): v_mfma_f64_16x16x4_f64, A[i][k] = Y[k][i0 + i], B[k][j] = Y[k][j0 + j]
 // (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double fs_d4 __attribute__((ext_vector_type(4)));
-template <int TMAX> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<double> a) {
+template <int TMAX, typename TR = double> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<double, TR> a) {
   const int seg = blockIdx.x, ti = blockIdx.y, lane = threadIdx.x;
   const int T16 = a.NCP / 16;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
@@ -234,7 +234,7 @@ template <int TMAX> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<doubl
 // variable v of fat block k: v < B -> component v of the cut state; else landmark fat_lm[ptr[k] + (v - B) / ld],
 // component (v - B) % ld, or padding (unit diagonal).
 template <typename T> struct FsVar { int kind, lm, q; };   // kind 0 state, 1 landmark, 2 padding
-template <typename T> __device__ __forceinline__ FsVar<T> fs_var(const FsArgs<T> &a, int k, int v) {
+template <typename T, typename TR> __device__ __forceinline__ FsVar<T> fs_var(const FsArgs<T, TR> &a, int k, int v) {
   FsVar<T> o;
   if (v < a.B) { o.kind = 0; o.lm = -1; o.q = v; return o; }
   const int li = (v - a.B) / a.ld;
@@ -244,7 +244,7 @@ template <typename T> __device__ __forceinline__ FsVar<T> fs_var(const FsArgs<T>
   return o;
 }
 // sum over the rows of landmark lm of (Jacobian entry of state `st`, component r) * m_q
-template <typename T> __device__ __forceinline__ T fs_state_lm(const FsArgs<T> &a, int st, int r, int lm, int q) {
+template <typename T, typename TR> __device__ __forceinline__ T fs_state_lm(const FsArgs<T, TR> &a, int st, int r, int lm, int q) {
   T v = T(0);
   for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
     const int ls = a.lmrow_state[t];
@@ -254,7 +254,7 @@ template <typename T> __device__ __forceinline__ T fs_state_lm(const FsArgs<T> &
   }
   return v;
 }
-template <typename T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(FsArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(FsArgs<T, TR> a) {
   const int k = blockIdx.x, NB = a.NB, B = a.B;
   const int cut = a.cuts[k];
   const T *AL = (k > 0) ? a.Aseg + (size_t)(k - 1) * a.NCP * a.NCP : nullptr;   // segment on the left: this block is its RIGHT fat
@@ -351,7 +351,7 @@ template <typename T> __device__ __forceinline__ void fat_chol_lds(T *Lm, int NB
   }
 }
 
-template <typename T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T> a, FatLevel lv) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T, TR> a, FatLevel lv) {
   extern __shared__ __align__(16) unsigned char fat_smem[];
   const int NB = a.NB, LS = NB + 1, XS = 2 * NB + 1, NB2 = NB * NB;
   T *Lm = reinterpret_cast<T *>(fat_smem);
@@ -401,7 +401,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T
   }
 }
 
-template <typename T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T> a, FatLevel lv) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T, TR> a, FatLevel lv) {
   const int NB = a.NB, NB2 = NB * NB;
   const int *u = lv.upd + 3 * blockIdx.x;
   const int blk = u[0], ml = u[1], mr = u[2];     // ml: eliminated block whose RIGHT neighbour this is; mr: ... LEFT ...
@@ -420,7 +420,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs
 }
 
 // the last active block: dense Cholesky solve
-template <typename T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T> a, int top) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T, TR> a, int top) {
   extern __shared__ __align__(16) unsigned char fat_smem[];
   const int NB = a.NB, LS = NB + 1;
   T *Lm = reinterpret_cast<T *>(fat_smem);
@@ -445,7 +445,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T>
 }
 
 // x_m = L^-T (z - P x_l - Q x_r)
-template <typename T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T> a, FatLevel lv) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T, TR> a, FatLevel lv) {
   __shared__ T Ls[kFatMax * (kFatMax + 1)];
   __shared__ T xs[2 * kFatMax], ts[kFatMax];
   const int NB = a.NB, LS = NB + 1, NB2 = NB * NB, lane = threadIdx.x;
@@ -476,7 +476,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T>
 }
 
 // ---- scatter the fat solution: cut states -> x, landmarks -> dL
-template <typename T> __global__ void __launch_bounds__(256) k_fs_scatter(FsArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fs_scatter(FsArgs<T, TR> a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   if (tid < a.K * a.B) {
     const int k = tid / a.B, r = tid - k * a.B;
@@ -489,7 +489,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_fs_scatter(FsArgs
 }
 
 // ---- right-hand side of the interior states once the fat solution is known: rhs_s = g_s - G_s x_fat
-template <typename T, int B> __global__ void __launch_bounds__(128) k_fs_rhs(FsArgs<T> a) {
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(128) k_fs_rhs(FsArgs<T, TR> a) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= a.N || a.segid[s] < 0) return;
   T r[B];
@@ -520,7 +520,7 @@ template <typename T, int B> __global__ void __launch_bounds__(128) k_fs_rhs(FsA
       if (lm < 0) continue;
       T t = T(0);
       for (int q = 0; q < a.ld; q++) t += a.rowM[(size_t)rho * a.ld + q] * a.dL[(size_t)lm * a.ld + q];
-      const T *row = a.rowLR + (size_t)rho * 2 * B + half * B;
+      const TR *row = a.rowLR + (size_t)rho * 2 * B + half * B;
 #pragma unroll
       for (int k = 0; k < B; k++) r[k] -= row[k] * t;
     }
@@ -530,7 +530,7 @@ template <typename T, int B> __global__ void __launch_bounds__(128) k_fs_rhs(FsA
 }
 
 // ---- interior states: single right-hand side forward / backward sweep with the stored factors, one thread per segment
-template <typename T, int B> __global__ void __launch_bounds__(64) k_fs_solve1(FsArgs<T> a) {
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(64) k_fs_solve1(FsArgs<T, TR> a) {
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= a.K - 1) return;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;

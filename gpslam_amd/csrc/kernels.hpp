@@ -90,6 +90,18 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 // ------------------------------------------------------------------ K1: GP prior rows
 
+// fp32 arithmetic only: every factor here is invariant under a common translation of the variables it touches, and the
+// states sit in HBM as fp64.  Before the arithmetic drops to float the translations are re-centred on the factor's
+// first pose IN FP64, so that a Jacobian computed 1e5 m from the origin is as accurate as one computed at the origin
+// (a float holds 1e5 m to 8 mm: the 0.1 m step between consecutive states would carry 4 digits).  The fp64
+// instantiations do not re-centre: their results stay bit-identical to what the oracle parity tests pinned.
+template <int MF> struct TransPart {
+  static constexpr int n = (MF == POSE3) ? 3 : (MF == POSE2 ? 2 : (MF == ROT3 ? 0 : MTraits<MF>::pd));
+  static constexpr int off = (MF == POSE3) ? 9 : 0;
+};
+template <typename T> struct IsF64 { static constexpr bool v = false; };
+template <> struct IsF64<double> { static constexpr bool v = true; };
+
 // Inputs (states, landmarks, factor parameters) are ALWAYS fp64 in HBM; T is the arithmetic / row-table type.  In the
 // fp32 mode (GPSLAM_FP32) the Jacobian rows, the normal equations and the solver run with T = float, while the residual
 // is evaluated by the T = double error pass of the same kernels, which then also deposits its whitened error as the
@@ -185,8 +197,15 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
   if (valid) {
     const int i = a.left[f];
     dt = a.dt[f];
+    double q1[12], q2[12];
 #pragma unroll
-    for (int k = 0; k < 12; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
+    for (int k = 0; k < 12; k++) { q1[k] = a.pose[(size_t)k * a.stride + i]; q2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
+    if (!IsF64<T>::v) {
+#pragma unroll
+      for (int k = 9; k < 12; k++) { q2[k] -= q1[k]; q1[k] = 0.0; }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
 #pragma unroll
     for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
   }
@@ -290,8 +309,17 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
     const int i = a.left[f];
     dt = a.dt[f];
     T p1[pd], p2[pd], v1[d], v2[d];
+    {
+      double q1[pd], q2[pd];
 #pragma unroll
-    for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
+      for (int k = 0; k < pd; k++) { q1[k] = a.pose[(size_t)k * a.stride + i]; q2[k] = a.pose[(size_t)k * a.stride + i + 1]; }
+      if (!IsF64<T>::v) {
+#pragma unroll
+        for (int k = TransPart<MF>::off; k < TransPart<MF>::off + TransPart<MF>::n; k++) { q2[k] -= q1[k]; q1[k] = 0.0; }
+      }
+#pragma unroll
+      for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
+    }
 #pragma unroll
     for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
     if constexpr (MF == POSE3) {
@@ -439,15 +467,28 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
 #pragma unroll
       for (int k = 0; k < d; k++) e[k] = T(a.vel[(size_t)k * a.stride + i] - a.meas[(size_t)f * d + k]);
     } else {
-      T x1[pd], m[pd];
+      T x1[pd], m[pd], x2[pd];
+      {
+        double q1[pd], qm[pd], q2[pd];
 #pragma unroll
-      for (int k = 0; k < pd; k++) { x1[k] = a.pose[(size_t)k * a.stride + i]; m[k] = a.meas[(size_t)f * pd + k]; }
+        for (int k = 0; k < pd; k++) {
+          q1[k] = a.pose[(size_t)k * a.stride + i];
+          qm[k] = a.meas[(size_t)f * pd + k];
+          q2[k] = (KIND == 2) ? a.pose[(size_t)k * a.stride + i + 1] : 0.0;
+        }
+        if (!IsF64<T>::v) {   // re-centre on x1: PriorFactor compares (prior, x1), BetweenFactor (x1, x2) with a relative measurement
+#pragma unroll
+          for (int k = TransPart<MF>::off; k < TransPart<MF>::off + TransPart<MF>::n; k++) {
+            if (KIND == 0) qm[k] -= q1[k]; else q2[k] -= q1[k];
+            q1[k] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < pd; k++) { x1[k] = T(q1[k]); m[k] = T(qm[k]); x2[k] = T(q2[k]); }
+      }
       if (KIND == 0) {
         PoseFactors<T, MF, JAC>::prior(m, x1, a.chart, e, H1);
       } else {
-        T x2[pd];
-#pragma unroll
-        for (int k = 0; k < pd; k++) x2[k] = a.pose[(size_t)k * a.stride + i + 1];
         PoseFactors<T, MF, JAC>::between(m, x1, x2, a.chart, e, H1, H2);
       }
     }
@@ -541,8 +582,22 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ);
       constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ);
       T p1[pd], v1[d], p2[pd], v2[d];
+      double org[3] = {0.0, 0.0, 0.0};      // fp32 arithmetic: translations re-centred on the first pose (see TransPart)
+      {
+        double q1[pd], q2[pd];
 #pragma unroll
-      for (int k = 0; k < pd; k++) { p1[k] = a.pose[(size_t)k * a.stride + i]; p2[k] = two ? a.pose[(size_t)k * a.stride + i + 1] : T(0); }
+        for (int k = 0; k < pd; k++) { q1[k] = a.pose[(size_t)k * a.stride + i]; q2[k] = two ? a.pose[(size_t)k * a.stride + i + 1] : 0.0; }
+        if (!IsF64<T>::v) {
+#pragma unroll
+          for (int k = 0; k < TransPart<MF>::n; k++) {
+            if (k < 3) org[k] = q1[TransPart<MF>::off + k];
+            if (two) q2[TransPart<MF>::off + k] -= q1[TransPart<MF>::off + k];
+            q1[TransPart<MF>::off + k] = 0.0;
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
+      }
 #pragma unroll
       for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = two ? a.vel[(size_t)k * a.stride + i + 1] : T(0); }
       if constexpr (MF == POSE3 && two) {
@@ -558,7 +613,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       T pt[3] = {T(0), T(0), T(0)};
       if (haslm) {
         lm = a.lm[f];
-        for (int q = 0; q < a.ld; q++) pt[q] = a.lmk[(size_t)lm * a.ld + q];
+        for (int q = 0; q < a.ld; q++) pt[q] = T(a.lmk[(size_t)lm * a.ld + q] - org[q]);
       }
       ICoef<T> kc = {T(0), T(0), T(0), T(0)};
       if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ)
@@ -795,10 +850,11 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
 
 // ------------------------------------------------------------------ landmark border (Schur complement)
 
-template <typename T> struct LmArgs {
+// TR: type of the Jacobian row tables (float on fp32 handles, whose normal equations and solver stay fp64)
+template <typename T, typename TR = T> struct LmArgs {
   int N, R, B, L, ld, nl;   // R = 1 + nl
   int Nx;                   // solution slots in x: N, or N + 1 when a halo state follows the segment
-  const T *rowLR, *rowE, *rowM;
+  const TR *rowLR, *rowE, *rowM;
   const int *lmrow;         // row ids of rows that touch a landmark, grouped by landmark
   const int *lmrow_state;   // left state of each such row
   const int *lmrow_ptr;     // L + 1
@@ -823,12 +879,12 @@ template <typename T> struct LmArgs {
 };
 
 // t[j][c] = JL_rho . X_s[:, c] + JR_rho . X_{s+1}[:, c]
-template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T, TR> a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = tid / a.R, c = tid - j * a.R;
   if (j >= a.nlmrows) return;
   const int rho = a.lmrow[j], s = a.lmrow_state[j];
-  const T *row = a.rowLR + (size_t)rho * 2 * a.B;
+  const TR *row = a.rowLR + (size_t)rho * 2 * a.B;
   const T *x0 = a.x + ((size_t)s * a.R + c) * a.B;
   T acc = T(0);
   for (int k = 0; k < a.B; k++) acc += row[k] * x0[k];
@@ -845,7 +901,7 @@ template <typename T> __global__ void __launch_bounds__(128) k_lm_t(LmArgs<T> a)
 // (q, c) = (component of the landmark, column) running down the chunk; a second kernel adds the chunks of a landmark
 // in order, the priors and the damping.
 constexpr int kLmChunk = 64;
-template <typename T> __global__ void __launch_bounds__(256) k_lm_reduce_part(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_lm_reduce_part(LmArgs<T, TR> a) {
   const int ch = blockIdx.x;
   const int W = a.ld * a.R;                       // (q, c) pairs, <= 84
   const int nsub = 256 / W;                       // row phases per pair (the loop is a chain of dependent loads)
@@ -877,7 +933,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_lm_reduce_part(Lm
   }
 }
 // one wave per (al, c): lanes stride over the chunks of the landmark, then a fixed-order wave sum
-template <typename T> __global__ void __launch_bounds__(64) k_lm_reduce(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_lm_reduce(LmArgs<T, TR> a) {
   const int al = blockIdx.x / a.R, c = blockIdx.x - al * a.R;
   const int lm = al / a.ld, q = al - lm * a.ld;
   const int cl = c - 1;
@@ -903,7 +959,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_lm_reduce(LmArgs<T
 // Dense SPD solve of the (small) landmark system, S = columns 1..nl of a.S (upper part), rhs = column 0 -> dL.
 // One wave, right-looking Cholesky in LDS: step j scales column j (lane per row) and applies the rank-1 update to the
 // trailing block and to the rhs (lane per entry); then the back-substitution.  nl <= 27.
-template <typename T> __global__ void __launch_bounds__(64) k_lm_solve(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_lm_solve(LmArgs<T, TR> a) {
   constexpr int NM = kMaxRhs - 1;
   __shared__ T M[NM][NM + 1];      // lower triangle becomes L; +1: no bank conflicts down a column
   __shared__ T y[NM];
@@ -949,7 +1005,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_lm_solve(LmArgs<T>
 }
 
 // delta_p = x0 - Z dL  (in place in column 0 of x)
-template <typename T> __global__ void __launch_bounds__(256) k_lm_correct(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_lm_correct(LmArgs<T, TR> a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int s = tid / a.B, k = tid - s * a.B;
   if (s >= a.N) return;
@@ -960,7 +1016,7 @@ template <typename T> __global__ void __launch_bounds__(256) k_lm_correct(LmArgs
 }
 
 // landmarks += dL; out[0] = max |dL| (single block)
-template <typename T> __global__ void __launch_bounds__(64) k_lm_update(LmArgs<T> a, double *out_max) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_lm_update(LmArgs<T, TR> a, double *out_max) {
   T mx = T(0);
   const bool bad = a.flag && *a.flag;          // indeterminate system: leave the landmarks where they are
   for (int i = threadIdx.x; i < a.nl; i += 64) {
@@ -972,7 +1028,7 @@ template <typename T> __global__ void __launch_bounds__(64) k_lm_update(LmArgs<T
 }
 
 // error of the landmark priors (PriorFactor<Point>), single block
-template <typename T> __global__ void __launch_bounds__(128) k_lmprior_err(LmArgs<T> a) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(128) k_lmprior_err(LmArgs<T, TR> a) {
   T err = T(0);
   for (int k = threadIdx.x; k < a.npri; k += 128)
     for (int q = 0; q < a.ld; q++) {
@@ -1001,13 +1057,13 @@ template <typename T> __global__ void __launch_bounds__(256) k_gather_delta(cons
 
 // ------------------------------------------------------------------ K3: assemble normal equations
 
-template <typename T> struct AsmArgs {
+template <typename T, typename TR = T> struct AsmArgs {
   int N, R;               // states, rhs columns (1 + border)
   const int *rowptr;      // N + 2 entries; rows of left state s: [rowptr[s], rowptr[s+1]); rowptr[-1] handled by s > 0
-  const T *rowLR, *rowE;
+  const TR *rowLR, *rowE;
   const int *crowptr;     // compact rows (velocity-free Jacobians) of left state s: [crowptr[s], crowptr[s+1])
-  const T *rowC, *rowCE;  // Mc x B = [d/dpose_left (B/2) | d/dpose_right (B/2)], Mc
-  const T *rowM;          // M x ld (border) or null
+  const TR *rowC, *rowCE; // Mc x B = [d/dpose_left (B/2) | d/dpose_right (B/2)], Mc
+  const TR *rowM;         // M x ld (border) or null
   const int *rowLm;       // landmark id per row or -1
   int ld;
   T *blk;                 // N records [D | O | G]
@@ -1023,8 +1079,8 @@ template <typename T> struct AsmArgs {
 // group of state s - 1 (-> D_s += R^T R).  Compared with letting every group re-read the rows of s - 1 this
 // removes the second pass over the row table (2x HBM over-fetch measured, profiles/round1_v3) and a third of the
 // loop iterations.  DS operations of one wave execute in order, so no barrier is needed; two buffers alternate.
-template <typename T, int B, int WPB = 4>
-__global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
+template <typename T, int B, int WPB = 4, typename TR = T>
+__global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T, TR> a) {
   constexpr int G = 64 / B;                       // lane groups per wave (the first one is the ghost)
   static_assert(G >= 2, "needs at least one real state per wave");
   const int lane = threadIdx.x & 63;
@@ -1069,7 +1125,7 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
   const int n_last = max(n_own - 1, 0);
   auto ld = [&](int i, T &Lc, T &Rc, T &e) {
     const int rho = rp_s + min(i, n_last);
-    const T *row = a.rowLR + (size_t)rho * 2 * B;
+    const TR *row = a.rowLR + (size_t)rho * 2 * B;
     Lc = row[g >= 1 ? c : B + c];
     Rc = row[B + c];
     e = a.rowE[rho];
@@ -1134,7 +1190,7 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T> a) {
     const int cc = c < Dh ? c : 0;
     auto ldc = [&](int i, T &Lc, T &Rc, T &e) {
       const int rho = crp + min(i, cn_last);
-      const T *row = a.rowC + (size_t)rho * B;
+      const TR *row = a.rowC + (size_t)rho * B;
       Lc = row[g >= 1 ? cc : Dh + cc];
       Rc = row[Dh + cc];
       e = a.rowCE[rho];

@@ -234,6 +234,34 @@ template <typename T> GD M3<T> se3_Q(V3<T> w, V3<T> rho) {
   return T(-0.5) * Y + a * t1 + b * t2m + c * t3m;
 }
 
+// fp32: the coefficients by their series in th^2 below th^2 = 0.25 (see factors.hpp, "fp32 arithmetic")
+GD M3<float> se3_Q(V3<float> w, V3<float> rho) {
+  const float u = dot(w, w);
+  float a, b, c;
+  if (u < 0.25f) {
+    a = 1.f / 6 - u * (1.f / 120 - u * (1.f / 5040 - u * (1.f / 362880 - u * (1.f / 39916800))));
+    b = -1.f / 24 + u * (1.f / 720 - u * (1.f / 40320 - u * (1.f / 3628800 - u * (1.f / 479001600))));
+    const float qd = -1.f / 120 + u * (1.f / 5040 - u * (1.f / 362880 - u * (1.f / 39916800)));
+    c = -0.5f * (b - 3.f * qd);
+  } else {
+    const float th = sqrt(u), s = sin(th), co = cos(th);
+    const float t3 = u * th, t4 = u * u, t5 = t4 * th;
+    a = (th - s) / t3;
+    b = (1.f - 0.5f * u - co) / t4;
+    c = -0.5f * (b - 3.f * (th - s - t3 / 6.f) / t5);
+  }
+  const M3<float> X = skew(w), Y = skew(rho);
+  const M3<float> XY = X * Y, YX = Y * X, XYX = X * YX;
+  return -0.5f * Y + a * (XY + YX - XYX) + b * (X * XY + YX * X - 3.f * XYX) + c * (XYX * X + X * XYX);
+}
+GD M3<float> so3_jrinv(V3<float> w) {
+  const float u = dot(w, w);
+  const float c = (u < 0.25f) ? 1.f / 12 + u * (1.f / 720 + u * (1.f / 30240 + u * (1.f / 1209600)))
+                              : 1.f / u - (1.f + cos(sqrt(u))) / (2.f * sqrt(u) * sin(sqrt(u)));
+  const M3<float> X = skew(w);
+  return M3<float>::identity() + 0.5f * X + c * (X * X);
+}
+
 // rightJacobianPose3inv (Pose3utils.cpp:192-200) = Pose3::LogmapDerivative in terms of xi
 template <typename T> GD BL6<T> se3_jrinv(V6<T> xi) {
   const M3<T> Jw = so3_jrinv(xi.w);

@@ -31,3 +31,16 @@ def test_reference_style_cpp_tests_pass_on_gpu():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def test_fp32_math_on_the_host():
+    """tests/cpp/fp32_math_tests.cpp: blended coefficients and the exact derivative that replaces the reference's h = 1e-6
+    finite difference in the fp32 mode; hipcc's host pass, runs on the CPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "fp32_math_tests")
+    src = os.path.join(ROOT, "tests", "cpp", "fp32_math_tests.cpp")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < max(os.path.getmtime(src), os.path.getmtime(os.path.join(ROOT, "gpslam_amd", "csrc", "factors.hpp")),
+                                                              os.path.getmtime(os.path.join(ROOT, "gpslam_amd", "csrc", "lie.hpp"))):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all fp32 math tests passed" in out.stdout
