@@ -167,6 +167,10 @@ void orc_odometry_2dlinear(const double *measured, const double *pose1, const do
 
 int orc_pose_dim(int kind);
 int orc_tangent_dim(int kind);
+/* OpenMP threads used to EVALUATE factors (linearize / error); accumulation and elimination stay serial and in factor
+ * order, so results are bit-identical for any count.  0 = all cores; default 1. */
+void orc_set_threads(int n);
+int orc_get_threads(void);
 void orc_retract(int kind, int chart, const double *x, const double *delta, double *out);
 void orc_local(int kind, int chart, const double *x, const double *y, double *v);
 void orc_prior_factor(int kind, int chart, const double *prior, const double *x, double *e, double *H);

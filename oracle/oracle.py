@@ -69,6 +69,12 @@ def default_params(**kw):
     return p
 
 
+def set_threads(n=0):
+    """OpenMP threads for factor evaluation (0 = all cores); results do not depend on the count."""
+    lib().orc_set_threads(int(n))
+    return lib().orc_get_threads()
+
+
 def _d(a):
     """contiguous float64 array + pointer (None -> NULL)"""
     if a is None:

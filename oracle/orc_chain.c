@@ -18,6 +18,9 @@
 #include "orc_math.h"
 
 #include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 enum {
   F_GP = 0, F_POSE_PRIOR, F_VEL_PRIOR, F_BETWEEN, F_LM_PRIOR, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT,
@@ -430,15 +433,36 @@ int orc_chain_linearize_gp(const orc_chain *c, double *errors, double *jac) {
   return (int)k;
 }
 
+/* Threads (OpenMP): the factors are EVALUATED in parallel -- what GTSAM built with TBB does in
+ * NonlinearFactorGraph::linearize / error -- into per-factor storage and then accumulated serially in factor order, so
+ * every result is bit-identical for any thread count.  The elimination stays sequential: the elimination tree of a
+ * chain in chain order is a path.  orc_set_threads(0) = all cores (default 1: the tests and the 1-core baseline). */
+static int g_threads = 1;
+void orc_set_threads(int n) {
+#ifdef _OPENMP
+  g_threads = n > 0 ? n : omp_get_num_procs();
+#else
+  (void)n;
+  g_threads = 1;
+#endif
+}
+int orc_get_threads(void) { return g_threads; }
+
 int orc_chain_error(const orc_chain *c, double *err) {
-  double total = 0.0;
+  double *fe = (double *)malloc(sizeof(double) * (size_t)(c->nf > 0 ? c->nf : 1));
+  int bad = 0;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
   for (int i = 0; i < c->nf; i++) {
     double we[MAXR];
     int ur, ul;
     int rows = factor_eval(c, &c->f[i], 0, we, NULL, NULL, NULL, &ur, &ul);
-    if (rows < 0) return rows;
-    total += 0.5 * orc_dot(rows, we, we);   /* NoiseModelFactor::error = 0.5 |R e|^2 */
+    if (rows < 0) { bad = rows; fe[i] = 0.0; }
+    else fe[i] = 0.5 * orc_dot(rows, we, we);   /* NoiseModelFactor::error = 0.5 |R e|^2 */
   }
+  double total = 0.0;
+  for (int i = 0; i < c->nf; i++) total += fe[i];
+  free(fe);
+  if (bad) return bad;
   *err = total;
   return 0;
 }
@@ -466,12 +490,17 @@ static int build_neq(const orc_chain *c, orc_neq *q) {
     q->gL = (double *)calloc((size_t)nl, sizeof(double));
   }
   double total = 0.0;
+  /* pass 1 (parallel): evaluate every factor into its own slot; pass 2 (serial, factor order): accumulate */
+  typedef struct { double we[MAXR], JL[MAXR * MAXB], JR[MAXR * MAXB], Jm[MAXR * 3]; int rows, ur, ul; } lin_t;
+  lin_t *lin = (lin_t *)malloc(sizeof(lin_t) * (size_t)(c->nf > 0 ? c->nf : 1));
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int k = 0; k < c->nf; k++)
+    lin[k].rows = factor_eval(c, &c->f[k], 1, lin[k].we, lin[k].JL, lin[k].JR, lin[k].Jm, &lin[k].ur, &lin[k].ul);
   for (int k = 0; k < c->nf; k++) {
     const orc_factor *f = &c->f[k];
-    double we[MAXR], JL[MAXR * MAXB], JR[MAXR * MAXB], Jm[MAXR * 3];
-    int ur, ul;
-    int rows = factor_eval(c, f, 1, we, JL, JR, Jm, &ur, &ul);
-    if (rows < 0) { neq_free(q); return rows; }
+    const double *we = lin[k].we, *JL = lin[k].JL, *JR = lin[k].JR, *Jm = lin[k].Jm;
+    const int ur = lin[k].ur, ul = lin[k].ul, rows = lin[k].rows;
+    if (rows < 0) { free(lin); neq_free(q); return rows; }
     total += 0.5 * orc_dot(rows, we, we);
     const int i = f->idx;
     const int is_lm_only = (f->type == F_LM_PRIOR);
@@ -511,6 +540,7 @@ static int build_neq(const orc_chain *c, orc_neq *q) {
       }
     }
   }
+  free(lin);
   q->err = total;
   return 0;
 }
