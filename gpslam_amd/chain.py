@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
-    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan",
+    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas",
 ]
 
 
@@ -235,6 +235,18 @@ class ChainSolver:
         H = np.zeros((self.n_gp, 4, self.b, self.d)) if jac else None
         self._chk(self.lib.gpslam_hip_linearize_gp(self._h, _p(e), _p(H)), "linearize_gp")
         return e, H
+
+    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2}
+
+    def linearize_meas(self, kind, count):
+        """Unwhitened (e, J) of the `count` measurement factors of one kind (MEAS_* order of include/gpslam_hip.h):
+        e (count, rows), J (count, rows, 4d + 3) = [H1 | H2 | H3 | H4 | H5 padded to 3]."""
+        rows = self.MEAS_ROWS[kind]
+        e = np.zeros((count, rows))
+        J = np.zeros((count, rows, 2 * self.b + 3))
+        n = self._chk(self.lib.gpslam_hip_linearize_meas(self._h, int(kind), _p(e), _p(J)), "linearize_meas")
+        assert n == count, (n, count)
+        return e, J
 
     def error(self):
         out = C.c_double(0.0)

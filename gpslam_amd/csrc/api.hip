@@ -685,6 +685,10 @@ int gpslam_hip_linearize_gp(gpslam_hip_handle *h, double *errors, double *jacobi
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_linearize_gp(h, errors, jacobians) : impl64::gpslam_hip_linearize_gp(h, errors, jacobians);
 }
+int gpslam_hip_linearize_meas(gpslam_hip_handle *h, int32_t kind, double *errors, double *jacobians) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_linearize_meas(h, kind, errors, jacobians) : impl64::gpslam_hip_linearize_meas(h, kind, errors, jacobians);
+}
 int gpslam_hip_error(gpslam_hip_handle *h, double *err) {
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_error(h, err) : impl64::gpslam_hip_error(h, err);

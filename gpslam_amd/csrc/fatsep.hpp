@@ -123,7 +123,6 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 // G~_j = G_j - E_{j-1}^T Y_{j-1},  Y_j = W_j G~_j.  Columns: [0, NB) left fat block, [NB, 2 NB) right fat block, 2 NB rhs.
 template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, c = threadIdx.x;
-  if (c >= a.NC) return;
   const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
   const int j0 = cutL + 1, n = cutR - cutL - 1;
   const bool is_rhs = (c == 2 * a.NB);
@@ -131,65 +130,100 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
   const int cc = is_rhs ? 0 : (right ? c - a.NB : c);
   const int kf = seg + (right ? 1 : 0);
   const bool is_state = !is_rhs && cc < B;
+  bool active = c < a.NC;
   int lm = -1, q = 0;
-  if (!is_rhs && !is_state) {
+  if (active && !is_rhs && !is_state) {
     const int li = (cc - B) / a.ld;
     q = (cc - B) - li * a.ld;
     if (a.fat_lm_ptr[kf] + li < a.fat_lm_ptr[kf + 1]) lm = a.fat_lm[a.fat_lm_ptr[kf] + li];
-    if (lm < 0) return;     // padding column: Y stays zero (cleared once at compile time)
+    if (lm < 0) active = false;     // padding column: Y stays zero (cleared once at compile time)
   }
   int cur = 0, end = 0;
   if (lm >= 0) { cur = a.lmrow_ptr[lm]; end = a.lmrow_ptr[lm + 1]; }
+  // rows of other segments come first in the landmark's list: skip them once, then keep the state of the next row in a
+  // register so that a step without a row of this landmark (most steps) issues no dependent load at all
+  while (cur < end && a.lmrow_state[cur] < j0 - 1) cur++;
+  int nxt = (cur < end) ? a.lmrow_state[cur] : 0x7fffffff;
   T y[B];
 #pragma unroll
   for (int r = 0; r < B; r++) y[r] = T(0);
+  // [W_s | E_{s-1}] of the current state are the same for every column: staged through LDS, the next state's being
+  // fetched (one value per thread) while the current step computes
+  constexpr int FW = 2 * B * B;
+  __shared__ T Fs[2][FW];
+  const int tid = threadIdx.x;
+  auto fac_at = [&](int s, int k) -> T {     // k < B*B: W_s[k]; else E_{s-1}[k - B*B] (zero for the first interior state)
+    if (k < B * B) return a.fac[(size_t)s * FW + k];
+    return (s > j0) ? a.fac[(size_t)(s - 1) * FW + k] : T(0);
+  };
+  constexpr int PF = (FW + 63) / 64;          // values per thread (the block has at least 64 threads)
+  const int nt = blockDim.x;
+  if (n > 0)
+    for (int k = tid; k < FW; k += nt) Fs[0][k] = fac_at(j0, k);
+  __syncthreads();
   for (int jj = 0; jj < n; jj++) {
     const int s = j0 + jj;
-    T G[B];
+    const T *fw = Fs[jj & 1], *fep = Fs[jj & 1] + B * B;
+    T pre[PF];
 #pragma unroll
-    for (int r = 0; r < B; r++) G[r] = T(0);
-    if (is_rhs) {
-      const T *gp = a.blk + (size_t)s * a.BS + 2 * B * B;
+    for (int u = 0; u < PF; u++) pre[u] = (jj + 1 < n && tid + u * nt < FW) ? fac_at(s + 1, tid + u * nt) : T(0);
+    if (active) {
+      T G[B];
 #pragma unroll
-      for (int r = 0; r < B; r++) G[r] = gp[r];
-    } else if (is_state) {
-      if (!right && jj == 0) {            // H[cutL + 1, cutL] = O_cutL
-        const T *op = a.blk + (size_t)cutL * a.BS + B * B;
+      for (int r = 0; r < B; r++) G[r] = T(0);
+      if (is_rhs) {
+        const T *gp = a.blk + (size_t)s * a.BS + 2 * B * B;
 #pragma unroll
-        for (int r = 0; r < B; r++) G[r] = op[r * B + cc];
-      } else if (right && jj == n - 1) {  // H[cutR - 1, cutR] = O_{cutR-1}^T
-        const T *op = a.blk + (size_t)s * a.BS + B * B;
+        for (int r = 0; r < B; r++) G[r] = gp[r];
+      } else if (is_state) {
+        if (!right && jj == 0) {            // H[cutL + 1, cutL] = O_cutL
+          const T *op = a.blk + (size_t)cutL * a.BS + B * B;
 #pragma unroll
-        for (int r = 0; r < B; r++) G[r] = op[cc * B + r];
+          for (int r = 0; r < B; r++) G[r] = op[r * B + cc];
+        } else if (right && jj == n - 1) {  // H[cutR - 1, cutR] = O_{cutR-1}^T
+          const T *op = a.blk + (size_t)s * a.BS + B * B;
+#pragma unroll
+          for (int r = 0; r < B; r++) G[r] = op[cc * B + r];
+        }
+      } else if (nxt <= s) {
+        while (cur < end && a.lmrow_state[cur] < s - 1) cur++;
+        int t = cur;
+        for (; t < end && a.lmrow_state[t] <= s; t++) {
+          const int rho = a.lmrow[t];
+          const T m = a.rowM[(size_t)rho * a.ld + q];
+          const TR *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
+#pragma unroll
+          for (int r = 0; r < B; r++) G[r] += row[r] * m;
+        }
+        // next step that needs a look: rows of state s contribute again at s + 1 (their right halves), later rows at
+        // their own state
+        int t2 = cur;
+        while (t2 < end && a.lmrow_state[t2] < s) t2++;
+        nxt = (t2 < end) ? max(a.lmrow_state[t2], s + 1) : 0x7fffffff;
       }
-    } else {
-      while (cur < end && a.lmrow_state[cur] < s - 1) cur++;
-      for (int t = cur; t < end && a.lmrow_state[t] <= s; t++) {
-        const int rho = a.lmrow[t];
-        const T m = a.rowM[(size_t)rho * a.ld + q];
-        const TR *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
+      if (jj > 0) {
 #pragma unroll
-        for (int r = 0; r < B; r++) G[r] += row[r] * m;
+        for (int k = 0; k < B; k++)
+#pragma unroll
+          for (int r = 0; r < B; r++) G[r] -= fep[k * B + r] * y[k];
       }
+#pragma unroll
+      for (int r = 0; r < B; r++) {
+        T acc = T(0);
+#pragma unroll
+        for (int k = 0; k <= r; k++) acc += fw[r * B + k] * G[k];
+        y[r] = acc;
+      }
+      T *yp = a.Y + (size_t)s * B * a.NCP + c;
+#pragma unroll
+      for (int r = 0; r < B; r++) yp[(size_t)r * a.NCP] = y[r];
     }
-    const T *fp = a.fac + (size_t)s * 2 * B * B;
-    if (jj > 0) {
-      const T *ep = fp - 2 * B * B + B * B;    // E_{j-1}
+    if (jj + 1 < n) {
 #pragma unroll
-      for (int k = 0; k < B; k++)
-#pragma unroll
-        for (int r = 0; r < B; r++) G[r] -= ep[k * B + r] * y[k];
+      for (int u = 0; u < PF; u++)
+        if (tid + u * nt < FW) Fs[(jj + 1) & 1][tid + u * nt] = pre[u];
     }
-#pragma unroll
-    for (int r = 0; r < B; r++) {
-      T acc = T(0);
-#pragma unroll
-      for (int k = 0; k <= r; k++) acc += fp[r * B + k] * G[k];
-      y[r] = acc;
-    }
-    T *yp = a.Y + (size_t)s * B * a.NCP + c;
-#pragma unroll
-    for (int r = 0; r < B; r++) yp[(size_t)r * a.NCP] = y[r];
+    __syncthreads();
   }
 }
 
@@ -197,9 +231,9 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 // cores.  One wave per (segment, 16-row tile): v_mfma_f64_16x16x4_f64, A[i][k] = Y[k][i0 + i], B[k][j] = Y[k][j0 + j]
 // (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double fs_d4 __attribute__((ext_vector_type(4)));
+// Y^T Y is symmetric: only the tiles on and below the diagonal (tile column <= tile row) are formed; readers use fs_sym.
 template <int TMAX, typename TR = double> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<double, TR> a) {
   const int seg = blockIdx.x, ti = blockIdx.y, lane = threadIdx.x;
-  const int T16 = a.NCP / 16;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   const int kdim = n * a.B;
   const double *Yb = a.Y + (size_t)j0 * a.B * a.NCP;
@@ -214,7 +248,7 @@ template <int TMAX, typename TR = double> __global__ void __launch_bounds__(64) 
     const double av = ok ? yr[ti * 16 + cl] : 0.0;
 #pragma unroll
     for (int t = 0; t < TMAX; t++) {
-      if (t < T16) {
+      if (t <= ti) {
         const double bv = ok ? yr[t * 16 + cl] : 0.0;
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
       }
@@ -223,11 +257,15 @@ template <int TMAX, typename TR = double> __global__ void __launch_bounds__(64) 
   double *out = a.Aseg + (size_t)seg * a.NCP * a.NCP;
 #pragma unroll
   for (int t = 0; t < TMAX; t++) {
-    if (t < T16) {
+    if (t <= ti) {
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) out[(size_t)(ti * 16 + kl + 4 * rg) * a.NCP + t * 16 + cl] = acc[t][rg];
     }
   }
+}
+// entry (i, j) of a segment's symmetric Schur complement, stored by its lower tile triangle
+template <typename T> __device__ __forceinline__ T fs_sym(const T *A, int ncp, int i, int j) {
+  return (i >= j) ? A[(size_t)i * ncp + j] : A[(size_t)j * ncp + i];
 }
 
 // ---- fat blocks: direct terms minus the Schur complements of the two neighbouring segments.
@@ -282,8 +320,8 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
           }
       }
       if (r == c) v += a.lambda;
-      if (AL) v -= AL[(size_t)(NB + r) * a.NCP + NB + c];
-      if (AR) v -= AR[(size_t)r * a.NCP + c];
+      if (AL) v -= fs_sym(AL, a.NCP, NB + r, NB + c);
+      if (AR) v -= fs_sym(AR, a.NCP, r, c);
     }
     a.Dfat[(size_t)k * NB * NB + idx] = v;
     if (k < a.K - 1) {       // link k -> k + 1: H[fat k+1 variable r, fat k variable c]
@@ -294,7 +332,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
         if (wr.kind == 0 && vc.kind == 0) { if (cut1 == cut + 1) o = bp[B * B + r * B + c]; }
         else if (wr.kind == 0 && vc.kind == 1) o = fs_state_lm(a, cut1, r, vc.lm, vc.q);
         else if (wr.kind == 1 && vc.kind == 0) o = fs_state_lm(a, cut, c, wr.lm, wr.q);
-        o -= AR[(size_t)(NB + r) * a.NCP + c];
+        o -= fs_sym(AR, a.NCP, NB + r, c);
       }
       a.link[(size_t)k * NB * NB + idx] = o;
     }
@@ -316,8 +354,8 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
       a.gL[(size_t)vr.lm * a.ld + vr.q] = g;   // undamped gradient (LM model)
     }
     if (vr.kind != 2) {
-      if (AL) g -= AL[(size_t)(NB + r) * a.NCP + 2 * NB];
-      if (AR) g -= AR[(size_t)r * a.NCP + 2 * NB];
+      if (AL) g -= fs_sym(AL, a.NCP, NB + r, 2 * NB);
+      if (AR) g -= fs_sym(AR, a.NCP, r, 2 * NB);
     }
     a.gfat[(size_t)k * NB + r] = g;
   }

@@ -543,6 +543,8 @@ template <typename T> struct MeasArgs {
   const double *sig;   // count x rows
   const double *coef;  // count x 4: l11, l12, p11, p12 (interpolated kinds)
   float *rowE32;       // error-only pass: fp32 copy of the whitened error (fp32 mode), or null
+  T *out_e, *out_J;    // inspection (gpslam_hip_linearize_meas): unwhitened e (count x rows) and per row
+                       // [H1 H2 | H3 H4 | H5 (3, zero padded)] exactly as evaluateError returns them, or null
   const double *aux;       // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
   const int *aidx;     // count: entry of each factor (one body_P_sensor / calibration PER FACTOR, as in the reference:
                        // GPInterpolatedRangeFactorPose3.h:46-54), or null: no sensor transform anywhere
@@ -809,6 +811,17 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         if (a.vw) {     // chain rule through convertVWtoVb (v1 / v2 hold the body velocities here)
 #pragma unroll
           for (int r = 0; r < rows; r++) { vw_row_transform(p1, v1, JL + r * b); vw_row_transform(p2, v2, JR + r * b); }
+        }
+      }
+      if (JAC && a.out_e) {
+#pragma unroll
+        for (int r = 0; r < rows; r++) {
+          a.out_e[(size_t)f * rows + r] = e[r];
+          T *o = a.out_J + ((size_t)f * rows + r) * (2 * b + 3);
+#pragma unroll
+          for (int c = 0; c < b; c++) { o[c] = JL[r * b + c]; o[b + c] = JR[r * b + c]; }
+#pragma unroll
+          for (int c = 0; c < 3; c++) o[2 * b + c] = Jm[r * 3 + c];
         }
       }
       const int row0 = (JAC || a.rowE32) ? a.row0[f] : 0;

@@ -179,6 +179,13 @@ int gpslam_hip_compile(gpslam_hip_handle *h);
  * NoiseModelFactor::unwhitenedError returns): errors count x 2d; jacobians count x 4 x 2d x d row-major
  * (may be NULL).  Returns the factor count. */
 int gpslam_hip_linearize_gp(gpslam_hip_handle *h, double *errors, double *jacobians);
+/* The same for the measurement factors of one kind (kind = GPSLAM_MEAS_*), in the order they were added: errors
+ * count x rows (unwhitened evaluateError), jacobians count x rows x (4d + 3) = per row [H1 (d) | H2 (d) | H3 (d) | H4 (d) |
+ * H5 (landmark, zero padded to 3)] (may be NULL); single-state factors leave H3 / H4 zero, factors without a landmark H5
+ * (e.g. gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98, GPInterpolatedAttitudeFactorRot3.h:61-83).  Returns the count. */
+enum { GPSLAM_MEAS_INTERP_RANGE = 0, GPSLAM_MEAS_RANGE = 1, GPSLAM_MEAS_INTERP_ATTITUDE = 2, GPSLAM_MEAS_INTERP_GPS = 3,
+       GPSLAM_MEAS_ODOMETRY2D = 4, GPSLAM_MEAS_BEARING_RANGE = 5, GPSLAM_MEAS_INTERP_PROJECTION = 6 };
+int gpslam_hip_linearize_meas(gpslam_hip_handle *h, int32_t kind, double *errors, double *jacobians);
 /* total graph error 0.5 * sum |R e|^2 (NonlinearFactorGraph::error) */
 int gpslam_hip_error(gpslam_hip_handle *h, double *err);
 /* one GaussNewtonOptimizer::iterate(): linearize, assemble, solve, retract, error */

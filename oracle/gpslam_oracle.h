@@ -242,6 +242,8 @@ int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left
                                     const double *K, const double *sensor);
 /* errors: count x rows (unwhitened); jac: count x 4 x rows x d row-major (H1..H4 for GP priors) */
 int orc_chain_linearize_gp(const orc_chain *c, double *errors, double *jac);
+/* unwhitened e and [H1 H2 | H3 H4 | H5] of the measurement factors of one type (5 + GPSLAM_MEAS_* of the HIP ABI) */
+int orc_chain_linearize_meas(const orc_chain *c, int type, double *errors, double *jac);
 int orc_chain_error(const orc_chain *c, double *err);
 int orc_chain_iterate_gn(orc_chain *c, orc_stats *st);
 int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_stats *st);

@@ -323,6 +323,17 @@ class Chain:
         call("orc_chain_linearize_gp", self._h, e, H)
         return e, H
 
+    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2}
+
+    def linearize_meas(self, kind, count):
+        """Unwhitened (e, J) per factor of one measurement kind (the HIP ABI's GPSLAM_MEAS_* numbering)."""
+        rows = self.MEAS_ROWS[kind]
+        e = np.zeros((count, rows))
+        J = np.zeros((count, rows, 2 * self.b + 3))
+        n = call("orc_chain_linearize_meas", self._h, 5 + int(kind), e, J)
+        assert n == count, (n, count)
+        return e, J
+
     def error(self):
         out = C.c_double(0.0)
         rc = lib().orc_chain_error(self._h, C.byref(out))

@@ -448,6 +448,33 @@ void orc_set_threads(int n) {
 }
 int orc_get_threads(void) { return g_threads; }
 
+/* Unwhitened evaluateError + Jacobians of every measurement factor of one type (F_INTERP_RANGE ...), in the order
+ * they were added: errors count x rows, jac count x rows x (2b + 3) = per row [H1 H2 | H3 H4 | H5 zero-padded to 3].
+ * The per-factor counterpart of gpslam_hip_linearize_meas: factor_eval's diagonally whitened rows times sigma. */
+int orc_chain_linearize_meas(const orc_chain *c, int type, double *errors, double *jac) {
+  const int b = c->b, ld = c->ld, W = 2 * b + 3;
+  size_t k = 0;
+  if (type < F_INTERP_RANGE) return -1;
+  for (int i = 0; i < c->nf; i++) {
+    const orc_factor *f = &c->f[i];
+    if (f->type != type) continue;
+    double we[MAXR], JL[MAXR * MAXB], JR[MAXR * MAXB], Jm[MAXR * 3];
+    int ur, ul;
+    int rows = factor_eval(c, f, 1, we, JL, JR, Jm, &ur, &ul);
+    if (rows < 0) return rows;
+    for (int r = 0; r < rows; r++) {
+      const double sg = f->sig[r];
+      errors[k * rows + r] = we[r] * sg;
+      double *o = jac + (k * rows + r) * W;
+      for (int q = 0; q < W; q++) o[q] = 0.0;
+      for (int q = 0; q < b; q++) { o[q] = JL[r * b + q] * sg; o[b + q] = JR[r * b + q] * sg; }
+      for (int q = 0; q < ld; q++) o[2 * b + q] = Jm[r * ld + q] * sg;
+    }
+    k++;
+  }
+  return (int)k;
+}
+
 int orc_chain_error(const orc_chain *c, double *err) {
   double *fe = (double *)malloc(sizeof(double) * (size_t)(c->nf > 0 ? c->nf : 1));
   int bad = 0;
