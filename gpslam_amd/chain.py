@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
-    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas",
+    "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
 ]
 
 
@@ -326,6 +326,15 @@ class ChainSolver:
         out = np.zeros(8, dtype=np.int32)
         self._chk(self.lib.gpslam_hip_segment_plan(self._h, _p(out)), "segment_plan")
         return dict(zip(("active", "C", "K", "NB", "NC", "NCP", "levels", "links"), (int(v) for v in out)))
+
+    def interpolate_poses_jac(self, left, dt, tau):
+        """interpolatePose with H1..H4: (poses (count, pose_dim), H (count, 4, d, d))."""
+        left, dt, tau = _i32(left), _f64(dt), _f64(tau)
+        out = np.zeros((len(left), self.pd))
+        H = np.zeros((len(left), 4, self.d, self.d))
+        self._chk(self.lib.gpslam_hip_interpolate_poses_jac(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out), _p(H)),
+                  "interpolate_poses_jac")
+        return out, H
 
     def last_timing(self):
         t = np.zeros(5)

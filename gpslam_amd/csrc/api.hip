@@ -636,8 +636,9 @@ int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5) {
   return 0;
 }
 
-int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
-                                 const double *tau, double *out_pose) {
+// interpolatePose (+ H1..H4 when out_H != NULL) of the current estimate; shared by the two entry points below
+static int interpolate_impl(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt, const double *tau,
+                            double *out_pose, double *out_H) {
   if (!h || count < 0 || (count > 0 && (!left || !dt || !tau || !out_pose))) return GPSLAM_E_INVALID;
   if (h->N < 2) return fail(h, GPSLAM_E_INVALID, "interpolation needs at least two states");
   const int mx = max_left(h);
@@ -647,34 +648,43 @@ int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int3
   }
   if (count == 0) return 0;
   (void)hipSetDevice(h->cfg.device);
-  const int pd = h->pd;
+  const int pd = h->pd, d = h->d;
   std::vector<double> coef((size_t)count * 4);
   for (int q = 0; q < count; q++) interp_coef(dt[q], tau[q], &coef[4 * (size_t)q]);
   std::vector<int> li(left, left + count);
   struct Scratch {   // query buffers live for this call only
-    DevBuf left, coef, out;
-    ~Scratch() { left.release(); coef.release(); out.release(); }
+    DevBuf left, coef, out, outH;
+    ~Scratch() { left.release(); coef.release(); out.release(); outH.release(); }
   } sc;
-  DevBuf &d_left = sc.left, &d_coef = sc.coef, &d_out = sc.out;
   int rc;
-  if ((rc = upload(h, d_left, li))) return rc;
-  if ((rc = upload(h, d_coef, coef))) return rc;
-  HIPCHK(d_out.reserve((size_t)count * pd * sizeof(double)));
+  if ((rc = upload(h, sc.left, li))) return rc;
+  if ((rc = upload(h, sc.coef, coef))) return rc;
+  HIPCHK(sc.out.reserve((size_t)count * pd * sizeof(double)));
+  if (out_H) HIPCHK(sc.outH.reserve((size_t)count * 4 * d * d * sizeof(double)));
   QueryArgs<double> a;
   a.pose = h->pose.as<double>(); a.vel = h->vel.as<double>(); a.stride = h->stride; a.count = count;
-  a.left = d_left.as<int>(); a.coef = d_coef.as<double>(); a.out = d_out.as<double>(); a.vw = h->vw;
+  a.left = sc.left.as<int>(); a.coef = sc.coef.as<double>(); a.out = sc.out.as<double>(); a.out_H = out_H ? sc.outH.as<double>() : nullptr;
+  a.vw = h->vw;
   dispatch_mf(h->mf, [&](auto tag) {
     constexpr int MF = decltype(tag)::value;
-    k_interp_query<double, MF><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
+    if (out_H) k_interp_query<double, MF, true><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
+    else k_interp_query<double, MF, false><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
   });
   HIPCHK(hipGetLastError());
-  std::vector<double> out((size_t)count * pd);
-  HIPCHK(hipMemcpyAsync(out.data(), d_out.p, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(out_pose, sc.out.p, (size_t)count * pd * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out_H) HIPCHK(hipMemcpyAsync(out_H, sc.outH.p, (size_t)count * 4 * d * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (size_t k = 0; k < out.size(); k++) out_pose[k] = out[k];
   return 0;
 }
-
+int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                 const double *tau, double *out_pose) {
+  return interpolate_impl(h, count, left, dt, tau, out_pose, nullptr);
+}
+int gpslam_hip_interpolate_poses_jac(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                     const double *tau, double *out_pose, double *out_H) {
+  if (!out_H) return GPSLAM_E_INVALID;
+  return interpolate_impl(h, count, left, dt, tau, out_pose, out_H);
+}
 
 // ---- precision dispatch: the handle was created GPSLAM_FP64 or GPSLAM_FP32
 int gpslam_hip_compile(gpslam_hip_handle *h) {

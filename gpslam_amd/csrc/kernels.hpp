@@ -1310,11 +1310,12 @@ template <typename T> struct QueryArgs {
   const double *coef;        // count x 4: l11, l12, p11, p12 for (dt[q], tau[q])
   int vw;                // Pose3 only: velocities are world-frame [v; w]
   T *out;                // count x pose_dim (AoS, the layout of gpslam_hip_get_states' rows)
+  T *out_H;              // JAC: count x 4 x d x d = H1..H4 of interpolatePose (GaussianProcessInterpolatorPose3.h:82-98)
 };
 
 // Batched GaussianProcessInterpolator{Linear,Pose2,Pose3,Rot3}::interpolatePose without Jacobians (the public
 // query use of the interpolators, gpslam.h:57-86): thread per query.
-template <typename T, int MF>
+template <typename T, int MF, bool JAC = false>
 __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1336,25 +1337,58 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
     }
   }
   T *o = a.out + (size_t)q * pd;
+  T *oh = JAC ? a.out_H + (size_t)q * 4 * d * d : nullptr;
   if constexpr (MF == LINEAR2 || MF == LINEAR3) {
     // p(tau) = Lambda_1 [p1; v1] + Psi_1 [p2; v2]   (GaussianProcessInterpolatorLinear.h:70-90)
 #pragma unroll
     for (int c = 0; c < d; c++) o[c] = k.l11 * p1[c] + k.l12 * v1[c] + k.p11 * p2[c] + k.p12 * v2[c];
+    if (JAC) {     // H_k = the d x d blocks of Lambda_1, Psi_1 (:83-86): scalar multiples of I for the shared Qc
+      const T cf[4] = {k.l11, k.l12, k.p11, k.p12};
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < d; r++)
+#pragma unroll
+          for (int c = 0; c < d; c++) oh[(m * d + r) * d + c] = (r == c) ? cf[m] : T(0);
+    }
   } else if constexpr (MF == POSE2) {
-    Interp3Out<T, false> unused;
-    const SE2<T> r = interp_pose2<T, false>(p1, v1, p2, v2, k, unused);
+    Interp3Out<T, JAC> jo;
+    const SE2<T> r = interp_pose2<T, JAC>(p1, v1, p2, v2, k, jo);
     o[0] = r.x; o[1] = r.y; o[2] = r.th;
+    if (JAC) { put_m3(jo.H1, oh, 3, 0, 0); put_m3(jo.H2, oh + 9, 3, 0, 0); put_m3(jo.H3, oh + 18, 3, 0, 0); put_m3(jo.H4, oh + 27, 3, 0, 0); }
   } else if constexpr (MF == ROT3) {
-    Interp3Out<T, false> unused;
-    const M3<T> r = interp_rot3<T, false>(p1, v1, p2, v2, k, unused);
+    Interp3Out<T, JAC> jo;
+    const M3<T> r = interp_rot3<T, JAC>(p1, v1, p2, v2, k, jo);
 #pragma unroll
     for (int c = 0; c < 9; c++) o[c] = r.m[c];
+    if (JAC) { put_m3(jo.H1, oh, 3, 0, 0); put_m3(jo.H2, oh + 9, 3, 0, 0); put_m3(jo.H3, oh + 18, 3, 0, 0); put_m3(jo.H4, oh + 27, 3, 0, 0); }
   } else {
-    Interp6Out<T, false> unused;
-    const SE3<T> r = interp_pose3<T, false>(p1, v1, p2, v2, k, unused);
+    Interp6Out<T, JAC> jo;
+    const SE3<T> r = interp_pose3<T, JAC>(p1, v1, p2, v2, k, jo);
 #pragma unroll
     for (int c = 0; c < 9; c++) o[c] = r.R.m[c];
     o[9] = r.t.x; o[10] = r.t.y; o[11] = r.t.z;
+    if (JAC) {
+#pragma unroll
+      for (int c = 0; c < 4 * 36; c++) oh[c] = T(0);
+      put_bl6(jo.H1, oh, 6, 0, 0); put_bl6(jo.H2, oh + 36, 6, 0, 0); put_bl6(jo.H3, oh + 72, 6, 0, 0); put_bl6(jo.H4, oh + 108, 6, 0, 0);
+      if (a.vw) {   // chain rule through convertVWtoVb, one 12-wide [d/dpose | d/dVb] segment per output row and state
+#pragma unroll
+        for (int rr = 0; rr < 6; rr++) {
+          T seg[12];
+#pragma unroll
+          for (int c = 0; c < 6; c++) { seg[c] = oh[rr * 6 + c]; seg[6 + c] = oh[36 + rr * 6 + c]; }
+          vw_row_transform(p1, v1, seg);
+#pragma unroll
+          for (int c = 0; c < 6; c++) { oh[rr * 6 + c] = seg[c]; oh[36 + rr * 6 + c] = seg[6 + c]; }
+#pragma unroll
+          for (int c = 0; c < 6; c++) { seg[c] = oh[72 + rr * 6 + c]; seg[6 + c] = oh[108 + rr * 6 + c]; }
+          vw_row_transform(p2, v2, seg);
+#pragma unroll
+          for (int c = 0; c < 6; c++) { oh[72 + rr * 6 + c] = seg[c]; oh[108 + rr * 6 + c] = seg[6 + c]; }
+        }
+      }
+    }
   }
 }
 

@@ -575,21 +575,146 @@ inline gtsam::detail::Desc gp(int manifold, gtsam::Key p1, gtsam::Key v1, gtsam:
   d.Qc = Qc->covariance();      // getQc(Qc_model), gpslam/gp/GPutils.cpp:16-20
   return d;
 }
+
+// ---- evaluateError / interpolatePose of ONE factor (what the reference's unit tests call, e.g.
+// gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:43-60).  There is no CPU implementation of the factor maths in this
+// library: a two-state device session is built around the arguments and the batched kernels evaluate the single
+// factor (gpslam_hip_linearize_gp / gpslam_hip_linearize_meas / gpslam_hip_interpolate_poses_jac).
+struct Single {
+  gpslam_hip_handle *h = nullptr;
+  int d = 0, pd = 0, ld = 0;
+  Single(int manifold, int landmark_dim, const std::vector<double> &p1, const std::vector<double> &v1, const std::vector<double> &p2,
+         const std::vector<double> &v2, const gtsam::Matrix *Qc, const std::vector<double> *lm) {
+    static const int dd[5] = {2, 3, 3, 6, 3}, pdd[5] = {2, 3, 3, 12, 9};
+    d = dd[manifold]; pd = pdd[manifold]; ld = landmark_dim;
+    if ((int)p1.size() != pd || (int)p2.size() != pd || (int)v1.size() != d || (int)v2.size() != d)
+      throw std::invalid_argument("evaluateError: argument types do not match the factor's manifold");
+    gpslam_hip_config cfg;
+    std::memset(&cfg, 0, sizeof(cfg));
+    cfg.manifold = manifold; cfg.precision = GPSLAM_FP64;
+    cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;
+    cfg.landmark_dim = ld; cfg.nranks = 1;
+    if (gpslam_hip_create(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+    std::vector<double> P(p1), V(v1);
+    P.insert(P.end(), p2.begin(), p2.end());
+    V.insert(V.end(), v2.begin(), v2.end());
+    gtsam::detail::check(gpslam_hip_set_states(h, 2, P.data(), V.data()), h, "set_states");
+    if (Qc) {
+      if (Qc->rows != d) throw std::invalid_argument("Qc_model dimension does not match the manifold");
+      gtsam::detail::check(gpslam_hip_set_qc(h, Qc->a.data()), h, "set_qc");
+    }
+    if (lm) gtsam::detail::check(gpslam_hip_set_landmarks(h, 1, lm->data()), h, "set_landmarks");
+  }
+  ~Single() { if (h) gpslam_hip_destroy(h); }
+  Single(const Single &) = delete;
+  Single &operator=(const Single &) = delete;
+};
+inline void fill(gtsam::Matrix *H, int rows, int cols, const double *src, int src_ld) {
+  if (!H) return;
+  *H = gtsam::Matrix(rows, cols);
+  for (int r = 0; r < rows; r++)
+    for (int c = 0; c < cols; c++) (*H)(r, c) = src[(size_t)r * src_ld + c];
+}
+// GaussianProcessPrior*::evaluateError: e (2d) and H1..H4 (2d x d each)
+inline gtsam::Vector gp_evaluate(const gtsam::detail::Desc &f, const std::vector<double> &p1, const std::vector<double> &v1,
+                                 const std::vector<double> &p2, const std::vector<double> &v2, gtsam::Matrix *H1, gtsam::Matrix *H2,
+                                 gtsam::Matrix *H3, gtsam::Matrix *H4) {
+  Single s(f.manifold, 0, p1, v1, p2, v2, &f.Qc, nullptr);
+  const int32_t left = 0;
+  gtsam::detail::check(gpslam_hip_add_gp_priors(s.h, 1, &left, &f.dt), s.h, "add_gp_priors");
+  gtsam::detail::check(gpslam_hip_compile(s.h), s.h, "compile");
+  const int d = s.d, b = 2 * d;
+  gtsam::Vector e(b);
+  std::vector<double> J((size_t)4 * b * d);
+  gtsam::detail::check(gpslam_hip_linearize_gp(s.h, e.data(), J.data()), s.h, "linearize_gp");
+  gtsam::Matrix *H[4] = {H1, H2, H3, H4};
+  for (int m = 0; m < 4; m++) fill(H[m], b, d, J.data() + (size_t)m * b * d, d);
+  return e;
+}
+// measurement factors: e (rows) and H1..H4 (rows x d), H5 (rows x landmark_dim)
+inline gtsam::Vector meas_evaluate(const gtsam::detail::Desc &f, const std::vector<double> &p1, const std::vector<double> &v1,
+                                   const std::vector<double> &p2, const std::vector<double> &v2, const std::vector<double> *lm,
+                                   gtsam::Matrix *H1, gtsam::Matrix *H2, gtsam::Matrix *H3, gtsam::Matrix *H4, gtsam::Matrix *H5) {
+  const int ld = lm ? (int)lm->size() : 0;
+  Single s(f.manifold, ld, p1, v1, p2, v2, f.Qc.rows ? &f.Qc : nullptr, lm);
+  const int32_t zero = 0;
+  const double *sens = f.sensor.empty() ? nullptr : f.sensor.data();
+  int kind = -1, rows = 1;
+  switch (f.type) {
+    case gtsam::detail::F_INTERP_RANGE:
+      kind = GPSLAM_MEAS_INTERP_RANGE; rows = 1;
+      gtsam::detail::check(gpslam_hip_add_interp_range(s.h, 1, &zero, &zero, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), s.h, "add_interp_range");
+      break;
+    case gtsam::detail::F_RANGE:
+      kind = GPSLAM_MEAS_RANGE; rows = 1;
+      gtsam::detail::check(gpslam_hip_add_range(s.h, 1, &zero, &zero, f.meas.data(), f.sig.data()), s.h, "add_range");
+      break;
+    case gtsam::detail::F_INTERP_ATT:
+      kind = GPSLAM_MEAS_INTERP_ATTITUDE; rows = 2;
+      gtsam::detail::check(gpslam_hip_add_interp_attitude(s.h, 1, &zero, f.aux.data(), f.aux.data() + 3, f.sig.data(), &f.dt, &f.tau), s.h, "add_interp_attitude");
+      break;
+    case gtsam::detail::F_INTERP_GPS:
+      kind = GPSLAM_MEAS_INTERP_GPS; rows = 3;
+      gtsam::detail::check(gpslam_hip_add_interp_gps(s.h, 1, &zero, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), s.h, "add_interp_gps");
+      break;
+    case gtsam::detail::F_ODOM2D:
+      kind = GPSLAM_MEAS_ODOMETRY2D; rows = 3;
+      gtsam::detail::check(gpslam_hip_add_odometry2d(s.h, 1, &zero, f.meas.data(), f.sig.data()), s.h, "add_odometry2d");
+      break;
+    case gtsam::detail::F_BEARING_RANGE:
+      kind = GPSLAM_MEAS_BEARING_RANGE; rows = 2;
+      gtsam::detail::check(gpslam_hip_add_bearing_range(s.h, 1, &zero, &zero, &f.meas[0], &f.meas[1], f.sig.data()), s.h, "add_bearing_range");
+      break;
+    case gtsam::detail::F_INTERP_PROJ:
+      kind = GPSLAM_MEAS_INTERP_PROJECTION; rows = 2;
+      gtsam::detail::check(gpslam_hip_add_interp_projection(s.h, 1, &zero, &zero, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), s.h, "add_interp_projection");
+      break;
+    default: throw std::invalid_argument("evaluateError: not a measurement factor");
+  }
+  gtsam::detail::check(gpslam_hip_compile(s.h), s.h, "compile");
+  const int d = s.d, W = 4 * d + 3;
+  gtsam::Vector e(rows);
+  std::vector<double> J((size_t)rows * W);
+  gtsam::detail::check(gpslam_hip_linearize_meas(s.h, kind, e.data(), J.data()), s.h, "linearize_meas");
+  gtsam::Matrix *H[4] = {H1, H2, H3, H4};
+  for (int m = 0; m < 4; m++) fill(H[m], rows, d, J.data() + (size_t)m * d, W);
+  if (ld) fill(H5, rows, ld, J.data() + (size_t)4 * d, W);
+  return e;
+}
+template <typename POSE, typename VEL>
+inline POSE interpolate_one(int manifold, const gtsam::Matrix &Qc, double delta_t, double tau, const POSE &p1, const VEL &v1,
+                            const POSE &p2, const VEL &v2, gtsam::Matrix *H1, gtsam::Matrix *H2, gtsam::Matrix *H3, gtsam::Matrix *H4) {
+  Single s(manifold, 0, gtsam::detail::VT<POSE>::pack(p1), gtsam::detail::VT<VEL>::pack(v1), gtsam::detail::VT<POSE>::pack(p2),
+           gtsam::detail::VT<VEL>::pack(v2), &Qc, nullptr);
+  const int32_t left = 0;
+  const int d = s.d;
+  std::vector<double> out(s.pd), H((size_t)4 * d * d);
+  gtsam::detail::check(gpslam_hip_interpolate_poses_jac(s.h, 1, &left, &delta_t, &tau, out.data(), H.data()), s.h, "interpolate_poses_jac");
+  gtsam::Matrix *Hs[4] = {H1, H2, H3, H4};
+  for (int m = 0; m < 4; m++) fill(Hs[m], d, d, H.data() + (size_t)m * d * d, d);
+  return gtsam::detail::VT<POSE>::un(out);
+}
 }  // namespace detail_g
 
-#define GPSLAM_GP_PRIOR(CLS, MANIFOLD)                                                                          \
+#define GPSLAM_GP_PRIOR(CLS, MANIFOLD, POSE, VEL)                                                                          \
   class CLS : public gtsam::NonlinearFactor {                                                                   \
    public:                                                                                                      \
     CLS(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,      \
         const gtsam::SharedNoiseModel &Qc_model) { d_ = detail_g::gp(MANIFOLD, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model); } \
+    /** evaluateError(pose1, vel1, pose2, vel2, H1..H4): the reference's signature with pointers for boost::optional */ \
+    gtsam::Vector evaluateError(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::Matrix *H1 = nullptr, \
+                                gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const { \
+      return detail_g::gp_evaluate(d_, gtsam::detail::VT<POSE>::pack(pose1), gtsam::detail::VT<VEL>::pack(vel1),      \
+                                   gtsam::detail::VT<POSE>::pack(pose2), gtsam::detail::VT<VEL>::pack(vel2), H1, H2, H3, H4); \
+    }                                                                                                           \
     GPSLAM_FACTOR_BOILERPLATE(CLS, 4)                                                                           \
   };
 /// gpslam/gp/GaussianProcessPriorPose3.h:43-49
-GPSLAM_GP_PRIOR(GaussianProcessPriorPose3, GPSLAM_POSE3)
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose3, GPSLAM_POSE3, gtsam::Pose3, gtsam::Vector6)
 /// gpslam/gp/GaussianProcessPriorPose2.h:41-47
-GPSLAM_GP_PRIOR(GaussianProcessPriorPose2, GPSLAM_POSE2)
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose2, GPSLAM_POSE2, gtsam::Pose2, gtsam::Vector3)
 /// gpslam/gp/GaussianProcessPriorRot3.h:41-47
-GPSLAM_GP_PRIOR(GaussianProcessPriorRot3, GPSLAM_ROT3)
+GPSLAM_GP_PRIOR(GaussianProcessPriorRot3, GPSLAM_ROT3, gtsam::Rot3, gtsam::Vector3)
 
 /// gpslam/gp/GaussianProcessPriorLinear.h:47-53 (Dim = 2 or 3, gpslam.h:177-181)
 template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFactor {
@@ -598,6 +723,13 @@ template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFac
                              const gtsam::SharedNoiseModel &Qc_model) {
     static_assert(Dim == 2 || Dim == 3, "GaussianProcessPriorLinear<DOF = {2, 3}>");
     d_ = detail_g::gp(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model);
+  }
+  /// gpslam/gp/GaussianProcessPriorLinear.h:63-83
+  gtsam::Vector evaluateError(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
+                              const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
+                              gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+    typedef gtsam::detail::VT<gtsam::VectorN<Dim>> P;
+    return detail_g::gp_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), H1, H2, H3, H4);
   }
   GPSLAM_FACTOR_BOILERPLATE(GaussianProcessPriorLinear<Dim>, 4)
 };
@@ -613,6 +745,13 @@ class GPInterpolatedRangeFactorPose2 : public gtsam::NonlinearFactor {
     d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = {body_P_sensor->x, body_P_sensor->y, body_P_sensor->theta};
   }
+  /// gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98
+  gtsam::Vector evaluateError(const gtsam::Pose2 &pose1, const gtsam::Vector3 &vel1, const gtsam::Pose2 &pose2, const gtsam::Vector3 &vel2, const gtsam::Point2 &point,
+                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+    const std::vector<double> lm = {point.x, point.y};
+    return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose2>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Pose2>::pack(pose2),
+                                   gtsam::detail::VT<gtsam::Vector3>::pack(vel2), &lm, H1, H2, H3, H4, H5);
+  }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose2, 5)
 };
 
@@ -627,6 +766,13 @@ class GPInterpolatedRangeFactorPose3 : public gtsam::NonlinearFactor {
     d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
+  /// gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
+  gtsam::Vector evaluateError(const gtsam::Pose3 &pose1, const gtsam::Vector6 &vel1, const gtsam::Pose3 &pose2, const gtsam::Vector6 &vel2, const gtsam::Point3 &point,
+                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+    const std::vector<double> lm = {point.x, point.y, point.z};
+    return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
+                                   gtsam::detail::VT<gtsam::Vector6>::pack(vel2), &lm, H1, H2, H3, H4, H5);
+  }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose3, 5)
 };
 
@@ -639,6 +785,13 @@ class GPInterpolatedRangeFactor2DLinear : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_LINEAR3;
     d_.k[0] = pose1Key; d_.k[1] = vel1Key; d_.k[2] = pose2Key; d_.k[3] = vel2Key; d_.k[4] = pointKey;
     d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+  }
+  /// gpslam/slam/GPInterpolatedRangeFactor2DLinear.h:60-88
+  gtsam::Vector evaluateError(const gtsam::Vector3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Vector3 &pose2, const gtsam::Vector3 &vel2, const gtsam::Point2 &point,
+                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+    typedef gtsam::detail::VT<gtsam::Vector3> P;
+    const std::vector<double> lm = {point.x, point.y};
+    return detail_g::meas_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), &lm, H1, H2, H3, H4, H5);
   }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactor2DLinear, 5)
 };
@@ -654,6 +807,12 @@ class GPInterpolatedAttitudeFactorRot3 : public gtsam::NonlinearFactor {
     d_.aux = {nZ.p[0], nZ.p[1], nZ.p[2], bRef.p[0], bRef.p[1], bRef.p[2]};
     d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
   }
+  /// gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:61-83
+  gtsam::Vector evaluateError(const gtsam::Rot3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Rot3 &pose2, const gtsam::Vector3 &vel2,
+                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+    return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Rot3>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Rot3>::pack(pose2),
+                                   gtsam::detail::VT<gtsam::Vector3>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
+  }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedAttitudeFactorRot3, 4)
 };
 
@@ -668,6 +827,12 @@ class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
     d_.meas = {measured.x, measured.y, measured.z}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance();
     d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
+  }
+  /// gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
+  gtsam::Vector evaluateError(const gtsam::Pose3 &pose1, const gtsam::Vector6 &vel1, const gtsam::Pose3 &pose2, const gtsam::Vector6 &vel2,
+                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+    return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
+                                   gtsam::detail::VT<gtsam::Vector6>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
   }
   GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3, 4)
 };
@@ -752,6 +917,43 @@ class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
     d_.meas = {betweenMeasured[0], betweenMeasured[1], betweenMeasured[2]}; d_.sig = gtsam::sigmas_of(model);
   }
   GPSLAM_FACTOR_BOILERPLATE(OdometryFactor2DLinear, 2)
+};
+
+// ---- GaussianProcessInterpolator{Linear, Pose2, Pose3, Rot3}: the public query use of the interpolators (gpslam.h:57-86):
+// ctor (Qc_model, delta_t, tau), interpolatePose(pose1, vel1, pose2, vel2, H1..H4)
+#define GPSLAM_INTERPOLATOR(CLS, MANIFOLD, POSE, VEL)                                                            \
+  class CLS {                                                                                                    \
+   public:                                                                                                       \
+    CLS(const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau)                                     \
+        : Qc_(Qc_model->covariance()), delta_t_(delta_t), tau_(tau) {}                                           \
+    POSE interpolatePose(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::Matrix *H1 = nullptr, \
+                         gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const { \
+      return detail_g::interpolate_one<POSE, VEL>(MANIFOLD, Qc_, delta_t_, tau_, pose1, vel1, pose2, vel2, H1, H2, H3, H4); \
+    }                                                                                                            \
+   private:                                                                                                      \
+    gtsam::Matrix Qc_;                                                                                           \
+    double delta_t_, tau_;                                                                                       \
+  };
+/// gpslam/gp/GaussianProcessInterpolatorPose3.h:43-105
+GPSLAM_INTERPOLATOR(GaussianProcessInterpolatorPose3, GPSLAM_POSE3, gtsam::Pose3, gtsam::Vector6)
+/// gpslam/gp/GaussianProcessInterpolatorPose2.h:42-89
+GPSLAM_INTERPOLATOR(GaussianProcessInterpolatorPose2, GPSLAM_POSE2, gtsam::Pose2, gtsam::Vector3)
+/// gpslam/gp/GaussianProcessInterpolatorRot3.h:42-86
+GPSLAM_INTERPOLATOR(GaussianProcessInterpolatorRot3, GPSLAM_ROT3, gtsam::Rot3, gtsam::Vector3)
+/// gpslam/gp/GaussianProcessInterpolatorLinear.h:52-90 (Dim = 2 or 3)
+template <int Dim> class GaussianProcessInterpolatorLinear {
+ public:
+  GaussianProcessInterpolatorLinear(const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau)
+      : Qc_(Qc_model->covariance()), delta_t_(delta_t), tau_(tau) { static_assert(Dim == 2 || Dim == 3, "DOF = {2, 3}"); }
+  gtsam::VectorN<Dim> interpolatePose(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
+                                      const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
+                                      gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+    return detail_g::interpolate_one<gtsam::VectorN<Dim>, gtsam::VectorN<Dim>>(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, Qc_, delta_t_, tau_,
+                                                                               pose1, vel1, pose2, vel2, H1, H2, H3, H4);
+  }
+ private:
+  gtsam::Matrix Qc_;
+  double delta_t_, tau_;
 };
 
 }  // namespace gpslam

@@ -217,6 +217,10 @@ int gpslam_hip_block_tridiag_solve(gpslam_hip_handle *h, int32_t N, const double
  * an optimisation is the use the MATLAB wrapper exports the interpolators for. */
 int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
                                  const double *tau, double *out_pose);
+/* ... with the Jacobians of the interpolated pose with respect to (pose_left, vel_left, pose_right, vel_right):
+ * out_H count x 4 x d x d = H1..H4 of interpolatePose (gpslam/gp/GaussianProcessInterpolatorPose3.h:82-98, gpslam.h:57-86) */
+int gpslam_hip_interpolate_poses_jac(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                     const double *tau, double *out_pose, double *out_H);
 /* the plan of the segmented landmark elimination chosen by compile(): out = {active (0 / 1), segment length C, fat
  * blocks K, fat block size NB, border columns NC per segment, NC rounded up to MFMA tiles, cyclic-reduction levels,
  * link blocks} */

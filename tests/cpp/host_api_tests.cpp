@@ -300,6 +300,86 @@ static void test_projection_optimization_and_trajectory_query() {
   EXPECT(q.size() == 3 && near3(pcam1.t, q[0].t, 1e-6) && near3(pcam2.t, q[1].t, 1e-6) && near3(pcam3.t, q[2].t, 1e-6));
 }
 
+// evaluateError / interpolatePose of single factors, the calls the reference's factor tests make
+// (gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:43-60, testGaussianProcessPriorLinear.cpp:45-50,
+// gpslam/slam/tests/testGPInterpolatedRangeFactorPose2.cpp:55-64, gpslam/gp/tests/testGaussianProcessInterpolatorPose3.cpp:33-39)
+static void test_evaluate_error_and_interpolators() {
+  {   // GaussianProcessPriorPose3: constant forward velocity 1 m/s, dt = 1 -> zero error (testGaussianProcessPriorPose3.cpp:69-74)
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+    GaussianProcessPriorPose3 factor(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 1.0, Qc_model);
+    Pose3 p1, p2(Rot3(), Point3(1, 0, 0));
+    Vector6 v = {0, 0, 0, 1, 0, 0};
+    Matrix H1, H2, H3, H4;
+    Vector e = factor.evaluateError(p1, v, p2, v, &H1, &H2, &H3, &H4);
+    EXPECT(e.size() == 12);
+    for (double x : e) EXPECT_NEAR(0.0, x, 1e-12);
+    EXPECT(H1.rows == 12 && H1.cols == 6 && H4.rows == 12 && H4.cols == 6);
+    for (int i = 0; i < 6; i++) { EXPECT_NEAR(-1.0, H2(i, i), 1e-12); EXPECT_NEAR(-1.0, H2(6 + i, i), 1e-12); }   // H2 = [-dt I; -I]
+    for (int i = 0; i < 6; i++) EXPECT_NEAR(1.0, H3(i, i), 1e-9);                                                 // identity relative pose: Hlog = I
+    // H1 numerically: perturb the first pose's translation along body x (first-order: t + R dx)
+    const double h = 1e-6;
+    Pose3 pp(Rot3(), Point3(h, 0, 0)), pm(Rot3(), Point3(-h, 0, 0));
+    Vector ep = factor.evaluateError(pp, v, p2, v), em = factor.evaluateError(pm, v, p2, v);
+    for (int r = 0; r < 12; r++) EXPECT_NEAR((ep[r] - em[r]) / (2 * h), H1(r, 3), 1e-6);
+  }
+  {   // GaussianProcessPriorLinear<3>: e = [p1 + dt v1 - p2; v1 - v2], H1 = [I; 0], H2 = [dt I; I], H3 = [-I; 0], H4 = [0; -I]
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    GaussianProcessPriorLinear<3> factor(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc_model);
+    Vector3 p1 = {1, 2, 3}, v1 = {0.5, -0.5, 1}, p2 = {1.2, 1.7, 3.3}, v2 = {0.4, -0.2, 0.9};
+    Matrix H1, H2, H3, H4;
+    Vector e = factor.evaluateError(p1, v1, p2, v2, &H1, &H2, &H3, &H4);
+    for (int i = 0; i < 3; i++) {
+      EXPECT_NEAR(p1[i] + 0.1 * v1[i] - p2[i], e[i], 1e-14);
+      EXPECT_NEAR(v1[i] - v2[i], e[3 + i], 1e-14);
+      EXPECT_NEAR(1.0, H1(i, i), 0); EXPECT_NEAR(0.1, H2(i, i), 0); EXPECT_NEAR(1.0, H2(3 + i, i), 0);
+      EXPECT_NEAR(-1.0, H3(i, i), 0); EXPECT_NEAR(-1.0, H4(3 + i, i), 0); EXPECT_NEAR(0.0, H4(i, i), 0);
+    }
+  }
+  {   // GPInterpolatedRangeFactorPose2: H5 against central differences in the landmark (a vector space)
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.001 * Matrix::Identity(3));
+    auto meas_model = noiseModel::Isotropic::Sigma(1, 0.1);
+    Pose2 sensor(0.2, -0.1, 0.3);
+    GPInterpolatedRangeFactorPose2 factor(4.5, meas_model, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2),
+                                          Symbol('l', 1), 0.1, 0.04, &sensor);
+    Pose2 p1(0, 0, 0.1), p2(0.1, 0.02, 0.15);
+    Vector3 v1 = {1, 0.1, 0.3}, v2 = {1.1, 0.2, 0.4};
+    Point2 land(3.0, 2.5);
+    Matrix H1, H5;
+    Vector e = factor.evaluateError(p1, v1, p2, v2, land, &H1, nullptr, nullptr, nullptr, &H5);
+    EXPECT(e.size() == 1 && H5.rows == 1 && H5.cols == 2 && H1.rows == 1 && H1.cols == 3);
+    const double h = 1e-6;
+    const double dx = (factor.evaluateError(p1, v1, p2, v2, Point2(land.x + h, land.y))[0] - factor.evaluateError(p1, v1, p2, v2, Point2(land.x - h, land.y))[0]) / (2 * h);
+    const double dy = (factor.evaluateError(p1, v1, p2, v2, Point2(land.x, land.y + h))[0] - factor.evaluateError(p1, v1, p2, v2, Point2(land.x, land.y - h))[0]) / (2 * h);
+    EXPECT_NEAR(dx, H5(0, 0), 1e-7);
+    EXPECT_NEAR(dy, H5(0, 1), 1e-7);
+    EXPECT_NEAR(1.0, H5(0, 0) * H5(0, 0) + H5(0, 1) * H5(0, 1), 1e-12);   // d range / d point is a unit vector
+  }
+  {   // interpolators: tau = 0 reproduces the first state with H1 = I, H2..H4 = 0; the midpoint of a constant-velocity
+      // motion is the halfway pose (testGaussianProcessInterpolatorPose3.cpp:60-66 scenario)
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+    Pose3 p1, p2(Rot3(), Point3(0.1, 0, 0));
+    Vector6 v = {0, 0, 0, 1, 0, 0};
+    GaussianProcessInterpolatorPose3 at0(Qc_model, 0.1, 0.0), mid(Qc_model, 0.1, 0.05);
+    Matrix H1, H2, H3, H4;
+    Pose3 q0 = at0.interpolatePose(p1, v, p2, v, &H1, &H2, &H3, &H4);
+    EXPECT(near3(p1.t, q0.t, 1e-12) && nearR(p1.R, q0.R, 1e-12));
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) { EXPECT_NEAR(i == j ? 1.0 : 0.0, H1(i, j), 1e-9); EXPECT_NEAR(0.0, H3(i, j), 1e-9); EXPECT_NEAR(0.0, H4(i, j), 1e-9); }
+    Pose3 qm = mid.interpolatePose(p1, v, p2, v);
+    EXPECT(near3(Point3(0.05, 0, 0), qm.t, 1e-12) && nearR(p1.R, qm.R, 1e-12));
+    auto Qc3 = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    GaussianProcessInterpolatorLinear<3> lin(Qc3, 0.1, 0.03);
+    Vector3 a = {0, 0, 0}, va = {1, 2, 3}, b = {0.1, 0.2, 0.3};
+    Vector3 ql = lin.interpolatePose(a, va, b, va);
+    EXPECT_NEAR(0.03, ql[0], 1e-12); EXPECT_NEAR(0.06, ql[1], 1e-12); EXPECT_NEAR(0.09, ql[2], 1e-12);
+    GaussianProcessInterpolatorPose2 i2(Qc3, 0.1, 0.05);
+    Pose2 r2 = i2.interpolatePose(Pose2(0, 0, 0), Vector3{1, 0, 0}, Pose2(0.1, 0, 0), Vector3{1, 0, 0});
+    EXPECT_NEAR(0.05, r2.x, 1e-12); EXPECT_NEAR(0.0, r2.y, 1e-12); EXPECT_NEAR(0.0, r2.theta, 1e-12);
+    GaussianProcessInterpolatorRot3 i3(Qc3, 0.1, 0.05);
+    Rot3 r3 = i3.interpolatePose(Rot3(), Vector3{0, 0, 1}, Rot3::Ypr(0.1, 0, 0), Vector3{0, 0, 1});
+    EXPECT(nearR(Rot3::Ypr(0.05, 0, 0), r3, 1e-10));
+  }
+}
+
 static void test_error_conventions() {
   auto model = noiseModel::Isotropic::Sigma(3, 0.1);
   auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
@@ -330,6 +410,7 @@ int main() {
   test_range_bearing_2dlinear_optimization();
   test_gp_prior_pose3vw_optimization();
   test_projection_optimization_and_trajectory_query();
+  test_evaluate_error_and_interpolators();
   test_error_conventions();
   if (failures == 0) std::printf("host_api_tests: all tests passed\n");
   return failures == 0 ? 0 : 1;

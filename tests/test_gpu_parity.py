@@ -323,3 +323,28 @@ def test_interpolate_poses_query(kind):
         assert np.abs(got[1] - pose[left[1] + 1]).max() <= 1e-10
     with pytest.raises(Exception):
         dev.interpolate_poses([39], [0.1], [0.05])
+
+
+@pytest.mark.parametrize("kind", KINDS, ids=[NAMES[k] for k in KINDS])
+def test_interpolate_poses_jacobians(kind):
+    """H1..H4 of GaussianProcessInterpolator*::interpolatePose (gpslam.h:57-86, e.g. GaussianProcessInterpolatorPose3.h:82-98)
+    query by query against the oracle's interpolators; the SE(3) rows that pass through the h = 1e-6 difference 1e-7."""
+    orc, dev, c = build_pair(kind, 30, seed=9)
+    rng = np.random.default_rng(12)
+    Q = 40
+    left = rng.integers(0, 29, Q).astype(np.int32)
+    d = O.TANGENT_DIM[kind]
+    Qc = np.diag(0.01 + 0.02 * np.random.default_rng(9 + 77).random(d))
+    if d > 1:
+        Qc[0, 1] = Qc[1, 0] = 0.003
+    dt = np.asarray(c["dt"])[left]
+    tau = rng.uniform(-0.1, 1.1, Q) * dt
+    pose, vel = dev.get_states()
+    got, H = dev.interpolate_poses_jac(left, dt, tau)
+    tol = 1e-7 if kind == O.POSE3 else 1e-10
+    for q in range(Q):
+        Lam, Psi = O.lambda_psi(d, Qc, dt[q], tau[q])
+        want, Hw = O.interpolate(kind, Lam, Psi, pose[left[q]], vel[left[q]], pose[left[q] + 1], vel[left[q] + 1], jac=True)
+        assert np.abs(got[q] - want).max() <= 1e-11 * max(1.0, np.abs(want).max())
+        for m in range(4):
+            assert np.abs(H[q, m] - Hw[m]).max() <= tol * max(1.0, np.abs(Hw[m]).max()), (q, m, np.abs(H[q, m] - Hw[m]).max())
