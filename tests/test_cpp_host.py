@@ -44,3 +44,16 @@ def test_fp32_math_on_the_host():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all fp32 math tests passed" in out.stdout
+
+
+def test_gtsam_adapter_header_is_a_valid_translation_unit_without_gtsam():
+    """gpslam_amd/host/gtsam_adapter.hpp is guarded by __has_include(<gtsam/...>): in this image (no GTSAM) it must
+    preprocess to nothing and compile cleanly next to the ABI header."""
+    src = os.path.join(ROOT, "tests", "cpp", "_adapter_tu.cpp")
+    with open(src, "w") as f:
+        f.write('#include "../../gpslam_amd/host/gtsam_adapter.hpp"\n#include "../../include/gpslam_hip.h"\n'
+                '#ifdef GPSLAM_HIP_HAVE_GTSAM\n#error "GTSAM unexpectedly present: run the adapter tests instead"\n#endif\nint main() { return 0; }\n')
+    try:
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", src])
+    finally:
+        os.remove(src)
