@@ -540,8 +540,10 @@ template <typename T, bool JAC> struct PoseFactors<T, ROT3, JAC> {
       put_m3(HL, H2, 3, 0, 0);
     }
   }
-  static GD void retract(const T *x, const T *dlt, int, T *out) {
-    const M3<T> r = as_m3(x) * so3_exp<T>({dlt[0], dlt[1], dlt[2]});
+  // chart: CHART_EXPMAP R Exp(w) (GTSAM >= 4.1, GTSAM_ROT3_EXPMAP) or CHART_FIRST_ORDER = GTSAM 4.0's default R Cayley(w)
+  static GD void retract(const T *x, const T *dlt, int chart, T *out) {
+    const V3<T> w = {dlt[0], dlt[1], dlt[2]};
+    const M3<T> r = as_m3(x) * (chart == CHART_FIRST_ORDER ? so3_cayley<T>(w) : so3_exp<T>(w));
 #pragma unroll
     for (int i = 0; i < 9; i++) out[i] = r.m[i];
   }
@@ -564,8 +566,12 @@ template <typename T, bool JAC> struct PoseFactors<T, POSE3, JAC> {
       put_bl6(HL, H2, 6, 0, 0);
     }
   }
-  static GD void retract(const T *x, const T *dlt, int, T *out) {
-    const SE3<T> r = se3_compose(as_se3(x), se3_exp(as_v6(dlt)));
+  // chart: CHART_EXPMAP T Expmap(xi) (GTSAM >= 4.1, GTSAM_POSE3_EXPMAP) or CHART_FIRST_ORDER = GTSAM 4.0's default
+  // Pose3::ChartAtOrigin::Retract: T * Pose3(Rot3::Retract(w), v), i.e. (R Cayley(w), t + R v)
+  static GD void retract(const T *x, const T *dlt, int chart, T *out) {
+    const V6<T> xi = as_v6(dlt);
+    const SE3<T> ex = (chart == CHART_FIRST_ORDER) ? SE3<T>{so3_cayley(xi.w), xi.v} : se3_exp(xi);
+    const SE3<T> r = se3_compose(as_se3(x), ex);
 #pragma unroll
     for (int i = 0; i < 9; i++) out[i] = r.R.m[i];
     out[9] = r.t.x; out[10] = r.t.y; out[11] = r.t.z;

@@ -145,6 +145,17 @@ template <typename T> GD V3<T> so3_log(const M3<T> &R) {
   return {mag * (R.m[7] - R.m[5]), mag * (R.m[2] - R.m[6]), mag * (R.m[3] - R.m[1])};
 }
 
+// Rot3::CayleyChart::Retract: the default Rot3 retraction of a GTSAM 4.0 build without GTSAM_ROT3_EXPMAP (SURVEY.md
+// Appendix A); agrees with Expmap to second order, so the fixed point of an optimisation does not depend on it
+template <typename T> GD M3<T> so3_cayley(V3<T> w) {
+  const T x = w.x, y = w.y, z = w.z;
+  const T x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+  const T f = T(1) / (T(4) + x2 + y2 + z2), f2 = T(2) * f;
+  return {{(T(4) + x2 - y2 - z2) * f, (xy - T(2) * z) * f2, (xz + T(2) * y) * f2,
+           (xy + T(2) * z) * f2, (T(4) - x2 + y2 - z2) * f, (yz - T(2) * x) * f2,
+           (xz - T(2) * y) * f2, (yz + T(2) * x) * f2, (T(4) - x2 - y2 + z2) * f}};
+}
+
 // right Jacobian Jr(w) (SO3::ExpmapDerivative; rightJacobianRot3, Pose3utils.cpp:203-212)
 template <typename T> GD M3<T> so3_jr(V3<T> w) {
   const T th2 = dot(w, w);

@@ -38,6 +38,11 @@ extern "C" {
 typedef struct gpslam_hip_handle gpslam_hip_handle;
 
 enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 3, GPSLAM_ROT3 = 4 };
+/* retract chart of the state update (and, for POSE2, of PriorFactor / BetweenFactor's Local):
+ * EXPMAP       x Exp(delta) on every manifold (GTSAM >= 4.1 defaults; GTSAM_ROT3_EXPMAP / GTSAM_POSE3_EXPMAP /
+ *              SLOW_BUT_CORRECT_EXPMAP builds of 4.0)
+ * FIRST_ORDER  GTSAM 4.0's default charts: POSE2 x * Pose2(dx, dy, dtheta); ROT3 R * Cayley(w);
+ *              POSE3 (R * Cayley(w), t + R v).  All charts agree to first order: the fixed point is the same. */
 enum { GPSLAM_CHART_EXPMAP = 0, GPSLAM_CHART_FIRST_ORDER = 1 };
 enum { GPSLAM_FP64 = 0, GPSLAM_FP32 = 1 };
 /* velocity parameterisation of a POSE3 chain (config.reserved[3]):
@@ -61,7 +66,7 @@ typedef struct {
   int32_t manifold;      /* GPSLAM_LINEAR2 .. GPSLAM_ROT3 */
   int32_t precision;     /* GPSLAM_FP64 (GPSLAM_FP32: reserved) */
   int32_t device;        /* HIP device ordinal */
-  int32_t chart;         /* retract / local chart for POSE2 priors, odometry and retract */
+  int32_t chart;         /* GPSLAM_CHART_* */
   int32_t landmark_dim;  /* 0 (no landmarks), 2 or 3 */
   int32_t chunk;         /* level-0 chunk length of the partitioned solver; 0 = default */
   int32_t rank, nranks;  /* contiguous-segment sharding: this handle owns segment `rank` of `nranks` */

@@ -335,6 +335,17 @@ static void chart_local(int kind, int chart, const double *h, double *v, double 
   }
 }
 
+/* Rot3::CayleyChart::Retract (GTSAM 4.0 geometry/Rot3M.cpp, recalled: SURVEY.md Appendix A "Default retract in 4.0:
+ * Cayley"): R(w) = (I + W/2)(I - W/2)^-1 written out; "parity unpinned" like every chart default */
+static void orc_rot3_cayley(const double *w, double *R) {
+  const double x = w[0], y = w[1], z = w[2];
+  const double x2 = x * x, y2 = y * y, z2 = z * z, xy = x * y, xz = x * z, yz = y * z;
+  const double f = 1.0 / (4.0 + x2 + y2 + z2), f2 = 2.0 * f;
+  R[0] = (4 + x2 - y2 - z2) * f; R[1] = (xy - 2 * z) * f2; R[2] = (xz + 2 * y) * f2;
+  R[3] = (xy + 2 * z) * f2; R[4] = (4 - x2 + y2 - z2) * f; R[5] = (yz - 2 * x) * f2;
+  R[6] = (xz - 2 * y) * f2; R[7] = (yz + 2 * x) * f2; R[8] = (4 - x2 - y2 + z2) * f;
+}
+
 void orc_retract(int kind, int chart, const double *x, const double *delta, double *out) {
   switch (kind) {
     case ORC_LINEAR2:
@@ -350,12 +361,18 @@ void orc_retract(int kind, int chart, const double *x, const double *delta, doub
     } break;
     case ORC_POSE3: {
       double ex[12];
-      orc_pose3_expmap(delta, ex, NULL);
+      if (chart == ORC_CHART_FIRST_ORDER) {   /* GTSAM 4.0 default: Pose3(Rot3::Retract(w) [Cayley], v) */
+        orc_rot3_cayley(delta, ex);
+        ex[9] = delta[3]; ex[10] = delta[4]; ex[11] = delta[5];
+      } else {
+        orc_pose3_expmap(delta, ex, NULL);
+      }
       orc_pose3_compose(x, ex, out, NULL, NULL);
     } break;
     case ORC_ROT3: {
       double ex[9];
-      orc_rot3_expmap(delta, ex, NULL);
+      if (chart == ORC_CHART_FIRST_ORDER) orc_rot3_cayley(delta, ex);
+      else orc_rot3_expmap(delta, ex, NULL);
       orc_rot3_compose(x, ex, out, NULL, NULL);
     } break;
     default: break;

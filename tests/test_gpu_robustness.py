@@ -128,3 +128,24 @@ def test_pose2_prior_between_rows_match_oracle_at_large_residual(chart):
     D1, O1, g1, _ = dev.normal_equations()
     for a, b in ((D0, D1), (O0, O1), (g0, g1)):
         assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(a).max())
+
+
+@pytest.mark.parametrize("kind", [O.ROT3, O.POSE3], ids=["rot3", "pose3"])
+def test_gtsam40_default_retract_charts(kind):
+    """GPSLAM_CHART_FIRST_ORDER on Rot3 / Pose3 = GTSAM 4.0's default retractions (Cayley rotation, first-order
+    translation): iterations in lock step with the oracle under the same chart, and the fixed point
+    equals the Expmap chart's (all charts agree to first order)."""
+    from test_gpu_parity import build_pair
+    orc_c, dev_c, c = build_pair(kind, 120, seed=31, chart=O.CHART_FIRST_ORDER)
+    orc_e, dev_e, _ = build_pair(kind, 120, seed=31, chart=O.CHART_EXPMAP)
+    first = None
+    for it in range(8):
+        _, s0 = orc_c.iterate_gn()
+        _, s1 = dev_c.iterate_gn()
+        _, s2 = dev_e.iterate_gn()
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), it
+        if it == 0:
+            first = (s1.error_after, s2.error_after)
+    assert first[0] != first[1]                      # the charts do differ away from the fixed point
+    states_close(kind, *orc_c.get_states(), *dev_c.get_states(), rel=1e-9)
+    states_close(kind, *dev_e.get_states(), *dev_c.get_states(), rel=1e-8)
