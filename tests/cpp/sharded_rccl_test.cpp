@@ -1,0 +1,118 @@
+// The C++ sharded host (gpslam_amd/host/sharded_host.hpp: C ABI phases + RCCL called directly) against the unsharded solve.
+// One process drives every visible GPU (1 on the build farm: the forced-sharded single rank still goes through
+// ncclAllGather; on an 8-GPU node the same binary runs 8 ranks).  GaussianProcessPriorLinear<3> chain + position fixes.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../gpslam_amd/host/sharded_host.hpp"
+
+static void ok(int rc, gpslam_hip_handle *h, const char *what) {
+  if (rc < 0) { std::printf("FAILED %s: %s\n", what, h ? gpslam_hip_last_error(h) : ""); std::exit(1); }
+}
+
+struct Problem {
+  int N;
+  std::vector<double> pose, vel, fix;      // N x 3 each
+  std::vector<int32_t> fix_idx;
+  double dt = 0.1;
+};
+
+static Problem make(int N) {
+  Problem p;
+  p.N = N;
+  p.pose.resize((size_t)N * 3); p.vel.resize((size_t)N * 3);
+  unsigned s = 12345u;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xFFFF) / 65536.0 - 0.5; };
+  for (int i = 0; i < N; i++)
+    for (int k = 0; k < 3; k++) {
+      const double t = 0.1 * i;
+      p.pose[(size_t)i * 3 + k] = std::sin(0.05 * t + k) * 10.0 + 0.2 * rnd();
+      p.vel[(size_t)i * 3 + k] = 0.5 * std::cos(0.05 * t + k) + 0.2 * rnd();
+    }
+  for (int i = 0; i < N; i += 10) {
+    p.fix_idx.push_back(i);
+    for (int k = 0; k < 3; k++) p.fix.push_back(std::sin(0.005 * i + k) * 10.0 + 0.05 * rnd());
+  }
+  return p;
+}
+
+// the factors whose LEFT (or only) state lies in [lo, hi) go to this handle, indices relative to lo
+static gpslam_hip_handle *build(const Problem &p, int device, int rank, int nranks, bool force_sharded, int lo, int hi) {
+  gpslam_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.manifold = GPSLAM_LINEAR3; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.rank = rank; cfg.nranks = nranks;
+  cfg.reserved[0] = force_sharded ? 1 : 0;
+  gpslam_hip_handle *h = nullptr;
+  if (gpslam_hip_create(&cfg, &h) != 0) { std::printf("FAILED create\n"); std::exit(1); }
+  const int n = hi - lo;
+  ok(gpslam_hip_set_states(h, n, &p.pose[(size_t)lo * 3], &p.vel[(size_t)lo * 3]), h, "set_states");
+  if (hi < p.N) ok(gpslam_hip_set_halo_state(h, &p.pose[(size_t)hi * 3], &p.vel[(size_t)hi * 3]), h, "set_halo_state");
+  const double Qc[9] = {0.01, 0, 0, 0, 0.01, 0, 0, 0, 0.01};
+  ok(gpslam_hip_set_qc(h, Qc), h, "set_qc");
+  std::vector<int32_t> left;
+  std::vector<double> dts;
+  for (int i = lo; i < hi && i < p.N - 1; i++) { left.push_back(i - lo); dts.push_back(p.dt); }
+  ok(gpslam_hip_add_gp_priors(h, (int)left.size(), left.data(), dts.data()), h, "add_gp_priors");
+  std::vector<int32_t> fi;
+  std::vector<double> fm, fs;
+  for (size_t k = 0; k < p.fix_idx.size(); k++)
+    if (p.fix_idx[k] >= lo && p.fix_idx[k] < hi) {
+      fi.push_back(p.fix_idx[k] - lo);
+      for (int q = 0; q < 3; q++) { fm.push_back(p.fix[k * 3 + q]); fs.push_back(0.1); }
+    }
+  ok(gpslam_hip_add_pose_priors(h, (int)fi.size(), fi.data(), fm.data(), fs.data()), h, "add_pose_priors");
+  if (lo == 0) {
+    const int32_t z = 0;
+    const double vs[3] = {0.05, 0.05, 0.05};
+    ok(gpslam_hip_add_vel_priors(h, 1, &z, &p.vel[0], vs), h, "add_vel_priors");
+  }
+  ok(gpslam_hip_compile(h), h, "compile");
+  return h;
+}
+
+int main() {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { std::printf("FAILED: no HIP device\n"); return 1; }
+  const int P = std::min(ndev, 8);
+  const int N = 4000 * P;
+  const Problem p = make(N);
+  // reference: the whole chain on one device
+  gpslam_hip_handle *ref = build(p, 0, 0, 1, false, 0, N);
+  gpslam_hip_stats st_ref;
+  for (int it = 0; it < 2; it++) ok(gpslam_hip_iterate_gn(ref, &st_ref), ref, "iterate_gn");
+  std::vector<double> xr((size_t)N * 3), vr((size_t)N * 3);
+  ok(gpslam_hip_get_states(ref, xr.data(), vr.data()), ref, "get_states");
+  // sharded: P ranks, RCCL
+  std::vector<int> devs(P);
+  for (int r = 0; r < P; r++) devs[r] = r;
+  gpslam_hip_stats st;
+  double worst = 0.0;
+  {
+    gpslam_hip::ShardedDriver drv(devs);
+    std::vector<gpslam_hip_handle *> hs;
+    for (int r = 0; r < P; r++) {
+      const int lo = (int)((long)r * N / P), hi = (int)((long)(r + 1) * N / P);
+      hs.push_back(build(p, devs[r], r, P, P == 1, lo, hi));
+      drv.add(hs.back());
+    }
+    for (int it = 0; it < 2; it++) st = drv.iterate(0.0, true);
+    drv.synchronize();
+    for (int r = 0; r < P; r++) {
+      const int lo = (int)((long)r * N / P), hi = (int)((long)(r + 1) * N / P);
+      std::vector<double> x((size_t)(hi - lo) * 3), v((size_t)(hi - lo) * 3);
+      ok(gpslam_hip_get_states(hs[r], x.data(), v.data()), hs[r], "get_states");
+      for (size_t k = 0; k < x.size(); k++) {
+        worst = std::fmax(worst, std::fabs(x[k] - xr[(size_t)lo * 3 + k]));
+        worst = std::fmax(worst, std::fabs(v[k] - vr[(size_t)lo * 3 + k]));
+      }
+    }
+    for (gpslam_hip_handle *h : hs) gpslam_hip_destroy(h);
+  }
+  gpslam_hip_destroy(ref);
+  std::printf("ranks %d, states %d: error %.9e (unsharded %.9e), max |difference| %.3e\n", P, N, st.error_after, st_ref.error_after, worst);
+  const bool pass = worst <= 1e-9 && std::fabs(st.error_after - st_ref.error_after) <= 1e-9 * std::fmax(1.0, st_ref.error_after);
+  std::printf(pass ? "sharded_rccl_test: all tests passed\n" : "sharded_rccl_test: FAILED\n");
+  return pass ? 0 : 1;
+}

@@ -57,3 +57,28 @@ def test_gtsam_adapter_header_is_a_valid_translation_unit_without_gtsam():
         subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", src])
     finally:
         os.remove(src)
+
+
+def _build_sharded_exe():
+    import gpslam_amd
+    gpslam_amd.load_library()
+    libdir = os.path.join(ROOT, "gpslam_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cpp", "sharded_rccl_test")
+    src = os.path.join(ROOT, "tests", "cpp", "sharded_rccl_test.cpp")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", ROOT, "-I", "/opt/rocm/include", src, "-o", exe,
+           "-L", libdir, "-lgpslam_hip", "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_sharded_host_compiles_against_rccl():
+    assert os.path.exists(_build_sharded_exe())
+
+
+@pytest.mark.gpu
+def test_cpp_sharded_host_runs_rccl_on_every_visible_gpu():
+    """gpslam_amd/host/sharded_host.hpp: phase1 -> ncclAllGather -> phase2 from C++, one rank per visible GPU (a forced-
+    sharded single rank on a 1-GPU box), against the unsharded solve."""
+    out = subprocess.run([_build_sharded_exe()], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
