@@ -322,3 +322,25 @@ def test_every_measurement_mix_sharded(kind, sensor, P):
         assert np.abs(ranks[0][0].get_landmarks() - ref.get_landmarks()).max() <= 1e-8
     for r in ranks:
         r[0].close()
+
+
+def test_two_process_rccl_when_two_gpus_are_visible():
+    """One process per GPU over RCCL / xGMI (the deployment shape; tests/rccl_worker.py): runs whenever the box shows at
+    least two devices, on up to eight of them; a single-GPU box (the build farm) skips -- the in-process forms above
+    and tests/cpp/sharded_rccl_test.cpp cover the code path there."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < 2:
+        pytest.skip("needs >= 2 visible GPUs (found %d)" % ndev)
+    world = min(ndev, 8)
+    port = 29900 + os.getpid() % 90
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(4000 * world)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "RCCL_WORKERS_OK" in outs[0]
