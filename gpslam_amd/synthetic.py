@@ -231,8 +231,12 @@ def pose2_local_landmarks_chain(N, L=None, seed=0, dt=0.1, rate=0.44, window=200
                 range_dt=np.full(len(left), dt), range_tau=tau)
 
 
-def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sigma=0.1):
-    """C5 (reference-faithful variant): SO(3) GP chain with interpolated attitude (accelerometer) factors."""
+def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sigma=0.1, refs=1):
+    """C5 (reference-faithful variant): SO(3) GP chain with interpolated attitude (accelerometer) factors.
+    refs = 1: every factor observes the body z axis, as matlab/GPAHRSexample.m:169-173 does with the accelerometer alone
+    (heading is then held only by the prior on x0 and the GP smoothness: a nearly flat direction, Gauss-Newton does not
+    converge from a perturbed start).  refs = 2: factors alternate between the body z and the body x axis
+    (accelerometer + magnetometer, both are GPInterpolatedAttitudeFactorRot3 with their own bRef): fully observable."""
     rng = np.random.default_rng(SEED_BASE + 5 + seed)
     i = np.arange(N - 1)
     omega = np.stack([0.3 * np.sin(0.004 * i), 0.2 * np.cos(0.006 * i + 0.5), 0.4 + 0.1 * np.sin(0.002 * i)], -1)
@@ -247,7 +251,10 @@ def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sig
     tau = dt * (np.tile(np.arange(per_interval), N - 1) + rng.random(M)) / per_interval
     Rm = R[left] @ so3_exp(tau[:, None] * omega[left])     # true attitude at the measurement times
     bref = np.array([0.0, 0.0, 1.0])                       # body reference axis (Unit3(0, 0, 1), AttitudeFactorRot3.h:48)
-    nz = Rm @ bref + acc_sigma * rng.standard_normal((M, 3))
+    brefs = np.tile(bref, (M, 1))
+    if refs == 2:
+        brefs[1::2] = [1.0, 0.0, 0.0]
+    nz = np.einsum("nij,nj->ni", Rm, brefs) + acc_sigma * rng.standard_normal((M, 3))
     nz /= np.linalg.norm(nz, axis=1, keepdims=True)        # measured nav-frame direction of the body axis
     init = R @ so3_exp(0.05 * rng.standard_normal((N, 3)))
     return dict(kind=ROT3, name="C5 rot3 GP prior + interpolated attitude", N=N, qc=qc_sigma ** 2 * np.eye(3),
@@ -255,16 +262,18 @@ def rot3_attitude_chain(N, per_interval=4, seed=0, dt=0.1, qc_sigma=1.0, acc_sig
                 gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),
                 prior_idx=np.array([0], dtype=np.int32), prior_pose=R[:1].reshape(1, 9), prior_sig=np.full((1, 3), 1e-2),
                 vprior_idx=np.array([0], dtype=np.int32), vprior=omega[:1].copy(), vprior_sig=np.full((1, 3), 0.1),
-                att_left=left, att_nz=nz, att_bref=np.tile(bref, (M, 1)), att_sigma=np.full((M, 2), acc_sigma),
+                att_left=left, att_nz=nz, att_bref=brefs, att_sigma=np.full((M, 2), acc_sigma),
                 att_dt=np.full(M, dt), att_tau=tau)
 
 
-def pose3_gps_chain(N, per_interval=4, seed=0, dt=0.1):
-    """C5 (SE(3) variant): the C3 chain without odometry but with GPInterpolatedGPSFactorPose3 at 4x the state rate."""
+def pose3_gps_chain(N, per_interval=4, seed=0, dt=0.1, keep_odometry=False):
+    """C5 (SE(3) variant): the C3 chain with GPInterpolatedGPSFactorPose3 at 4x the state rate, without odometry
+    (position fixes alone: the attitude is weakly observable, Gauss-Newton creeps) or with it (keep_odometry)."""
     p = pose3_chain(N, seed=seed, dt=dt)
     rng = np.random.default_rng(SEED_BASE + 55 + seed)
     for k in ("between_left", "between_meas", "between_sig"):
-        p.pop(k)
+        if not keep_odometry:
+            p.pop(k)
     M = (N - 1) * per_interval
     left = np.repeat(np.arange(N - 1), per_interval).astype(np.int32)
     tau = dt * (np.tile(np.arange(per_interval), N - 1) + rng.random(M)) / per_interval

@@ -11,7 +11,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- \
-  python $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.log 2>&1
+  python $ROOT/bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $OUT/bench_under_rocprof.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_ANY" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INSTS_LDS GRBM_GUI_ACTIVE"; do
   D=$OUT/pmc_$(echo $C | tr ' ' '_' | cut -c1-40)
   (cd $ROOT && rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- python scripts/profile_iter.py > $D.log 2>&1)
