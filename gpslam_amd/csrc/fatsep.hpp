@@ -67,17 +67,36 @@ __device__ __forceinline__ void fs_wave_sync() {
 template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(64) k_fs_factor(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, lane = threadIdx.x;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
-  __shared__ T A[B * B], E[B * B], W[B * B];
+  __shared__ T A[B * B], E[B * B], W[B * B], Os[B * B];
+  // the chain is walked strictly in order (every step needs the previous state's E), so a step's only memory latency is
+  // the fetch of its own block record: the NEXT state's [D | O] is requested before the current state is factorised
+  constexpr int PF = (B * B + 63) / 64;
+  T preD[PF], preO[PF];
+  auto fetch = [&](int s) {
+    const T *bp = a.blk + (size_t)s * a.BS;
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int idx = lane + 64 * u;
+      preD[u] = (idx < B * B) ? bp[idx] : T(0);
+      preO[u] = (idx < B * B) ? bp[B * B + idx] : T(0);
+    }
+  };
+  if (n > 0) fetch(j0);
   for (int jj = 0; jj < n; jj++) {
     const int s = j0 + jj;
-    const T *bp = a.blk + (size_t)s * a.BS;
-    for (int idx = lane; idx < B * B; idx += 64) {
-      const int r = idx / B, c = idx - r * B;
-      T v = bp[idx] + (r == c ? a.lambda : T(0));
-      if (jj > 0)
-        for (int k = 0; k < B; k++) v -= E[k * B + r] * E[k * B + c];
-      A[idx] = v;
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int idx = lane + 64 * u;
+      if (idx < B * B) {
+        const int r = idx / B, c = idx - r * B;
+        T v = preD[u] + (r == c ? a.lambda : T(0));
+        if (jj > 0)
+          for (int k = 0; k < B; k++) v -= E[k * B + r] * E[k * B + c];
+        A[idx] = v;
+        Os[idx] = preO[u];
+      }
     }
+    if (jj + 1 < n) fetch(s + 1);
     fs_wave_sync();
     for (int p = 0; p < B; p++) {
       T dd = A[p * B + p];
@@ -110,7 +129,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
     for (int idx = lane; idx < B * B; idx += 64) {
       const int r = idx / B, c = idx - r * B;
       T e = T(0);
-      for (int k = 0; k <= r; k++) e += W[r * B + k] * bp[B * B + c * B + k];   // (W O^T)[r][c] = sum_k W[r][k] O[c][k]
+      for (int k = 0; k <= r; k++) e += W[r * B + k] * Os[c * B + k];   // (W O^T)[r][c] = sum_k W[r][k] O[c][k]
       fp[idx] = W[idx];
       fp[B * B + idx] = e;
       E[idx] = e;
@@ -232,34 +251,80 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 // (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double fs_d4 __attribute__((ext_vector_type(4)));
 // Y^T Y is symmetric: only the tiles on and below the diagonal (tile column <= tile row) are formed; readers use fs_sym.
-template <int TMAX, typename TR = double> __global__ void __launch_bounds__(64) k_fs_syrk(FsArgs<double, TR> a) {
-  const int seg = blockIdx.x, ti = blockIdx.y, lane = threadIdx.x;
+// One 4-wave workgroup per segment.  The K dimension is walked in chunks of KC rows that the workgroup stages ONCE in
+// LDS (coalesced 16-byte loads into registers while the matrix cores work on the current chunk, committed to the other
+// LDS buffer afterwards); every wave owns a fixed subset of the tiles (round robin over the lower triangle) and feeds
+// its MFMAs from LDS.  The first version let every (segment, tile row) wave stream its operand columns from L2 / HBM
+// itself: 4.5x the traffic of Y, 4.8 ms at 1e6 states, bandwidth bound; staged, Y is read once (2.1 ms: 31 TFLOP/s of
+// fp64 MFMA).  A variant with the tile loop specialised per tile count (branch-free k loop) needed 156 VGPRs and was
+// slower (2.9 ms).
+template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) k_fs_syrk(FsArgs<double, TR> a) {
+  constexpr int KC = 24;                                   // rows per chunk: 4 states of 6, 2 of 12, 6 of 4
+  extern __shared__ __align__(16) unsigned char syrk_smem[];
+  double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x NCP
+  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int NCP = a.NCP, T16 = NCP / 16, ntiles = T16 * (T16 + 1) / 2;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   const int kdim = n * a.B;
-  const double *Yb = a.Y + (size_t)j0 * a.B * a.NCP;
-  fs_d4 acc[TMAX];
+  const double *Yb = a.Y + (size_t)j0 * a.B * NCP;
+  fs_d4 acc[TPW];
+  int tti[TPW], ttj[TPW];
 #pragma unroll
-  for (int t = 0; t < TMAX; t++) acc[t] = fs_d4{0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < TPW; q++) {
+    acc[q] = fs_d4{0.0, 0.0, 0.0, 0.0};
+    const int pidx = wv + 4 * q;                            // tile p of the lower triangle, row-major: (ti, tj <= ti)
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= pidx) ti++;
+    tti[q] = ti;
+    ttj[q] = pidx - ti * (ti + 1) / 2;
+  }
+  typedef double V2 __attribute__((ext_vector_type(2)));
+  const int chunk_v2 = KC * NCP / 2;                        // 16-byte pieces per chunk
+  constexpr int PV = (KC * 144 / 2 + 255) / 256;            // pieces per thread at the widest NCP (144)
+  V2 pre[PV];
+  auto fetch = [&](int c) {                                 // global -> registers (in flight under the MFMAs)
+    const int k0 = c * KC;
+#pragma unroll
+    for (int u = 0; u < PV; u++) {
+      const int v = tid + u * 256;
+      pre[u] = V2{0.0, 0.0};
+      if (v < chunk_v2 && k0 + (2 * v) / NCP < kdim) pre[u] = *reinterpret_cast<const V2 *>(Yb + (size_t)k0 * NCP + 2 * v);
+    }
+  };
+  auto commit = [&](int which) {                            // registers -> LDS
+#pragma unroll
+    for (int u = 0; u < PV; u++) {
+      const int v = tid + u * 256;
+      if (v < chunk_v2) *reinterpret_cast<V2 *>(buf + (size_t)which * KC * NCP + 2 * v) = pre[u];
+    }
+  };
+  const int nchunks = (kdim + KC - 1) / KC;
+  if (nchunks > 0) { fetch(0); commit(0); }
+  __syncthreads();
   const int kl = lane >> 4, cl = lane & 15;
-  for (int k0 = 0; k0 < kdim; k0 += 4) {
-    const int k = k0 + kl;
-    const bool ok = k < kdim;
-    const double *yr = Yb + (size_t)(ok ? k : 0) * a.NCP;
-    const double av = ok ? yr[ti * 16 + cl] : 0.0;
+  for (int c = 0; c < nchunks; c++) {
+    if (c + 1 < nchunks) fetch(c + 1);
+    const double *bb = buf + (size_t)(c & 1) * KC * NCP;
 #pragma unroll
-    for (int t = 0; t < TMAX; t++) {
-      if (t <= ti) {
-        const double bv = ok ? yr[t * 16 + cl] : 0.0;
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    for (int k4 = 0; k4 < KC; k4 += 4) {
+      const double *yr = bb + (size_t)(k4 + kl) * NCP;
+#pragma unroll
+      for (int q = 0; q < TPW; q++) {
+        if (wv + 4 * q < ntiles) {
+          const double av = yr[tti[q] * 16 + cl], bv = yr[ttj[q] * 16 + cl];
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
+        }
       }
     }
+    if (c + 1 < nchunks) commit((c + 1) & 1);
+    __syncthreads();
   }
-  double *out = a.Aseg + (size_t)seg * a.NCP * a.NCP;
+  double *out = a.Aseg + (size_t)seg * NCP * NCP;
 #pragma unroll
-  for (int t = 0; t < TMAX; t++) {
-    if (t <= ti) {
+  for (int q = 0; q < TPW; q++) {
+    if (wv + 4 * q < ntiles) {
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) out[(size_t)(ti * 16 + kl + 4 * rg) * a.NCP + t * 16 + cl] = acc[t][rg];
+      for (int rg = 0; rg < 4; rg++) out[(size_t)(tti[q] * 16 + kl + 4 * rg) * NCP + ttj[q] * 16 + cl] = acc[q][rg];
     }
   }
 }
@@ -572,57 +637,113 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
   const int seg = blockIdx.x * blockDim.x + threadIdx.x;
   if (seg >= a.K - 1) return;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
+  if (n <= 0) return;
+  constexpr int NW = B * (B + 1) / 2;       // W is lower triangular
+  // every step depends on the previous one, so its only latency is the fetch of its own operands: the next state's
+  // [W (lower) | E | rhs] are requested one step ahead
+  T cw[NW], ce[B * B], cr[B], nw[NW], ne[B * B], nr[B];
+  auto loadW = [&](const T *fp, T *w) {
+    int q = 0;
+#pragma unroll
+    for (int r = 0; r < B; r++)
+#pragma unroll
+      for (int k = 0; k <= r; k++) w[q++] = fp[r * B + k];
+  };
   T y[B];
 #pragma unroll
   for (int k = 0; k < B; k++) y[k] = T(0);
+  {   // forward: operands of state s are W_s, E_{s-1}, rhs_s
+    const T *fp = a.fac + (size_t)j0 * 2 * B * B;
+    loadW(fp, cw);
+#pragma unroll
+    for (int k = 0; k < B * B; k++) ce[k] = T(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) cr[k] = a.rhs[(size_t)j0 * B + k];
+  }
   for (int jj = 0; jj < n; jj++) {
     const int s = j0 + jj;
-    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    if (jj + 1 < n) {
+      const T *fp = a.fac + (size_t)(s + 1) * 2 * B * B;
+      loadW(fp, nw);
+#pragma unroll
+      for (int k = 0; k < B * B; k++) ne[k] = fp[k - B * B];       // E_s sits right before fac[s + 1]
+#pragma unroll
+      for (int k = 0; k < B; k++) nr[k] = a.rhs[(size_t)(s + 1) * B + k];
+    }
     T t[B];
 #pragma unroll
-    for (int k = 0; k < B; k++) t[k] = a.rhs[(size_t)s * B + k];
-    if (jj > 0) {
-      const T *ep = fp - B * B;
+    for (int k = 0; k < B; k++) t[k] = cr[k];
 #pragma unroll
-      for (int k = 0; k < B; k++)
+    for (int k = 0; k < B; k++)
 #pragma unroll
-        for (int r = 0; r < B; r++) t[r] -= ep[k * B + r] * y[k];
-    }
+      for (int r = 0; r < B; r++) t[r] -= ce[k * B + r] * y[k];
+    {
+      int q = 0;
 #pragma unroll
-    for (int r = 0; r < B; r++) {
-      T acc = T(0);
+      for (int r = 0; r < B; r++) {
+        T acc = T(0);
 #pragma unroll
-      for (int k = 0; k <= r; k++) acc += fp[r * B + k] * t[k];
-      y[r] = acc;
+        for (int k = 0; k <= r; k++) acc += cw[q++] * t[k];
+        y[r] = acc;
+      }
     }
 #pragma unroll
     for (int k = 0; k < B; k++) a.rhs[(size_t)s * B + k] = y[k];     // y~_s, read back by the backward sweep
+#pragma unroll
+    for (int k = 0; k < NW; k++) cw[k] = nw[k];
+#pragma unroll
+    for (int k = 0; k < B * B; k++) ce[k] = ne[k];
+#pragma unroll
+    for (int k = 0; k < B; k++) cr[k] = nr[k];
   }
   T xn[B];
 #pragma unroll
   for (int k = 0; k < B; k++) xn[k] = T(0);
+  {   // backward: operands of state s are W_s, E_s, y~_s (E of the last interior state multiplies x = 0)
+    const int s = j0 + n - 1;
+    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    loadW(fp, cw);
+#pragma unroll
+    for (int k = 0; k < B * B; k++) ce[k] = fp[B * B + k];
+#pragma unroll
+    for (int k = 0; k < B; k++) cr[k] = a.rhs[(size_t)s * B + k];
+  }
   for (int jj = n - 1; jj >= 0; jj--) {
     const int s = j0 + jj;
-    const T *fp = a.fac + (size_t)s * 2 * B * B;
+    if (jj > 0) {
+      const T *fp = a.fac + (size_t)(s - 1) * 2 * B * B;
+      loadW(fp, nw);
+#pragma unroll
+      for (int k = 0; k < B * B; k++) ne[k] = fp[B * B + k];
+#pragma unroll
+      for (int k = 0; k < B; k++) nr[k] = a.rhs[(size_t)(s - 1) * B + k];
+    }
     T t[B];
 #pragma unroll
-    for (int k = 0; k < B; k++) t[k] = a.rhs[(size_t)s * B + k];
+    for (int k = 0; k < B; k++) t[k] = cr[k];
     if (jj < n - 1) {
-      const T *ep = fp + B * B;          // E_s couples s to s + 1
 #pragma unroll
       for (int r = 0; r < B; r++)
 #pragma unroll
-        for (int k = 0; k < B; k++) t[r] -= ep[r * B + k] * xn[k];
+        for (int k = 0; k < B; k++) t[r] -= ce[r * B + k] * xn[k];
     }
 #pragma unroll
-    for (int r = 0; r < B; r++) {        // x = W^T t
-      T acc = T(0);
+    for (int r = 0; r < B; r++) xn[r] = T(0);
+    {      // x = W^T t
+      int q = 0;
 #pragma unroll
-      for (int k = r; k < B; k++) acc += fp[k * B + r] * t[k];
-      xn[r] = acc;
+      for (int k = 0; k < B; k++)
+#pragma unroll
+        for (int r = 0; r <= k; r++) xn[r] += cw[q++] * t[k];
     }
 #pragma unroll
     for (int k = 0; k < B; k++) a.x[(size_t)s * B + k] = xn[k];
+#pragma unroll
+    for (int k = 0; k < NW; k++) cw[k] = nw[k];
+#pragma unroll
+    for (int k = 0; k < B * B; k++) ce[k] = ne[k];
+#pragma unroll
+    for (int k = 0; k < B; k++) cr[k] = nr[k];
   }
 }
 
