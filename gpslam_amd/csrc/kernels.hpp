@@ -1767,6 +1767,92 @@ template <int K> __device__ __forceinline__ void row_bcast12(const double *s, do
         "v"(s[10]), "v"(s[11]), "n"(K));
 }
 
+
+// v_fmac_f64_dpp D, S0, S1 row_newbcast:K  computes  D += S0[lane K of the 16-lane row] * S1  -- the broadcast of a pivot /
+// source row fused INTO the multiply-add.  It is the one double-precision ALU instruction gfx950's assembler accepts with
+// a DPP operand besides v_mov_b64 (v_fma_f64 / v_add_f64 / v_mul_f64 are rejected), it issues at the plain v_fma_f64
+// rate (scripts/ubench/valu_rates.hip: 4.96 cycles per wave instruction, semantics checked there) and it performs the
+// same single rounding as fma(-m, bcast, d) with the negated multiplier passed in -- so every "broadcast the row, then
+// multiply-add" pair of the row-layout kernels becomes ONE instruction with bit-identical results.  As with the
+// v_mov_b64_dpp blocks, each block opens with s_nop 1 (DPP read of a freshly written VGPR) and never reads through DPP a
+// register that an earlier instruction of the same block wrote.
+#define GPS_FMAC_ROW "row_mask:0xf bank_mask:0xf\n\t"
+// d[q] += bcast_K(s[q]) * m, q = 0..11
+template <int K> __device__ __forceinline__ void fmac_bcast12(double *d, const double *s, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %12, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %13, %24 row_newbcast:%25 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %14, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %15, %24 row_newbcast:%25 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %16, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %17, %24 row_newbcast:%25 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %6, %18, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %19, %24 row_newbcast:%25 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %8, %20, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %21, %24 row_newbcast:%25 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %10, %22, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %23, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
+        "+v"(d[10]), "+v"(d[11])
+      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
+        "v"(s[11]), "v"(m), "n"(K));
+}
+// d[q] += bcast_K(d[q]) * m, q = 0..11 (a Gauss-Jordan row operation: the pivot row is lane K of the same registers)
+template <int K> __device__ __forceinline__ void fmac_self12(double *d, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %0, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %1, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %2, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %3, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %4, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %5, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %6, %6, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %7, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %8, %8, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %9, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %10, %10, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %11, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
+        "+v"(d[10]), "+v"(d[11])
+      : "v"(m), "n"(K));
+}
+// the same on four consecutive entries (the columns right of the pivot shrink as the elimination proceeds)
+template <int K> __device__ __forceinline__ void fmac_self4(double *d, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+      : "v"(m), "n"(K));
+}
+// two scalars: d0 += bcast_K(s) * m0, d1 += bcast_K(s) * m1 (d0 may be s itself only through fmac_self1)
+template <int K> __device__ __forceinline__ void fmac_bcast2(double &d0, double &d1, double s, double m0, double m1) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+      : "+v"(d0), "+v"(d1)
+      : "v"(s), "v"(m0), "v"(m1), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fmac_bcast1(double &d0, double s, double m0) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(s), "v"(m0), "n"(K));
+}
+template <int K> __device__ __forceinline__ void fmac_self1(double &d0, double m0) {
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(m0), "n"(K));
+}
+// d[k] += s[lane k] * m, k = 0..N-1: the GATHER form (one source register, twelve broadcast lanes) of the assembly wave
+template <int N> __device__ __forceinline__ void fmac_gather(double *d, double s, double m);
+template <> __device__ __forceinline__ void fmac_gather<12>(double *d, double s, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %12, %13 row_newbcast:0 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %12, %13 row_newbcast:1 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %12, %13 row_newbcast:2 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %12, %13 row_newbcast:3 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %12, %13 row_newbcast:4 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %12, %13 row_newbcast:5 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %6, %12, %13 row_newbcast:6 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %12, %13 row_newbcast:7 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %8, %12, %13 row_newbcast:8 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %12, %13 row_newbcast:9 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %10, %12, %13 row_newbcast:10 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %12, %13 row_newbcast:11 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
+        "+v"(d[10]), "+v"(d[11])
+      : "v"(s), "v"(m));
+}
+template <> __device__ __forceinline__ void fmac_gather<6>(double *d, double s, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %6, %7 row_newbcast:0 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %6, %7 row_newbcast:1 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %6, %7 row_newbcast:2 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %6, %7 row_newbcast:3 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %6, %7 row_newbcast:4 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %6, %7 row_newbcast:5 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+      : "v"(s), "v"(m));
+}
 __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a) {
   constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2;                                  // 16-byte pieces of a record
@@ -1879,18 +1965,16 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
       const double inv = fast_rcp(piv);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
-      const double mp = isk ? 0.0 : Dr[k] * inv;
-      double tb[B];
-      row_bcast12<k>(Dr, tb);
-#pragma unroll
-      for (int q = k + 1; q < B; q++) Dr[q] = fma(-mp, tb[q], Dr[q]);
-      row_bcast12<k>(Or, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) Or[q] = fma(-mp, tb[q], Or[q]);
-      row_bcast12<k>(Fr, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) Fr[q] = fma(-mp, tb[q], Fr[q]);
-      gr = fma(-mp, row_bcast<k>(gr), gr);
+      const double nmp = isk ? 0.0 : -(Dr[k] * inv);
+      // row r -= (D~[r][k] / pivot) * row k, the pivot row fused into the multiply-add (fmac_self*): of D~ only the columns
+      // right of the pivot still matter, in blocks of four (entries at or left of the pivot inside a block become garbage
+      // that nothing reads again)
+      if (k < 3) fmac_self4<k>(Dr, nmp);
+      if (k < 7) fmac_self4<k>(Dr + 4, nmp);
+      if (k < 11) fmac_self4<k>(Dr + 8, nmp);
+      fmac_self12<k>(Or, nmp);
+      fmac_self12<k>(Fr, nmp);
+      fmac_self1<k>(gr, nmp);
     });
     if (bad && live && r == 0) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
@@ -1930,18 +2014,10 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     // two passes, so that at most seven 12-vectors are live: rows of U_j first (O_j^T is dead afterwards) ...
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double ol = Ol[i], gg = Gr[i];
-      double tb[B];
-      row_bcast12<i>(Or, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) {
-        Dn[q] = fma(-ol, tb[q], Dn[q]);
-        Gn[q] = fma(-gg, tb[q], Gn[q]);
-      }
-      const double yb = row_bcast<i>(gr);
-      gn = fma(-ol, yb, gn);
-      as_ = fma(-gg, yb, as_);
-      __builtin_amdgcn_sched_barrier(0);   // one source row at a time (the scheduler otherwise batches all 144 broadcasts)
+      const double nol = -Ol[i], ngg = -Gr[i];
+      fmac_bcast12<i>(Dn, Or, nol);        // D~_{j+1} -= O_j[r][i] * (row i of U_j)
+      fmac_bcast12<i>(Gn, Or, ngg);        // G_{j+1}  -= G_j[r][i] * (row i of U_j)
+      fmac_bcast2<i>(gn, as_, gr, nol, ngg);
     });
     // (pinned here: the compiler otherwise sinks the G_{j+1} sums below the output branch at the end of the step and
     //  spills all 144 broadcast values to feed them there)
@@ -1953,15 +2029,9 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double ol = Ol[i], gg = Gr[i];
-      double tb[B];
-      row_bcast12<i>(Fr, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) {
-        Fn[q] = fma(-ol, tb[q], Fn[q]);
-        Ar[q] = fma(-gg, tb[q], Ar[q]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      const double nol = -Ol[i], ngg = -Gr[i];
+      fmac_bcast12<i>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast12<i>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2131,13 +2201,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
           const int i = i0 + q;
           const bool ok = i < nf;
           const double Lv = ok ? fL[q] : 0.0, Rv = ok ? fR[q] : 0.0, ev = ok ? fE[q] : 0.0;
-          double tb[B];
-          lane_gather<12>(Lv, tb);
-#pragma unroll
-          for (int k = 0; k < B; k++) { Dacc[k] = fma(Lv, tb[k], Dacc[k]); Oacc[k] = fma(Rv, tb[k], Oacc[k]); }
-          lane_gather<12>(Rv, tb);
-#pragma unroll
-          for (int k = 0; k < B; k++) RRacc[k] = fma(Rv, tb[k], RRacc[k]);
+          fmac_gather<12>(Dacc, Lv, Lv);     // D[r][k] += L[k] L[r]: the row's element of lane k fused into the multiply-add
+          fmac_gather<12>(Oacc, Lv, Rv);     // O[r][k] += L[k] R[r]
+          fmac_gather<12>(RRacc, Rv, Rv);    // carry[r][k] += R[k] R[r]
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
           ldf(i + PF, fL[q], fR[q], fE[q]);
@@ -2150,13 +2216,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
           const int i = i0 + q;
           const bool ok = (i < nc) && (r < Dh);
           const double Lv = ok ? cL[q] : 0.0, Rv = ok ? cR[q] : 0.0, ev = (i < nc) ? cE[q] : 0.0;
-          double tb[Dh];
-          lane_gather<6>(Lv, tb);
-#pragma unroll
-          for (int k = 0; k < Dh; k++) { Dacc[k] = fma(Lv, tb[k], Dacc[k]); Oacc[k] = fma(Rv, tb[k], Oacc[k]); }
-          lane_gather<6>(Rv, tb);
-#pragma unroll
-          for (int k = 0; k < Dh; k++) RRacc[k] = fma(Rv, tb[k], RRacc[k]);
+          fmac_gather<6>(Dacc, Lv, Lv);
+          fmac_gather<6>(Oacc, Lv, Rv);
+          fmac_gather<6>(RRacc, Rv, Rv);
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
           ldc(i + PF, cL[q], cR[q], cE[q]);
@@ -2241,18 +2303,16 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       const double inv = fast_rcp(piv);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
-      const double mp = isk ? 0.0 : Dr[k] * inv;
-      double tb[B];
-      row_bcast12<k>(Dr, tb);
-#pragma unroll
-      for (int q = k + 1; q < B; q++) Dr[q] = fma(-mp, tb[q], Dr[q]);
-      row_bcast12<k>(Or, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) Or[q] = fma(-mp, tb[q], Or[q]);
-      row_bcast12<k>(Fr, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) Fr[q] = fma(-mp, tb[q], Fr[q]);
-      gr = fma(-mp, row_bcast<k>(gr), gr);
+      const double nmp = isk ? 0.0 : -(Dr[k] * inv);
+      // row r -= (D~[r][k] / pivot) * row k, the pivot row fused into the multiply-add (fmac_self*): of D~ only the columns
+      // right of the pivot still matter, in blocks of four (entries at or left of the pivot inside a block become garbage
+      // that nothing reads again)
+      if (k < 3) fmac_self4<k>(Dr, nmp);
+      if (k < 7) fmac_self4<k>(Dr + 4, nmp);
+      if (k < 11) fmac_self4<k>(Dr + 8, nmp);
+      fmac_self12<k>(Or, nmp);
+      fmac_self12<k>(Fr, nmp);
+      fmac_self1<k>(gr, nmp);
     });
     if (bad && live && r == 0) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
@@ -2286,15 +2346,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double ol = Ol[i], gg = Gr[i];
-      double tb[B];
-      row_bcast12<i>(Or, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) Dn[q] = fma(-ol, tb[q], Dn[q]);
-      const double yb = row_bcast<i>(gr);
-      gn = fma(-ol, yb, gn);
-      as_ = fma(-gg, yb, as_);
-      __builtin_amdgcn_sched_barrier(0);
+      const double nol = -Ol[i], ngg = -Gr[i];
+      fmac_bcast12<i>(Dn, Or, nol);
+      fmac_bcast2<i>(gn, as_, gr, nol, ngg);
     });
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Dn[k]));
@@ -2303,15 +2357,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double ol = Ol[i], gg = Gr[i];
-      double tb[B];
-      row_bcast12<i>(Fr, tb);
-#pragma unroll
-      for (int q = 0; q < B; q++) {
-        Fn[q] = fma(-ol, tb[q], Fn[q]);
-        Ar[q] = fma(-gg, tb[q], Ar[q]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      const double nol = -Ol[i], ngg = -Gr[i];
+      fmac_bcast12<i>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast12<i>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -43,6 +43,12 @@ template <int MODE> __global__ void k(double *p, long long *cyc, int iters) {
       REP16(asm volatile("v_mul_f64 %0, %0, %8\n\tv_mul_f64 %1, %1, %8\n\tv_mul_f64 %2, %2, %8\n\tv_mul_f64 %3, %3, %8\n\t"
                          "v_mul_f64 %4, %4, %8\n\tv_mul_f64 %5, %5, %8\n\tv_mul_f64 %6, %6, %8\n\tv_mul_f64 %7, %7, %8"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
+    } else if (MODE == 8) { // v_fmac_f64_dpp row_newbcast: D += bcast(S0) * S1 -- broadcast fused into the multiply-add
+      REP16(asm volatile("v_fmac_f64_dpp %0, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %2, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %3, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %4, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %5, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                         "v_fmac_f64_dpp %6, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %7, %8, %8 row_newbcast:3 row_mask:0xf bank_mask:0xf"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b));)
     } else if (MODE == 7) { // v_rcp_f64
       REP16(asm volatile("v_rcp_f64 %0, %0\n\tv_rcp_f64 %1, %1\n\tv_rcp_f64 %2, %2\n\tv_rcp_f64 %3, %3\n\t"
                          "v_rcp_f64 %4, %4\n\tv_rcp_f64 %5, %5\n\tv_rcp_f64 %6, %6\n\tv_rcp_f64 %7, %7"
@@ -70,7 +76,22 @@ template <int MODE> void run(const char *name, int waves_per_simd) {
   hipFree(p); hipFree(c);
 }
 
+// semantics check of v_fmac_f64_dpp row_newbcast:k : d[lane] += s0[16 * (lane / 16) + k] * s1[lane]
+__global__ void k_sem(double *out) {
+  const int lane = threadIdx.x;
+  double d = 1000.0 + lane, s0 = 1.0 + lane, s1 = 0.5 * lane;
+  asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:5 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s0), "v"(s1));
+  out[lane] = d;
+}
+
 int main() {
+  {
+    double *o; hipMalloc(&o, 512); k_sem<<<1, 64>>>(o); double h[64]; hipMemcpy(h, o, 512, hipMemcpyDeviceToHost);
+    int bad = 0;
+    for (int l = 0; l < 64; l++) { const double want = 1000.0 + l + (1.0 + 16 * (l / 16) + 5) * 0.5 * l; if (h[l] != want) bad++; }
+    printf("v_fmac_f64_dpp row_newbcast semantics (d += s0[row lane k] * s1): %s\n", bad ? "MISMATCH" : "ok");
+    hipFree(o);
+  }
   for (int w : {1, 2, 4}) {
     run<0>("v_fma_f64 (8 independent chains)", w);
     run<6>("v_mul_f64", w);
@@ -80,6 +101,7 @@ int main() {
     run<4>("v_fma_f64 dependent chain", w);
     run<5>("4 x dpp64 + 4 dependent fma", w);
     run<7>("v_rcp_f64", w);
+    run<8>("v_fmac_f64_dpp row_newbcast", w);
   }
   return 0;
 }
