@@ -36,7 +36,8 @@ def build(force=False, verbose=False):
     if not force and up_to_date():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [_hipcc()] + FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    extra = os.environ.get("GPSLAM_HIPCC_FLAGS", "").split()      # e.g. -DGPS_ABLATE_ASM for the timing ablations of DESIGN.md
+    cmd = [_hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=CSRC)

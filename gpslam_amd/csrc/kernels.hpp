@@ -2155,14 +2155,17 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     // ================================================================ ASM: images 0 .. steps + 1
     // Everything that has a memory latency is requested one state ahead: the row pointers of state t + 2 and the first
     // PF rows (full-width and compact) of state t + 1 are in flight while state t is accumulated.
-    constexpr int PF = 6, Dh = B / 2;
+    // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
+    // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
+    // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
+    constexpr int PF = 6, PC = 6, Dh = B / 2;
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     double carry[B], carry_g = 0.0;
 #pragma unroll
     for (int k = 0; k < B; k++) carry[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
-    double fL[PF], fR[PF], fE[PF], cL[PF], cR[PF], cE[PF];   // the two operand rings
+    double fL[PF], fR[PF], fE[PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
     int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
@@ -2182,7 +2185,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       rp = live ? p0 : 0; nf = live ? p1 - p0 : 0;
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
 #pragma unroll
-      for (int q = 0; q < PF; q++) { ldf(q, fL[q], fR[q], fE[q]); ldc(q, cL[q], cR[q], cE[q]); }
+      for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
+#pragma unroll
+      for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);
     };
     auto assemble = [&](int kimg) {
       const bool live = valid && (s + kimg) < e;
@@ -2201,18 +2206,20 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
           const int i = i0 + q;
           const bool ok = i < nf;
           const double Lv = ok ? fL[q] : 0.0, Rv = ok ? fR[q] : 0.0, ev = ok ? fE[q] : 0.0;
+#ifndef GPS_ABLATE_ASM   /* timing ablation only (wrong results): the assembly wave keeps its loads and barriers, skips the sums */
           fmac_gather<12>(Dacc, Lv, Lv);     // D[r][k] += L[k] L[r]: the row's element of lane k fused into the multiply-add
           fmac_gather<12>(Oacc, Lv, Rv);     // O[r][k] += L[k] R[r]
           fmac_gather<12>(RRacc, Rv, Rv);    // carry[r][k] += R[k] R[r]
+#endif
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
           ldf(i + PF, fL[q], fR[q], fE[q]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      for (int i0 = 0; i0 < ncm; i0 += PF) {             // compact rows (velocity-free): six columns each side
+      for (int i0 = 0; i0 < ncm; i0 += PC) {             // compact rows (velocity-free): six columns each side
 #pragma unroll
-        for (int q = 0; q < PF; q++) {
+        for (int q = 0; q < PC; q++) {
           const int i = i0 + q;
           const bool ok = (i < nc) && (r < Dh);
           const double Lv = ok ? cL[q] : 0.0, Rv = ok ? cR[q] : 0.0, ev = (i < nc) ? cE[q] : 0.0;
@@ -2221,7 +2228,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
           fmac_gather<6>(RRacc, Rv, Rv);
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
-          ldc(i + PF, cL[q], cR[q], cE[q]);
+          ldc(i + PC, cL[q], cR[q], cE[q]);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -2296,6 +2303,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     const double *cur = IMG + ((t + 1) & 1) * 4 * BS, *nxt = IMG + (t & 1) * 4 * BS;   // images t + 1 and t + 2
     double invs = 1.0;
     bool bad = false;
+#ifndef GPS_ABLATE_ELIM   /* timing ablation only (wrong results): the elimination wave keeps its LDS traffic, stores and barriers */
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       const double piv = row_bcast<k>(Dr[k]);
@@ -2314,6 +2322,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       fmac_self12<k>(Fr, nmp);
       fmac_self1<k>(gr, nmp);
     });
+#endif
     if (bad && live && r == 0) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
     double Ol[B];
@@ -2344,23 +2353,27 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     for (int k = 0; k < B; k++) Dn[k] = nxt[ro + k];
     gn = nxt[co + 2 * B * B];
     __builtin_amdgcn_sched_barrier(0);
+#ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
       fmac_bcast12<i>(Dn, Or, nol);
       fmac_bcast2<i>(gn, as_, gr, nol, ngg);
     });
+#endif
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Dn[k]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
+#ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
       fmac_bcast12<i>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
       fmac_bcast12<i>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
