@@ -71,6 +71,39 @@ def cpu_baseline(problem, iters=3, threads=1):
                 seconds_per_iteration=dt / iters)
 
 
+def reference_baseline(problem):
+    """the real gpslam factors on real GTSAM, if (and only if) both are installed where this
+    runs.  They are in neither the build image nor on the GPU box, so this normally reports that, and never a number."""
+    import shutil
+    import struct
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "bench", "gtsam_reference.cpp")
+    with tempfile.TemporaryDirectory() as td:
+        exe = os.path.join(td, "gtsam_reference")
+        cxx = shutil.which("g++")
+        if cxx is None:
+            return {"available": False, "why": "no host compiler"}
+        r = subprocess.run([cxx, "-O3", "-std=c++11", src, "-o", exe, "-lgpslam", "-lgtsam", "-ltbb"], capture_output=True, text=True)
+        if r.returncode != 0:
+            r = subprocess.run([cxx, "-O3", "-std=c++11", src, "-o", exe], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"available": False, "why": "bench/gtsam_reference.cpp did not build"}
+        pb = os.path.join(td, "problem.bin")
+        p = problem
+        with open(pb, "wb") as f:
+            f.write(struct.pack("<qdd", p["N"], float(p["gp_dt"][0]), float(p["qc"][0, 0])))
+            f.write(np.ascontiguousarray(np.concatenate([p["pose"], p["vel"]], axis=1)).tobytes())
+            f.write(np.ascontiguousarray(p["between_meas"]).tobytes())
+            f.write(struct.pack("<d", float(p["between_sig"][0, 0])))
+            f.write(np.ascontiguousarray(p["prior_pose"][0]).tobytes())
+            f.write(struct.pack("<d", float(p["prior_sig"][0, 0])))
+        r = subprocess.run([exe, pb, "3"], capture_output=True, text=True)
+        if r.returncode != 0:
+            return {"available": False, "why": r.stdout.strip() or "reference binary failed"}
+        return {"available": True, "kind": "reference", "runs": [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]}
+
+
 def extras(gpslam_amd, S, device):
     """Driver-visible measurements beyond the headline line: the north-star 1e6-state run, the other
     BASELINE configs on one GPU, the fp32 / fp64 tolerance sweep of config 5.  Everything here runs AFTER the contract's
@@ -336,6 +369,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, threads=1)
             out["cpu_baseline_all_cores"] = cpu_baseline(problem, threads=0)
+            out["reference_gtsam_baseline"] = reference_baseline(problem)
         if world == 1 and not args.no_extras:
             out["extras"] = extras(gpslam_amd, S, local_rank)
         print(json.dumps(out))
