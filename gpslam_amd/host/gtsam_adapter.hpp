@@ -11,7 +11,7 @@
 //      before; the subclass only keeps the constructor arguments readable (the reference stores delta_t_, tau_, GPbase_
 //      private and offers no getters: gpslam/gp/GaussianProcessPriorPose3.h:31, gpslam/slam/GPInterpolatedRangeFactorPose2.h:26-32).
 //   2. replace   gtsam::LevenbergMarquardtOptimizer opt(graph, init, params);   by
-//                gpslam_hip::HipChainOptimizer opt(graph, init, params);
+//                gpslam_hip::HipChainOptimizerPose3 opt(graph, init, params);   (…Pose2 for SE(2) graphs)
 //      iterate() / optimize() / error() / values() / iterations() / lambda() keep GTSAM's meaning
 //      (call sites: matlab/PlazaPose2.m:208-228, gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:185-188).
 // Graph requirements are those of the C ABI (include/gpslam_hip.h): keys Symbol('x'|'v'|'l', i), chain order, one Qc.
