@@ -4,8 +4,8 @@ Host-side Python mirror of the C ABI in include/gpslam_hip.h (the C++ mirror wit
 names lives in gpslam_amd/host/).  All compute happens in gpslam_amd/lib/libgpslam_hip.so (hand-written HIP
 for gfx950); importing this package never falls back to a CPU implementation.
 """
-from .chain import (ChainSolver, GpslamHipError, LINEAR2, LINEAR3, POSE2, POSE3, ROT3, CHART_EXPMAP,
+from .chain import (ChainSolver, GpslamHipError, LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS, CHART_EXPMAP,
                     CHART_FIRST_ORDER, FP32, FP64, POSE_DIM, TANGENT_DIM, Params, Stats, load_library)
 
-__all__ = ["ChainSolver", "GpslamHipError", "LINEAR2", "LINEAR3", "POSE2", "POSE3", "ROT3", "CHART_EXPMAP",
+__all__ = ["ChainSolver", "GpslamHipError", "LINEAR2", "LINEAR3", "POSE2", "POSE3", "ROT3", "ROT3_BIAS", "CHART_EXPMAP",
            "CHART_FIRST_ORDER", "FP32", "FP64", "POSE_DIM", "TANGENT_DIM", "Params", "Stats", "load_library"]

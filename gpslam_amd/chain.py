@@ -10,11 +10,11 @@ import numpy as np
 
 from . import build as _build
 
-LINEAR2, LINEAR3, POSE2, POSE3, ROT3 = 0, 1, 2, 3, 4
+LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
 FP64, FP32 = 0, 1
-POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9}
-TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3}
+POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9, ROT3_BIAS: 12}
+TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3, ROT3_BIAS: 6}
 
 # every symbol include/gpslam_hip.h declares
 ABI_SYMBOLS = [
@@ -31,6 +31,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
+    "gpslam_hip_add_ahrs",
 ]
 
 
@@ -196,6 +197,16 @@ class ChainSolver:
         return self._chk(self.lib.gpslam_hip_add_interp_attitude(self._h, len(left), _p(left), _p(nZ), _p(bRef),
                                                                  _p(sigma), _p(dt), _p(tau)), "add_interp_attitude")
 
+    def add_ahrs(self, left, delta_R, dR_dbias, bias_hat, delta_tij, cov, omega_coriolis=None):
+        """gtsam::AHRSFactor(x_left, x_left+1, b_left, pim, omegaCoriolis) -- matlab/GPAHRSexample.m:131-137; the
+        arrays are the PreintegratedAhrsMeasurements state per factor (gpslam_amd.ahrs.Preintegrated)."""
+        left = _i32(left)
+        delta_R, dR_dbias, bias_hat = _f64(delta_R), _f64(dR_dbias), _f64(bias_hat)
+        delta_tij, cov = _f64(delta_tij), _f64(cov)
+        cor = None if omega_coriolis is None else _f64(omega_coriolis)
+        return self._chk(self.lib.gpslam_hip_add_ahrs(self._h, len(left), _p(left), _p(delta_R), _p(dR_dbias), _p(bias_hat),
+                                                      _p(delta_tij), _p(cov), None if cor is None else _p(cor)), "add_ahrs")
+
     def add_interp_gps(self, left, measured, sigmas, dt, tau, sensor=None):
         left = _i32(left)
         measured, sigmas, dt, tau = _f64(measured), _f64(sigmas), _f64(dt), _f64(tau)
@@ -236,7 +247,7 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_linearize_gp(self._h, _p(e), _p(H)), "linearize_gp")
         return e, H
 
-    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2}
+    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2, 7: 3}
 
     def linearize_meas(self, kind, count):
         """Unwhitened (e, J) of the `count` measurement factors of one kind (MEAS_* order of include/gpslam_hip.h):

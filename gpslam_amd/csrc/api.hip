@@ -188,6 +188,7 @@ template <typename F> void dispatch_mf(int mf, F &&f) {
     case POSE2: f(std::integral_constant<int, POSE2>{}); break;
     case POSE3: f(std::integral_constant<int, POSE3>{}); break;
     case ROT3: f(std::integral_constant<int, ROT3>{}); break;
+    case ROT3_BIAS: f(std::integral_constant<int, ROT3_BIAS>{}); break;
   }
 }
 template <typename F> void dispatch_b(int b, F &&f) {
@@ -206,6 +207,7 @@ template <typename F> void dispatch_fk(int fk, F &&f) {
     case 4: f(std::integral_constant<int, 4>{}); break;
     case 5: f(std::integral_constant<int, 5>{}); break;
     case 6: f(std::integral_constant<int, 6>{}); break;
+    case 7: f(std::integral_constant<int, 7>{}); break;
   }
 }
 
@@ -369,7 +371,7 @@ void gpslam_hip_default_params(gpslam_hip_params *p) {
 
 int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (!cfg || !out) return GPSLAM_E_INVALID;
-  if (cfg->manifold < 0 || cfg->manifold > 4) return GPSLAM_E_INVALID;
+  if (cfg->manifold < 0 || cfg->manifold > GPSLAM_ROT3_BIAS) return GPSLAM_E_INVALID;
   if (cfg->precision != GPSLAM_FP64 && cfg->precision != GPSLAM_FP32) return GPSLAM_E_INVALID;
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
@@ -382,7 +384,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   h->cfg = *cfg;
   if (h->cfg.nranks < 1) h->cfg.nranks = 1;
   h->mf = cfg->manifold;
-  static const int dd[5] = {2, 3, 3, 6, 3}, pdd[5] = {2, 3, 3, 12, 9};
+  static const int dd[6] = {2, 3, 3, 6, 3, 6}, pdd[6] = {2, 3, 3, 12, 9, 12};
   h->d = dd[h->mf];
   h->pd = pdd[h->mf];
   h->b = 2 * h->d;
@@ -447,7 +449,15 @@ int gpslam_hip_set_stream(gpslam_hip_handle *h, void *stream) {
 
 int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc) {
   if (!h || !Qc) return GPSLAM_E_INVALID;
-  double U[36];
+  double U[36], Qpad[36];
+  if (h->mf == ROT3_BIAS) {   // Qc is the 3 x 3 of GaussianProcessPriorRot3; bias and pad components: identity (see GpPrior<ROT3_BIAS>)
+    std::memset(Qpad, 0, sizeof(Qpad));
+    for (int i = 0; i < 3; i++) {
+      for (int j = 0; j < 3; j++) Qpad[i * 6 + j] = Qc[i * 3 + j];
+      Qpad[(3 + i) * 6 + 3 + i] = 1.0;
+    }
+    Qc = Qpad;
+  }
   if (!make_U(h->d, Qc, U)) return fail(h, GPSLAM_E_NOT_SPD, "Qc is not positive definite");
   std::memcpy(h->Qc, Qc, sizeof(double) * h->d * h->d);
   std::memcpy(h->U, U, sizeof(double) * h->d * h->d);
@@ -580,7 +590,26 @@ int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t count, const in
       for (int q = 0; q < 3; q++) m[6 * (size_t)k + 3 * part + q] = v[q] / n;
     }
   }
-  return add_meas(h, FK_INTERP_ATT, 2, 6, true, false, true, h->mf == ROT3, count, left, nullptr, m.data(), sigma, dt, tau, nullptr);
+  return add_meas(h, FK_INTERP_ATT, 2, 6, true, false, true, h->mf == ROT3 || h->mf == ROT3_BIAS, count, left, nullptr, m.data(), sigma, dt, tau, nullptr);
+}
+int gpslam_hip_add_ahrs(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *delta_R,
+                        const double *dR_dbias, const double *bias_hat, const double *delta_tij, const double *cov,
+                        const double *omega_coriolis) {
+  if (!h) return GPSLAM_E_INVALID;
+  if (count > 0 && (!delta_R || !dR_dbias || !bias_hat || !delta_tij || !cov)) return GPSLAM_E_INVALID;
+  std::vector<double> m((size_t)std::max(count, 0) * kAhrsWidth, 0.0), ones((size_t)std::max(count, 0) * 3, 1.0);
+  for (int k = 0; k < count; k++) {
+    double *o = &m[(size_t)k * kAhrsWidth];
+    std::memcpy(o, delta_R + 9 * (size_t)k, 9 * sizeof(double));
+    std::memcpy(o + 9, dR_dbias + 9 * (size_t)k, 9 * sizeof(double));
+    std::memcpy(o + 18, bias_hat + 3 * (size_t)k, 3 * sizeof(double));
+    o[21] = delta_tij[k];
+    if (omega_coriolis) std::memcpy(o + 22, omega_coriolis, 3 * sizeof(double));
+    // noiseModel::Gaussian::Covariance(preintMeasCov): whitening by R, R^T R = cov^-1
+    if (!make_U(3, cov + 9 * (size_t)k, o + 25)) return fail(h, GPSLAM_E_NOT_SPD, "AHRS pre-integrated covariance is not positive definite");
+  }
+  return add_meas(h, FK_AHRS, 3, kAhrsWidth, true, false, false, h->mf == ROT3_BIAS, count, left, nullptr, m.data(), ones.data(),
+                  nullptr, nullptr, nullptr);
 }
 int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas, const double *dt, const double *tau, const double *sensor) {

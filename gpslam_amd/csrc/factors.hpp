@@ -16,7 +16,9 @@
 
 namespace gps {
 
-enum Manifold : int { LINEAR2 = 0, LINEAR3 = 1, POSE2 = 2, POSE3 = 3, ROT3 = 4 };
+// ROT3_BIAS: the AHRS state of matlab/GPAHRSexample.m:69-202 -- pose slot = (Rot3 x_i, gyroscope bias b_i), velocity slot =
+// (angular velocity v_i, three pad components pinned to zero): a 12-wide block, so the chain solver's Pose3 kernels apply
+enum Manifold : int { LINEAR2 = 0, LINEAR3 = 1, POSE2 = 2, POSE3 = 3, ROT3 = 4, ROT3_BIAS = 5 };
 enum Chart : int { CHART_EXPMAP = 0, CHART_FIRST_ORDER = 1 };
 
 template <int M> struct MTraits;
@@ -25,6 +27,7 @@ template <> struct MTraits<LINEAR3> { static constexpr int d = 3, pd = 3; };
 template <> struct MTraits<POSE2> { static constexpr int d = 3, pd = 3; };
 template <> struct MTraits<POSE3> { static constexpr int d = 6, pd = 12; };
 template <> struct MTraits<ROT3> { static constexpr int d = 3, pd = 9; };
+template <> struct MTraits<ROT3_BIAS> { static constexpr int d = 6, pd = 12; };
 
 // ---- conversions between flat register arrays and the Lie types
 template <typename T> GD M3<T> as_m3(const T *p) {
@@ -400,6 +403,36 @@ template <typename T, bool JAC> struct GpPrior<T, ROT3, JAC> {
   }
 };
 
+// GaussianProcessPriorRot3 on the (x, v) part of the AHRS state.  The bias has no GP prior in the recipe (it is tied by
+// BetweenFactorVector, GPAHRSexample.m:143); the three pad components are pinned by unit rows (pad_1 in the top half,
+// pad_2 in the bottom half), which keeps the 12-wide block non-singular without any extra factor set.  The handle's
+// Qc is diag(Qc_rot, I_3) (set_qc pads it), so the whitening leaves the pad rows decoupled from the rotation rows.
+template <typename T, bool JAC> struct GpPrior<T, ROT3_BIAS, JAC> {
+  static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
+    T e3[6], Jt3[JAC ? 36 : 1], Jb3[JAC ? 36 : 1];
+    GpPrior<T, ROT3, JAC>::eval(p1, v1, p2, v2, dt, e3, Jt3, Jb3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) { e[i] = e3[i]; e[3 + i] = v1[3 + i]; e[6 + i] = e3[3 + i]; e[9 + i] = v2[3 + i]; }
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < 6 * 24; i++) { Jt[i] = T(0); Jb[i] = T(0); }
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            Jt[r * 24 + 12 * s + c] = Jt3[r * 12 + 6 * s + c];           // d/d theta_s
+            Jt[r * 24 + 12 * s + 6 + c] = Jt3[r * 12 + 6 * s + 3 + c];   // d/d omega_s
+            Jb[r * 24 + 12 * s + c] = Jb3[r * 12 + 6 * s + c];
+            Jb[r * 24 + 12 * s + 6 + c] = Jb3[r * 12 + 6 * s + 3 + c];
+          }
+#pragma unroll
+      for (int c = 0; c < 3; c++) { Jt[(3 + c) * 24 + 9 + c] = T(1); Jb[(3 + c) * 24 + 21 + c] = T(1); }
+    }
+  }
+};
+
 template <typename T, bool JAC> struct GpPrior<T, POSE3, JAC> {
   static GD void eval(const T *p1, const T *v1, const T *p2, const T *v2, T dt, T *e, T *Jt, T *Jb) {
     const SE3<T> a = as_se3(p1), b = as_se3(p2);
@@ -577,6 +610,79 @@ template <typename T, bool JAC> struct PoseFactors<T, POSE3, JAC> {
     out[9] = r.t.x; out[10] = r.t.y; out[11] = r.t.z;
   }
 };
+
+// SO(3) x R^3 (rotation, bias): PriorFactorRot3 / PriorFactorVector / BetweenFactorVector of the AHRS recipe
+// (GPAHRSexample.m:118-121, :143) are the two halves of these 6-row factors; the half that is not wanted gets an infinite
+// sigma (weight zero).
+template <typename T, bool JAC> struct PoseFactors<T, ROT3_BIAS, JAC> {
+  static GD void prior(const T *pr, const T *x, int chart, T *e, T *H) {
+    T H3[JAC ? 9 : 1];
+    PoseFactors<T, ROT3, JAC>::prior(pr, x, chart, e, H3);
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[3 + i] = x[9 + i] - pr[9 + i];
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < 36; i++) H[i] = T(0);
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) H[r * 6 + c] = H3[r * 3 + c];
+        H[(3 + r) * 6 + 3 + r] = T(1);
+      }
+    }
+  }
+  static GD void between(const T *m, const T *x1, const T *x2, int chart, T *e, T *H1, T *H2) {
+    T A[JAC ? 9 : 1], B[JAC ? 9 : 1];
+    PoseFactors<T, ROT3, JAC>::between(m, x1, x2, chart, e, A, B);
+#pragma unroll
+    for (int i = 0; i < 3; i++) e[3 + i] = (x2[9 + i] - x1[9 + i]) - m[9 + i];
+    if (JAC) {
+#pragma unroll
+      for (int i = 0; i < 36; i++) { H1[i] = T(0); H2[i] = T(0); }
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { H1[r * 6 + c] = A[r * 3 + c]; H2[r * 6 + c] = B[r * 3 + c]; }
+        H1[(3 + r) * 6 + 3 + r] = T(-1);
+        H2[(3 + r) * 6 + 3 + r] = T(1);
+      }
+    }
+  }
+  static GD void retract(const T *x, const T *dlt, int chart, T *out) {
+    PoseFactors<T, ROT3, false>::retract(x, dlt, chart, out);
+#pragma unroll
+    for (int i = 0; i < 3; i++) out[9 + i] = x[9 + i] + dlt[3 + i];
+  }
+};
+
+// gtsam::AHRSFactor::evaluateError (GTSAM 4.0 gtsam/navigation/AHRSFactor.cpp -- third-party, not under /root/reference;
+// call site matlab/GPAHRSexample.m:131-137).  prm = [deltaRij (9) | delRdelBiasOmega (9) | biasHat (3) | deltaTij |
+// omegaCoriolis (3)] of the PreintegratedAhrsMeasurements:
+//   omega   = Log(deltaRij Exp(delRdelBiasOmega (bias - biasHat)))           PreintegratedAhrsMeasurements::predict
+//   c       = Ri^T omegaCoriolis deltaTij                                     integrateCoriolis
+//   fR      = Log(Exp(omega - c)^T Ri^T Rj)
+//   H1 = Jr^-1(fR) (-(Ri^T Rj)^T + fRrot^T Jr(omega - c) [c]x),  H2 = Jr^-1(fR),
+//   H3 = -Jr^-1(fR) fRrot^T Jr(omega - c) Jr^-1(omega) Jr(delRdelBiasOmega db) delRdelBiasOmega
+template <typename T, bool JAC>
+GD void ahrs_factor(const M3<T> &Ri, const M3<T> &Rj, V3<T> bias, const T *prm, T *e, M3<T> &H1, M3<T> &H2, M3<T> &H3) {
+  const M3<T> dR = as_m3(prm), D = as_m3(prm + 9);
+  const V3<T> binc = bias - V3<T>{prm[18], prm[19], prm[20]};
+  const V3<T> bio = D * binc;
+  const V3<T> om = so3_log(dR * so3_exp(bio));
+  const V3<T> cor = prm[21] * tmul(Ri, V3<T>{prm[22], prm[23], prm[24]});
+  const V3<T> com = om - cor;
+  const M3<T> aR = transpose(Ri) * Rj;
+  const M3<T> fRrot = transpose(so3_exp(com)) * aR;
+  const V3<T> fR = so3_log(fRrot);
+  e[0] = fR.x; e[1] = fR.y; e[2] = fR.z;
+  if (JAC) {
+    const M3<T> Dexp = so3_jr(com), Dlog = so3_jrinv(fR);
+    const M3<T> fRt = transpose(fRrot);
+    H1 = Dlog * (neg(transpose(aR)) + fRt * (Dexp * skew(cor)));
+    H2 = Dlog;
+    H3 = neg(Dlog * (fRt * (Dexp * (so3_jrinv(om) * (so3_jr(bio) * D)))));
+  }
+}
 
 }  // namespace gps
 

@@ -96,7 +96,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // (a float holds 1e5 m to 8 mm: the 0.1 m step between consecutive states would carry 4 digits).  The fp64
 // instantiations do not re-centre: their results stay bit-identical to what the oracle parity tests pinned.
 template <int MF> struct TransPart {
-  static constexpr int n = (MF == POSE3) ? 3 : (MF == POSE2 ? 2 : (MF == ROT3 ? 0 : MTraits<MF>::pd));
+  static constexpr int n = (MF == POSE3) ? 3 : (MF == POSE2 ? 2 : ((MF == ROT3 || MF == ROT3_BIAS) ? 0 : MTraits<MF>::pd));
   static constexpr int off = (MF == POSE3) ? 9 : 0;
 };
 template <typename T> struct IsF64 { static constexpr bool v = false; };
@@ -526,8 +526,9 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
 
 // ------------------------------------------------------------------ K2: measurement factors
 
-enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5, FK_INTERP_PROJ = 6 };
-constexpr int kNumMeasKinds = 7;
+enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5, FK_INTERP_PROJ = 6, FK_AHRS = 7 };
+constexpr int kNumMeasKinds = 8;
+constexpr int kAhrsWidth = 34;   // per-factor parameters of FK_AHRS: the 25 of ahrs_factor() + sqrt information R (3 x 3, upper triangular)
 constexpr int kMeasAux = 18;
 template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
@@ -558,7 +559,8 @@ template <typename T> struct MeasArgs {
 // valid (manifold, kind) pairs; everything else is rejected on the host and compiles to an empty kernel
 template <int MF, int FK> struct MeasValid {
   static constexpr bool v = ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && (MF == POSE2 || MF == POSE3 || MF == LINEAR3)) ||
-                            (FK == FK_INTERP_ATT && MF == ROT3) || ((FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ) && MF == POSE3) ||
+                            (FK == FK_INTERP_ATT && (MF == ROT3 || MF == ROT3_BIAS)) || (FK == FK_AHRS && MF == ROT3_BIAS) ||
+                            ((FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ) && MF == POSE3) ||
                             ((FK == FK_ODOM2D || FK == FK_BEARING_RANGE) && MF == LINEAR3);
 };
 
@@ -581,7 +583,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
     for (int r = 0; r < rows; r++) wgt[r] = T(0);
     if (f < a.count) {
       const int i = a.idx[f];
-      constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ);
+      constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ || FK == FK_AHRS);
       constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ);
       T p1[pd], v1[d], p2[pd], v2[d];
       double org[3] = {0.0, 0.0, 0.0};      // fp32 arithmetic: translations re-centred on the first pose (see TransPart)
@@ -717,8 +719,30 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
           const V3<T> n1 = -rowmul(q1, RS), n2 = -rowmul(q2, RS);       // D_nRef_R = -Bq^T R [bRef]x
           const T d00 = dot(z1, q1), d01 = dot(z1, q2), d10 = dot(z2, q1), d11 = dot(z2, q2);   // Bz^T Bq
           const V3<T> h0 = d00 * n1 + d01 * n2, h1 = d10 * n1 + d11 * n2;
-          put_v3(rowmul(h0, o.H1), JL); put_v3(rowmul(h0, o.H2), JL + 3); put_v3(rowmul(h0, o.H3), JR); put_v3(rowmul(h0, o.H4), JR + 3);
-          put_v3(rowmul(h1, o.H1), JL + b); put_v3(rowmul(h1, o.H2), JL + b + 3); put_v3(rowmul(h1, o.H3), JR + b); put_v3(rowmul(h1, o.H4), JR + b + 3);
+          // (the velocity columns start at d: 3 for Rot3 states, 6 for the AHRS state whose pose slot also holds the bias)
+          put_v3(rowmul(h0, o.H1), JL); put_v3(rowmul(h0, o.H2), JL + d); put_v3(rowmul(h0, o.H3), JR); put_v3(rowmul(h0, o.H4), JR + d);
+          put_v3(rowmul(h1, o.H1), JL + b); put_v3(rowmul(h1, o.H2), JL + b + d); put_v3(rowmul(h1, o.H3), JR + b); put_v3(rowmul(h1, o.H4), JR + b + d);
+        }
+      } else if constexpr (FK == FK_AHRS) {
+        // gtsam::AHRSFactor(x_i, x_i+1, b_i, pim) (matlab/GPAHRSexample.m:131-137); noise model = Gaussian with the
+        // pre-integrated covariance: the rows are whitened here by its square-root information R (sigmas = 1 below),
+        // except in the inspection call, which returns the unwhitened evaluateError() values
+        const double *pp = a.meas + (size_t)f * a.mw;
+        T prm[25];
+#pragma unroll
+        for (int k = 0; k < 25; k++) prm[k] = T(pp[k]);
+        M3<T> A, B, C;
+        ahrs_factor<T, JAC>(as_m3(p1), as_m3(p2), V3<T>{p1[9], p1[10], p1[11]}, prm, e, A, B, C);
+        const bool whiten = !(JAC && a.out_e);
+        T Rw[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) Rw[k] = whiten ? T(pp[25 + k]) : ((k == 0 || k == 4 || k == 8) ? T(1) : T(0));
+        const V3<T> ew = as_m3(Rw) * V3<T>{e[0], e[1], e[2]};
+        e[0] = ew.x; e[1] = ew.y; e[2] = ew.z;
+        if (JAC) {
+          put_m3(as_m3(Rw) * A, JL, b, 0, 0);     // d/dx_i
+          put_m3(as_m3(Rw) * C, JL, b, 0, 3);     // d/db_i
+          put_m3(as_m3(Rw) * B, JR, b, 0, 0);     // d/dx_i+1
         }
       } else if constexpr (FK == FK_INTERP_GPS) {
         // GPInterpolatedGPSFactorPose3::evaluateError, gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
@@ -1362,6 +1386,22 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
 #pragma unroll
     for (int c = 0; c < 9; c++) o[c] = r.m[c];
     if (JAC) { put_m3(jo.H1, oh, 3, 0, 0); put_m3(jo.H2, oh + 9, 3, 0, 0); put_m3(jo.H3, oh + 18, 3, 0, 0); put_m3(jo.H4, oh + 27, 3, 0, 0); }
+  } else if constexpr (MF == ROT3_BIAS) {
+    // the rotation is interpolated (GaussianProcessInterpolatorRot3); the bias slot returns the left state's bias, the one
+    // an AHRSFactor over this interval uses
+    Interp3Out<T, JAC> jo;
+    const M3<T> r = interp_rot3<T, JAC>(p1, v1, p2, v2, k, jo);
+#pragma unroll
+    for (int c = 0; c < 9; c++) o[c] = r.m[c];
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[9 + c] = p1[9 + c];
+    if (JAC) {
+#pragma unroll
+      for (int c = 0; c < 4 * 36; c++) oh[c] = T(0);
+      put_m3(jo.H1, oh, 6, 0, 0); put_m3(jo.H2, oh + 36, 6, 0, 0); put_m3(jo.H3, oh + 72, 6, 0, 0); put_m3(jo.H4, oh + 108, 6, 0, 0);
+#pragma unroll
+      for (int c = 0; c < 3; c++) oh[(3 + c) * 6 + 3 + c] = T(1);
+    }
   } else {
     Interp6Out<T, JAC> jo;
     const SE3<T> r = interp_pose3<T, JAC>(p1, v1, p2, v2, k, jo);

@@ -208,7 +208,8 @@ class Values {
 
 // ---------------------------------------------------------------- factors
 namespace detail {
-enum FType { F_GP, F_POSE_PRIOR, F_VEL_PRIOR, F_LM_PRIOR, F_BETWEEN, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT, F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ };
+enum FType { F_GP, F_POSE_PRIOR, F_VEL_PRIOR, F_LM_PRIOR, F_BETWEEN, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT, F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ,
+             F_BIAS_PRIOR, F_BIAS_BETWEEN, F_AHRS, F_ATTITUDE };
 struct Desc {   // what a factor hands to the graph compiler
   FType type;
   int manifold = -1;                 // GPSLAM_* the factor requires, -1 = any
@@ -250,6 +251,7 @@ template <typename T> class PriorFactor : public NonlinearFactor {
     const unsigned char c = symbolChr(key);
     if (vt == detail::T_POINT2 || vt == detail::T_POINT3) d_.type = detail::F_LM_PRIOR;
     else if (c == 'v') d_.type = detail::F_VEL_PRIOR;
+    else if (c == 'b' && vt == detail::T_VEC3) d_.type = detail::F_BIAS_PRIOR;   // PriorFactorVector(b_1) of the AHRS recipe
     else d_.type = detail::F_POSE_PRIOR;
     d_.k[0] = key; d_.meas = detail::VT<T>::pack(prior); d_.sig = sigmas_of(model);
   }
@@ -259,7 +261,8 @@ template <typename T> class PriorFactor : public NonlinearFactor {
 template <typename T> class BetweenFactor : public NonlinearFactor {
  public:
   BetweenFactor(Key key1, Key key2, const T &measured, const SharedNoiseModel &model) {
-    d_.type = detail::F_BETWEEN; d_.k[0] = key1; d_.k[2] = key2; d_.meas = detail::VT<T>::pack(measured); d_.sig = sigmas_of(model);
+    d_.type = (symbolChr(key1) == 'b' && detail::VT<T>::t == detail::T_VEC3) ? detail::F_BIAS_BETWEEN : detail::F_BETWEEN;
+    d_.k[0] = key1; d_.k[2] = key2; d_.meas = detail::VT<T>::pack(measured); d_.sig = sigmas_of(model);
   }
   GPSLAM_FACTOR_BOILERPLATE(BetweenFactor<T>, 2)
 };
@@ -311,6 +314,7 @@ struct Session {
   std::vector<uint64_t> lm_index;
   std::vector<bool> has_vel;                // velocity key present in the user's Values
   bool vw = false;                          // Pose3VW family: 'v' and 'w' keys hold world-frame 3-vectors
+  bool bias = false;                        // AHRS graph: 'b' keys (gyroscope bias) ride in the pose slot of a GPSLAM_ROT3_BIAS chain
   Values values;
   ~Session() { if (h) gpslam_hip_destroy(h); }
 
@@ -332,7 +336,7 @@ struct Session {
   // classify the variables, map keys to chain positions, create the handle, upload states
   void build(const NonlinearFactorGraph &graph, const Values &init, int device = 0) {
     values = init;
-    std::map<uint64_t, const Value *> poses, vels, omegas, lms;
+    std::map<uint64_t, const Value *> poses, vels, omegas, lms, biases;
     bool any_vw = false, any_body = false;
     for (auto &fp : graph.factors()) {
       const Desc f = fp->describe();
@@ -346,25 +350,36 @@ struct Session {
       if (kv.second.type == T_POINT2 || kv.second.type == T_POINT3) lms[symbolIndex(kv.first)] = &kv.second;
       else if (c == 'v') vels[symbolIndex(kv.first)] = &kv.second;
       else if (vw && c == 'w') omegas[symbolIndex(kv.first)] = &kv.second;
+      else if (c == 'b' && kv.second.type == T_VEC3) biases[symbolIndex(kv.first)] = &kv.second;
       else poses[symbolIndex(kv.first)] = &kv.second;
     }
     if (poses.empty()) throw std::invalid_argument("no pose variables (keys other than 'v' / landmarks) in the Values");
     manifold = manifold_of(poses.begin()->second->type);
     if (manifold < 0) throw std::invalid_argument("unsupported pose type");
-    static const int dd[5] = {2, 3, 3, 6, 3}, pdd[5] = {2, 3, 3, 12, 9};
+    if (!biases.empty()) {   // matlab/GPAHRSexample.m: x_i Rot3, v_i Vector3, b_i Vector3 -> one (rotation, bias | omega, pad) state
+      if (manifold != GPSLAM_ROT3) throw std::invalid_argument("bias variables ('b' keys) need Rot3 states");
+      manifold = GPSLAM_ROT3_BIAS;
+      bias = true;
+    }
+    static const int dd[6] = {2, 3, 3, 6, 3, 6}, pdd[6] = {2, 3, 3, 12, 9, 12};
     d = dd[manifold]; pd = pdd[manifold];
     ld = lms.empty() ? 0 : (lms.begin()->second->type == T_POINT2 ? 2 : 3);
     N = (int)poses.size(); L = (int)lms.size();
     std::vector<double> P((size_t)N * pd), V((size_t)N * d, 0.0), LM((size_t)L * (ld ? ld : 1));
     int i = 0;
     for (auto &kv : poses) {
-      if (manifold_of(kv.second->type) != manifold) throw std::invalid_argument("mixed pose types");
+      if (manifold_of(kv.second->type) != (bias ? (int)GPSLAM_ROT3 : manifold)) throw std::invalid_argument("mixed pose types");
       state_index.push_back(kv.first);
-      std::memcpy(&P[(size_t)i * pd], kv.second->d.data(), sizeof(double) * pd);
+      std::memcpy(&P[(size_t)i * pd], kv.second->d.data(), sizeof(double) * (bias ? 9 : pd));
+      if (bias) {
+        auto bi = biases.find(kv.first);
+        if (bi != biases.end()) std::memcpy(&P[(size_t)i * pd + 9], bi->second->d.data(), sizeof(double) * 3);
+        else std::memset(&P[(size_t)i * pd + 9], 0, sizeof(double) * 3);
+      }
       auto vi = vels.find(kv.first);
       has_vel.push_back(vi != vels.end());
       if (vi != vels.end()) {
-        const int want = vw ? 3 : d;
+        const int want = (vw || bias) ? 3 : d;
         if ((int)vi->second->d.size() != want) throw std::invalid_argument("velocity dimension does not match the pose manifold");
         std::memcpy(&V[(size_t)i * d], vi->second->d.data(), sizeof(double) * want);
       }
@@ -397,9 +412,10 @@ struct Session {
     std::vector<double> qc_used;
     for (auto &fp : graph.factors()) {
       const Desc f = fp->describe();
-      if (f.manifold >= 0 && f.manifold != manifold) throw std::invalid_argument("factor type does not match the pose type in the Values");
+      if (f.manifold >= 0 && f.manifold != manifold && !(bias && f.manifold == GPSLAM_ROT3))
+        throw std::invalid_argument("factor type does not match the pose type in the Values");
       auto set_qc = [&](const Matrix &Qc) {
-        if (Qc.rows != d) throw std::invalid_argument("Qc_model dimension does not match the manifold");
+        if (Qc.rows != (bias ? 3 : d)) throw std::invalid_argument("Qc_model dimension does not match the manifold");
         if (!qc_set) { check(gpslam_hip_set_qc(h, Qc.a.data()), h, "set_qc"); qc_set = true; qc_used = Qc.a; }
         else if (Qc.a != qc_used) throw std::invalid_argument("all GP factors of one graph must share one Qc_model (one Qc per handle)");
       };
@@ -418,11 +434,62 @@ struct Session {
           int32_t l = adjacent(f.k[0], f.k[2]);
           check(gpslam_hip_add_gp_priors(h, 1, &l, &f.dt), h, "add_gp_priors");
         } break;
-        case F_POSE_PRIOR: { int32_t s = state_of(f.k[0]); check(gpslam_hip_add_pose_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_pose_priors"); } break;
+        case F_POSE_PRIOR: {
+          int32_t s = state_of(f.k[0]);
+          if (bias) {   // PriorFactorRot3 on the rotation half of the (rotation, bias) state; the bias half is switched off
+            std::vector<double> m(12, 0.0), sg(6, INFINITY);
+            std::memcpy(m.data(), f.meas.data(), sizeof(double) * 9);
+            std::memcpy(sg.data(), f.sig.data(), sizeof(double) * 3);
+            check(gpslam_hip_add_pose_priors(h, 1, &s, m.data(), sg.data()), h, "add_pose_priors");
+          } else {
+            check(gpslam_hip_add_pose_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_pose_priors");
+          }
+        } break;
+        case F_BIAS_PRIOR: {
+          if (!bias) throw std::invalid_argument("PriorFactor on a 'b' key needs bias variables in the Values");
+          int32_t s = state_of(f.k[0]);
+          std::vector<double> m = {1, 0, 0, 0, 1, 0, 0, 0, 1, f.meas[0], f.meas[1], f.meas[2]};
+          std::vector<double> sg = {INFINITY, INFINITY, INFINITY, f.sig[0], f.sig[1], f.sig[2]};
+          check(gpslam_hip_add_pose_priors(h, 1, &s, m.data(), sg.data()), h, "add_pose_priors");
+        } break;
+        case F_BIAS_BETWEEN: {
+          if (!bias) throw std::invalid_argument("BetweenFactor on 'b' keys needs bias variables in the Values");
+          int32_t l = adjacent(f.k[0], f.k[2]);
+          std::vector<double> m = {1, 0, 0, 0, 1, 0, 0, 0, 1, f.meas[0], f.meas[1], f.meas[2]};
+          std::vector<double> sg = {INFINITY, INFINITY, INFINITY, f.sig[0], f.sig[1], f.sig[2]};
+          check(gpslam_hip_add_between(h, 1, &l, m.data(), sg.data()), h, "add_between");
+        } break;
+        case F_AHRS: {   // gtsam::AHRSFactor(x_i, x_j, b_i, pim, omegaCoriolis): meas = deltaRij | delRdelBiasOmega | biasHat | deltaTij | cov
+          if (!bias) throw std::invalid_argument("AHRSFactor needs bias variables ('b' keys) in the Values");
+          int32_t l = adjacent(f.k[0], f.k[2]);
+          if (symbolIndex(f.k[4]) != symbolIndex(f.k[0])) throw std::invalid_argument("AHRSFactor: the bias key must belong to the first rotation's state");
+          check(gpslam_hip_add_ahrs(h, 1, &l, &f.meas[0], &f.meas[9], &f.meas[18], &f.meas[21], &f.meas[22], f.aux.empty() ? nullptr : f.aux.data()), h, "add_ahrs");
+        } break;
+        case F_ATTITUDE: {   // gtsam::Rot3AttitudeFactor(x_s): the interpolated factor at tau = delta_t sits exactly on the right state
+          if (manifold != GPSLAM_ROT3 && manifold != GPSLAM_ROT3_BIAS) throw std::invalid_argument("Rot3AttitudeFactor needs Rot3 states");
+          const int st = state_of(f.k[0]);
+          int32_t l = st > 0 ? st - 1 : 0;
+          const double one = 1.0, tau = st > 0 ? 1.0 : 0.0;
+          if (N < 2) throw std::invalid_argument("Rot3AttitudeFactor needs a chain of at least two states");
+          check(gpslam_hip_add_interp_attitude(h, 1, &l, f.aux.data(), f.aux.data() + 3, f.sig.data(), &one, &tau), h, "add_interp_attitude");
+        } break;
         case F_VEL_PRIOR: { if (vw) throw std::invalid_argument("PriorFactor<Vector3> on a 'v' / 'w' key of a Pose3VW graph is not supported yet");
-          int32_t s = state_of(f.k[0]); check(gpslam_hip_add_vel_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_vel_priors"); } break;
+          int32_t s = state_of(f.k[0]);
+          std::vector<double> m = f.meas, sg = f.sig;
+          if (bias) { m.resize(6, 0.0); sg.resize(6, 1.0); }     // the three pad components of the velocity slot
+          check(gpslam_hip_add_vel_priors(h, 1, &s, m.data(), sg.data()), h, "add_vel_priors"); } break;
         case F_LM_PRIOR: { int32_t s = lm_of(f.k[0]); check(gpslam_hip_add_landmark_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_landmark_priors"); } break;
-        case F_BETWEEN: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_between(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_between"); } break;
+        case F_BETWEEN: {
+          int32_t l = adjacent(f.k[0], f.k[2]);
+          if (bias) {   // BetweenFactorRot3 on the rotation half
+            std::vector<double> m(12, 0.0), sg(6, INFINITY);
+            std::memcpy(m.data(), f.meas.data(), sizeof(double) * 9);
+            std::memcpy(sg.data(), f.sig.data(), sizeof(double) * 3);
+            check(gpslam_hip_add_between(h, 1, &l, m.data(), sg.data()), h, "add_between");
+          } else {
+            check(gpslam_hip_add_between(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_between");
+          }
+        } break;
         case F_INTERP_RANGE: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
           check(gpslam_hip_add_interp_range(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_range"); } break;
         case F_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]); check(gpslam_hip_add_range(h, 1, &s, &m, f.meas.data(), f.sig.data()), h, "add_range"); } break;
@@ -460,13 +527,16 @@ struct Session {
         kv.second.d.assign(LM.begin() + (size_t)j * ld, LM.begin() + (size_t)(j + 1) * ld);
       } else if (c == 'v') {
         const int s = state_of(kv.first);
-        kv.second.d.assign(V.begin() + (size_t)s * d, V.begin() + (size_t)s * d + (vw ? 3 : d));
+        kv.second.d.assign(V.begin() + (size_t)s * d, V.begin() + (size_t)s * d + ((vw || bias) ? 3 : d));
+      } else if (bias && c == 'b' && kv.second.type == T_VEC3) {
+        const int s = state_of(kv.first);
+        kv.second.d.assign(P.begin() + (size_t)s * pd + 9, P.begin() + (size_t)(s + 1) * pd);
       } else if (vw && c == 'w') {
         const int s = state_of(kv.first);
         kv.second.d.assign(V.begin() + (size_t)s * d + 3, V.begin() + (size_t)(s + 1) * d);
       } else {
         const int s = state_of(kv.first);
-        kv.second.d.assign(P.begin() + (size_t)s * pd, P.begin() + (size_t)(s + 1) * pd);
+        kv.second.d.assign(P.begin() + (size_t)s * pd, P.begin() + (size_t)s * pd + (bias ? 9 : pd));
       }
     }
   }
@@ -558,6 +628,108 @@ class LevenbergMarquardtOptimizer : public NonlinearOptimizer {
  private:
   LevenbergMarquardtParams lm_;
   double lambda_;
+};
+
+// ---------------------------------------------------------------- AHRS (gtsam/navigation/AHRSFactor.h, GTSAM 4.0; third party)
+/// gtsam::PreintegratedAhrsMeasurements(biasHat, measuredOmegaCovariance): the constructor matlab/GPAHRSexample.m:188 uses.
+/// integrateMeasurement restates PreintegratedRotation::integrateMeasurement + the covariance propagation of AHRSFactor.cpp:
+///   incrR = Expmap((omega - biasHat) dt), D = ExpmapDerivative(.);  deltaTij += dt;  deltaRij = deltaRij incrR;
+///   delRdelBiasOmega = incrR^T delRdelBiasOmega - D dt;  preintMeasCov = incrR^T preintMeasCov incrR + gyroCov dt
+class PreintegratedAhrsMeasurements {
+ public:
+  PreintegratedAhrsMeasurements(const Vector3 &biasHat, const Matrix &measuredOmegaCovariance) : bias_hat_(biasHat), gyro_cov_(measuredOmegaCovariance) {
+    if (gyro_cov_.rows != 3 || gyro_cov_.cols != 3) throw std::invalid_argument("measuredOmegaCovariance must be 3 x 3");
+    resetIntegration();
+  }
+  void resetIntegration() {
+    std::memset(st_, 0, sizeof(st_));
+    st_[0] = st_[4] = st_[8] = 1.0;
+    dtij_ = 0.0;
+  }
+  void integrateMeasurement(const Vector3 &measuredOmega, double deltaT) {
+    double th[3], incr[9], D[9];
+    for (int i = 0; i < 3; i++) th[i] = (measuredOmega[i] - bias_hat_[i]) * deltaT;
+    expmap(th, incr, D);
+    dtij_ += deltaT;
+    double t[9], u[9];
+    mm(st_, incr, t, false);
+    std::memcpy(st_, t, sizeof(t));                                   // deltaRij
+    mm(incr, st_ + 9, t, true);
+    for (int i = 0; i < 9; i++) st_[9 + i] = t[i] - D[i] * deltaT;     // delRdelBiasOmega
+    mm(incr, st_ + 18, t, true);
+    mm(t, incr, u, false);
+    for (int i = 0; i < 9; i++) st_[18 + i] = u[i] + gyro_cov_.a[i] * deltaT;   // preintMeasCov
+  }
+  double deltaTij() const { return dtij_; }
+  Rot3 deltaRij() const { Rot3 r; std::memcpy(r.R, st_, sizeof(r.R)); return r; }
+  Matrix delRdelBiasOmega() const { return mat(st_ + 9); }
+  Matrix preintMeasCov() const { return mat(st_ + 18); }
+  const Vector3 &biasHat() const { return bias_hat_; }
+  /// [deltaRij (9) | delRdelBiasOmega (9) | biasHat (3) | deltaTij | preintMeasCov (9)]: the arguments of gpslam_hip_add_ahrs
+  std::vector<double> packed() const {
+    std::vector<double> m(st_, st_ + 18);
+    m.insert(m.end(), bias_hat_.begin(), bias_hat_.end());
+    m.push_back(dtij_);
+    m.insert(m.end(), st_ + 18, st_ + 27);
+    return m;
+  }
+ private:
+  static Matrix mat(const double *p) { Matrix m(3, 3); std::memcpy(m.a.data(), p, 9 * sizeof(double)); return m; }
+  static void mm(const double *A, const double *B, double *C, bool transA) {
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) {
+        double s = 0.0;
+        for (int k = 0; k < 3; k++) s += (transA ? A[3 * k + i] : A[3 * i + k]) * B[3 * k + j];
+        C[3 * i + j] = s;
+      }
+  }
+  /// Rot3::Expmap (Rodrigues) + SO3::ExpmapDerivative with GTSAM's theta^2 <= epsilon branches
+  static void expmap(const double *w, double *R, double *J) {
+    const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+    const double W[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+    const double I[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (th2 <= 2.220446049250313e-16) {
+      for (int i = 0; i < 9; i++) { R[i] = I[i] + W[i]; J[i] = I[i]; }
+      return;
+    }
+    const double th = std::sqrt(th2);
+    double K[9], KK[9];
+    for (int i = 0; i < 9; i++) K[i] = W[i] / th;
+    mm(K, K, KK, false);
+    const double sh = std::sin(th / 2.0), a = std::sin(th), b = 2.0 * sh * sh;
+    for (int i = 0; i < 9; i++) {
+      R[i] = I[i] + a * K[i] + b * KK[i];
+      J[i] = I[i] - ((1.0 - std::cos(th)) / th) * K[i] + (1.0 - std::sin(th) / th) * KK[i];
+    }
+  }
+  Vector3 bias_hat_;
+  Matrix gyro_cov_;
+  double st_[27];
+  double dtij_ = 0.0;
+};
+
+/// gtsam::AHRSFactor(rot_i, rot_j, bias, preintegratedMeasurements, omegaCoriolis) -- matlab/GPAHRSexample.m:131-137.
+/// Evaluated on the device (gpslam_hip_add_ahrs); the bias key must carry the index of rot_i (b_{k-1} with x_{k-1}).
+class AHRSFactor : public NonlinearFactor {
+ public:
+  AHRSFactor(Key rot_i, Key rot_j, Key bias, const PreintegratedAhrsMeasurements &pim, const Vector3 &omegaCoriolis = Vector3()) {
+    d_.type = detail::F_AHRS; d_.manifold = GPSLAM_ROT3_BIAS;
+    d_.k[0] = rot_i; d_.k[2] = rot_j; d_.k[4] = bias;
+    d_.meas = pim.packed();
+    if (omegaCoriolis[0] != 0.0 || omegaCoriolis[1] != 0.0 || omegaCoriolis[2] != 0.0) d_.aux = {omegaCoriolis[0], omegaCoriolis[1], omegaCoriolis[2]};
+  }
+  GPSLAM_FACTOR_BOILERPLATE(AHRSFactor, 3)
+};
+
+/// gtsam::Rot3AttitudeFactor(key, nZ, model, bRef) -- matlab/GPAHRSexample.m:160-163
+class Rot3AttitudeFactor : public NonlinearFactor {
+ public:
+  Rot3AttitudeFactor(Key key, const Unit3 &nZ, const SharedNoiseModel &model, const Unit3 &bRef = Unit3(0, 0, 1)) {
+    d_.type = detail::F_ATTITUDE; d_.k[0] = key;
+    d_.aux = {nZ.p[0], nZ.p[1], nZ.p[2], bRef.p[0], bRef.p[1], bRef.p[2]};
+    d_.sig = sigmas_of(model);
+  }
+  GPSLAM_FACTOR_BOILERPLATE(Rot3AttitudeFactor, 1)
 };
 
 }  // namespace gtsam

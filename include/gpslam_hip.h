@@ -37,7 +37,14 @@ extern "C" {
 
 typedef struct gpslam_hip_handle gpslam_hip_handle;
 
-enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 3, GPSLAM_ROT3 = 4 };
+enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 3, GPSLAM_ROT3 = 4, GPSLAM_ROT3_BIAS = 5 };
+/* GPSLAM_ROT3_BIAS: the AHRS state of matlab/GPAHRSexample.m:69-202 (gtsam keys x_i Rot3, v_i Vector3, b_i Vector3):
+ *   pose slot (12 doubles) = [R row-major (9) | gyroscope bias b_i (3)],  tangent (dtheta, db)
+ *   velocity slot (6)      = [angular velocity v_i (3) | 0 0 0],           the three pads stay zero
+ * set_qc takes the 3 x 3 Qc of GaussianProcessPriorRot3; add_gp_priors = GaussianProcessPriorRot3 on (x, v);
+ * add_pose_priors = [PriorFactorRot3 ; PriorFactorVector(b)] and add_between = [BetweenFactorRot3 ; BetweenFactorVector(b)]
+ * with 6 sigmas each, INFINITY switching a half off; add_vel_priors: 6 sigmas, the last three ignored;
+ * add_interp_attitude = GPInterpolatedAttitudeFactorRot3; gpslam_hip_add_ahrs = gtsam::AHRSFactor. */
 /* retract chart of the state update (and, for POSE2, of PriorFactor / BetweenFactor's Local):
  * EXPMAP       x Exp(delta) on every manifold (GTSAM >= 4.1 defaults; GTSAM_ROT3_EXPMAP / GTSAM_POSE3_EXPMAP /
  *              SLOW_BUT_CORRECT_EXPMAP builds of 4.0)
@@ -152,6 +159,16 @@ int gpslam_hip_add_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx
 /* GPInterpolatedAttitudeFactorRot3(keys, dt, tau, Qc, model, nZ, bRef) -- GPInterpolatedAttitudeFactorRot3.h:44-51 */
 int gpslam_hip_add_interp_attitude(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *nZ,
                                    const double *bRef, const double *sigma, const double *dt, const double *tau);
+/* gtsam::AHRSFactor(x_left, x_left+1, b_left, PreintegratedAhrsMeasurements, omegaCoriolis) -- GTSAM 4.0
+ * gtsam/navigation/AHRSFactor.h (third party; call site matlab/GPAHRSexample.m:128-137).  GPSLAM_ROT3_BIAS handles only.
+ * Per factor, the state of the pre-integration after its last integrateMeasurement():
+ *   delta_R (9, deltaRij row-major), dR_dbias (9, delRdelBiasOmega), bias_hat (3), delta_tij (1),
+ *   cov (9, preintMeasCov: the factor's Gaussian noise model, SPD)
+ * omega_coriolis: 3 doubles shared by the call, or NULL (the recipe passes zeros).
+ * gpslam_amd/host/gpslam_host.hpp and gpslam_amd/ahrs.py restate PreintegratedAhrsMeasurements::integrateMeasurement. */
+int gpslam_hip_add_ahrs(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *delta_R,
+                        const double *dR_dbias, const double *bias_hat, const double *delta_tij, const double *cov,
+                        const double *omega_coriolis);
 /* GPInterpolatedGPSFactorPose3 -- gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54 */
 int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas, const double *dt, const double *tau, const double *sensor);
@@ -189,7 +206,7 @@ int gpslam_hip_linearize_gp(gpslam_hip_handle *h, double *errors, double *jacobi
  * H5 (landmark, zero padded to 3)] (may be NULL); single-state factors leave H3 / H4 zero, factors without a landmark H5
  * (e.g. gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98, GPInterpolatedAttitudeFactorRot3.h:61-83).  Returns the count. */
 enum { GPSLAM_MEAS_INTERP_RANGE = 0, GPSLAM_MEAS_RANGE = 1, GPSLAM_MEAS_INTERP_ATTITUDE = 2, GPSLAM_MEAS_INTERP_GPS = 3,
-       GPSLAM_MEAS_ODOMETRY2D = 4, GPSLAM_MEAS_BEARING_RANGE = 5, GPSLAM_MEAS_INTERP_PROJECTION = 6 };
+       GPSLAM_MEAS_ODOMETRY2D = 4, GPSLAM_MEAS_BEARING_RANGE = 5, GPSLAM_MEAS_INTERP_PROJECTION = 6, GPSLAM_MEAS_AHRS = 7 };
 int gpslam_hip_linearize_meas(gpslam_hip_handle *h, int32_t kind, double *errors, double *jacobians);
 /* total graph error 0.5 * sum |R e|^2 (NonlinearFactorGraph::error) */
 int gpslam_hip_error(gpslam_hip_handle *h, double *err);

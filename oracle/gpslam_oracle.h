@@ -42,7 +42,12 @@ extern "C" {
 #endif
 
 /* manifold kinds (same numbering as include/gpslam_hip.h) */
-enum { ORC_LINEAR2 = 0, ORC_LINEAR3 = 1, ORC_POSE2 = 2, ORC_POSE3 = 3, ORC_ROT3 = 4 };
+enum { ORC_LINEAR2 = 0, ORC_LINEAR3 = 1, ORC_POSE2 = 2, ORC_POSE3 = 3, ORC_ROT3 = 4, ORC_ROT3_BIAS = 5 };
+/* ORC_ROT3_BIAS: the AHRS state of matlab/GPAHRSexample.m (x_i Rot3, v_i angular velocity, b_i gyro bias) in the 12-wide
+ * layout of include/gpslam_hip.h: pose = [R (9) | bias (3)], velocity = [omega (3) | three pads].
+ * PARITY UNPINNED against GTSAM for the AHRSFactor (gtsam/navigation/AHRSFactor.cpp, GTSAM 4.0, not under
+ * /root/reference): restated from the published algorithm; pinned by 50-digit evaluation and finite differences of the
+ * same formulas (tests/golden/highprec_pins.json). */
 enum { ORC_CHART_EXPMAP = 0, ORC_CHART_FIRST_ORDER = 1 };
 
 /* ---- Lie groups (orc_lie.c) ---- */
@@ -174,6 +179,14 @@ int orc_get_threads(void);
 void orc_retract(int kind, int chart, const double *x, const double *delta, double *out);
 void orc_local(int kind, int chart, const double *x, const double *y, double *v);
 void orc_prior_factor(int kind, int chart, const double *prior, const double *x, double *e, double *H);
+/* gtsam::AHRSFactor::evaluateError (GTSAM 4.0, third party).  prm[25] = deltaRij (9) | delRdelBiasOmega (9) | biasHat (3) |
+ * deltaTij | omegaCoriolis (3); e[3]; H1 = d/dRi, H2 = d/dRj, H3 = d/dbias (3 x 3 each, may be NULL). */
+void orc_ahrs_factor(const double *Ri, const double *Rj, const double *bias, const double *prm, double *e, double *H1,
+                     double *H2, double *H3);
+/* PreintegratedAhrsMeasurements::integrateMeasurement (GTSAM 4.0): st[28] = deltaRij (9) | delRdelBiasOmega (9) |
+ * deltaTij | preintMeasCov (9); start from orc_ahrs_preint_reset. */
+void orc_ahrs_preint_reset(double *st);
+void orc_ahrs_preint_integrate(double *st, const double *bias_hat, const double *gyro_cov, const double *omega, double dt);
 void orc_between_factor(int kind, int chart, const double *measured, const double *x1, const double *x2, double *e,
                         double *H1, double *H2);
 
@@ -243,6 +256,8 @@ int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left
 /* errors: count x rows (unwhitened); jac: count x 4 x rows x d row-major (H1..H4 for GP priors) */
 int orc_chain_linearize_gp(const orc_chain *c, double *errors, double *jac);
 /* unwhitened e and [H1 H2 | H3 H4 | H5] of the measurement factors of one type (5 + GPSLAM_MEAS_* of the HIP ABI) */
+int orc_chain_add_ahrs(orc_chain *c, int count, const int32_t *left, const double *delta_R, const double *dR_dbias,
+                       const double *bias_hat, const double *delta_tij, const double *cov, const double *omega_coriolis);
 int orc_chain_linearize_meas(const orc_chain *c, int type, double *errors, double *jac);
 int orc_chain_error(const orc_chain *c, double *err);
 int orc_chain_iterate_gn(orc_chain *c, orc_stats *st);

@@ -13,10 +13,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-LINEAR2, LINEAR3, POSE2, POSE3, ROT3 = 0, 1, 2, 3, 4
+LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
-POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9}
-TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3}
+POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9, ROT3_BIAS: 12}
+TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3, ROT3_BIAS: 6}
 
 
 def build(force=False):
@@ -129,6 +129,23 @@ def rot3_ypr(y, p, r):
 
 def pose3(ypr, t):
     return np.concatenate([rot3_ypr(*ypr), A(t)])
+
+
+def ahrs_factor(Ri, Rj, bias, prm, jac=True):
+    """gtsam::AHRSFactor::evaluateError; prm = [deltaRij 9 | delRdelBiasOmega 9 | biasHat 3 | deltaTij | omegaCoriolis 3]."""
+    e, H1, H2, H3 = np.zeros(3), np.zeros((3, 3)), np.zeros((3, 3)), np.zeros((3, 3))
+    call("orc_ahrs_factor", A(Ri), A(Rj), A(bias), A(prm), e, H1 if jac else None, H2 if jac else None, H3 if jac else None)
+    return e, H1, H2, H3
+
+
+def ahrs_preintegrate(omegas, dts, bias_hat, gyro_cov):
+    """PreintegratedAhrsMeasurements after integrating the given samples: (deltaRij, delRdelBiasOmega, deltaTij, cov)."""
+    st = np.zeros(28)
+    call("orc_ahrs_preint_reset", st)
+    bh, gc = A(bias_hat), A(gyro_cov)
+    for w, dt in zip(np.asarray(omegas, dtype=np.float64), dts):
+        call("orc_ahrs_preint_integrate", st, bh, gc, A(w), float(dt))
+    return st[0:9].reshape(3, 3).copy(), st[9:18].reshape(3, 3).copy(), float(st[18]), st[19:28].reshape(3, 3).copy()
 
 
 def lambda_psi(D, Qc, dt, tau):
@@ -294,6 +311,11 @@ class Chain:
         left, _ = _i(left)
         return call("orc_chain_add_interp_attitude", self._h, len(left), left, A(nZ), A(bRef), A(sigma), A(dt), A(tau))
 
+    def add_ahrs(self, left, delta_R, dR_dbias, bias_hat, delta_tij, cov, omega_coriolis=None):
+        left, _ = _i(left)
+        return call("orc_chain_add_ahrs", self._h, len(left), left, A(delta_R), A(dR_dbias), A(bias_hat), A(delta_tij),
+                    A(cov), None if omega_coriolis is None else A(omega_coriolis))
+
     def add_interp_gps(self, left, measured, sigmas, dt, tau, sensor=None):
         left, _ = _i(left)
         return call("orc_chain_add_interp_gps", self._h, len(left), left, A(measured), A(sigmas), A(dt), A(tau),
@@ -323,7 +345,7 @@ class Chain:
         call("orc_chain_linearize_gp", self._h, e, H)
         return e, H
 
-    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2}
+    MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2, 7: 3}
 
     def linearize_meas(self, kind, count):
         """Unwhitened (e, J) per factor of one measurement kind (the HIP ABI's GPSLAM_MEAS_* numbering)."""

@@ -24,7 +24,7 @@
 
 enum {
   F_GP = 0, F_POSE_PRIOR, F_VEL_PRIOR, F_BETWEEN, F_LM_PRIOR, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT,
-  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ
+  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ, F_AHRS
 };
 
 typedef struct {
@@ -37,6 +37,7 @@ typedef struct {
   double aux[6];    /* attitude: nZ(3), bRef(3) */
   int has_sensor;
   double sensor[12];
+  double ahrs[34];  /* F_AHRS: the 25 parameters of orc_ahrs_factor + square-root information R (3 x 3 upper triangular) */
 } orc_factor;
 
 struct orc_chain {
@@ -85,7 +86,16 @@ void orc_chain_destroy(orc_chain *c) {
   free(c->pose); free(c->vel); free(c->lmk); free(c->f); free(c);
 }
 
-int orc_chain_set_qc(orc_chain *c, const double *Qc) { orc_copy(c->d * c->d, Qc, c->Qc); return 0; }
+int orc_chain_set_qc(orc_chain *c, const double *Qc) {
+  if (c->kind == ORC_ROT3_BIAS) {   /* 3 x 3 Qc of GaussianProcessPriorRot3; bias / pad components: identity (see gp_eval) */
+    orc_eye(6, c->Qc);
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) c->Qc[i * 6 + j] = Qc[i * 3 + j];
+    return 0;
+  }
+  orc_copy(c->d * c->d, Qc, c->Qc);
+  return 0;
+}
 int orc_chain_set_velocity_world(orc_chain *c, int on) {
   if (on && c->kind != ORC_POSE3) return -2;
   c->vw = on ? 1 : 0;
@@ -251,6 +261,27 @@ int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left
   return 0;
 }
 
+int orc_chain_add_ahrs(orc_chain *c, int count, const int32_t *left, const double *delta_R, const double *dR_dbias,
+                       const double *bias_hat, const double *delta_tij, const double *cov, const double *omega_coriolis) {
+  if (c->kind != ORC_ROT3_BIAS) return -2;
+  for (int k = 0; k < count; k++) {
+    orc_factor *f = new_factor(c, F_AHRS);
+    f->idx = left[k];
+    orc_copy(9, delta_R + 9 * (size_t)k, f->ahrs);
+    orc_copy(9, dR_dbias + 9 * (size_t)k, f->ahrs + 9);
+    orc_copy(3, bias_hat + 3 * (size_t)k, f->ahrs + 18);
+    f->ahrs[21] = delta_tij[k];
+    if (omega_coriolis) orc_copy(3, omega_coriolis, f->ahrs + 22);
+    /* noiseModel::Gaussian::Covariance(preintMeasCov): R with R^T R = cov^-1 */
+    double inv[9];
+    if (orc_inv(3, cov + 9 * (size_t)k, inv)) return -1;
+    orc_copy(9, inv, f->ahrs + 25);
+    if (orc_chol_upper(3, f->ahrs + 25)) return -1;
+    f->sig[0] = f->sig[1] = f->sig[2] = 1.0;
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------ factor evaluation */
 
 static void gp_eval(const orc_chain *c, const orc_factor *f, double *e, double *H1, double *H2, double *H3, double *H4) {
@@ -265,6 +296,24 @@ static void gp_eval(const orc_chain *c, const orc_factor *f, double *e, double *
       else orc_gp_prior_pose3(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4);
       break;
     case ORC_ROT3: orc_gp_prior_rot3(p1, v1, p2, v2, f->dt, e, H1, H2, H3, H4); break;
+    case ORC_ROT3_BIAS: {
+      /* GaussianProcessPriorRot3 on (x, v) (GPAHRSexample.m:149-152); the bias has no GP prior; the pads are pinned by
+       * unit rows: e = [r - v1 dt; pad1; v2 - v1; pad2], rows / columns in the 6-wide (theta, bias | omega, pad) layout */
+      double e3[6], A1[18], A2[18], A3[18], A4[18];
+      orc_gp_prior_rot3(p1, v1, p2, v2, f->dt, e3, H1 ? A1 : NULL, H2 ? A2 : NULL, H3 ? A3 : NULL, H4 ? A4 : NULL);
+      for (int i = 0; i < 3; i++) { e[i] = e3[i]; e[3 + i] = v1[3 + i]; e[6 + i] = e3[3 + i]; e[9 + i] = v2[3 + i]; }
+      double *H[4] = {H1, H2, H3, H4};
+      const double *A[4] = {A1, A2, A3, A4};
+      for (int m = 0; m < 4; m++) {
+        if (!H[m]) continue;
+        orc_zero(72, H[m]);
+        for (int half = 0; half < 2; half++)
+          for (int r = 0; r < 3; r++)
+            for (int q = 0; q < 3; q++) H[m][(6 * half + r) * 6 + q] = A[m][(3 * half + r) * 3 + q];
+      }
+      if (H2) for (int q = 0; q < 3; q++) H2[(3 + q) * 6 + 3 + q] = 1.0;     /* d pad1 / d pad1 */
+      if (H4) for (int q = 0; q < 3; q++) H4[(9 + q) * 6 + 3 + q] = 1.0;     /* d pad2 / d pad2 */
+    } break;
   }
 }
 
@@ -365,13 +414,40 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
       if (want_jac) { PUT(JL, H1, 0, d); PUT(Jm, H5, 0, ld); }
       break;
     case F_INTERP_ATT:
-      if (c->kind != ORC_ROT3) return -2;
       rows = 2;
+      if (c->kind == ORC_ROT3_BIAS) {   /* the rotation part of the AHRS state; Qc = the 3 x 3 corner */
+        double Q3[9];
+        for (int i = 0; i < 3; i++)
+          for (int j = 0; j < 3; j++) Q3[i * 3 + j] = c->Qc[i * 6 + j];
+        if (orc_calcLambda(3, Q3, f->dt, f->tau, Lam) || orc_calcPsi(3, Q3, f->dt, f->tau, Psi)) return -1;
+        orc_interp_attitude_rot3(Lam, Psi, f->aux, f->aux + 3, p1, v1, p2, v2, e, H1, H2, H3, H4);
+        *uses_right = 1;
+        if (want_jac) { PUT(JL, H1, 0, 3); PUT(JL, H2, d, 3); PUT(JR, H3, 0, 3); PUT(JR, H4, d, 3); }
+        break;
+      }
+      if (c->kind != ORC_ROT3) return -2;
       if (orc_calcLambda(d, c->Qc, f->dt, f->tau, Lam) || orc_calcPsi(d, c->Qc, f->dt, f->tau, Psi)) return -1;
       orc_interp_attitude_rot3(Lam, Psi, f->aux, f->aux + 3, p1, v1, p2, v2, e, H1, H2, H3, H4);
       *uses_right = 1;
       if (want_jac) { PUT(JL, H1, 0, d); PUT(JL, H2, d, d); PUT(JR, H3, 0, d); PUT(JR, H4, d, d); }
       break;
+    case F_AHRS: {
+      if (c->kind != ORC_ROT3_BIAS) return -2;
+      rows = 3;
+      double A[9], B[9], C3[9], t[9];
+      orc_ahrs_factor(p1, p2, p1 + 9, f->ahrs, e, want_jac ? A : NULL, want_jac ? B : NULL, want_jac ? C3 : NULL);
+      *uses_right = 1;
+      /* Gaussian noise model: whiten by the full R (the diagonal step below then multiplies by 1) */
+      const double *R = f->ahrs + 25;
+      double we3[3];
+      orc_mm(3, 3, 1, R, e, we3);
+      orc_copy(3, we3, e);
+      if (want_jac) {
+        orc_mm(3, 3, 3, R, A, t); PUT(JL, t, 0, 3);
+        orc_mm(3, 3, 3, R, C3, t); PUT(JL, t, 3, 3);
+        orc_mm(3, 3, 3, R, B, t); PUT(JR, t, 0, 3);
+      }
+    } break;
     case F_INTERP_GPS:
       if (c->kind != ORC_POSE3) return -2;
       rows = 3;
@@ -462,6 +538,15 @@ int orc_chain_linearize_meas(const orc_chain *c, int type, double *errors, doubl
     int ur, ul;
     int rows = factor_eval(c, f, 1, we, JL, JR, Jm, &ur, &ul);
     if (rows < 0) return rows;
+    if (type == F_AHRS) {   /* full (non-diagonal) whitening: evaluate the factor itself for the unwhitened values */
+      double A[9], B[9], C3[9];
+      const double *p1 = c->pose + (size_t)f->idx * c->pd;
+      orc_ahrs_factor(p1, p1 + c->pd, p1 + 9, f->ahrs, we, A, B, C3);
+      orc_zero(MAXR * b, JL);
+      orc_zero(MAXR * b, JR);
+      for (int r = 0; r < 3; r++)
+        for (int q = 0; q < 3; q++) { JL[r * b + q] = A[r * 3 + q]; JL[r * b + 3 + q] = C3[r * 3 + q]; JR[r * b + q] = B[r * 3 + q]; }
+    }
     for (int r = 0; r < rows; r++) {
       const double sg = f->sig[r];
       errors[k * rows + r] = we[r] * sg;

@@ -300,6 +300,7 @@ int orc_pose_dim(int kind) {
     case ORC_POSE2: return 3;
     case ORC_POSE3: return 12;
     case ORC_ROT3: return 9;
+    case ORC_ROT3_BIAS: return 12;
     default: return -1;
   }
 }
@@ -310,6 +311,7 @@ int orc_tangent_dim(int kind) {
     case ORC_POSE2: return 3;
     case ORC_POSE3: return 6;
     case ORC_ROT3: return 3;
+    case ORC_ROT3_BIAS: return 6;
     default: return -1;
   }
 }
@@ -375,6 +377,10 @@ void orc_retract(int kind, int chart, const double *x, const double *delta, doub
       else orc_rot3_expmap(delta, ex, NULL);
       orc_rot3_compose(x, ex, out, NULL, NULL);
     } break;
+    case ORC_ROT3_BIAS:   /* SO(3) x R^3: rotation by the Rot3 chart, bias additive */
+      orc_retract(ORC_ROT3, chart, x, delta, out);
+      for (int i = 0; i < 3; i++) out[9 + i] = x[9 + i] + delta[3 + i];
+      break;
     default: break;
   }
 }
@@ -390,7 +396,20 @@ void orc_local(int kind, int chart, const double *x, const double *y, double *v)
     case ORC_POSE2: { double inv[3], h[3]; orc_pose2_inverse(x, inv, NULL); orc_pose2_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
     case ORC_POSE3: { double inv[12], h[12]; orc_pose3_inverse(x, inv, NULL); orc_pose3_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
     case ORC_ROT3: { double inv[9], h[9]; orc_rot3_inverse(x, inv, NULL); orc_rot3_compose(inv, y, h, NULL, NULL); chart_local(kind, chart, h, v, NULL); } break;
+    case ORC_ROT3_BIAS:
+      orc_local(ORC_ROT3, chart, x, y, v);
+      for (int i = 0; i < 3; i++) v[3 + i] = y[9 + i] - x[9 + i];
+      break;
     default: break;
+  }
+}
+
+/* embed a 3 x 3 rotation block and +-identity on the bias into the 6 x 6 Jacobian of the (rotation, bias) product */
+static void embed_rb(const double *H3, double sgn, double *H) {
+  orc_zero(36, H);
+  for (int r = 0; r < 3; r++) {
+    for (int q = 0; q < 3; q++) H[r * 6 + q] = H3[r * 3 + q];
+    H[(3 + r) * 6 + 3 + r] = sgn;
   }
 }
 
@@ -405,6 +424,12 @@ void orc_prior_factor(int kind, int chart, const double *prior, const double *x,
     case ORC_POSE2: { double inv[3], h[3]; orc_pose2_inverse(prior, inv, NULL); orc_pose2_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
     case ORC_POSE3: { double inv[12], h[12]; orc_pose3_inverse(prior, inv, NULL); orc_pose3_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
     case ORC_ROT3: { double inv[9], h[9]; orc_rot3_inverse(prior, inv, NULL); orc_rot3_compose(inv, x, h, NULL, NULL); chart_local(kind, chart, h, e, H); } break;
+    case ORC_ROT3_BIAS: {   /* [PriorFactorRot3; PriorFactorVector(bias)] (GPAHRSexample.m:118-121) */
+      double H3[9];
+      orc_prior_factor(ORC_ROT3, chart, prior, x, e, H ? H3 : NULL);
+      for (int i = 0; i < 3; i++) e[3 + i] = x[9 + i] - prior[9 + i];
+      if (H) embed_rb(H3, 1.0, H);
+    } break;
     default: break;
   }
 }
@@ -449,6 +474,85 @@ void orc_between_factor(int kind, int chart, const double *measured, const doubl
       if (H1) { double hxT[9]; orc_tr(3, 3, hx, hxT); orc_mm(3, 3, 3, Hl, hxT, H1); orc_scale(9, -1.0, H1); }   /* Ad(R^-1) = R^T */
       if (H2) orc_copy(9, Hl, H2);
     } break;
+    case ORC_ROT3_BIAS: {   /* [BetweenFactorRot3; BetweenFactorVector(bias)] (GPAHRSexample.m:143) */
+      double A[9], B[9];
+      orc_between_factor(ORC_ROT3, chart, measured, x1, x2, e, H1 ? A : NULL, H2 ? B : NULL);
+      for (int i = 0; i < 3; i++) e[3 + i] = (x2[9 + i] - x1[9 + i]) - measured[9 + i];
+      if (H1) embed_rb(A, -1.0, H1);
+      if (H2) embed_rb(B, 1.0, H2);
+    } break;
     default: break;
   }
+}
+
+/* ---------------------------------------------------------------- gtsam::AHRSFactor (GTSAM 4.0, third party)
+ * gtsam/navigation/AHRSFactor.cpp: PreintegratedAhrsMeasurements::integrateMeasurement / predict and
+ * AHRSFactor::evaluateError; gtsam/navigation/PreintegratedRotation.cpp: integrateMeasurement, biascorrectedDeltaRij,
+ * integrateCoriolis.  Call sites: matlab/GPAHRSexample.m:128-137 (integrate, factor), :188 (new pim).
+ * NOT under /root/reference -- restated from the published algorithm:
+ *   incrR = Exp((omega_meas - biasHat) dt), D = ExpmapDerivative(that);  deltaTij += dt;  deltaRij = deltaRij incrR;
+ *   delRdelBiasOmega = incrR^T delRdelBiasOmega - D dt;   preintMeasCov = incrR^T preintMeasCov incrR + gyroCov dt
+ *   predict(bias) = Log(deltaRij Exp(delRdelBiasOmega (bias - biasHat)))
+ *   fR = Log(Exp(predict - Ri^T omegaCoriolis deltaTij)^T Ri^T Rj) */
+void orc_ahrs_preint_reset(double *st) {
+  orc_zero(28, st);
+  st[0] = st[4] = st[8] = 1.0;
+}
+void orc_ahrs_preint_integrate(double *st, const double *bias_hat, const double *gyro_cov, const double *omega, double dt) {
+  double th[3], incr[9], D[9], incrT[9], t[9], u[9];
+  for (int i = 0; i < 3; i++) th[i] = (omega[i] - bias_hat[i]) * dt;
+  orc_rot3_expmap(th, incr, D);
+  st[18] += dt;
+  orc_mm(3, 3, 3, st, incr, t);
+  orc_copy(9, t, st);
+  orc_tr(3, 3, incr, incrT);
+  orc_mm(3, 3, 3, incrT, st + 9, t);
+  for (int i = 0; i < 9; i++) st[9 + i] = t[i] - D[i] * dt;
+  orc_mm(3, 3, 3, incrT, st + 19, t);     /* Fr = d(deltaRij incrR)/d deltaRij = incrR^T */
+  orc_mm(3, 3, 3, t, incr, u);
+  for (int i = 0; i < 9; i++) st[19 + i] = u[i] + gyro_cov[i] * dt;
+}
+
+void orc_ahrs_factor(const double *Ri, const double *Rj, const double *bias, const double *prm, double *e, double *H1,
+                     double *H2, double *H3) {
+  const double *dR = prm, *D = prm + 9, *bh = prm + 18, dtij = prm[21], *wc = prm + 22;
+  double binc[3], bio[3], ex[9], Jbio[9], bc[9], om[3], Jom[9];
+  for (int i = 0; i < 3; i++) binc[i] = bias[i] - bh[i];
+  orc_mm(3, 3, 1, D, binc, bio);
+  orc_rot3_expmap(bio, ex, Jbio);                 /* deltaRij.expmap(v, none, H): H = ExpmapDerivative(v) */
+  orc_mm(3, 3, 3, dR, ex, bc);
+  orc_rot3_logmap(bc, om, Jom);
+  double RiT[9], cor[3], com[3];
+  orc_tr(3, 3, Ri, RiT);
+  orc_mm(3, 3, 1, RiT, wc, cor);
+  for (int i = 0; i < 3; i++) { cor[i] *= dtij; com[i] = om[i] - cor[i]; }
+  double cdR[9], Dexp[9], cdRT[9], aR[9], fRrot[9], Dlog[9];
+  orc_rot3_expmap(com, cdR, Dexp);
+  orc_mm(3, 3, 3, RiT, Rj, aR);
+  orc_tr(3, 3, cdR, cdRT);
+  orc_mm(3, 3, 3, cdRT, aR, fRrot);
+  orc_rot3_logmap(fRrot, e, Dlog);
+  if (H1 || H3) {
+    double fRt[9], t[9], u[9];
+    orc_tr(3, 3, fRrot, fRt);
+    if (H1) {
+      double S[9], aRT[9];
+      orc_skew(cor, S);
+      orc_mm(3, 3, 3, Dexp, S, t);               /* -D_coriolis */
+      orc_mm(3, 3, 3, fRt, t, u);
+      orc_tr(3, 3, aR, aRT);
+      for (int i = 0; i < 9; i++) u[i] -= aRT[i];
+      orc_mm(3, 3, 3, Dlog, u, H1);
+    }
+    if (H3) {
+      double v[9];
+      orc_mm(3, 3, 3, Jbio, D, t);               /* biascorrectedDeltaRij's H */
+      orc_mm(3, 3, 3, Jom, t, u);                /* predict's H */
+      orc_mm(3, 3, 3, Dexp, u, t);               /* JbiasOmega */
+      orc_mm(3, 3, 3, fRt, t, v);
+      orc_mm(3, 3, 3, Dlog, v, H3);
+      orc_scale(9, -1.0, H3);
+    }
+  }
+  if (H2) orc_copy(9, Dlog, H2);
 }

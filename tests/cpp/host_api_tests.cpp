@@ -7,6 +7,8 @@
 // (Optimization) and gpslam/slam/tests/testGPInterpolatedProjectionFactorPose3.cpp (optimization).
 #include <cmath>
 #include <cstdio>
+#include <cstring>
+#include <vector>
 #include <stdexcept>
 
 #include "../../gpslam_amd/host/gpslam_host.hpp"
@@ -402,6 +404,128 @@ static void test_error_conventions() {
   EXPECT(threw);
 }
 
+// matlab/GPAHRSexample.m in miniature, built with the GTSAM-named classes (PriorFactor<Rot3>, PriorFactor<Vector3> on a 'b'
+// key, AHRSFactor + PreintegratedAhrsMeasurements, BetweenFactor<Vector3>, GaussianProcessPriorRot3, Rot3AttitudeFactor,
+// GPInterpolatedAttitudeFactorRot3) and, with the same numbers, through the C ABI directly: identical results.
+static Rot3 rot_exp(double wx, double wy, double wz) {
+  const double th = std::sqrt(wx * wx + wy * wy + wz * wz);
+  Rot3 r;
+  if (th < 1e-12) return r;
+  const double k[3] = {wx / th, wy / th, wz / th}, s = std::sin(th), c = 1.0 - std::cos(th);
+  const double K[9] = {0, -k[2], k[1], k[2], 0, -k[0], -k[1], k[0], 0};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      double kk = 0.0;
+      for (int q = 0; q < 3; q++) kk += K[3 * i + q] * K[3 * q + j];
+      r.R[3 * i + j] = (i == j ? 1.0 : 0.0) + s * K[3 * i + j] + c * kk;
+    }
+  return r;
+}
+static void test_ahrs_graph_with_bias_states() {
+  const int N = 24;
+  const double dt = 0.01, w[3] = {0.3, -0.2, 0.5}, bt[3] = {0.004, -0.003, 0.002};
+  auto Qc_model = noiseModel::Gaussian::Covariance(1e4 * Matrix::Identity(3));
+  auto acc_model = noiseModel::Isotropic::Sigma(2, 0.1);
+  Matrix gyro_cov = 1e-3 * Matrix::Identity(3);
+  NonlinearFactorGraph graph;
+  Values init;
+  std::vector<Rot3> truth;
+  for (int k = 0; k < N; k++) truth.push_back(rot_exp(w[0] * k * dt, w[1] * k * dt, w[2] * k * dt));
+  auto gravity_in_body = [&](const Rot3 &R) { return Unit3(R.R[6], R.R[7], R.R[8]); };   // R^T (0, 0, 1)
+  graph.add(PriorFactor<Rot3>(Symbol('x', 1), truth[0], noiseModel::Isotropic::Sigma(3, 0.1)));
+  graph.add(PriorFactor<Vector3>(Symbol('b', 1), Vector3{0, 0, 0}, noiseModel::Isotropic::Sigma(3, 1e-2)));
+  // the same factors as plain arrays for the C ABI
+  std::vector<int32_t> left;
+  std::vector<double> dR, D, bh, tij, cov, gpdt, att_nz, att_b, att_sig, att_dt, att_tau;
+  std::vector<int32_t> att_left;
+  for (int k = 1; k < N; k++) {
+    PreintegratedAhrsMeasurements pim(Vector3{0, 0, 0}, gyro_cov);
+    for (int q = 0; q < 2; q++) pim.integrateMeasurement(Vector3{w[0] + bt[0], w[1] + bt[1], w[2] + bt[2]}, dt / 2);
+    graph.add(AHRSFactor(Symbol('x', k), Symbol('x', k + 1), Symbol('b', k), pim));
+    graph.add(BetweenFactor<Vector3>(Symbol('b', k), Symbol('b', k + 1), Vector3{0, 0, 0}, noiseModel::Isotropic::Sigma(3, 1e-4)));
+    graph.add(GaussianProcessPriorRot3(Symbol('x', k), Symbol('v', k), Symbol('x', k + 1), Symbol('v', k + 1), dt, Qc_model));
+    const std::vector<double> m = pim.packed();
+    left.push_back(k - 1);
+    dR.insert(dR.end(), m.begin(), m.begin() + 9); D.insert(D.end(), m.begin() + 9, m.begin() + 18);
+    bh.insert(bh.end(), m.begin() + 18, m.begin() + 21); tij.push_back(m[21]); cov.insert(cov.end(), m.begin() + 22, m.end());
+    gpdt.push_back(dt);
+    const Unit3 g = gravity_in_body(truth[k]);
+    double tau = 1.0, d_t = 1.0;   // Rot3AttitudeFactor on x_{k+1} (the host maps it to tau = delta_t = 1)
+    if (k % 3 == 0) {                // every third one sits inside the interval instead
+      const Rot3 mid = rot_exp(w[0] * (k - 0.6) * dt, w[1] * (k - 0.6) * dt, w[2] * (k - 0.6) * dt);
+      const Unit3 gm = gravity_in_body(mid);
+      graph.add(GPInterpolatedAttitudeFactorRot3(Symbol('x', k), Symbol('v', k), Symbol('x', k + 1), Symbol('v', k + 1), dt, 0.4 * dt, Qc_model,
+                                                 acc_model, Unit3(0, 0, 1), gm));
+      att_b.insert(att_b.end(), gm.p, gm.p + 3); tau = 0.4 * dt; d_t = dt;
+    } else {
+      graph.add(Rot3AttitudeFactor(Symbol('x', k + 1), Unit3(0, 0, 1), acc_model, g));
+      att_b.insert(att_b.end(), g.p, g.p + 3);
+    }
+    att_left.push_back(k - 1); att_nz.insert(att_nz.end(), {0.0, 0.0, 1.0}); att_sig.insert(att_sig.end(), {0.1, 0.1});
+    att_dt.push_back(d_t); att_tau.push_back(tau);
+  }
+  for (int k = 1; k <= N; k++) {
+    init.insert(Symbol('x', k), Rot3());
+    init.insert(Symbol('b', k), Vector3{0, 0, 0});
+    init.insert(Symbol('v', k), Vector3{0, 0, 0});
+  }
+  LevenbergMarquardtOptimizer opt(graph, init);
+  const double e0 = opt.error();
+  opt.optimize();
+  const Values res = opt.values();
+  EXPECT(opt.error() < 1e-3 * e0 && opt.iterations() > 1 && opt.iterations() < 50);
+  for (int k = 1; k <= N; k += 5) EXPECT(nearR(truth[k - 1], res.at<Rot3>(Symbol('x', k)), 0.02));
+  EXPECT(nearV(Vector3{w[0], w[1], w[2]}, res.at<Vector3>(Symbol('v', N / 2)), 0.05));
+  EXPECT(std::fabs(res.at<Vector3>(Symbol('b', N))[0]) < 1e-2);
+
+  // ---- the same problem through the C ABI
+  gpslam_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.manifold = GPSLAM_ROT3_BIAS; cfg.nranks = 1;
+  gpslam_hip_handle *h = nullptr;
+  EXPECT(gpslam_hip_create(&cfg, &h) == 0);
+  std::vector<double> P((size_t)N * 12, 0.0), V((size_t)N * 6, 0.0);
+  for (int k = 0; k < N; k++) P[12 * k] = P[12 * k + 4] = P[12 * k + 8] = 1.0;
+  EXPECT(gpslam_hip_set_states(h, N, P.data(), V.data()) == 0);
+  const double Qc3[9] = {1e4, 0, 0, 0, 1e4, 0, 0, 0, 1e4};
+  EXPECT(gpslam_hip_set_qc(h, Qc3) == 0);
+  const double inf = INFINITY;
+  int32_t zero = 0;
+  {
+    double m[12], sg[6] = {0.1, 0.1, 0.1, inf, inf, inf};
+    std::memcpy(m, truth[0].R, sizeof(double) * 9); m[9] = m[10] = m[11] = 0.0;
+    EXPECT(gpslam_hip_add_pose_priors(h, 1, &zero, m, sg) == 0);
+    double mb[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, sb[6] = {inf, inf, inf, 1e-2, 1e-2, 1e-2};
+    EXPECT(gpslam_hip_add_pose_priors(h, 1, &zero, mb, sb) == 0);
+  }
+  for (int k = 0; k < N - 1; k++) {
+    double mb[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0}, sb[6] = {inf, inf, inf, 1e-4, 1e-4, 1e-4};
+    int32_t l = k;
+    EXPECT(gpslam_hip_add_between(h, 1, &l, mb, sb) == 0);
+  }
+  EXPECT(gpslam_hip_add_ahrs(h, N - 1, left.data(), dR.data(), D.data(), bh.data(), tij.data(), cov.data(), nullptr) == 0);
+  EXPECT(gpslam_hip_add_gp_priors(h, N - 1, left.data(), gpdt.data()) == 0);
+  EXPECT(gpslam_hip_add_interp_attitude(h, N - 1, att_left.data(), att_nz.data(), att_b.data(), att_sig.data(), att_dt.data(), att_tau.data()) == 0);
+  EXPECT(gpslam_hip_compile(h) == 0);
+  double e_abi = 0.0;
+  EXPECT(gpslam_hip_error(h, &e_abi) == 0);
+  EXPECT_NEAR(e_abi, e0, 1e-9 * e0);
+  gpslam_hip_params prm;
+  gpslam_hip_default_params(&prm);
+  prm.use_lm = 1;
+  gpslam_hip_stats st;
+  EXPECT(gpslam_hip_optimize(h, &prm, &st) >= 0);
+  EXPECT_NEAR(st.error_after, opt.error(), 1e-9 * std::max(1e-12, opt.error()) + 1e-15);
+  EXPECT(gpslam_hip_get_states(h, P.data(), V.data()) == 0);
+  for (int k = 0; k < N; k++) {
+    const Rot3 r = res.at<Rot3>(Symbol('x', k + 1));
+    for (int q = 0; q < 9; q++) EXPECT_NEAR(P[12 * k + q], r.R[q], 1e-10);
+    const Vector3 b = res.at<Vector3>(Symbol('b', k + 1)), v = res.at<Vector3>(Symbol('v', k + 1));
+    for (int q = 0; q < 3; q++) { EXPECT_NEAR(P[12 * k + 9 + q], b[q], 1e-10); EXPECT_NEAR(V[6 * k + q], v[q], 1e-9); EXPECT(V[6 * k + 3 + q] == 0.0); }
+  }
+  gpslam_hip_destroy(h);
+}
+
 int main() {
   test_gp_prior_pose3_optimization();
   test_gp_prior_pose2_rot3_linear_optimization();
@@ -412,6 +536,7 @@ int main() {
   test_projection_optimization_and_trajectory_query();
   test_evaluate_error_and_interpolators();
   test_error_conventions();
+  test_ahrs_graph_with_bias_states();
   if (failures == 0) std::printf("host_api_tests: all tests passed\n");
   return failures == 0 ? 0 : 1;
 }

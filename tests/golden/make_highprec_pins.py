@@ -147,6 +147,60 @@ def whitening_case(Qc, dt):
     return dict(Qc=fl(Qc), dt=float(dt), R=fl(L.T))
 
 
+def so3_log(R):
+    th = mp.acos((R[0, 0] + R[1, 1] + R[2, 2] - 1) / 2)
+    k = th / (2 * mp.sin(th)) if th != 0 else mp.mpf(1) / 2
+    return [k * (R[2, 1] - R[1, 2]), k * (R[0, 2] - R[2, 0]), k * (R[1, 0] - R[0, 1])]
+
+
+def ahrs_case(wi, wj, bias, bias_hat, samples, gyro_cov, coriolis):
+    """gtsam::PreintegratedAhrsMeasurements::integrateMeasurement + AHRSFactor::evaluateError (GTSAM 4.0, published
+    algorithm; see oracle/orc_factors.c), value in 50 digits, Jacobians by central differences at h = 1e-20 under the
+    right perturbations Ri Exp(d), Rj Exp(d), bias + d -- independent of the closed-form Jacobian chain."""
+    M = lambda v: [mp.mpf(x) for x in v]
+    wi, wj, bias, bias_hat, coriolis = M(wi), M(wj), M(bias), M(bias_hat), M(coriolis)
+    gc = mp.matrix(gyro_cov)
+    dR, D, dtij, cov = mp.eye(3), mp.zeros(3, 3), mp.mpf(0), mp.zeros(3, 3)
+    for om, dt in samples:
+        dt = mp.mpf(dt)
+        th = [(mp.mpf(om[i]) - bias_hat[i]) * dt for i in range(3)]
+        incr = mp.expm(skew(th))
+        dtij += dt
+        dR = dR * incr
+        D = incr.T * D - series_jr(skew(th)) * dt
+        cov = incr.T * cov * incr + gc * dt
+
+    def fR(di, dj, db):
+        Ri = mp.expm(skew(wi)) * mp.expm(skew(di))
+        Rj = mp.expm(skew(wj)) * mp.expm(skew(dj))
+        binc = mp.matrix([bias[i] + db[i] - bias_hat[i] for i in range(3)])
+        bio = D * binc
+        om = so3_log(dR * mp.expm(skew([bio[i] for i in range(3)])))
+        cor = Ri.T * mp.matrix(coriolis) * dtij
+        com = [om[i] - cor[i] for i in range(3)]
+        return so3_log(mp.expm(skew(com)).T * Ri.T * Rj)
+
+    z = [mp.mpf(0)] * 3
+    e = fR(z, z, z)
+    h = mp.mpf(10) ** -20
+    H = []
+    for which in range(3):
+        Hm = mp.zeros(3, 3)
+        for k in range(3):
+            dp = [h if i == k else mp.mpf(0) for i in range(3)]
+            dm = [-x for x in dp]
+            args_p = [z, z, z]
+            args_m = [z, z, z]
+            args_p[which], args_m[which] = dp, dm
+            fp, fm = fR(*args_p), fR(*args_m)
+            for i in range(3):
+                Hm[i, k] = (fp[i] - fm[i]) / (2 * h)
+        H.append(Hm)
+    return dict(Ri=fl(mp.expm(skew(wi))), Rj=fl(mp.expm(skew(wj))), bias=fl(bias), bias_hat=fl(bias_hat),
+                samples=[[[float(x) for x in om], float(dt)] for om, dt in samples], gyro_cov=gyro_cov, coriolis=fl(coriolis),
+                delta_R=fl(dR), dR_dbias=fl(D), delta_tij=float(dtij), cov=fl(cov), e=fl(e), H1=fl(H[0]), H2=fl(H[1]), H3=fl(H[2]))
+
+
 def main():
     pins = dict(
         note="mpmath %s, %d digits; generated by tests/golden/make_highprec_pins.py" % (mp.__version__, mp.mp.dps),
@@ -164,6 +218,14 @@ def main():
             ([0.1, -0.2, 0.3], [0.0, 0.0, 1.0], [0.0, 0.0, 1.0]),
             ([0.5, 0.4, -0.3], [0.1, -0.2, 0.97], [0.0, 0.1, 1.0]),
             ([1.0, -1.0, 0.5], [0.7, 0.1, -0.7], [1.0, 0.0, 0.0]))],
+        ahrs=[
+            ahrs_case([0.1, -0.2, 0.3], [0.12, -0.18, 0.33], [0.002, -0.001, 0.0005], [0, 0, 0],
+                      [([0.5, 0.6, 1.0], 0.006), ([0.45, 0.7, 0.9], 0.0065)], [[1e-3, 0, 0], [0, 1e-3, 0], [0, 0, 1e-3]], [0, 0, 0]),
+            ahrs_case([1.0, 0.5, -0.8], [1.1, 0.3, -0.9], [0.05, 0.02, -0.03], [0.01, -0.01, 0.02],
+                      [([1.0, -2.0, 0.5], 0.01), ([1.2, -1.8, 0.4], 0.012), ([0.9, -2.2, 0.7], 0.009)],
+                      [[2e-3, 1e-4, 0], [1e-4, 1e-3, -2e-4], [0, -2e-4, 3e-3]], [0.01, -0.02, 0.03]),
+            ahrs_case([0.0, 0.0, 0.0], [1e-4, -2e-4, 1e-4], [0, 0, 0], [0, 0, 0],
+                      [([0.02, -0.03, 0.02], 0.005)], [[1e-3, 0, 0], [0, 1e-3, 0], [0, 0, 1e-3]], [0, 0, 7.29e-5])],
         whitening=[whitening_case([[0.01, 0.003, 0.0], [0.003, 0.02, -0.001], [0.0, -0.001, 0.015]], 0.1),
                    whitening_case([[0.01, 0.0], [0.0, 0.01]], 0.1),
                    whitening_case([[1.0, 0.2, 0.1, 0, 0, 0], [0.2, 2.0, 0.3, 0, 0, 0], [0.1, 0.3, 1.5, 0, 0, 0.1],

@@ -1,0 +1,162 @@
+"""GPU parity for the AHRS state with gyroscope bias (GPSLAM_ROT3_BIAS; matlab/GPAHRSexample.m):
+the factor set on random states against the oracle through the C ABI, the recipe on the real IMU log in lock step with the
+oracle, and the full 50 s of the script on the GPU against the motion-capture ground truth."""
+import os
+
+import numpy as np
+import pytest
+
+from gpslam_amd import ahrs
+from oracle import oracle as O
+from test_ahrs_recipe import run_recipe
+from test_gpu_parity import gpu
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def data():
+    return ahrs.load(os.path.join(HERE, "golden", "ahrs_imu.npz"))
+
+
+def hip_chain(**kw):
+    g = gpu()
+    return g.ChainSolver(g.ROT3_BIAS, **kw)
+
+
+def random_pair(N=96, seed=5, coriolis=None):
+    """random attitude trajectory with biases, pre-integrations of a few noisy gyro samples per interval, accelerometer
+    directions at random times: every factor kind of the recipe, on the oracle and on the device"""
+    rng = np.random.default_rng(seed)
+    pose, vel = np.zeros((N, 12)), np.zeros((N, 6))
+    R = ahrs.rot_from_ypr(0.3, -0.2, 0.1)
+    w = 0.5 * rng.standard_normal(3)
+    dt = 0.01 + 0.02 * rng.random(N - 1)
+    bias = 0.01 * rng.standard_normal(3)
+    gc = np.diag(1e-3 * (1 + rng.random(3))) + 1e-4 * np.ones((3, 3))
+    bh = np.array([1e-3, -1e-3, 2e-3])
+    A = {k: [] for k in ("dR", "D", "t", "cov")}
+    for i in range(N):
+        pose[i, :9], pose[i, 9:] = R.reshape(9), bias
+        vel[i, :3] = w
+        if i == N - 1:
+            break
+        pim = ahrs.Preintegrated(bh, gc)
+        for _ in range(3):
+            pim.integrate(w + bias + 0.01 * rng.standard_normal(3), dt[i] / 3)
+        A["dR"].append(pim.delta_R); A["D"].append(pim.dR_dbias); A["t"].append(pim.delta_tij); A["cov"].append(pim.cov)
+        R = R @ ahrs.so3_exp(w * dt[i])[0]
+        w = w + 0.05 * rng.standard_normal(3)
+        bias = bias + 1e-4 * rng.standard_normal(3)
+    truth = pose.copy()
+    for i in range(N):      # noisy initial values
+        pose[i, :9] = (pose[i, :9].reshape(3, 3) @ ahrs.so3_exp(0.02 * rng.standard_normal(3))[0]).reshape(9)
+    pose[:, 9:] += 1e-3 * rng.standard_normal((N, 3))
+    vel[:, :3] += 0.05 * rng.standard_normal((N, 3))
+    M = 2 * N
+    left = rng.integers(0, N - 1, M).astype(np.int32)
+    tau = dt[left] * rng.random(M)
+    tau[::5] = dt[left[::5]]            # Rot3AttitudeFactor on the right state = tau = dt
+    bref = np.array([truth[l, :9].reshape(3, 3).T @ np.array([0.0, 0.0, 9.81]) + 0.05 * rng.standard_normal(3) for l in left])
+
+    def fill(s):
+        s.set_states(pose, vel)
+        s.set_qc(np.diag([0.5, 0.7, 0.6]) + 0.05)
+        s.add_pose_priors([0], truth[:1], np.array([[0.1, 0.1, 0.1, 1e-2, 1e-2, 1e-2]]))
+        bm = np.tile(np.concatenate([np.eye(3).reshape(9), np.zeros(3)]), (N - 1, 1))
+        s.add_between(np.arange(N - 1, dtype=np.int32), bm, np.tile([np.inf] * 3 + [1e-3] * 3, (N - 1, 1)))
+        s.add_ahrs(np.arange(N - 1, dtype=np.int32), np.array(A["dR"]).reshape(-1, 9), np.array(A["D"]).reshape(-1, 9),
+                   np.tile(bh, (N - 1, 1)), np.array(A["t"]), np.array(A["cov"]).reshape(-1, 9), coriolis)
+        s.add_gp_priors(np.arange(N - 1, dtype=np.int32), dt)
+        s.add_interp_attitude(left, np.tile([0.0, 0.0, 1.0], (M, 1)), bref, np.full((M, 2), 0.1), dt[left], tau)
+        s.compile()
+        return s
+
+    return fill(O.Chain(O.ROT3_BIAS)), fill(hip_chain()), N, M
+
+
+def rot_states_close(a, b, tol):
+    for x, y in zip(a, b):
+        assert np.abs(x[:9].reshape(3, 3).T @ y[:9].reshape(3, 3) - np.eye(3)).max() <= tol
+    assert np.abs(a[:, 9:] - b[:, 9:]).max() <= tol
+
+
+@pytest.mark.parametrize("coriolis", [None, (0.01, -0.02, 0.03)], ids=["plain", "coriolis"])
+def test_factor_values_and_jacobians(coriolis):
+    orc, dev, N, M = random_pair(coriolis=coriolis)
+    e0, J0 = orc.linearize_meas(7, N - 1)            # gtsam::AHRSFactor: unwhitened e, [H1 (x_i) | H3 (b_i) | 0 | H2 (x_j) | 0]
+    e1, J1 = dev.linearize_meas(7, N - 1)
+    assert np.abs(e0 - e1).max() <= 1e-13 and np.abs(J0 - J1).max() <= 1e-11
+    assert np.abs(J0[:, :, 0:6]).max() > 0.5 and np.abs(J0[:, :, 6:12]).max() == 0.0 and np.abs(J0[:, :, 15:]).max() == 0.0
+    e0, J0 = orc.linearize_meas(2, M)                # GPInterpolatedAttitudeFactorRot3 on the rotation part of the state
+    e1, J1 = dev.linearize_meas(2, M)
+    assert np.abs(e0 - e1).max() <= 1e-13 and np.abs(J0 - J1).max() <= 1e-11
+    assert np.abs(J0[:, :, 3:6]).max() == 0.0 and np.abs(J0[:, :, 9:12]).max() == 0.0     # no bias / pad columns
+    g0, H0 = orc.linearize_gp()
+    g1, H1 = dev.linearize_gp()
+    assert np.abs(g0 - g1).max() <= 1e-12 and np.abs(H0 - H1).max() <= 1e-11
+    assert abs(orc.error() - dev.error()) <= 1e-11 * orc.error()
+
+
+@pytest.mark.parametrize("lm", [False, True], ids=["gn", "lm"])
+def test_iterations_in_lock_step(lm):
+    orc, dev, N, _ = random_pair(N=160, seed=8)
+    lam0 = lam1 = 1e-5
+    for it in range(6):
+        if lm:
+            _, s0, lam0 = orc.iterate_lm(lam0)[:3]
+            _, s1, lam1 = dev.iterate_lm(lam1)[:3]
+            assert lam0 == lam1
+        else:
+            _, s0 = orc.iterate_gn()
+            _, s1 = dev.iterate_gn()
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(s0.error_after, 1e-12), (it, s0.error_after, s1.error_after)
+    p0, v0 = orc.get_states()
+    p1, v1 = dev.get_states()
+    rot_states_close(p0, p1, 1e-9)
+    assert np.abs(v0 - v1).max() <= 1e-9 * max(1.0, np.abs(v0).max())
+    assert np.abs(v1[:, 3:]).max() == 0.0                     # pads never move
+    assert s1.delta_inf_norm < 1e-6
+
+
+def test_recipe_matches_oracle_on_the_real_log(data):
+    """GPAHRSexample.m on 5 s of the log (827 states): gyro-only LM initialisation, then the full graph under the
+    script's stopping rule -- same iteration counts, same errors, same states as the oracle."""
+    g = gpu()
+    a = run_recipe(lambda: O.Chain(O.ROT3_BIAS), O.default_params, data, dataset_max_time=5.0)
+    b = run_recipe(lambda: hip_chain(), lambda **kw: g.ChainSolver(g.ROT3_BIAS).default_params(**kw), data, dataset_max_time=5.0)
+    assert a[1][:2] == b[1][:2] and a[4] == b[4]
+    assert abs(a[3] - b[3]) <= 1e-9 * a[3]
+    assert np.allclose(a[5], b[5], rtol=1e-8, atol=1e-12)
+    rot_states_close(a[6], b[6], 1e-9)
+    assert np.abs(a[7] - b[7]).max() <= 1e-8 * max(1.0, np.abs(a[7]).max())
+
+
+def test_recipe_with_interpolated_accelerometer_factors(data):
+    """state rate below the accelerometer rate: most attitude factors sit between states (tau < dt)"""
+    g = gpu()
+    kw = dict(dataset_max_time=4.0, gyro_dt=0.03, acc_dt=0.01)
+    a = run_recipe(lambda: O.Chain(O.ROT3_BIAS), O.default_params, data, **kw)
+    b = run_recipe(lambda: hip_chain(), lambda **k: g.ChainSolver(g.ROT3_BIAS).default_params(**k), data, **kw)
+    assert np.sum(a[0]["att_tau"] < a[0]["att_dt"] - 1e-12) > 100
+    assert a[4] == b[4] and np.allclose(a[5], b[5], rtol=1e-8, atol=1e-12)
+    rot_states_close(a[6], b[6], 1e-9)
+
+
+def test_full_recipe_against_motion_capture(data):
+    """The script's full run (datasetMaxTime = 50 s, ~8300 states) on the GPU: converges under its stopping rule, follows
+    the motion-capture pitch / roll, and the accelerometer keeps what the gyro-only solution loses to drift."""
+    g = gpu()
+    p, gy, gp, e0, it, trace, fp, fv = run_recipe(lambda: hip_chain(), lambda **k: g.ChainSolver(g.ROT3_BIAS).default_params(**k), data)
+    assert p["N"] > 8000 and gy[0] == 0 and gy[2] < 1e-9
+    assert it < 30 and trace[-1] < 0.5 * e0
+    gt = ahrs.ground_truth_ypr(data, p["state_time"])
+    est = np.array([ahrs.rot_ypr(r[:9]) for r in fp])
+    gyr = np.array([ahrs.rot_ypr(r[:9]) for r in gp])
+    wrap = lambda x: np.arctan2(np.sin(x), np.cos(x))
+    rms_est = np.sqrt(np.mean(wrap(est[:, 1:] - gt[:, 1:]) ** 2, axis=0))
+    rms_gyr = np.sqrt(np.mean(wrap(gyr[:, 1:] - gt[:, 1:]) ** 2, axis=0))
+    assert np.all(rms_est < 0.1), (rms_est, rms_gyr)
+    assert rms_est.sum() <= rms_gyr.sum() * 1.05, (rms_est, rms_gyr)
+    assert np.abs(fp[:, 9:]).max() < 2e-2 and np.abs(fv[:, 3:]).max() == 0.0
