@@ -66,7 +66,7 @@ def load_library():
     """Load libgpslam_hip.so, building it with hipcc if needed.  Raises if that is impossible."""
     global _lib
     if _lib is None:
-        path = _build.build()
+        path = os.environ.get("GPSLAM_LIB") or _build.build()     # GPSLAM_LIB: an alternative build (A/B timing of kernel variants)
         if not os.path.exists(path):
             raise GpslamHipError("libgpslam_hip.so is missing and could not be built; there is no CPU fallback")
         _lib = C.CDLL(path)

@@ -283,23 +283,23 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
   }
 }
 
-// MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
-template <typename T, int MF, int MODE, bool VW = false>
-__global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
+// One 128-thread block of GP-prior factors; bid = block index among the GP blocks.  stage / srow: the block's LDS staging
+// area (2 * 64 * (2b + 2) elements of T and 128 ints when MODE == 0), owned by the calling kernel so that k_lin can share
+// one area between its factor types.
+template <typename T, int MF, int MODE, bool VW>
+__device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *stage, int *srow) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   constexpr bool JAC = (MODE != 1);
   constexpr int LS = 2 * b + 2;                       // staging stride (16-byte aligned, conflict-free for b128)
-  __shared__ T stage[MODE == 0 ? 2 * 64 * LS : 1];
-  __shared__ int srow[MODE == 0 ? 128 : 1];
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = bid * 128 + threadIdx.x;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool valid = f < a.count;
   T err = T(0);
   if constexpr (MF == POSE3 && MODE == 0) {
     srow[threadIdx.x] = valid ? a.row0[f] : -1;
-    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * LS, srow + wv * 64, lane, err);
+    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * 14 /* the half-row stride of gp_pose3_rows */, srow + wv * 64, lane, err);
     const T tot = block_sum(T(0.5) * err);
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.partial[bid] = tot;
     return;
   }
   T e[b];
@@ -422,8 +422,17 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   }
   if (MODE != 2) {
     const T tot = block_sum(T(0.5) * err);
-    if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+    if (threadIdx.x == 0) a.partial[bid] = tot;
   }
+}
+
+// MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
+template <typename T, int MF, int MODE, bool VW = false>
+__global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
+  constexpr int LS = 4 * MTraits<MF>::d + 2;
+  __shared__ T stage[MODE == 0 ? 2 * 64 * LS : 1];
+  __shared__ int srow[MODE == 0 ? 128 : 1];
+  gp_block<T, MF, MODE, VW>(a, blockIdx.x, stage, srow);
 }
 
 // ------------------------------------------------------------------ unary / between rows
@@ -442,15 +451,13 @@ template <typename T> struct FacArgs {
 
 // KIND 0: PriorFactor<Pose>, 1: PriorFactor<Vector> on the velocity, 2: BetweenFactor<Pose>(x_i, x_i+1)
 template <typename T, int MF, int KIND, bool JAC>
-__global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
+__device__ __forceinline__ void simple_block(const FacArgs<T> &a, const int bid, T *stage, int *srow) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   // PriorFactor<Pose> and BetweenFactor<Pose> have no velocity columns: they go to the compact row table,
   // [d/dpose_left (d) | d/dpose_right (d)] per row, which halves what K3 has to read for them
   constexpr int W = (KIND == 1) ? 2 * b : 2 * d;
   constexpr int LS = W + 2;
-  __shared__ T stage[JAC ? 2 * 64 * LS : 1];
-  __shared__ int srow[JAC ? 128 : 1];
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int f = bid * 128 + threadIdx.x;
   const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool valid = f < a.count;
   T err = T(0);
@@ -521,7 +528,50 @@ __global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
     }
   }
   const T tot = block_sum(T(0.5) * err);
-  if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+  if (threadIdx.x == 0) a.partial[bid] = tot;
+}
+
+template <typename T, int MF, int KIND, bool JAC>
+__global__ void __launch_bounds__(128) k_simple(FacArgs<T> a) {
+  constexpr int LS = ((KIND == 1) ? 4 * MTraits<MF>::d : 2 * MTraits<MF>::d) + 2;
+  __shared__ T stage[JAC ? 2 * 64 * LS : 1];
+  __shared__ int srow[JAC ? 128 : 1];
+  simple_block<T, MF, KIND, JAC>(a, blockIdx.x, stage, srow);
+}
+
+// K1 of a Gauss-Newton iteration in ONE launch: the GP priors, the pose / velocity priors and the between factors share the
+// grid, the register-heavy GP blocks first and the light streaming blocks behind them, which fill the issue slots and the
+// store bandwidth the GP waves leave (measured on 1e5 Pose3 states: 0.539 ms per iteration; the same kernels on two streams
+// with an event fork / join 0.556; GP and between blocks alternating 0.568).
+template <typename T> struct LinArgs {
+  GpArgs<T> gp;
+  FacArgs<T> fac[3];      // pose priors, velocity priors, between factors
+  int nb_gp, nb[3];       // blocks per type (0: type absent)
+  int interleave;         // 1: GP and between blocks alternate; 0: all GP blocks first
+};
+// VP: the launch contains velocity priors (full-width rows).  Without them a Pose3 launch stages half rows only (the GP
+// prior writes its rows in halves, pose priors / between factors have compact rows): 14 KB of LDS instead of 27 KB, so that
+// every workgroup of a 1e5-state launch is resident at once.
+template <typename T, int MF, bool VW, bool VP>
+__global__ void __launch_bounds__(128) k_lin(LinArgs<T> a) {
+  constexpr int LS = (MF == POSE3 && !VP) ? 2 * MTraits<MF>::d + 2 : 4 * MTraits<MF>::d + 2;
+  __shared__ T stage[2 * 64 * LS];
+  __shared__ int srow[128];
+  int bid = blockIdx.x;
+  const int pair = a.interleave ? min(a.nb_gp, a.nb[2]) : 0;
+  if (bid < 2 * pair) {                                    // interleaved part: even = GP, odd = between
+    if (bid & 1) simple_block<T, MF, 2, true>(a.fac[2], bid >> 1, stage, srow);
+    else gp_block<T, MF, 0, VW>(a.gp, bid >> 1, stage, srow);
+    return;
+  }
+  bid -= 2 * pair;
+  if (bid < a.nb_gp - pair) { gp_block<T, MF, 0, VW>(a.gp, pair + bid, stage, srow); return; }
+  bid -= a.nb_gp - pair;
+  if (bid < a.nb[2] - pair) { simple_block<T, MF, 2, true>(a.fac[2], pair + bid, stage, srow); return; }
+  bid -= a.nb[2] - pair;
+  if (bid < a.nb[0]) { simple_block<T, MF, 0, true>(a.fac[0], bid, stage, srow); return; }
+  bid -= a.nb[0];
+  if constexpr (VP) simple_block<T, MF, 1, true>(a.fac[1], bid, stage, srow);
 }
 
 // ------------------------------------------------------------------ K2: measurement factors
@@ -2212,12 +2262,20 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = rp + min(i, max(nf - 1, 0));
       const double *row = u.rowLR + (size_t)rho * 2 * B;
+#ifdef GPS_ABLATE_LOAD   /* timing ablation only: no row traffic */
+      Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
+#else
       Lv = row[rr]; Rv = row[B + rr]; ev = u.rowE[rho];
+#endif
     };
     auto ldc = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = cp + min(i, max(nc - 1, 0));
       const double *row = u.rowC + (size_t)rho * B;
+#ifdef GPS_ABLATE_LOAD
+      Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
+#else
       Lv = row[rc]; Rv = row[Dh + rc]; ev = u.rowCE[rho];
+#endif
     };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
     auto open_state = [&](int kimg, int p0, int p1, int q0, int q1) {
@@ -2380,7 +2438,11 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       OUTR[co + 2 * B * B] = gr;
     }
     lds_barrier();                       // step t
+#ifdef GPS_ABLATE_STORE   /* timing ablation only: the factor records stay in LDS */
+    if (live && j < 0) {
+#else
     if (live) {
+#endif
       V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
 #pragma unroll
       for (int q = 0; q < NV; q++) {
