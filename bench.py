@@ -289,6 +289,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N > 1: what the one data-path collective of an iteration costs (all ranks take part; outside the contract clock):
+    # device time of `reps` all-gathers of the 3.6 KB interface records between events on the stream RCCL is ordered against
+    collective_ms = None
+    if world > 1:
+        reps = 50
+        for _ in range(5):
+            sv.exchange()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            sv.exchange()
+        e1.record()
+        torch.cuda.synchronize()
+        tc = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)      # (every rank executes exactly the same sequence of collectives)
+        collective_ms = float(tc.item())
+
     if rank == 0:
         # per-kernel device time (hipEvents on the handle's stream) of the per-GPU workload, for the roofline
         if world == 1:
@@ -359,13 +377,17 @@ def main():
                                   if fused and dom == 2 else None)},
         }
         # K1 (batched evaluateError + Jacobians of the GP priors) standalone and inside an iteration, where it shares the
-        # chip with k_simple on the side stream: the linearise phase = both kernels, overlapped
+        # launch (k_lin) with the prior and between factors
         k1_bytes = alg[0] + (2 * 96 + 6 * 104) * (N - 1)           # + BetweenFactor<Pose3> rows (k_simple, compact table)
         out["k1_batched_jacobian"] = {
             "standalone_ms": float(kms[0]), "standalone_frac_of_hbm": alg[0] / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "in_iteration_linearize_phase_ms": float(phase[0]) / 3,
             "in_iteration_frac_of_hbm": k1_bytes / (float(phase[0]) / 3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "in-iteration = k_gp + k_simple overlapped on two streams, algorithmic bytes of both"}
+            "note": ""}
+        if collective_ms is not None:
+            out["collective"] = {"kind": "ncclAllGather of the interface records (RCCL), one per iteration", "bytes_per_rank": int(send.numel() * send.element_size()),
+                                 "ms_per_iteration": collective_ms, "share_of_step": collective_ms / ms_per_step}
+        out["k1_batched_jacobian"]["note"] = "in-iteration = k_lin: GP priors + priors + between factors in one launch, algorithmic bytes of all of them"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, threads=1)
             out["cpu_baseline_all_cores"] = cpu_baseline(problem, threads=0)
