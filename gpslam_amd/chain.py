@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
-    "gpslam_hip_add_ahrs",
+    "gpslam_hip_add_ahrs", "gpslam_hip_plan_info",
 ]
 
 
@@ -331,6 +331,12 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_interpolate_poses(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out)),
                   "interpolate_poses")
         return out
+
+    def plan_info(self):
+        """What compile() chose: dict(levels, chunk0, chunk_upper, fused, structured_gp, rows_full, rows_compact, R)."""
+        out = (C.c_int32 * 8)()
+        self._chk(self.lib.gpslam_hip_plan_info(self._h, out), "plan_info")
+        return dict(zip(("levels", "chunk0", "chunk_upper", "fused", "structured_gp", "rows_full", "rows_compact", "R"), list(out)))
 
     def segment_plan(self):
         """dict of the segmented landmark elimination's plan (active, C, K, NB, NC, NCP, levels, links)."""

@@ -93,6 +93,9 @@ struct gpslam_hip_handle {
   DevBuf lm_gL;             // undamped landmark gradient of the segmented path (the dense path keeps it behind lm_S)
   bool fuse_ok = false;     // k_fused_level0 applies to this graph (compile())
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
+  bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
+  bool struct_now = false;  // ... and the linearisation / elimination being enqueued do so
+  DevBuf gps, gpidx, dU;
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   double ph_lambda = 0.0;
@@ -328,7 +331,10 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // kernels that exist for fp64 only (hand-written 64-bit DPP row layout, v_mfma_f64): the fp32 instantiation of the
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
-inline void launch_fused_k(const FusedArgs<double> &u, int grid, hipStream_t st) { k_fused_level0<<<dim3(grid), dim3(128), 0, st>>>(u); }
+inline void launch_fused_k(const FusedArgs<double> &u, int grid, hipStream_t st) {
+  if (u.gps) k_fused_level0<true><<<dim3(grid), dim3(128), 0, st>>>(u);
+  else k_fused_level0<false><<<dim3(grid), dim3(128), 0, st>>>(u);
+}
 inline void launch_fused_k(const FusedArgs<float> &, int, hipStream_t) {}
 inline void launch_rows_k(const FwdArgs<double> &a, int grid, hipStream_t st) { k_chunk_forward_rows<<<dim3(grid), dim3(64), 0, st>>>(a); }
 inline void launch_rows_k(const FwdArgs<float> &, int, hipStream_t) {}
@@ -418,7 +424,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
                     &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowC, &h->rowCE, &h->crowptr, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
                     &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
-                    &h->api_e, &h->api_H};
+                    &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU};
   for (DevBuf *b : bufs) b->release();
   for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
   for (MeasSet &s : h->ms) s.release();
@@ -646,6 +652,17 @@ int gpslam_hip_clear_factors(gpslam_hip_handle *h) {
     s.any_aux = false;
   }
   h->compiled = false;
+  return 0;
+}
+
+int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]) {
+  int rc = need_compiled(h);
+  if (rc) return rc;
+  if (!out8) return GPSLAM_E_INVALID;
+  const bool fused = h->fuse_ok && h->lv.size() >= 2;
+  const int32_t v[8] = {(int32_t)h->lv.size(), h->lv.empty() ? 0 : h->lv[0].m, h->lv.size() > 1 ? h->lv[1].m : 0, fused ? 1 : 0,
+                        (fused && h->struct_ok) ? 1 : 0, h->M, h->Mc, h->R};
+  for (int i = 0; i < 8; i++) out8[i] = v[i];
   return 0;
 }
 

@@ -119,7 +119,20 @@ template <typename T> struct GpArgs {
   T *out_e, *out_H;       // MODE 2: API layout
   UMat<T> U;
   int vw;                 // Pose3 only: velocities are world-frame [v; w] (the *Pose3VW factors)
+  T *gps;                 // Pose3, MODE 0: structured records (kGps* below) instead of rows in rowLR / rowE, or null
 };
+
+// Structured record of one GaussianProcessPriorPose3 (what k_fused_level0's assembly wave reads when K1 feeds it directly).
+// Of the whitened 12 x 24 Jacobian [L | R] only the pose columns are data; the velocity columns are
+//   L[rho][6..11] = k2 U[rho]  (top rows),  -sc U[rho]  (bottom rows)          H2 = [-dt I; -I]      (GaussianProcessPriorPose3.h:86)
+//   R[rho][6..11] = sb WJ[rho] (top rows),   sc WJ[rho] (bottom rows), WJ = U Jr^-1(r)   H4 = [0; Jinv]   (:95)
+// with U = chol_upper(Qc^-1) the same for every factor: 196 doubles per factor instead of 312.
+//   [rho * 18 + 0..5]   R[rho][0..5]        rho = 0..5 (top rows)        written in K1's "right state" phase,
+//   [rho * 18 + 6..11]  WJ[rho][0..5]                                    144 contiguous bytes per rho
+//   [rho * 18 + 12..17] R[6 + rho][0..5]    (bottom rows)
+//   [108 + rho * 12 + 0..5] L[rho][0..5],  [.. + 6..11] L[6 + rho][0..5]  "left state" phase, 96 bytes per rho
+//   [180..191] whitened error,  [192] k2 = -(sa dt + sb), [193] sb, [194] sc, [195] pad
+constexpr int kGpsLen = 196, kGpsL = 108, kGpsE = 180, kGpsS = 192;
 
 // Cooperative row store: every lane of a wave has deposited one row (W doubles, W even) of ITS factor in the wave's
 // LDS staging buffer; the wave then writes the 64 rows as 16-byte pieces, consecutive lanes on consecutive pieces of
@@ -128,9 +141,9 @@ template <typename T> struct GpArgs {
 // srow[l] = first row of lane l's factor in the row table, or -1.
 // wave_store_part: the lanes staged HW (even) doubles each with stride HW + 2; they land at columns
 // [coloff, coloff + HW) of row (first row of the lane's factor) + roff of a table with W doubles per row.
-template <typename T, int W, int HW>
+template <typename T, int W, int HW, int LS = HW + 2>
 __device__ __forceinline__ void wave_store_part(const T *st, const int *srow, int lane, int roff, int coloff, T *table) {
-  constexpr int P = HW / 2, LS = HW + 2;
+  constexpr int P = HW / 2;
   typedef T V2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int t = 0; t < P; t++) {
@@ -184,9 +197,11 @@ __device__ __forceinline__ void utri_times_bl6_row(const T *U, const BL6<T> &M, 
 // U x (block lower-triangular) products row by row, skipping the structural zeros.  Peak live state is FD + two
 // 6x6 blocks instead of two 6 x 24 arrays, which is what lets two waves share a SIMD.
 template <typename T, bool VW>
-__device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, int f, T *st, const int *sr, int lane, T &err) {
+__device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, int f, T *st, int *sr, int lane, T &err) {
   constexpr int LS = 14;
-  T *mine = st + lane * LS;
+  const bool structured = !VW && a.gps != nullptr;      // (the VW chain rule mixes the velocity columns: rows only)
+  T *mine = st + lane * (structured ? 20 : LS);
+  if (structured) sr[lane] = valid ? f : -1;            // structured records are indexed by factor, not by row
   const T *U = a.U.u;
   T p1[12], p2[12], v1[6], v2[6];
   T dt = T(1);
@@ -242,7 +257,12 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       mine[rho] = wt;
       mine[6 + rho] = wb;
     }
-    wave_store_scalars<T, 12>(st, sr, lane, a.rowE);
+    if (structured) {
+      mine[12] = -(sa * dt + sb); mine[13] = sb; mine[14] = sc; mine[15] = T(0);
+      wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, kGpsE, a.gps);
+    } else {
+      wave_store_scalars<T, 12>(st, sr, lane, a.rowE);
+    }
   }
   const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90) -- computed once, used twice
   {   // right state: H3 = [Jinv; FD Jinv] (:88-93), H4 = [0; Jinv] (:95)
@@ -252,6 +272,12 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       T x[6], y[6];
       utri_times_bl6_row(U, Jinv, rho, x);
       utri_times_bl6_row(U, P3, rho, y);
+      if (structured) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = x[c]; mine[12 + c] = sc * y[c]; }
+        wave_store_part<T, kGpsLen, 18, 20>(st, sr, lane, 0, rho * 18, a.gps);
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sb * x[c]; }
       if (VW) vw_row_transform(p2, v2, mine);
@@ -271,6 +297,12 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       T x[6], y[6];
       utri_times_bl6_row(U, J, rho, x);
       utri_times_bl6_row(U, P1, rho, y);
+      if (structured) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sc * y[c]; }
+        wave_store_part<T, kGpsLen, 12, 20>(st, sr, lane, 0, kGpsL + rho * 12, a.gps);
+        continue;
+      }
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = (c >= rho) ? k2 * U[rho * 6 + c] : T(0); }
       if (VW) vw_row_transform(p1, v1, mine);
@@ -297,7 +329,7 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
   T err = T(0);
   if constexpr (MF == POSE3 && MODE == 0) {
     srow[threadIdx.x] = valid ? a.row0[f] : -1;
-    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * 14 /* the half-row stride of gp_pose3_rows */, srow + wv * 64, lane, err);
+    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * 20 /* gp_pose3_rows: half rows (14) or structured pieces (20) per lane */, srow + wv * 64, lane, err);
     const T tot = block_sum(T(0.5) * err);
     if (threadIdx.x == 0) a.partial[bid] = tot;
     return;
@@ -554,7 +586,7 @@ template <typename T> struct LinArgs {
 // every workgroup of a 1e5-state launch is resident at once.
 template <typename T, int MF, bool VW, bool VP>
 __global__ void __launch_bounds__(128) k_lin(LinArgs<T> a) {
-  constexpr int LS = (MF == POSE3 && !VP) ? 2 * MTraits<MF>::d + 2 : 4 * MTraits<MF>::d + 2;
+  constexpr int LS = (MF == POSE3 && !VP) ? 20 : 4 * MTraits<MF>::d + 2;
   __shared__ T stage[2 * 64 * LS];
   __shared__ int srow[128];
   int bid = blockIdx.x;
@@ -2172,6 +2204,9 @@ template <typename T> struct FusedArgs {
   const T *rowLR, *rowE;  // M x 24, M
   const int *crowptr;     // compact rows
   const T *rowC, *rowCE;  // Mc x 12, Mc
+  const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
+  const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
+  const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
 };
 
 template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
@@ -2216,6 +2251,9 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ST: every full-width row of the chain belongs to a GP prior and K1 delivers those as structured records (u.gps): the
+// full-width row ring is replaced by the record ring (a kernel with both spills: 256 VGPRs + 176 B of scratch, 0.34 ms).
+template <bool ST>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
   const FwdArgs<double> &a = u.f;
   constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
@@ -2248,17 +2286,38 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = 6, PC = 6, Dh = B / 2;
+    constexpr int PF = 6, PC = ST ? 4 : 6, Dh = B / 2;   // (ST: the record ring takes the registers of two compact-ring slots)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     double carry[B], carry_g = 0.0;
 #pragma unroll
     for (int k = 0; k < B; k++) carry[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
-    double fL[PF], fR[PF], fE[PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
+    double fL[ST ? 1 : PF], fR[ST ? 1 : PF], fE[ST ? 1 : PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
     int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
+    // structured GP prior of the state (u.gps): lanes 0..5 fetch the pose columns of its rows, six rows at a time; lanes
+    // 6..11 form the velocity columns from U (L) and from the record's WJ block (R) -- see kGps* in GpArgs
+    constexpr bool st_on = ST;
+    const bool lo6 = r < Dh;
+    const int r6 = r < Dh ? r : (r < B ? r - Dh : 0);
+    constexpr int GH = ST ? Dh : 1;
+    // Lanes 6..11 fetch through the SAME ring slots what their velocity columns are multiples of: U[q][r - 6] (a 288-byte
+    // table, L1 resident) in the L slot and WJ[q][r - 6] of the record in the R slot -- no registers beyond the ring.
+    double gL[GH], gR[GH], gE[GH], kk2 = 0.0, ksb = 0.0, ksc = 0.0;
+#pragma unroll
+    for (int q = 0; q < GH; q++) { gL[q] = 0.0; gR[q] = 0.0; gE[q] = 0.0; }
+    int gp = -1;
+    int gpn = st_on ? u.gpidx[min(s + 1, ptr_max)] : -1, gpnn = st_on ? u.gpidx[min(s + 2, ptr_max)] : -1;
+    auto ldg = [&](int q, int half) {                    // row 6 * half + q of the record
+      if constexpr (ST) {
+        const double *rec = u.gps + (size_t)max(gp, 0) * kGpsLen;
+        gL[q] = lo6 ? rec[kGpsL + q * 12 + 6 * half + r6] : u.Ud[q * Dh + r6];
+        gR[q] = rec[q * 18 + (lo6 ? 12 * half : 6) + r6];
+        gE[q] = rec[kGpsE + 6 * half + q];
+      }
+    };
     auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = rp + min(i, max(nf - 1, 0));
       const double *row = u.rowLR + (size_t)rho * 2 * B;
@@ -2278,12 +2337,21 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
 #endif
     };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
-    auto open_state = [&](int kimg, int p0, int p1, int q0, int q1) {
+    auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g) {
       const bool live = valid && (s + kimg) < e;
-      rp = live ? p0 : 0; nf = live ? p1 - p0 : 0;
+      gp = (live && st_on) ? g : -1;
+      rp = (live && !ST) ? p0 : 0; nf = (live && !ST) ? p1 - p0 : 0;   // ST: the only full-width rows are the GP priors' (host-checked)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
+      if constexpr (ST) {
+        const double *rec = u.gps + (size_t)max(gp, 0) * kGpsLen;
 #pragma unroll
-      for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
+        for (int q = 0; q < Dh; q++) ldg(q, 0);
+        kk2 = rec[kGpsS]; ksb = rec[kGpsS + 1]; ksc = rec[kGpsS + 2];
+      }
+      if constexpr (!ST) {
+#pragma unroll
+        for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
+      }
 #pragma unroll
       for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);
     };
@@ -2298,6 +2366,29 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
 #pragma unroll
       for (int k = 0; k < B; k++) { Dacc[k] = carry[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
       gacc = carry_g;
+      if constexpr (ST) {                                // the structured GP prior: its 12 rows, top half then bottom half
+        const bool okg = gp >= 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          const double kL = half ? -ksc : kk2, kR = half ? ksc : ksb;
+#pragma unroll
+          for (int q = 0; q < Dh; q++) {
+            const double Lv = okg ? (lo6 ? gL[q] : kL * gL[q]) : 0.0;
+            const double Rv = okg ? (lo6 ? gR[q] : kR * gR[q]) : 0.0;
+            const double ev = okg ? gE[q] : 0.0;
+#ifndef GPS_ABLATE_ASM
+            fmac_gather<12>(Dacc, Lv, Lv);
+            fmac_gather<12>(Oacc, Lv, Rv);
+            fmac_gather<12>(RRacc, Rv, Rv);
+#endif
+            gacc = fma(-Lv, ev, gacc);
+            grr = fma(-Rv, ev, grr);
+            if (half == 0) ldg(q, 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+      if constexpr (!ST)
       for (int i0 = 0; i0 < nfm; i0 += PF) {             // full-width rows
 #pragma unroll
         for (int q = 0; q < PF; q++) {
@@ -2338,10 +2429,11 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       for (int k = 0; k < B; k++) carry[k] = RRacc[k];
       carry_g = grr;
       // the next state: its row range is known, open its rings; fetch the pointers of the state after it
-      open_state(kimg + 1, rpn, rpnn, cpn, cpnn);
-      rpn = rpnn; cpn = cpnn;
+      open_state(kimg + 1, rpn, rpnn, cpn, cpnn, gpn);
+      rpn = rpnn; cpn = cpnn; gpn = gpnn;
       rpnn = u.rowptr[min(s + kimg + 3, ptr_max)];
       cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
+      if (st_on) gpnn = u.gpidx[min(s + kimg + 3, ptr_max)];
     };
     auto write_img = [&](int buf) {
       if (rowlane) {
@@ -2351,7 +2443,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
         img[co + 2 * B * B] = gacc;
       }
     };
-    open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn);
+    open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, st_on ? u.gpidx[min(s, ptr_max)] : -1);
     assemble(0); write_img(0);
     assemble(1); write_img(1);
     lds_barrier();                       // P: images 0 and 1 are there

@@ -243,6 +243,11 @@ int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int3
  * out_H count x 4 x d x d = H1..H4 of interpolatePose (gpslam/gp/GaussianProcessInterpolatorPose3.h:82-98, gpslam.h:57-86) */
 int gpslam_hip_interpolate_poses_jac(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
                                      const double *tau, double *out_pose, double *out_H);
+/* What compile() chose for the chain solver (introspection for tests and tuning; no reference counterpart):
+ * out8 = {levels of the hierarchy, level-0 chunk length, upper chunk length, assembly fused into the level-0 elimination
+ * (k_fused_level0) 0/1, GP priors handed to it as structured records instead of Jacobian rows 0/1, rows in the
+ * full-width table, rows in the compact table, right-hand-side columns R}. */
+int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]);
 /* the plan of the segmented landmark elimination chosen by compile(): out = {active (0 / 1), segment length C, fat
  * blocks K, fat block size NB, border columns NC per segment, NC rounded up to MFMA tiles, cyclic-reduction levels,
  * link blocks} */

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:      # before anything loads libgpslam_hip.so: torch ships its own HIP runtime, and whichever loads first must be it
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

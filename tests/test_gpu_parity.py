@@ -46,7 +46,7 @@ def random_chain(kind, N, seed, motion=0.3, noise=0.05):
     return dict(truth_pose=pose, truth_vel=vel, pose=init_pose, vel=init_vel, dt=dt)
 
 
-def build_pair(kind, N, seed, chart=None, with_between=True, chunk=0):
+def build_pair(kind, N, seed, chart=None, with_between=True, chunk=0, vel_priors=True):
     """The same problem on the oracle and on the GPU.  chart=None: GTSAM's default chart of the manifold
     (first-order for Pose2, Expmap otherwise)."""
     if chart is None:
@@ -67,7 +67,8 @@ def build_pair(kind, N, seed, chart=None, with_between=True, chunk=0):
         # so the 1e-9 fixed-point tolerance is above cond * eps
         fix = np.arange(0, N, 20)
         s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.01))
-        s.add_vel_priors([0, N - 1], c["truth_vel"][[0, N - 1]], np.full((2, d), 0.05))
+        if vel_priors:
+            s.add_vel_priors([0, N - 1], c["truth_vel"][[0, N - 1]], np.full((2, d), 0.05))
         if with_between and N > 1:
             meas = []
             for i in range(N - 1):

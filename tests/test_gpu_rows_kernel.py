@@ -25,6 +25,50 @@ def test_pose3_chunk_shapes(chunk):
         T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
 
 
+@pytest.mark.parametrize("chunk", [2, 3, 5, 13, 16, 0])
+def test_pose3_structured_gp_records(chunk):
+    """Chains whose only full-width rows are GP priors: K1 hands them to the fused kernel as structured records (the
+    velocity columns of the whitened Jacobian are multiples of U and of U Jr^-1, synthesised by the assembly wave) instead of
+    rows.  Same shapes as above, against the oracle."""
+    for N in ((chunk + 2, 4 * chunk + 1, 5 * chunk + 3, 7 * chunk + 2, 211, 1500) if chunk else (40, 211, 1500, 6000)):
+        orc, dev, c = T.build_pair(O.POSE3, N, seed=300 + N, chunk=chunk, vel_priors=False)
+        info = dev.plan_info()
+        assert info["structured_gp"] == (1 if info["fused"] else 0) and info["rows_full"] == 12 * (N - 1)
+        for _ in range(3):
+            rc0, s0 = orc.iterate_gn()
+            rc1, s1 = dev.iterate_gn()
+            assert rc0 == 0 and rc1 == 0, (N, chunk)
+            assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), (N, chunk)
+        (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+        T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
+    assert info["fused"] == 1 and info["structured_gp"] == 1      # (N = 1500: more than one level for every chunk length)
+
+
+def test_structured_records_reproduce_the_row_path_bit_for_bit():
+    """The same chain with and without a (zero-weight) velocity prior: the prior's full-width row switches the structured
+    records off, its infinite sigma makes it contribute exactly nothing -- the two paths must agree to the last bit."""
+    N = 900
+    res = []
+    for extra in (False, True):
+        orc, dev, c = T.build_pair(O.POSE3, N, seed=77, vel_priors=False)
+        if extra:
+            dev.clear_factors()
+            d = 6
+            dev.add_gp_priors(np.arange(N - 1), c["dt"])
+            fix = np.arange(0, N, 20)
+            dev.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.01))
+            ident = O.pose3((0, 0, 0), (0, 0, 0))
+            meas = np.stack([O.retract(O.POSE3, ident, O.local(O.POSE3, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
+            dev.add_between(np.arange(N - 1), meas, np.full((N - 1, d), 0.02))
+            dev.add_vel_priors([5], np.zeros((1, d)), np.full((1, d), np.inf))
+            dev.compile()
+        assert dev.plan_info()["structured_gp"] == (0 if extra else 1)
+        for _ in range(3):
+            dev.iterate_gn()
+        res.append(dev.get_states())
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+
+
 def test_pose3_levenberg_marquardt_through_rows_kernel():
     orc, dev, c = T.build_pair(O.POSE3, 300, seed=9, chunk=13)
     lam0 = lam1 = 1e-3
