@@ -250,6 +250,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 // cores.  One wave per (segment, 16-row tile): v_mfma_f64_16x16x4_f64, A[i][k] = Y[k][i0 + i], B[k][j] = Y[k][j0 + j]
 // (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double fs_d4 __attribute__((ext_vector_type(4)));
+__host__ __device__ inline int fs_lds_stride(int ncp) { return ((ncp + 31) / 32) * 32 + 16; }
 // Y^T Y is symmetric: only the tiles on and below the diagonal (tile column <= tile row) are formed; readers use fs_sym.
 // One 4-wave workgroup per segment.  The K dimension is walked in chunks of KC rows that the workgroup stages ONCE in
 // LDS (coalesced 16-byte loads into registers while the matrix cores work on the current chunk, committed to the other
@@ -257,13 +258,21 @@ typedef double fs_d4 __attribute__((ext_vector_type(4)));
 // its MFMAs from LDS.  The first version let every (segment, tile row) wave stream its operand columns from L2 / HBM
 // itself: 4.5x the traffic of Y, 4.8 ms at 1e6 states, bandwidth bound; staged, Y is read once (2.1 ms: 31 TFLOP/s of
 // fp64 MFMA).  A variant with the tile loop specialised per tile count (branch-free k loop) needed 156 VGPRs and was
-// slower (2.9 ms).
+// slower (2.9 ms).  The sweep fused in front of this loop (thread per border column writing its Y rows straight into the LDS
+// chunk, k_fs_sweep_syrk: no 4.6 GB Y buffer at all) was measured SLOWER as well: 5.0 ms against 2.34 + 2.11 ms -- 252 VGPRs
+// (12 accumulator tiles + the sweep's state) leave two workgroups per CU, and per 24-row chunk the workgroup then pays the
+// sweep's four dependent steps (LDS-fed 6 x 6 products on two of its four waves), the gather of the next chunk's right-hand
+// sides and the MFMAs one after the other: 10 us per chunk instead of 4.3.
 template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) k_fs_syrk(FsArgs<double, TR> a) {
   constexpr int KC = 24;                                   // rows per chunk: 4 states of 6, 2 of 12, 6 of 4
   extern __shared__ __align__(16) unsigned char syrk_smem[];
-  double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x NCP
+  double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x LSP
   const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NCP = a.NCP, T16 = NCP / 16, ntiles = T16 * (T16 + 1) / 2;
+  // LDS row stride: a multiple of 32 doubles plus 16, so that the four chunk rows an MFMA operand load touches (16 lanes x
+  // 8 bytes each) fall into different bank groups; with the plain stride NCP = 96 they all hit the same banks (4-way
+  // conflict on every operand load: the kernel was LDS-bandwidth bound at 0.40 of the matrix peak)
+  const int LSP = fs_lds_stride(NCP);
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   const int kdim = n * a.B;
   const double *Yb = a.Y + (size_t)j0 * a.B * NCP;
@@ -295,7 +304,10 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
 #pragma unroll
     for (int u = 0; u < PV; u++) {
       const int v = tid + u * 256;
-      if (v < chunk_v2) *reinterpret_cast<V2 *>(buf + (size_t)which * KC * NCP + 2 * v) = pre[u];
+      if (v < chunk_v2) {
+        const int row = (2 * v) / NCP, col = 2 * v - row * NCP;
+        *reinterpret_cast<V2 *>(buf + (size_t)which * KC * LSP + (size_t)row * LSP + col) = pre[u];
+      }
     }
   };
   const int nchunks = (kdim + KC - 1) / KC;
@@ -304,10 +316,10 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
   const int kl = lane >> 4, cl = lane & 15;
   for (int c = 0; c < nchunks; c++) {
     if (c + 1 < nchunks) fetch(c + 1);
-    const double *bb = buf + (size_t)(c & 1) * KC * NCP;
+    const double *bb = buf + (size_t)(c & 1) * KC * LSP;
 #pragma unroll
     for (int k4 = 0; k4 < KC; k4 += 4) {
-      const double *yr = bb + (size_t)(k4 + kl) * NCP;
+      const double *yr = bb + (size_t)(k4 + kl) * LSP;
 #pragma unroll
       for (int q = 0; q < TPW; q++) {
         if (wv + 4 * q < ntiles) {
