@@ -96,6 +96,7 @@ struct gpslam_hip_handle {
   bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
   bool struct_now = false;  // ... and the linearisation / elimination being enqueued do so
   DevBuf gps, gpidx, dU;
+  int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
   double ph_lambda = 0.0;
@@ -467,6 +468,7 @@ int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc) {
   if (!make_U(h->d, Qc, U)) return fail(h, GPSLAM_E_NOT_SPD, "Qc is not positive definite");
   std::memcpy(h->Qc, Qc, sizeof(double) * h->d * h->d);
   std::memcpy(h->U, U, sizeof(double) * h->d * h->d);
+  h->U_version++;
   return 0;
 }
 

@@ -69,6 +69,23 @@ def test_structured_records_reproduce_the_row_path_bit_for_bit():
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
 
 
+def test_set_qc_after_compile_reaches_the_structured_path():
+    """set_qc after compile(): the row path reads U per launch, the structured records' assembly reads a device copy of U --
+    both must see the new Qc (same problem on the oracle)."""
+    orc, dev, c = T.build_pair(O.POSE3, 700, seed=21, vel_priors=False)
+    assert dev.plan_info()["structured_gp"] == 1
+    dev.iterate_gn(); orc.iterate_gn()
+    Qc = np.diag([0.05, 0.02, 0.03, 0.04, 0.06, 0.01])
+    Qc[0, 2] = Qc[2, 0] = 0.004
+    dev.set_qc(Qc); orc.set_qc(Qc)
+    for _ in range(3):
+        _, s0 = orc.iterate_gn()
+        _, s1 = dev.iterate_gn()
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after))
+    (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+    T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
+
+
 def test_pose3_levenberg_marquardt_through_rows_kernel():
     orc, dev, c = T.build_pair(O.POSE3, 300, seed=9, chunk=13)
     lam0 = lam1 = 1e-3
