@@ -95,7 +95,8 @@ struct gpslam_hip_handle {
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
   bool struct_now = false;  // ... and the linearisation / elimination being enqueued do so
-  DevBuf gps, gpidx, dU;
+  DevBuf gps, gpidx, dU, gsave2;
+  bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
@@ -425,7 +426,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
                     &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowC, &h->rowCE, &h->crowptr, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
                     &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
-                    &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU};
+                    &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU, &h->gsave2};
   for (DevBuf *b : bufs) b->release();
   for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
   for (MeasSet &s : h->ms) s.release();

@@ -2207,6 +2207,8 @@ template <typename T> struct FusedArgs {
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
+  T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
+                          // it that the PREVIOUS chunk's last rows contribute (gsave2; zero elsewhere); null: not wanted
 };
 
 template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
@@ -2435,24 +2437,29 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
       cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
       if (st_on) gpnn = u.gpidx[min(s + kimg + 3, ptr_max)];
     };
-    auto write_img = [&](int buf) {
+    auto write_img = [&](int buf, int kimg) {
       if (rowlane) {
         double *img = IMG + buf * 4 * BS;
 #pragma unroll
         for (int k = 0; k < B; k++) { img[ro + k] = Dacc[k]; img[ro + B * B + k] = Oacc[k]; }
         img[co + 2 * B * B] = gacc;
+        if (u.gsave && valid) {          // (LM) the gradient: a state's own record, and what the chunk's last rows owe the next separator
+          const int jg = s + kimg;
+          if (jg < e) u.gsave[(size_t)jg * B + r] = gacc;
+          else if (jg == e && e < a.n) u.gsave2[(size_t)e * B + r] = gacc;
+        }
       }
     };
     open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, st_on ? u.gpidx[min(s, ptr_max)] : -1);
-    assemble(0); write_img(0);
-    assemble(1); write_img(1);
+    assemble(0); write_img(0, 0);
+    assemble(1); write_img(1, 1);
     lds_barrier();                       // P: images 0 and 1 are there
     assemble(2);
     lds_barrier();                       // Q: ELIM has taken what it needs from image 0
-    write_img(0);
+    write_img(0, 2);
     for (int t = 0; t < steps; t++) {
       lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
-      if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1); }
+      if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1, t + 3); }
     }
     return;
   }
