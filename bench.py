@@ -303,7 +303,8 @@ def main():
             sv.exchange()
         e1.record()
         torch.cuda.synchronize()
-        tc = torch.tensor([e0.elapsed_time(e1) / reps], dtype=torch.float64, device="cuda")
+        local_ms = e0.elapsed_time(e1) / reps
+        tc = torch.tensor([local_ms], dtype=torch.float64, device="cuda")
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)      # (every rank executes exactly the same sequence of collectives)
         collective_ms = float(tc.item())
 
