@@ -334,8 +334,9 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
 inline void launch_fused_k(const FusedArgs<double> &u, int grid, hipStream_t st) {
-  if (u.gps) k_fused_level0<true><<<dim3(grid), dim3(128), 0, st>>>(u);
-  else k_fused_level0<false><<<dim3(grid), dim3(128), 0, st>>>(u);
+  if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
+  else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
+  else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);
 }
 inline void launch_fused_k(const FusedArgs<float> &, int, hipStream_t) {}
 inline void launch_rows_k(const FwdArgs<double> &a, int grid, hipStream_t st) { k_chunk_forward_rows<<<dim3(grid), dim3(64), 0, st>>>(a); }

@@ -2206,6 +2206,7 @@ template <typename T> struct FusedArgs {
   const T *rowC, *rowCE;  // Mc x 12, Mc
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
+  int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
   T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
                           // it that the PREVIOUS chunk's last rows contribute (gsave2; zero elsewhere); null: not wanted
@@ -2255,8 +2256,11 @@ __device__ __forceinline__ void lds_barrier() {
 
 // ST: every full-width row of the chain belongs to a GP prior and K1 delivers those as structured records (u.gps): the
 // full-width row ring is replaced by the record ring (a kernel with both spills: 256 VGPRs + 176 B of scratch, 0.34 ms).
-template <bool ST>
+// SV = 2: a structured chain that also has a few other full-width rows (a velocity prior or two): those are fetched where
+// they are used, without a ring (the pure variant stays free of that loop's registers: with it the kernel spills again).
+template <int SV>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
+  constexpr bool ST = SV != 0, ODD = SV == 2;
   const FwdArgs<double> &a = u.f;
   constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
@@ -2342,7 +2346,8 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g) {
       const bool live = valid && (s + kimg) < e;
       gp = (live && st_on) ? g : -1;
-      rp = (live && !ST) ? p0 : 0; nf = (live && !ST) ? p1 - p0 : 0;   // ST: the only full-width rows are the GP priors' (host-checked)
+      if (gp >= 0) p0 += B;                              // its 12 rows lead the state's range in the row table: not used
+      rp = (live && (!ST || ODD)) ? p0 : 0; nf = (live && (!ST || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
       if constexpr (ST) {
         const double *rec = u.gps + (size_t)max(gp, 0) * kGpsLen;
@@ -2388,6 +2393,23 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
             if (half == 0) ldg(q, 1);
             __builtin_amdgcn_sched_barrier(0);
           }
+        }
+      }
+      if constexpr (ODD) {
+        // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
+        // only the block step of a state that has one waits for it
+        for (int i = 0; i < nfm; i++) {
+          double Lv, Rv, ev;
+          ldf(i, Lv, Rv, ev);
+          const bool ok = i < nf;
+          Lv = ok ? Lv : 0.0; Rv = ok ? Rv : 0.0; ev = ok ? ev : 0.0;
+#ifndef GPS_ABLATE_ASM
+          fmac_gather<12>(Dacc, Lv, Lv);
+          fmac_gather<12>(Oacc, Lv, Rv);
+          fmac_gather<12>(RRacc, Rv, Rv);
+#endif
+          gacc = fma(-Lv, ev, gacc);
+          grr = fma(-Rv, ev, grr);
         }
       }
       if constexpr (!ST)

@@ -45,11 +45,12 @@ def test_pose3_structured_gp_records(chunk):
 
 
 def test_structured_records_reproduce_the_row_path_bit_for_bit():
-    """The same chain with and without a (zero-weight) velocity prior: the prior's full-width row switches the structured
-    records off, its infinite sigma makes it contribute exactly nothing -- the two paths must agree to the last bit."""
+    """The same chain three ways: structured records alone; with ONE zero-weight velocity prior (a full-width row the
+    structured kernel fetches without a ring); with nine of them (too many: the row path).  An infinite sigma makes a prior
+    contribute exactly nothing, so all three must agree to the last bit."""
     N = 900
     res = []
-    for extra in (False, True):
+    for extra in (0, 1, 9):
         orc, dev, c = T.build_pair(O.POSE3, N, seed=77, vel_priors=False)
         if extra:
             dev.clear_factors()
@@ -60,13 +61,16 @@ def test_structured_records_reproduce_the_row_path_bit_for_bit():
             ident = O.pose3((0, 0, 0), (0, 0, 0))
             meas = np.stack([O.retract(O.POSE3, ident, O.local(O.POSE3, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
             dev.add_between(np.arange(N - 1), meas, np.full((N - 1, d), 0.02))
-            dev.add_vel_priors([5], np.zeros((1, d)), np.full((1, d), np.inf))
+            where = np.arange(5, 5 + 37 * extra, 37)
+            dev.add_vel_priors(where, np.zeros((extra, d)), np.full((extra, d), np.inf))
             dev.compile()
-        assert dev.plan_info()["structured_gp"] == (0 if extra else 1)
+        info = dev.plan_info()
+        assert info["structured_gp"] == (0 if extra == 9 else 1) and info["rows_full"] == 12 * (N - 1) + 6 * extra
         for _ in range(3):
             dev.iterate_gn()
         res.append(dev.get_states())
-    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    for k in (1, 2):
+        assert np.array_equal(res[0][0], res[k][0]) and np.array_equal(res[0][1], res[k][1])
 
 
 def test_set_qc_after_compile_reaches_the_structured_path():
