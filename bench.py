@@ -373,8 +373,9 @@ def main():
                                            "profiles/latest_pmc.json (bytes per launch, same workload)",
                          "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom],
                          # what actually limits the kernel the HBM fraction is quoted for
-                         "note": ("VALU-issue bound, not HBM bound: two-wave workgroups (assembly + elimination), ~3200 fp64 "
-                                  "VALU instructions per workgroup block step, one fat wave of each kind per SIMD"
+                         "note": ("arithmetic and data path of equal length (timing ablations, DESIGN.md section 4): two-wave workgroups "
+                                  "(assembly + elimination), ~2100 fp64 VALU instructions per workgroup block step; measured traffic is below "
+                                  "the SURVEY 8(d) figure because the GP priors arrive as structured records (196 instead of 312 doubles)"
                                   if fused and dom == 2 else None)},
         }
         # K1 (batched evaluateError + Jacobians of the GP priors) standalone and inside an iteration, where it shares the
