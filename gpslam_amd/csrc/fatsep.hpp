@@ -56,76 +56,125 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   int *flag;
 };
 
+__device__ __forceinline__ double fs_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);          // the caller adds a residual step; without it the last-bit differences from
+  y = y * fma(-0.5 * x * y, y, 1.5);          // sqrt() moved the small-graph comparison with the dense-border path by 1.7e-9
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+__device__ __forceinline__ float fs_rsqrt(float x) {
+  float y = __builtin_amdgcn_rsqf(x);
+  return y * fmaf(-0.5f * x * y, y, 1.5f);
+}
 __device__ __forceinline__ void fs_wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// ---- block Cholesky along every segment interior.  One wave per segment, matrices in LDS.
+// ---- block Cholesky along every segment interior.  One wave per segment.
 // D~_j = D_j + lambda I - E_{j-1}^T E_{j-1} = L_j L_j^T;  W_j = L_j^-1;  E_j = W_j O_j^T  (O_j = H[j+1, j])
+// A state is three LDS hand-overs: lanes r * B + c form D~_j; EVERY lane then factors the whole B x B block in registers
+// (redundant, but a cooperative Cholesky is a barrier per pivot and column: the first version spent 4.6 us per state on 21
+// of them, 1.18 ms per iteration at 1e6 states) and inverts L; lane r publishes row r of W; lanes r * B + c form E_j.
+// The factors [W | E] leave in bursts of FL states through an LDS staging area: on gfx9-family parts loads and stores share
+// one in-order counter (vmcnt), so a loop that stores every step and waits for a prefetched load every step drains BOTH
+// every step.  (Measured at 1e6 states: 1.18 ms cooperative, 1.18 ms with the redundant factorisation alone, 1.04 ms with
+// the store bursts, 0.89 ms with v_rsq in place of sqrt and division; what remains is VALU work -- 3908 waves x 255 states
+// x ~700 instructions.)
 template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(64) k_fs_factor(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, lane = threadIdx.x;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   __shared__ T A[B * B], E[B * B], W[B * B], Os[B * B];
+  constexpr int FL = 8;                                   // states per store burst
+  __shared__ __attribute__((aligned(16))) T FACB[FL * 2 * B * B];
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  auto flush = [&](int first, int cnt) {                  // states first .. first + cnt - 1 (contiguous in fac)
+    V2 *dst = reinterpret_cast<V2 *>(a.fac + (size_t)first * 2 * B * B);
+    const V2 *src = reinterpret_cast<const V2 *>(FACB);
+    for (int q = lane; q < cnt * B * B; q += 64) dst[q] = src[q];
+  };
   // the chain is walked strictly in order (every step needs the previous state's E), so a step's only memory latency is
-  // the fetch of its own block record: the NEXT state's [D | O] is requested before the current state is factorised
-  constexpr int PF = (B * B + 63) / 64;
-  T preD[PF], preO[PF];
-  auto fetch = [&](int s) {
-    const T *bp = a.blk + (size_t)s * a.BS;
+  // the fetch of its own block record [D | O]: a ring of DEPTH records is kept in flight (a step is shorter than a load)
+  constexpr int PF = (B * B + 63) / 64, DEPTH = 4;
+  T preD[DEPTH][PF], preO[DEPTH][PF];
+  auto fetch = [&](int slot, int jn) {     // unconditional (clamped): a load under a branch would be waited for at once
+    const T *bp = a.blk + (size_t)(j0 + min(jn, max(n - 1, 0))) * a.BS;
 #pragma unroll
     for (int u = 0; u < PF; u++) {
-      const int idx = lane + 64 * u;
-      preD[u] = (idx < B * B) ? bp[idx] : T(0);
-      preO[u] = (idx < B * B) ? bp[B * B + idx] : T(0);
+      const int idx = min(lane + 64 * u, B * B - 1);
+      preD[slot][u] = bp[idx];
+      preO[slot][u] = bp[B * B + idx];
     }
   };
-  if (n > 0) fetch(j0);
-  for (int jj = 0; jj < n; jj++) {
+#pragma unroll
+  for (int q = 0; q < DEPTH; q++) fetch(q, q);
+  for (int j4 = 0; j4 < n; j4 += DEPTH) {
+#pragma unroll
+   for (int q = 0; q < DEPTH; q++) {
+    const int jj = j4 + q;
+    if (jj >= n) break;
     const int s = j0 + jj;
 #pragma unroll
     for (int u = 0; u < PF; u++) {
       const int idx = lane + 64 * u;
       if (idx < B * B) {
         const int r = idx / B, c = idx - r * B;
-        T v = preD[u] + (r == c ? a.lambda : T(0));
+        T v = preD[q][u] + (r == c ? a.lambda : T(0));
         if (jj > 0)
           for (int k = 0; k < B; k++) v -= E[k * B + r] * E[k * B + c];
         A[idx] = v;
-        Os[idx] = preO[u];
+        Os[idx] = preO[q][u];
       }
     }
-    if (jj + 1 < n) fetch(s + 1);
+    fetch(q, jj + DEPTH);
     fs_wave_sync();
+    // ---- every lane: L (lower triangle, row-major packed) and W = L^-1 in registers
+    T Lm[B][B], Wm[B][B], inv[B];
+#pragma unroll
+    for (int r = 0; r < B; r++)
+#pragma unroll
+      for (int c = 0; c <= r; c++) Lm[r][c] = A[r * B + c];
+    bool bad = false;
+#pragma unroll
     for (int p = 0; p < B; p++) {
-      T dd = A[p * B + p];
-      if (!(dd > T(0))) { if (lane == 0) *a.flag = 1; dd = T(1); }
-      const T l = sqrt(dd), inv = T(1) / l;
-      fs_wave_sync();
-      for (int r = p + lane; r < B; r += 64) A[r * B + p] = (r == p) ? l : A[r * B + p] * inv;
-      fs_wave_sync();
-      const int m2 = B - p - 1;
-      for (int idx = lane; idx < m2 * m2; idx += 64) {
-        const int r = p + 1 + idx / m2, c = p + 1 + idx % m2;
-        if (c <= r) A[r * B + c] -= A[r * B + p] * A[c * B + p];
-      }
-      fs_wave_sync();
+      T dd = Lm[p][p];
+      if (!(dd > T(0))) { bad = true; dd = T(1); }
+      // 1 / sqrt(dd) by v_rsq + two Newton steps instead of the IEEE sqrt and division sequences (~60 instructions of the
+      // ~750 every lane executes per state; the kernel is VALU-bound: 3908 waves of redundant 6 x 6 factorisations)
+      T y = fs_rsqrt(dd);
+      T l = dd * y;
+      l = fma(T(0.5) * y, fma(-l, l, dd), l);      // one residual step each: l and 1/l to the last bit or two
+      y = fma(y, fma(-l, y, T(1)), y);
+      inv[p] = y;
+      Lm[p][p] = l;
+#pragma unroll
+      for (int r = p + 1; r < B; r++) Lm[r][p] *= inv[p];
+#pragma unroll
+      for (int r = p + 1; r < B; r++)
+#pragma unroll
+        for (int c = p + 1; c <= r; c++) Lm[r][c] -= Lm[r][p] * Lm[c][p];
     }
-    if (lane < B) {          // column `lane` of W = L^-1
-      T w[B];
+    if (bad && lane == 0) *a.flag = 1;
+#pragma unroll
+    for (int c = 0; c < B; c++) {          // column c of W by forward substitution
 #pragma unroll
       for (int r = 0; r < B; r++) {
-        T sacc = (r == lane) ? T(1) : T(0);
+        if (r < c) { Wm[r][c] = T(0); continue; }
+        T sacc = (r == c) ? T(1) : T(0);
 #pragma unroll
-        for (int k = 0; k < r; k++) sacc -= A[r * B + k] * w[k];
-        w[r] = (r >= lane) ? sacc / A[r * B + r] : T(0);
+        for (int k = c; k < r; k++) sacc -= Lm[r][k] * Wm[k][c];
+        Wm[r][c] = sacc * inv[r];
       }
-#pragma unroll
-      for (int r = 0; r < B; r++) W[r * B + lane] = w[r];
     }
+#pragma unroll
+    for (int r = 0; r < B; r++)
+      if (lane == r) {
+#pragma unroll
+        for (int c = 0; c < B; c++) W[r * B + c] = Wm[r][c];
+      }
     fs_wave_sync();
-    T *fp = a.fac + (size_t)s * 2 * B * B;
+    T *fp = FACB + (size_t)(jj % FL) * 2 * B * B;
     for (int idx = lane; idx < B * B; idx += 64) {
       const int r = idx / B, c = idx - r * B;
       T e = T(0);
@@ -135,6 +184,11 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       E[idx] = e;
     }
     fs_wave_sync();
+    if (jj % FL == FL - 1 || jj == n - 1) {
+      flush(s - (jj % FL), (jj % FL) + 1);
+      fs_wave_sync();
+    }
+   }
   }
 }
 
