@@ -31,7 +31,8 @@ ABI_SYMBOLS = [
     "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
-    "gpslam_hip_add_ahrs", "gpslam_hip_plan_info",
+    "gpslam_hip_add_ahrs", "gpslam_hip_plan_info", "gpslam_hip_fs_set_split", "gpslam_hip_fs_split_info", "gpslam_hip_fs_set_top",
+    "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2",
 ]
 
 
@@ -414,6 +415,36 @@ class ChainSolver:
         ptr, nb = C.c_void_p(), C.c_size_t()
         self._chk(self.lib.gpslam_hip_landmark_reduce_buffer(self._h, C.byref(ptr), C.byref(nb)), "landmark_reduce_buffer")
         return ptr.value, nb.value
+
+    # ---- config 4 across GPUs: pieces of a chain joined at shared cut states (include/gpslam_hip.h, fs_set_split)
+    def fs_set_split(self, rank, nranks, first_lm=(), last_lm=()):
+        f = np.ascontiguousarray(first_lm, dtype=np.int32)
+        l = np.ascontiguousarray(last_lm, dtype=np.int32)
+        return self._chk(self.lib.gpslam_hip_fs_set_split(self._h, C.c_int32(rank), C.c_int32(nranks), _p(f) if len(f) else None, C.c_int32(len(f)),
+                                                          _p(l) if len(l) else None, C.c_int32(len(l))), "fs_set_split")
+
+    def fs_split_info(self):
+        out = (C.c_int32 * 4)()
+        self._chk(self.lib.gpslam_hip_fs_split_info(self._h, out), "fs_split_info")
+        return dict(fat_block=out[0], fat_blocks=out[1], segment_length=out[2], nb_top=out[3])
+
+    def fs_set_top(self, nb_top):
+        return self._chk(self.lib.gpslam_hip_fs_set_top(self._h, C.c_int32(nb_top)), "fs_set_top")
+
+    def fs_interface(self):
+        """(send pointer, bytes, recv pointer, bytes) of the interface record and of the gathered records."""
+        sp, rp = C.c_void_p(), C.c_void_p()
+        sb, rb = C.c_size_t(), C.c_size_t()
+        self._chk(self.lib.gpslam_hip_fs_interface(self._h, C.byref(sp), C.byref(sb), C.byref(rp), C.byref(rb)), "fs_interface")
+        return sp.value, sb.value, rp.value, rb.value
+
+    def fs_phase1(self, lam=0.0):
+        return self._chk(self.lib.gpslam_hip_fs_phase1(self._h, C.c_double(lam)), "fs_phase1")
+
+    def fs_phase2(self, want_stats=True):
+        st = Stats()
+        self._chk(self.lib.gpslam_hip_fs_phase2(self._h, C.byref(st) if want_stats else None), "fs_phase2")
+        return st
 
     def iterate_phase2(self, want_stats=True):
         st = Stats()

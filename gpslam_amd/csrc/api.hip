@@ -813,6 +813,42 @@ int gpslam_hip_landmark_reduce_buffer(gpslam_hip_handle *h, void **dev_ptr, size
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_landmark_reduce_buffer(h, dev_ptr, bytes) : impl64::gpslam_hip_landmark_reduce_buffer(h, dev_ptr, bytes);
 }
+int gpslam_hip_fs_set_split(gpslam_hip_handle *h, int32_t rank, int32_t nranks, const int32_t *first_lm, int32_t n_first,
+                            const int32_t *last_lm, int32_t n_last) {
+  if (!h) return GPSLAM_E_INVALID;
+  if (nranks < 1 || rank < 0 || rank >= nranks || n_first < 0 || n_last < 0 || (n_first && !first_lm) || (n_last && !last_lm))
+    return fail(h, GPSLAM_E_INVALID, "fs_set_split: bad rank / nranks / landmark lists");
+  if (sharded(h)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: create the handle with nranks = 1 (the pieces overlap in their shared cut states, there is no halo)");
+  if (h->cfg.precision == GPSLAM_FP32) return fail(h, GPSLAM_E_UNSUPPORTED, "fs_set_split: fp64 handles only");
+  if ((rank == 0 && n_first) || (rank == nranks - 1 && n_last)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: the two ends of the whole chain share nothing");
+  h->fs.split = true;
+  h->fs.rank = rank; h->fs.nranks = nranks; h->fs.nb_top = 0;
+  h->fs.first_lm.assign(first_lm, first_lm + n_first);
+  h->fs.last_lm.assign(last_lm, last_lm + n_last);
+  h->compiled = false;
+  return 0;
+}
+int gpslam_hip_fs_split_info(gpslam_hip_handle *h, int32_t out4[4]) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_split_info(h, out4) : impl64::gpslam_hip_fs_split_info(h, out4);
+}
+int gpslam_hip_fs_set_top(gpslam_hip_handle *h, int32_t nb_top) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_set_top(h, nb_top) : impl64::gpslam_hip_fs_set_top(h, nb_top);
+}
+int gpslam_hip_fs_interface(gpslam_hip_handle *h, void **send, size_t *send_bytes, void **recv, size_t *recv_bytes) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_interface(h, send, send_bytes, recv, recv_bytes)
+                                         : impl64::gpslam_hip_fs_interface(h, send, send_bytes, recv, recv_bytes);
+}
+int gpslam_hip_fs_phase1(gpslam_hip_handle *h, double lambda) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_phase1(h, lambda) : impl64::gpslam_hip_fs_phase1(h, lambda);
+}
+int gpslam_hip_fs_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_phase2(h, st) : impl64::gpslam_hip_fs_phase2(h, st);
+}
 int gpslam_hip_lm_begin(gpslam_hip_handle *h) {
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_lm_begin(h) : impl64::gpslam_hip_lm_begin(h);

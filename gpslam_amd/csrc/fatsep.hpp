@@ -53,6 +53,7 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   T *x;                              // N x B solution (R = 1 layout of the level-0 solution array)
   T *rhs;                            // N x B
   T lambda;
+  int last_fat_shared;               // split chains: the neighbour piece owns the damping of the last fat block's diagonal
   int *flag;
 };
 
@@ -450,7 +451,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
             v += w * w;
           }
       }
-      if (r == c) v += a.lambda;
+      if (r == c && !(a.last_fat_shared && k == a.K - 1)) v += a.lambda;
       if (AL) v -= fs_sym(AL, a.NCP, NB + r, NB + c);
       if (AR) v -= fs_sym(AR, a.NCP, r, c);
     }
@@ -642,6 +643,53 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_f
     fs_wave_sync();
   }
   for (int i = lane; i < NB; i += 64) a.xfat[(size_t)m * NB + i] = ts[i];
+}
+
+// ---- a chain split across GPUs (every piece runs from one shared cut state to the next; the shared cut and the landmarks
+// seen from both sides form a fat separator both neighbours hold).  The cyclic reduction of a piece stops at its two end
+// blocks; what is left of it is the interface record  [Dff | H(last, first) | Dll | g_first | g_last]  in blocks of NT
+// (the widest fat block of any piece; unit diagonal beyond the piece's own NB).
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fs_pack_record(FsArgs<T, TR> a, int end_link, int NT, T *rec) {
+  const int NB = a.NB, NB2 = NB * NB, NT2 = NT * NT, last = a.K - 1;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < NT2; idx += gridDim.x * blockDim.x) {
+    const int i = idx / NT, j = idx - i * NT;
+    const bool in = i < NB && j < NB;
+    const T pad = (i == j) ? T(1) : T(0);
+    rec[idx] = in ? a.Dfat[i * NB + j] : pad;
+    rec[NT2 + idx] = in ? a.link[(size_t)end_link * NB2 + i * NB + j] : T(0);
+    rec[2 * NT2 + idx] = in ? a.Dfat[(size_t)last * NB2 + i * NB + j] : pad;
+    if (idx < NT) {
+      rec[3 * NT2 + idx] = idx < NB ? a.gfat[idx] : T(0);
+      rec[3 * NT2 + NT + idx] = idx < NB ? a.gfat[(size_t)last * NB + idx] : T(0);
+    }
+  }
+}
+// the P gathered records -> the (P + 1)-block tridiagonal system of the shared separators (block j sits between piece j - 1
+// and piece j; blocks 0 and P are the two ends of the whole chain)
+template <typename T> __global__ void __launch_bounds__(256) k_fs_top_build(const T *recs, int P, int NT, T *D, T *link, T *g) {
+  const int NT2 = NT * NT, j = blockIdx.x;
+  const size_t RS = (size_t)3 * NT2 + 2 * NT;
+  const T *left = (j > 0) ? recs + (size_t)(j - 1) * RS : nullptr, *right = (j < P) ? recs + (size_t)j * RS : nullptr;
+  for (int idx = threadIdx.x; idx < NT2; idx += blockDim.x) {
+    T v = T(0);
+    if (left) v += left[2 * NT2 + idx];
+    if (right) v += right[idx];
+    D[(size_t)j * NT2 + idx] = v;
+    if (right) link[(size_t)j * NT2 + idx] = right[NT2 + idx];
+  }
+  for (int i = threadIdx.x; i < NT; i += blockDim.x) {
+    T v = T(0);
+    if (left) v += left[3 * NT2 + NT + i];
+    if (right) v += right[3 * NT2 + i];
+    g[(size_t)j * NT + i] = v;
+  }
+}
+// the solution of this piece's two end blocks out of the top system
+template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_fs_top_take(FsArgs<T, TR> a, const T *xtop, int rank, int NT) {
+  for (int i = threadIdx.x; i < a.NB; i += blockDim.x) {
+    a.xfat[i] = xtop[(size_t)rank * NT + i];
+    a.xfat[(size_t)(a.K - 1) * a.NB + i] = xtop[(size_t)(rank + 1) * NT + i];
+  }
 }
 
 // ---- scatter the fat solution: cut states -> x, landmarks -> dL
@@ -867,12 +915,62 @@ struct FatSepPlan {
   DevBuf d_cuts, d_segid, d_fat_lm_ptr, d_fat_lm, d_lm_fat, d_lm_slot, d_lmpri_ptr, d_lmpri, d_elim, d_upd;
   DevBuf fac, Y, Aseg, Dfat, link, gfat, Qbuf, S1, S2, sv, xfat, gL, rhs, partial;
   std::string err;
+  // a chain split across GPUs (gpslam_hip_fs_set_split): this handle holds piece `rank` of `nranks`; its first / last fat
+  // block is shared with the neighbour piece and holds exactly the landmarks first_lm / last_lm, in that order
+  bool split = false;
+  int rank = 0, nranks = 1, nb_top = 0, end_link = 0, ttop = 0;
+  std::vector<int> first_lm, last_lm;
+  std::vector<LevelHost> tlevels;
+  DevBuf send, recv, tD, tlink, tg, tQ, tS1, tS2, tsv, tx, d_telim, d_tupd;
 
   void release() {
     for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
-                      &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial})
+                      &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
+                      &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd})
       b->release();
     active = false;
+  }
+
+  // Level sets of the block cyclic reduction over K blocks in chain order: every level eliminates every other active block.
+  // keep_last: the last block is never eliminated (a piece of a split chain stops at its two end blocks; end_link then is
+  // the link between them).  elim: 6 ints per eliminated block, upd: 3 per survivor with an eliminated neighbour (FatLevel).
+  static void build_levels(int K, bool keep_last, std::vector<int> &elim, std::vector<int> &upd, std::vector<LevelHost> &levels,
+                           int &top, int &nlinks, int &end_link) {
+    elim.clear(); upd.clear(); levels.clear();
+    std::vector<int> active(K), linkidx(K > 0 ? K - 1 : 0);
+    for (int k = 0; k < K; k++) active[k] = k;
+    for (int k = 0; k + 1 < K; k++) linkidx[k] = k;
+    int next_link = K - 1;
+    while ((int)active.size() > (keep_last ? 2 : 1)) {
+      LevelHost lv;
+      lv.elim_off = (int)elim.size() / 6; lv.upd_off = (int)upd.size() / 3;
+      const int n = (int)active.size();
+      auto eliminated = [&](int q) { return q >= 0 && q < n && (q & 1) && !(keep_last && q == n - 1); };
+      std::vector<int> nact, nlink;
+      for (int i = 0; i < n; i++) {
+        if (eliminated(i)) continue;
+        nact.push_back(active[i]);
+        if (!eliminated(i - 1) && !eliminated(i + 1)) continue;
+        upd.push_back(active[i]);
+        upd.push_back(eliminated(i - 1) ? active[i - 1] : -1);
+        upd.push_back(eliminated(i + 1) ? active[i + 1] : -1);
+      }
+      for (int q = 1; q < n; q += 2) {
+        if (!eliminated(q)) { nlink.push_back(linkidx[q - 1]); continue; }   // the kept last block: its link stays
+        const int r = (q + 1 < n) ? active[q + 1] : -1;
+        const int lk_new = (r >= 0) ? next_link++ : -1;
+        elim.push_back(active[q]); elim.push_back(active[q - 1]); elim.push_back(r);
+        elim.push_back(linkidx[q - 1]); elim.push_back(r >= 0 ? linkidx[q] : -1); elim.push_back(lk_new);
+        if (r >= 0) nlink.push_back(lk_new);
+      }
+      lv.nelim = (int)elim.size() / 6 - lv.elim_off; lv.nupd = (int)upd.size() / 3 - lv.upd_off;
+      levels.push_back(lv);
+      active.swap(nact);
+      linkidx.swap(nlink);
+    }
+    top = active[0];
+    nlinks = std::max(next_link, 1);
+    end_link = linkidx.empty() ? 0 : linkidx[0];
   }
 
   static std::vector<int> make_cuts(int N, int C) {
@@ -896,9 +994,25 @@ struct FatSepPlan {
       fat_of.assign(L, 0);
       slot_of.assign(L, 0);
       bool ok = true;
+      // split chains: the shared end blocks hold exactly the listed landmarks, in the listed order (both neighbours build the
+      // same block); every other landmark keeps away from them
+      std::vector<int> forced(L, -1);
+      const bool lsh = split && rank > 0, rsh = split && rank < nranks - 1;
+      if (split) {
+        for (int l : first_lm) {
+          if (touch_lo[l] >= 0 && K >= 2 && touch_hi[l] > cuts[1]) { ok = false; break; }
+          forced[l] = 0; fat_of[l] = 0; slot_of[l] = counts[0]++;
+        }
+        for (int l : last_lm) {
+          if (!ok) break;
+          if (touch_lo[l] >= 0 && K >= 2 && touch_lo[l] < cuts[K - 2]) { ok = false; break; }
+          forced[l] = K - 1; fat_of[l] = K - 1; slot_of[l] = counts[K - 1]++;
+        }
+      }
       for (int l = 0; l < L && ok; l++) {
+        if (forced[l] >= 0) continue;
         int lo, hi;
-        if (touch_lo[l] < 0) { lo = hi = l % K; }
+        if (touch_lo[l] < 0) { lo = hi = std::min(std::max(l % K, lsh ? 1 : 0), rsh ? K - 2 : K - 1); }
         else {
           const int k_lo = (int)(std::upper_bound(cuts.begin(), cuts.end(), touch_lo[l]) - cuts.begin()) - 1;
           const int k_hi = (int)(std::lower_bound(cuts.begin(), cuts.end(), touch_hi[l]) - cuts.begin());
@@ -906,6 +1020,9 @@ struct FatSepPlan {
           lo = std::max(k_hi - 1, 0);
           hi = std::min(k_lo + 1, K - 1);
         }
+        if (lsh && lo == 0) lo = 1;
+        if (rsh && hi == K - 1) hi = K - 2;
+        if (lo > hi) { ok = false; break; }
         int best = lo;
         for (int k = lo + 1; k <= hi; k++) if (counts[k] < counts[best]) best = k;
         fat_of[l] = best;
@@ -917,7 +1034,9 @@ struct FatSepPlan {
       if (ok && nb <= kFatMax) { C = Ctry; NB = (nb + 3) & ~3; if (NB > kFatMax) NB = kFatMax; break; }
       if (c_forced > 0 || K <= 2) {
         err = ok ? "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 64)"
-                 : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists";
+                 : (split ? "no segmentation of this piece keeps its private landmarks off the shared end blocks and the shared ones inside the "
+                            "end segments: the piece is too short for the landmarks' windows of visibility (use fewer, longer pieces)"
+                          : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists");
         return false;
       }
       if (ok && nb > kFatMax) {   // longer segments only add landmarks per cut

@@ -284,3 +284,166 @@ class ShardedSolver:
         for k in range(iters):
             out = self.iterate(lam, want_stats=(k == iters - 1))
         return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Chains with many locally visible landmarks (BASELINE config 4) across GPUs: pieces joined at shared cut states.
+# The dense-border scheme above replicates every landmark on every rank; with 5e4 landmarks that is neither possible
+# nor needed -- a landmark is seen from a window of a few hundred states, so it belongs to ONE piece, or to the fat
+# separator between two neighbouring pieces (include/gpslam_hip.h, gpslam_hip_fs_set_split).
+
+def split_boundaries(N, P):
+    """States s_0 = 0 < s_1 < ... < s_P = N - 1: piece r holds the states [s_r, s_(r+1)], both ends included."""
+    b = partition(N - 1, P)
+    b[-1] = N - 1
+    return b
+
+
+def split_local_problem(problem, rank, nranks):
+    """Cut piece `rank` out of a global problem with range landmarks (gpslam_amd.synthetic format).  Every factor goes to
+    the piece its left (or only) state lies in -- the final state counts to the last piece; a landmark goes to every piece
+    that holds one of its range factors (at most two neighbours, else the pieces are shorter than its window of
+    visibility), its prior to the right-most of them.  Returns the local problem; `lm_global` maps its landmarks back,
+    `first_lm` / `last_lm` are the landmarks shared with the left / right neighbour, `own_lm` marks the landmarks whose
+    values this piece reports."""
+    p = problem
+    N, P = p["N"], nranks
+    s = split_boundaries(N, P)
+    lo, hi = s[rank], s[rank + 1]
+    last = rank == P - 1
+    out = dict(kind=p["kind"], name=p.get("name", ""), N=hi - lo + 1, qc=p["qc"], lo=lo, hi=hi,
+               pose=p["pose"][lo:hi + 1].copy(), vel=p["vel"][lo:hi + 1].copy(), linear=p.get("linear", False))
+
+    def mine(idx):
+        idx = np.asarray(idx)
+        return (idx >= lo) & ((idx < hi) | (last & (idx == hi)))
+
+    def cut(idx_key, keys):
+        if idx_key not in p:
+            return
+        idx = np.asarray(p[idx_key])
+        m = mine(idx)
+        out[idx_key] = (idx[m] - lo).astype(np.int32)
+        for k in keys:
+            out[k] = np.asarray(p[k])[m]
+
+    cut("gp_left", ["gp_dt"])
+    cut("prior_idx", ["prior_pose", "prior_sig"])
+    cut("vprior_idx", ["vprior", "vprior_sig"])
+    cut("between_left", ["between_meas", "between_sig"])
+    # landmarks: the piece of every range factor, then the pieces of every landmark
+    rl = np.asarray(p["range_left"])
+    rlm = np.asarray(p["range_lm"])
+    L = len(p["landmarks"])
+    piece_of = np.minimum(np.searchsorted(np.asarray(s), rl, side="right") - 1, P - 1)
+    pmin = np.full(L, P, dtype=np.int64)
+    pmax = np.full(L, -1, dtype=np.int64)
+    np.minimum.at(pmin, rlm, piece_of)
+    np.maximum.at(pmax, rlm, piece_of)
+    seen = pmax >= 0
+    pmin[~seen], pmax[~seen] = 0, 0                       # a landmark nobody measures: piece 0 keeps it (and its prior)
+    if (pmax - pmin > 1).any():
+        raise ValueError("a landmark is seen from more than two neighbouring pieces: use fewer, longer pieces")
+    local = np.nonzero((pmin <= rank) & (pmax >= rank))[0]
+    g2l = np.full(L, -1, dtype=np.int64)
+    g2l[local] = np.arange(len(local))
+    out["lm_global"] = local
+    out["landmarks"] = np.asarray(p["landmarks"])[local].copy()
+    out["first_lm"] = g2l[local[(pmin[local] < rank)]].astype(np.int32)
+    out["last_lm"] = g2l[local[(pmax[local] > rank)]].astype(np.int32)
+    out["own_lm"] = pmax[local] == rank
+    m = mine(rl)
+    out["range_left"] = (rl[m] - lo).astype(np.int32)
+    out["range_lm"] = g2l[rlm[m]].astype(np.int32)
+    for k in ("range_z", "range_sigma", "range_dt", "range_tau"):
+        out[k] = np.asarray(p[k])[m]
+    if "lprior_idx" in p:
+        li = np.asarray(p["lprior_idx"])
+        mk = pmax[li] == rank
+        out["lprior_idx"] = g2l[li[mk]].astype(np.int32)
+        out["lprior"] = np.asarray(p["lprior"])[mk]
+        out["lprior_sig"] = np.asarray(p["lprior_sig"])[mk]
+    return out
+
+
+def apply_split(lp, solver, rank, nranks):
+    """Feed a piece (split_local_problem) to a ChainSolver created with nranks = 1; fs_set_top still has to follow."""
+    from . import synthetic
+    solver.fs_set_split(rank, nranks, lp["first_lm"], lp["last_lm"])
+    return synthetic.apply(lp, solver)
+
+
+class SplitSolver:
+    """One piece of a chain with locally visible landmarks, one process per GPU (or, for tests, P handles in one process
+    with dist = None and `peers`).  iterate(): fs_phase1 -> ONE all-gather of the interface records -> fs_phase2."""
+
+    def __init__(self, backend, rank, nranks, dist=None, group=None):
+        import torch
+        self.backend, self.rank, self.nranks, self.dist, self.group = backend, rank, nranks, dist, group
+        backend.set_stream(torch.cuda.current_stream().cuda_stream)     # collectives are ordered against this stream
+        nb = backend.fs_split_info()["fat_block"]
+        self.nb_local = nb
+        self.send = self.recv = None
+        if dist is not None:
+            t = torch.tensor([nb], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+            self.set_top(int(t.item()))
+
+    def set_top(self, nb_top):
+        import torch
+        self.backend.fs_set_top(nb_top)
+        sp, sb, rp, rb = self.backend.fs_interface()
+        self.send = torch.as_tensor(_DevView(sp, sb), device="cuda")
+        self.recv = torch.as_tensor(_DevView(rp, rb), device="cuda")
+
+    def exchange(self):
+        if self.dist is None:
+            self.recv.view(self.nranks, -1)[self.rank].copy_(self.send)
+            return
+        chunks = list(self.recv.view(self.nranks, -1).unbind(0))
+        self.dist.all_gather(chunks, self.send, group=self.group)
+
+    def iterate(self, lam=0.0, want_stats=True):
+        self.backend.fs_phase1(lam)
+        self.exchange()
+        st = self.backend.fs_phase2(want_stats)
+        if not want_stats:
+            return None
+        vals = np.array([st.error_before, st.error_after, st.delta_inf_norm], dtype=np.float64)
+        if self.dist is not None:
+            import torch
+            t = torch.from_numpy(vals.copy()).cuda()
+            allv = [torch.empty_like(t) for _ in range(self.nranks)]
+            self.dist.all_gather(allv, t, group=self.group)
+            m = torch.stack(allv).cpu().numpy()
+            vals = np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max()])
+        return dict(error_before=float(vals[0]), error_after=float(vals[1]), delta_inf_norm=float(vals[2]))
+
+
+def iterate_pieces(pieces, lam=0.0):
+    """P SplitSolvers living in ONE process (tests, single-GPU timing): the all-gather is P^2 device copies."""
+    P = len(pieces)
+    for sv in pieces:
+        sv.backend.fs_phase1(lam)
+    for sv in pieces:
+        rv = sv.recv.view(P, -1)
+        for k in range(P):
+            rv[k].copy_(pieces[k].send)
+    sts = [sv.backend.fs_phase2(True) for sv in pieces]
+    return dict(error_before=sum(st.error_before for st in sts), error_after=sum(st.error_after for st in sts),
+                delta_inf_norm=max(st.delta_inf_norm for st in sts))
+
+
+def merge_pieces(problem, locals_, states, landmarks):
+    """Global (pose, vel, landmarks) from the pieces' results: a shared state is reported by the piece on its right, a
+    shared landmark by the right-most piece that holds it."""
+    N, L = problem["N"], len(problem["landmarks"])
+    pose = np.zeros_like(np.asarray(problem["pose"], dtype=np.float64))
+    vel = np.zeros_like(np.asarray(problem["vel"], dtype=np.float64))
+    lmk = np.array(problem["landmarks"], dtype=np.float64)
+    for lp, (ps, vs), lm in zip(locals_, states, landmarks):
+        pose[lp["lo"]:lp["hi"] + 1] = ps
+        vel[lp["lo"]:lp["hi"] + 1] = vs
+        own = lp["own_lm"]
+        lmk[lp["lm_global"][own]] = np.asarray(lm)[own]
+    return pose, vel, lmk

@@ -295,6 +295,26 @@ int gpslam_hip_lm_begin(gpslam_hip_handle *h);
 int gpslam_hip_lm_trial_phase1(gpslam_hip_handle *h, double lambda);
 int gpslam_hip_lm_trial_phase2(gpslam_hip_handle *h, double *out6);
 int gpslam_hip_lm_reject(gpslam_hip_handle *h);
+/* ---- chains with many locally visible landmarks (the segmented landmark elimination, BASELINE config 4) across GPUs ----
+ * The chain is split into P pieces that OVERLAP in one state: piece r holds the states [s_r, s_(r+1)] (both ends included),
+ * every factor whose left / only state lies in [s_r, s_(r+1)) (the last piece also those of the final state), and the
+ * landmarks its factors touch, in its own numbering.  A landmark seen from both sides of s_(r+1) is listed -- in the same
+ * order -- as a `last` landmark of piece r and a `first` landmark of piece r + 1 (its prior, if any, is given to ONE of the
+ * two); the shared state and these landmarks form a fat separator both pieces hold, and both apply the same update to it.
+ * Handles are created with nranks = 1 (no halo); before compile():  fs_set_split;  after compile(): fs_split_info ->
+ * out4 = {this piece's fat block size NB, fat blocks, segment length, nb_top}, then fs_set_top(max of NB over the pieces).
+ * One Gauss-Newton iteration:  fs_phase1(lambda)  -> interface record [Dff | H | Dll | g_first | g_last] in `send`
+ * (3 nb_top^2 + 2 nb_top doubles);  ONE all-gather of the records into `recv` (piece order);  fs_phase2: every piece solves
+ * the (P + 1)-block system of the shared separators redundantly, back-substitutes, retracts its states and landmarks
+ * (st: THIS piece's error terms and |delta|_inf; NULL skips the error pass).  GPInterpolatedRangeFactorPose2.h:64-98 over
+ * matlab/PlazaPose2.m:147-178's graph, at BASELINE config 4's size on more than one GPU. */
+int gpslam_hip_fs_set_split(gpslam_hip_handle *h, int32_t rank, int32_t nranks, const int32_t *first_lm, int32_t n_first,
+                            const int32_t *last_lm, int32_t n_last);
+int gpslam_hip_fs_split_info(gpslam_hip_handle *h, int32_t out4[4]);
+int gpslam_hip_fs_set_top(gpslam_hip_handle *h, int32_t nb_top);
+int gpslam_hip_fs_interface(gpslam_hip_handle *h, void **send, size_t *send_bytes, void **recv, size_t *recv_bytes);
+int gpslam_hip_fs_phase1(gpslam_hip_handle *h, double lambda);
+int gpslam_hip_fs_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
 /* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
 int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
 

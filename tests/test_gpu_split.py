@@ -1,0 +1,106 @@
+"""BASELINE config 4 across GPUs: the segmented landmark elimination on a chain split into pieces joined at shared cut
+states (include/gpslam_hip.h, gpslam_hip_fs_set_split; gpslam_amd/sharded.py, SplitSolver).  P handles on ONE device play
+the P ranks (the all-gather is a device copy), so the whole HIP path runs on the single-GPU build farm; the reference is the
+unsplit segmented solve of the same graph and, at the small size, the oracle's dense bordered solve."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _pieces(problem, P, segment_length=0):
+    import gpslam_amd
+    from gpslam_amd import sharded
+    locals_, pieces = [], []
+    for r in range(P):
+        lp = sharded.split_local_problem(problem, r, P)
+        s = gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=segment_length)
+        sharded.apply_split(lp, s, r, P)
+        locals_.append(lp)
+        pieces.append(sharded.SplitSolver(s, r, P))
+    nb_top = max(sv.nb_local for sv in pieces)
+    for sv in pieces:
+        sv.set_top(nb_top)
+    return locals_, pieces
+
+
+def _merged(problem, locals_, pieces):
+    from gpslam_amd import sharded
+    return sharded.merge_pieces(problem, locals_, [sv.backend.get_states() for sv in pieces], [sv.backend.get_landmarks() for sv in pieces])
+
+
+@pytest.mark.parametrize("P,N,L,window,C", [(1, 700, 35, 200, 0), (2, 2000, 100, 200, 0), (3, 3000, 150, 200, 0), (4, 3001, 150, 120, 128),
+                                            (5, 6000, 300, 200, 256), (8, 12000, 600, 200, 0)])
+def test_split_chain_equals_the_unsplit_segmented_solve(P, N, L, window, C):
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(N, L=L, window=window)
+    locals_, pieces = _pieces(problem, P, C)
+    ref = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True))
+    for it in range(6):
+        got = sharded.iterate_pieces(pieces)
+        _, st = ref.iterate_gn()
+        assert abs(got["error_before"] - st.error_before) <= 1e-9 * max(1.0, st.error_before)
+        assert abs(got["error_after"] - st.error_after) <= 1e-7 * max(1.0, st.error_after)
+        assert abs(got["delta_inf_norm"] - st.delta_inf_norm) <= 1e-6 * max(1.0, st.delta_inf_norm) + 1e-10
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p1, v1 = ref.get_states()
+    assert np.abs(pose - p1).max() <= 1e-9 * max(1.0, np.abs(p1).max())
+    assert np.abs(vel - v1).max() <= 1e-8 * max(1.0, np.abs(v1).max())
+    assert np.abs(lmk - ref.get_landmarks()).max() <= 1e-8 * max(1.0, np.abs(lmk).max())
+    # the two copies of every shared state / landmark moved in lock step (same top solve on both sides): bit-identical
+    for a, b, la, lb in zip(pieces[:-1], pieces[1:], locals_[:-1], locals_[1:]):
+        pa, va = a.backend.get_states()
+        pb, vb = b.backend.get_states()
+        assert np.array_equal(pa[-1], pb[0]) and np.array_equal(va[-1], vb[0])
+        assert np.array_equal(a.backend.get_landmarks()[la["last_lm"]], b.backend.get_landmarks()[lb["first_lm"]])
+    for sv in pieces:
+        sv.backend.close()
+    ref.close()
+
+
+def test_split_chain_against_the_oracle():
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(1200, L=60, window=120)
+    locals_, pieces = _pieces(problem, 3)
+    orc = S.apply(problem, O.Chain(O.POSE2, chart=O.CHART_FIRST_ORDER, landmark_dim=2))
+    for it in range(5):
+        got = sharded.iterate_pieces(pieces)
+        _, s0 = orc.iterate_gn()
+        assert abs(got["error_after"] - s0.error_after) <= 1e-7 * max(1.0, s0.error_after)
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p0, v0 = orc.get_states()
+    assert np.abs(pose - p0).max() <= 1e-8 * max(1.0, np.abs(p0).max())
+    assert np.abs(vel - v0).max() <= 1e-7 * max(1.0, np.abs(v0).max())
+    assert np.abs(lmk - orc.get_landmarks()).max() <= 1e-7 * max(1.0, np.abs(lmk).max())
+    for sv in pieces:
+        sv.backend.close()
+
+
+def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(2000, L=100, window=200)
+    lp = sharded.split_local_problem(problem, 0, 2)
+    s = gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2)
+    sharded.apply_split(lp, s, 0, 2)
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        s.iterate_gn()
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        s.fs_phase1(0.0)                       # fs_set_top has not been called
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        s.fs_set_top(4)                        # smaller than this piece's own fat blocks
+    s.fs_set_top(s.fs_split_info()["fat_block"])
+    s.fs_phase1(0.0)
+    s.close()
+    # pieces shorter than a landmark's window of visibility: refused when the problem is cut
+    with pytest.raises(ValueError):
+        sharded.split_local_problem(S.pose2_local_landmarks_chain(600, L=30, window=400), 1, 6)
+    # the two ends of the whole chain share nothing
+    t = gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2)
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        t.fs_set_split(0, 2, [1], [])
+    t.close()
