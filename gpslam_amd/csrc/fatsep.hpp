@@ -973,8 +973,15 @@ struct FatSepPlan {
     end_link = linkidx.empty() ? 0 : linkidx[0];
   }
 
-  static std::vector<int> make_cuts(int N, int C) {
+  // even: segments of (nearly) equal length <= C instead of a short last one -- the pieces of a split chain, whose LAST
+  // segment has to hold the whole window of every landmark shared with the neighbour
+  static std::vector<int> make_cuts(int N, int C, bool even = false) {
     std::vector<int> c;
+    if (even) {
+      const int nseg = std::max(1, (N - 1 + C - 1) / C);
+      for (int i = 0; i <= nseg; i++) c.push_back((int)(((long long)i * (N - 1)) / nseg));
+      return c;
+    }
     for (int s = 0; s < N - 1; s += C) c.push_back(s);
     if (c.empty() || c.back() != N - 1) c.push_back(N - 1);
     if (c.size() >= 3 && c[c.size() - 1] - c[c.size() - 2] < 2) c.erase(c.end() - 2);
@@ -988,7 +995,7 @@ struct FatSepPlan {
     N = N_; B = B_; ld = ld_; L = L_;
     if (N < 2) { err = "the segmented landmark elimination needs at least two states"; return false; }
     for (int Ctry = (c_forced > 0 ? c_forced : 32);; Ctry *= 2) {
-      cuts = make_cuts(N, Ctry);
+      cuts = make_cuts(N, Ctry, split);
       K = (int)cuts.size();
       counts.assign(K, 0);
       fat_of.assign(L, 0);

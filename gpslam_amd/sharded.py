@@ -377,24 +377,29 @@ class SplitSolver:
     """One piece of a chain with locally visible landmarks, one process per GPU (or, for tests, P handles in one process
     with dist = None and `peers`).  iterate(): fs_phase1 -> ONE all-gather of the interface records -> fs_phase2."""
 
-    def __init__(self, backend, rank, nranks, dist=None, group=None):
+    def __init__(self, backend, rank, nranks, dist=None, group=None, device="cuda"):
         import torch
         self.backend, self.rank, self.nranks, self.dist, self.group = backend, rank, nranks, dist, group
-        backend.set_stream(torch.cuda.current_stream().cuda_stream)     # collectives are ordered against this stream
+        self.device = device                      # "cpu": the numpy model of the two phases (tests/split_model.py) over gloo
+        if device == "cuda":
+            backend.set_stream(torch.cuda.current_stream().cuda_stream)     # collectives are ordered against this stream
         nb = backend.fs_split_info()["fat_block"]
         self.nb_local = nb
         self.send = self.recv = None
-        if dist is not None:
-            t = torch.tensor([nb], dtype=torch.int32, device="cuda")
+        if dist is not None:                      # the pieces agree on the block size of the interface record
+            t = torch.tensor([nb], dtype=torch.int32, device=device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
             self.set_top(int(t.item()))
 
     def set_top(self, nb_top):
         import torch
         self.backend.fs_set_top(nb_top)
-        sp, sb, rp, rb = self.backend.fs_interface()
-        self.send = torch.as_tensor(_DevView(sp, sb), device="cuda")
-        self.recv = torch.as_tensor(_DevView(rp, rb), device="cuda")
+        if self.device == "cuda":
+            sp, sb, rp, rb = self.backend.fs_interface()
+            self.send = torch.as_tensor(_DevView(sp, sb), device="cuda")
+            self.recv = torch.as_tensor(_DevView(rp, rb), device="cuda")
+        else:
+            self.send, self.recv = self.backend.fs_interface()
 
     def exchange(self):
         if self.dist is None:
@@ -412,7 +417,7 @@ class SplitSolver:
         vals = np.array([st.error_before, st.error_after, st.delta_inf_norm], dtype=np.float64)
         if self.dist is not None:
             import torch
-            t = torch.from_numpy(vals.copy()).cuda()
+            t = torch.from_numpy(vals.copy()).to(self.device)
             allv = [torch.empty_like(t) for _ in range(self.nranks)]
             self.dist.all_gather(allv, t, group=self.group)
             m = torch.stack(allv).cpu().numpy()

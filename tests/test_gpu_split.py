@@ -32,7 +32,7 @@ def _merged(problem, locals_, pieces):
 
 
 @pytest.mark.parametrize("P,N,L,window,C", [(1, 700, 35, 200, 0), (2, 2000, 100, 200, 0), (3, 3000, 150, 200, 0), (4, 3001, 150, 120, 128),
-                                            (5, 6000, 300, 200, 256), (8, 12000, 600, 200, 0)])
+                                            (5, 6000, 300, 200, 256), (8, 12000, 600, 200, 0), (4, 200000, 10000, 200, 0)])
 def test_split_chain_equals_the_unsplit_segmented_solve(P, N, L, window, C):
     import gpslam_amd
     from gpslam_amd import sharded, synthetic as S
@@ -104,3 +104,22 @@ def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
     with pytest.raises(gpslam_amd.GpslamHipError):
         t.fs_set_split(0, 2, [1], [])
     t.close()
+
+
+def test_split_chain_one_process_per_gpu_over_rccl():
+    """tests/rccl_split_worker.py, one process per visible GPU (up to eight) over RCCL; on the single-GPU build farm the
+    worker runs with world size 1 -- the collectives (the all-reduce of the record size, the all-gather of the records and
+    of the statistics) still go through torch.distributed / RCCL."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    world = max(1, min(torch.cuda.device_count(), 8))
+    port = 29500 + os.getpid() % 90
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_split_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(3000 * world)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "RCCL_SPLIT_OK" in outs[0]
