@@ -32,7 +32,8 @@ ABI_SYMBOLS = [
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
     "gpslam_hip_add_ahrs", "gpslam_hip_plan_info", "gpslam_hip_fs_set_split", "gpslam_hip_fs_split_info", "gpslam_hip_fs_set_top",
-    "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2",
+    "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
+    "gpslam_hip_fs_lm_trial_phase2",
 ]
 
 
@@ -445,6 +446,15 @@ class ChainSolver:
         st = Stats()
         self._chk(self.lib.gpslam_hip_fs_phase2(self._h, C.byref(st) if want_stats else None), "fs_phase2")
         return st
+
+    def fs_lm_trial_phase1(self, lam):
+        return self._chk(self.lib.gpslam_hip_fs_lm_trial_phase1(self._h, C.c_double(lam)), "fs_lm_trial_phase1")
+
+    def fs_lm_trial_phase2(self):
+        """[error, trial error, |delta|_inf, delta.g, |delta|^2, indefinite flag] of this piece."""
+        out = np.zeros(6)
+        self._chk(self.lib.gpslam_hip_fs_lm_trial_phase2(self._h, _p(out)), "fs_lm_trial_phase2")
+        return out
 
     def iterate_phase2(self, want_stats=True):
         st = Stats()

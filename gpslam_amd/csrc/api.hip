@@ -849,6 +849,14 @@ int gpslam_hip_fs_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st) {
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_phase2(h, st) : impl64::gpslam_hip_fs_phase2(h, st);
 }
+int gpslam_hip_fs_lm_trial_phase1(gpslam_hip_handle *h, double lambda) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_lm_trial_phase1(h, lambda) : impl64::gpslam_hip_fs_lm_trial_phase1(h, lambda);
+}
+int gpslam_hip_fs_lm_trial_phase2(gpslam_hip_handle *h, double *out6) {
+  if (!h) return GPSLAM_E_INVALID;
+  return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_fs_lm_trial_phase2(h, out6) : impl64::gpslam_hip_fs_lm_trial_phase2(h, out6);
+}
 int gpslam_hip_lm_begin(gpslam_hip_handle *h) {
   if (!h) return GPSLAM_E_INVALID;
   return h->cfg.precision == GPSLAM_FP32 ? impl32::gpslam_hip_lm_begin(h) : impl64::gpslam_hip_lm_begin(h);

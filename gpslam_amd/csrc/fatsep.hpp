@@ -692,6 +692,12 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_f
   }
 }
 
+// out[i] = x[i] for the landmarks this piece counts (own[landmark] != 0), 0 for those shared with the piece on its right
+template <typename T> __global__ void __launch_bounds__(256) k_fs_mask_mul(const T *x, const int *own, int ld, int n, T *out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = own[i / ld] ? x[i] : T(0);
+}
+
 // ---- scatter the fat solution: cut states -> x, landmarks -> dL
 template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fs_scatter(FsArgs<T, TR> a) {
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -921,12 +927,12 @@ struct FatSepPlan {
   int rank = 0, nranks = 1, nb_top = 0, end_link = 0, ttop = 0;
   std::vector<int> first_lm, last_lm;
   std::vector<LevelHost> tlevels;
-  DevBuf send, recv, tD, tlink, tg, tQ, tS1, tS2, tsv, tx, d_telim, d_tupd;
+  DevBuf send, recv, tD, tlink, tg, tQ, tS1, tS2, tsv, tx, d_telim, d_tupd, d_lm_own, lm_tmp;
 
   void release() {
     for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
                       &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
-                      &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd})
+                      &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp})
       b->release();
     active = false;
   }

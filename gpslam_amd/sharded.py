@@ -425,6 +425,84 @@ class SplitSolver:
         return dict(error_before=float(vals[0]), error_after=float(vals[1]), delta_inf_norm=float(vals[2]))
 
 
+    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+        """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the pieces: ShardedSolver.iterate_lm with the
+        split chain's trial steps.  Returns (stats dict, new lambda)."""
+        be = self.backend
+        be.lm_begin()
+        accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
+        while True:
+            be.fs_lm_trial_phase1(lam)
+            self.exchange()
+            s = self._reduce_lm_scalars(be.fs_lm_trial_phase2())
+            ok, err0 = lm_decision(s, lam, min_model_fidelity)
+            if ok:
+                new_err, dinf = float(s[1]), float(s[2])
+                lam = max(lam / lambda_factor, lambda_lower_bound)
+                accepted = True
+                break
+            be.lm_reject()
+            if lam >= lambda_upper_bound:
+                break
+            lam *= lambda_factor
+        return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
+                    accepted=accepted), lam
+
+    def _reduce_lm_scalars(self, loc):
+        if self.dist is None:
+            return np.asarray(loc, dtype=np.float64)
+        import torch
+        t = torch.from_numpy(np.asarray(loc, dtype=np.float64).copy()).to(self.device)
+        allv = [torch.empty_like(t) for _ in range(self.nranks)]
+        self.dist.all_gather(allv, t, group=self.group)
+        return reduce_lm_scalars(torch.stack(allv).cpu().numpy())
+
+
+def reduce_lm_scalars(m):
+    """rows = pieces: sum of (error, trial error, delta.g, |delta|^2), max of (|delta|_inf, indefinite flag)"""
+    return np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
+
+
+def lm_decision(s, lam, min_model_fidelity=1e-3):
+    """(accept?, current error) from the reduced scalars of one trial -- the test of gpslam_hip_iterate_lm"""
+    if s[5] == 0.0:
+        lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
+        if lin_change >= 0.0:
+            fidelity = (s[0] - s[1]) / lin_change if lin_change > 1e-20 else 0.0
+            if fidelity > min_model_fidelity:
+                return True, float(s[0])
+    return False, float(s[0])
+
+
+def iterate_pieces_lm(pieces, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+    """iterate_lm for P SplitSolvers living in ONE process (tests)."""
+    P = len(pieces)
+    for sv in pieces:
+        sv.backend.lm_begin()
+    accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
+    while True:
+        for sv in pieces:
+            sv.backend.fs_lm_trial_phase1(lam)
+        for sv in pieces:
+            rv = sv.recv.view(P, -1)
+            for k in range(P):
+                rv[k].copy_(pieces[k].send)
+        s = reduce_lm_scalars(np.stack([sv.backend.fs_lm_trial_phase2() for sv in pieces]))
+        ok, err0 = lm_decision(s, lam, min_model_fidelity)
+        if ok:
+            new_err, dinf = float(s[1]), float(s[2])
+            lam = max(lam / lambda_factor, lambda_lower_bound)
+            accepted = True
+            break
+        for sv in pieces:
+            sv.backend.lm_reject()
+        if lam >= lambda_upper_bound:
+            break
+        lam *= lambda_factor
+    return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
+                accepted=accepted), lam
+
+
 def iterate_pieces(pieces, lam=0.0):
     """P SplitSolvers living in ONE process (tests, single-GPU timing): the all-gather is P^2 device copies."""
     P = len(pieces)

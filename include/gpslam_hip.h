@@ -315,6 +315,13 @@ int gpslam_hip_fs_set_top(gpslam_hip_handle *h, int32_t nb_top);
 int gpslam_hip_fs_interface(gpslam_hip_handle *h, void **send, size_t *send_bytes, void **recv, size_t *recv_bytes);
 int gpslam_hip_fs_phase1(gpslam_hip_handle *h, double lambda);
 int gpslam_hip_fs_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
+/* LevenbergMarquardtOptimizer::iterate on a split chain (matlab/PlazaPose2.m:217-229 optimises this graph with it): the
+ * caller's loop, as for nranks > 1 below --  gpslam_hip_lm_begin;  repeat { fs_lm_trial_phase1(lambda); all-gather of the
+ * records; fs_lm_trial_phase2(out6); all-reduce of out6 (sum of [0], [1], [3], [4]; max of [2], [5]); accept, or
+ * gpslam_hip_lm_reject and a larger lambda }.  out6 as for gpslam_hip_lm_trial_phase2; a shared state / landmark enters
+ * |delta|^2 on the piece to its right only, delta . g adds up over the pieces as it is. */
+int gpslam_hip_fs_lm_trial_phase1(gpslam_hip_handle *h, double lambda);
+int gpslam_hip_fs_lm_trial_phase2(gpslam_hip_handle *h, double *out6);
 /* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
 int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
 

@@ -125,7 +125,7 @@ class SplitPieceModel:
         gf[:nf], gl[:nla] = sr[:nf], sr[nf:]
         self.send.copy_(torch.from_numpy(np.concatenate([Dff.ravel(), Hlf.ravel(), Dll.ravel(), gf, gl])))
 
-    def fs_phase2(self, want_stats=True):
+    def _solve_and_update(self):
         P, NT = self.P, self.nb_top
         NT2 = NT * NT
         rec = self.recv.numpy().reshape(P, 3 * NT2 + 2 * NT)
@@ -155,6 +155,27 @@ class SplitPieceModel:
             self.pose[i] = O.retract(self.kind, self.pose[i], xs[i, :d], self.chart)
             self.vel[i] += xs[i, d:]
         self.lmk += x[N * b:].reshape(self.lmk.shape)
+        return x, rhs, last
+
+    def fs_phase2(self, want_stats=True):
+        x = self._solve_and_update()[0]
         if not want_stats:
             return None
         return Stats(self._err_before, self._chain().error(), float(np.abs(x).max()))
+
+    # ---- Levenberg-Marquardt trial steps (the caller owns the loop: gpslam_amd/sharded.py, SplitSolver.iterate_lm)
+    def lm_begin(self):
+        self._saved = (self.pose.copy(), self.vel.copy(), self.lmk.copy())
+
+    def lm_reject(self):
+        self.pose, self.vel, self.lmk = (a.copy() for a in self._saved)
+
+    def fs_lm_trial_phase1(self, lam):
+        self.fs_phase1(lam)            # the state IS the linearisation point (lm_begin / lm_reject)
+
+    def fs_lm_trial_phase2(self):
+        x, rhs, last = self._solve_and_update()
+        own = np.ones(len(x), dtype=bool)
+        if self.rank < self.P - 1:
+            own[last] = False          # a shared unknown enters |delta|^2 on the piece to its right
+        return np.array([self._err_before, self._chain().error(), np.abs(x).max(), x @ rhs, x[own] @ x[own], 0.0])

@@ -80,6 +80,38 @@ def test_split_chain_against_the_oracle():
         sv.backend.close()
 
 
+@pytest.mark.parametrize("P", [1, 3])
+def test_split_levenberg_marquardt_follows_the_unsplit_lambda_schedule(P):
+    """LevenbergMarquardtOptimizer::iterate as matlab/PlazaPose2.m:217-229 drives it, from an open-loop dead-reckoned start
+    (no re-anchoring: the error falls from 1.5e7 to 1.8e3 over the first iterations), until the reference run has converged."""
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(2400, L=120, window=160, anchor=0)
+    locals_, pieces = _pieces(problem, P)
+    ref = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True))
+    lam_s = lam_r = 1e-5
+    lams = []
+    for it in range(8):
+        got, lam_s = sharded.iterate_pieces_lm(pieces, lam_s)
+        _, st, lam_r = ref.iterate_lm(lam_r)[:3]
+        lams.append(lam_r)
+        assert lam_s == lam_r and got["accepted"] == bool(st.accepted)
+        assert abs(got["error_before"] - st.error_before) <= 1e-8 * max(1.0, st.error_before)
+        assert abs(got["error_after"] - st.error_after) <= 1e-6 * max(1.0, st.error_after)
+        if st.error_before - st.error_after <= 1e-7 * st.error_before:
+            break           # converged: from here on accept / reject is decided by the rounding of err - newErr
+    assert len(lams) >= 4
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p1, v1 = ref.get_states()
+    assert np.abs(pose - p1).max() <= 1e-7 * max(1.0, np.abs(p1).max())
+    assert np.abs(lmk - ref.get_landmarks()).max() <= 1e-7 * max(1.0, np.abs(lmk).max())
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        pieces[0].backend.iterate_lm(1e-5)          # the loop is the caller's on a split chain
+    for sv in pieces:
+        sv.backend.close()
+    ref.close()
+
+
 def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
     import gpslam_amd
     from gpslam_amd import sharded, synthetic as S

@@ -15,12 +15,12 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _problem(N):
+def _problem(N, anchor=256):
     from gpslam_amd import synthetic as S
-    return S.pose2_local_landmarks_chain(N, L=N // 20, window=100)
+    return S.pose2_local_landmarks_chain(N, L=N // 20, window=100, anchor=anchor)
 
 
-def _worker(rank, world, port, N, out):
+def _worker(rank, world, port, N, out, lm=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -29,10 +29,16 @@ def _worker(rank, world, port, N, out):
     from gpslam_amd import sharded
     from oracle import oracle as O
     from split_model import SplitPieceModel
-    lp = sharded.split_local_problem(_problem(N), rank, world)
+    lp = sharded.split_local_problem(_problem(N, 0 if lm else 256), rank, world)   # LM: open-loop dead reckoning, a real descent
     backend = sharded.apply_split(lp, SplitPieceModel(O.POSE2, O.CHART_FIRST_ORDER, 2), rank, world)
     sv = sharded.SplitSolver(backend, rank, world, dist=dist, device="cpu")
-    hist = [sv.iterate() for _ in range(4)]
+    if lm:
+        hist, lam = [], 1e-5
+        for _ in range(4):
+            st, lam = sv.iterate_lm(lam)
+            hist.append(dict(st, lam=lam))
+    else:
+        hist = [sv.iterate() for _ in range(4)]
     torch.save(dict(lp=lp, states=backend.get_states(), lmk=backend.get_landmarks(), hist=hist), "%s.%d" % (out, rank))
     dist.destroy_process_group()
 
@@ -86,3 +92,34 @@ def test_the_cut_conserves_factors_landmarks_and_priors():
             assert len(lp["range_lm"]) == 0 or (lp["range_lm"].min() >= 0 and lp["range_lm"].max() < len(lp["landmarks"]))
     with pytest.raises(ValueError):
         sharded.split_local_problem(_problem(400), 1, 8)                    # pieces shorter than the window of visibility
+
+
+def test_split_levenberg_marquardt_matches_unsplit_oracle(tmp_path):
+    """SplitSolver.iterate_lm over gloo, world size 2: the decisions come from all-gathered scalars, so both ranks follow
+    the oracle's lambda schedule (matlab/PlazaPose2.m:217-229 optimises this kind of graph with LM)."""
+    sys.path.insert(0, ROOT)
+    from gpslam_amd import sharded, synthetic as S
+    from oracle import oracle as O
+    out = str(tmp_path / "res")
+    port = 25500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, 300, out, True), nprocs=2, join=True)
+    parts = [torch.load("%s.%d" % (out, r), weights_only=False) for r in range(2)]
+    problem = _problem(300, 0)
+    ref = S.apply(problem, O.Chain(O.POSE2, O.CHART_FIRST_ORDER, landmark_dim=2))
+    lam, compared = 1e-5, 0
+    for k in range(4):
+        _, st, lam = ref.iterate_lm(lam)[:3]
+        for p in parts:
+            h = p["hist"][k]
+            assert h["lam"] == lam and h["accepted"] == bool(st.accepted)
+            assert abs(h["error_after"] - st.error_after) <= 1e-8 * max(1.0, st.error_after)
+        compared += 1
+        if st.error_before - st.error_after <= 1e-7 * st.error_before:
+            break           # converged: accept / reject now hangs on the rounding of err - newErr
+    assert compared >= 2
+    if compared < 4:
+        return
+    pose, vel, lmk = sharded.merge_pieces(problem, [p["lp"] for p in parts], [p["states"] for p in parts], [p["lmk"] for p in parts])
+    p0, v0 = ref.get_states()
+    assert np.abs(pose - p0).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+    assert np.abs(lmk - ref.get_landmarks()).max() <= 1e-8 * max(1.0, np.abs(lmk).max())
