@@ -137,4 +137,109 @@ class ShardedDriver {
   std::vector<ShardedRank> ranks_;
 };
 
+// ---- chains with many locally visible landmarks (BASELINE config 4) across GPUs: pieces joined at shared cut states
+// (include/gpslam_hip.h, gpslam_hip_fs_set_split; the Python twin is gpslam_amd/sharded.py: SplitSolver).
+//   SplitDriver   one process over the pieces' devices.  Distinct devices: ncclCommInitAll + one grouped ncclAllGather of the
+//                 interface records per iteration.  All pieces on ONE device (the build farm, single-GPU runs of a chain
+//                 that was cut for other reasons): the gather is P * P device copies on one stream, no communicator.
+class SplitDriver {
+ public:
+  explicit SplitDriver(const std::vector<int> &devices) : devices_(devices), streams_(devices.size(), nullptr) {
+    local_ = true;
+    for (int d : devices_) local_ = local_ && d == devices_[0];
+    if (!local_) {
+      comms_.resize(devices_.size());
+      nccl_ok(ncclCommInitAll(comms_.data(), (int)devices_.size(), devices_.data()), "ncclCommInitAll");
+    }
+    for (size_t r = 0; r < devices_.size(); r++) {
+      hip_ok(hipSetDevice(devices_[r]), "hipSetDevice");
+      if (local_ && r > 0) { streams_[r] = streams_[0]; continue; }     // one device: one stream orders everything
+      hip_ok(hipStreamCreateWithFlags(&streams_[r], hipStreamNonBlocking), "hipStreamCreate");
+    }
+  }
+  ~SplitDriver() {
+    for (size_t r = 0; r < devices_.size(); r++) {
+      (void)hipSetDevice(devices_[r]);
+      (void)hipStreamSynchronize(streams_[r]);
+      if (!local_) (void)ncclCommDestroy(comms_[r]);
+      if (!local_ || r == 0) (void)hipStreamDestroy(streams_[r]);
+    }
+  }
+  int nranks() const { return (int)devices_.size(); }
+  /// register piece r's compiled handle (created with nranks = 1 on devices[r], gpslam_hip_fs_set_split(h, r, P, ...) before
+  /// compile()); after the last one the pieces agree on the block size of the interface record
+  void add(gpslam_hip_handle *h) {
+    if ((int)h_.size() >= nranks()) throw std::invalid_argument("more handles than pieces");
+    h_.push_back(h);
+    if ((int)h_.size() < nranks()) return;
+    int nb = 0;
+    for (gpslam_hip_handle *q : h_) {
+      int32_t info[4];
+      ok(q, gpslam_hip_fs_split_info(q, info), "fs_split_info");
+      nb = std::max(nb, (int)info[0]);
+    }
+    send_.resize(h_.size()); recv_.resize(h_.size());
+    for (size_t r = 0; r < h_.size(); r++) {
+      hip_ok(hipSetDevice(devices_[r]), "hipSetDevice");
+      ok(h_[r], gpslam_hip_set_stream(h_[r], (void *)streams_[r]), "set_stream");
+      ok(h_[r], gpslam_hip_fs_set_top(h_[r], nb), "fs_set_top");
+      size_t rb = 0;
+      ok(h_[r], gpslam_hip_fs_interface(h_[r], &send_[r], &rec_bytes_, &recv_[r], &rb), "fs_interface");
+    }
+  }
+  size_t record_bytes() const { return rec_bytes_; }
+  /// one Gauss-Newton (lambda = 0) / damped iteration over all pieces
+  gpslam_hip_stats iterate(double lambda = 0.0, bool want_stats = true) {
+    if ((int)h_.size() != nranks()) throw std::invalid_argument("register one handle per piece first");
+    for (size_t r = 0; r < h_.size(); r++) { use(r); ok(h_[r], gpslam_hip_fs_phase1(h_[r], lambda), "fs_phase1"); }
+    gather();
+    gpslam_hip_stats tot;
+    std::fill((char *)&tot, (char *)&tot + sizeof(tot), 0);
+    for (size_t r = 0; r < h_.size(); r++) {
+      gpslam_hip_stats st;
+      use(r);
+      ok(h_[r], gpslam_hip_fs_phase2(h_[r], want_stats ? &st : nullptr), "fs_phase2");
+      if (want_stats) {
+        tot.error_before += st.error_before;
+        tot.error_after += st.error_after;
+        tot.delta_inf_norm = std::max(tot.delta_inf_norm, st.delta_inf_norm);
+        tot.status = std::min(tot.status, st.status);
+      }
+    }
+    tot.iterations = 1;
+    tot.accepted = 1;
+    return tot;
+  }
+  void synchronize() {
+    for (size_t r = 0; r < devices_.size(); r++) { use(r); hip_ok(hipStreamSynchronize(streams_[r]), "hipStreamSynchronize"); }
+  }
+
+ private:
+  void use(size_t r) const { hip_ok(hipSetDevice(devices_[r]), "hipSetDevice"); }
+  static void ok(gpslam_hip_handle *h, int rc, const char *what) {
+    if (rc < 0) throw std::runtime_error(std::string(what) + " failed: " + gpslam_hip_last_error(h));
+  }
+  void gather() {
+    if (local_) {
+      for (size_t r = 0; r < h_.size(); r++)
+        for (size_t k = 0; k < h_.size(); k++)
+          hip_ok(hipMemcpyAsync((char *)recv_[r] + k * rec_bytes_, send_[k], rec_bytes_, hipMemcpyDeviceToDevice, streams_[0]), "hipMemcpyAsync");
+      return;
+    }
+    nccl_ok(ncclGroupStart(), "ncclGroupStart");
+    for (size_t r = 0; r < h_.size(); r++) {
+      use(r);
+      nccl_ok(ncclAllGather(send_[r], recv_[r], rec_bytes_, ncclChar, comms_[r], streams_[r]), "ncclAllGather");
+    }
+    nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+  }
+  std::vector<int> devices_;
+  std::vector<ncclComm_t> comms_;
+  std::vector<hipStream_t> streams_;
+  std::vector<gpslam_hip_handle *> h_;
+  std::vector<void *> send_, recv_;
+  size_t rec_bytes_ = 0;
+  bool local_ = true;
+};
+
 }  // namespace gpslam_hip

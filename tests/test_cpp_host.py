@@ -82,3 +82,28 @@ def test_cpp_sharded_host_runs_rccl_on_every_visible_gpu():
     out = subprocess.run([_build_sharded_exe()], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def _build_split_exe():
+    import gpslam_amd
+    gpslam_amd.load_library()
+    libdir = os.path.join(ROOT, "gpslam_amd", "lib")
+    exe = os.path.join(ROOT, "tests", "cpp", "split_rccl_test")
+    src = os.path.join(ROOT, "tests", "cpp", "split_rccl_test.cpp")
+    cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", ROOT, "-I", "/opt/rocm/include", src, "-o", exe,
+           "-L", libdir, "-lgpslam_hip", "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_cpp_split_host_compiles_against_rccl():
+    assert os.path.exists(_build_split_exe())
+
+
+@pytest.mark.gpu
+def test_cpp_split_host_runs_config4_pieces():
+    """gpslam_amd/host/sharded_host.hpp: SplitDriver -- BASELINE config 4's graph cut into pieces from C++ (one per visible GPU
+    over RCCL, and three on device 0 with device copies) against the unsplit solve."""
+    out = subprocess.run([_build_split_exe()], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
