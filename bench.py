@@ -170,6 +170,44 @@ def extras(gpslam_amd, S, device):
         "state_iterations_per_sec": 1000000 / (ms * 1e-3),
         "landmark_elimination": "segments + fat separators, segment Schur complements on v_mfma_f64_16x16x4_f64 (fatsep.hpp)"}
     s.close()
+    # the same graph across GPUs = pieces joined at shared fat separators (gpslam_amd/sharded.py: SplitSolver).  Here both
+    # pieces of a 2-way cut live on this one GPU and run one after the other: per-rank work of a 2-GPU run without its
+    # all-gather (2 records of ~40 KB).
+    try:
+        import torch
+        from gpslam_amd import sharded
+        pieces, locals_ = [], []
+        for r in range(2):
+            lp = sharded.split_local_problem(p, r, 2)
+            sp = gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device)
+            sharded.apply_split(lp, sp, r, 2)
+            locals_.append(lp)
+            pieces.append(sharded.SplitSolver(sp, r, 2))
+        nb_top = max(sv.nb_local for sv in pieces)
+        for sv in pieces:
+            sv.set_top(nb_top)
+        hist = [sharded.iterate_pieces(pieces) for _ in range(2)]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            for sv in pieces:
+                sv.backend.fs_phase1(0.0)
+            for sv in pieces:
+                rv = sv.recv.view(2, -1)
+                for k in range(2):
+                    rv[k].copy_(pieces[k].send)
+            for sv in pieces:
+                sv.backend.fs_phase2(False)
+        ev1.record()
+        torch.cuda.synchronize()
+        out["config4_pose2_1e6_landmarks_5e4_1gpu"]["split_in_2_pieces_on_this_gpu"] = {
+            "ms_per_rank_and_iteration": ev0.elapsed_time(ev1) / 3 / 2, "states_per_piece": [lp["N"] for lp in locals_],
+            "interface_record_bytes": int(pieces[0].send.numel() * 8), "error_after_2_iterations": hist[-1]["error_after"],
+            "note": "unsplit: ms_per_iteration_device above (1e6 states on one GPU); a piece holds 5e5"}
+        for sv in pieces:
+            sv.backend.close()
+    except Exception as e:      # an extra: never take the headline line down with it
+        out["config4_pose2_1e6_landmarks_5e4_1gpu"]["split_in_2_pieces_on_this_gpu"] = {"failed": repr(e)}
 
     # ---- config 5: fp32 vs fp64 tolerance sweep.  fp32 = fp32 Jacobian rows (the dominant HBM traffic) + fp64 residual,
     # normal equations and solver: the update cannot fall below cond(H) * eps32 * |whitened residual|, so
