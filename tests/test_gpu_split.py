@@ -122,6 +122,10 @@ def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
     with pytest.raises(gpslam_amd.GpslamHipError):
         s.iterate_gn()
     with pytest.raises(gpslam_amd.GpslamHipError):
+        s.run_gn(2)
+    with pytest.raises(gpslam_amd.GpslamHipError):
+        s.optimize()                           # every whole-chain driver ends in the same refusal
+    with pytest.raises(gpslam_amd.GpslamHipError):
         s.fs_phase1(0.0)                       # fs_set_top has not been called
     with pytest.raises(gpslam_amd.GpslamHipError):
         s.fs_set_top(4)                        # smaller than this piece's own fat blocks
