@@ -503,22 +503,106 @@ struct FatLevel {
   int nupd;
 };
 
-template <typename T> __device__ __forceinline__ void fat_chol_lds(T *Lm, int NB, int LS, int *flag) {
+// Cholesky of the NB x NB block in Lm (lower triangle, stride LS; NB is a multiple of 4) and X <- L^-1 X for the NX columns of X
+// (stride XS), four pivots at a time: every thread factors the 4 x 4 diagonal block in registers (ten LDS broadcasts, no
+// barrier), the rows below it and the four rows of X are multiplied by its inverse (one row / one column per thread), a
+// barrier, then ONE rank-4 update of the trailing triangle and of the rows of X below (eight operand reads that do not depend
+// on each other per entry), a barrier.  NB / 4 sequential steps of two barriers instead of NB steps of three: the unblocked
+// version spent 79 us per block at NB = 40, of which its waves sat 2/3 at barriers or behind single exposed LDS round trips
+// (one wave per SIMD: nothing else to issue).  The 4 x 4 factors go to Ld (10 per step: l00 l10 l11 l20 l21 l22 l30 l31 l32 l33);
+// the diagonal blocks of Lm keep their pre-factor values, so nobody waits before overwriting them.
+template <typename T> __device__ __forceinline__ void fat_factor_panel4(T *Lm, T *X, T *Ld, int NB, int LS, int XS, int NX, int *flag) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  for (int p = 0; p < NB; p++) {
-    T dd = Lm[p * LS + p];
-    if (!(dd > T(0))) { if (tid == 0) *flag = 1; dd = T(1); }
-    const T l = sqrt(dd), inv = T(1) / l;
+  const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
+  for (int p = 0; p < NB; p += 4) {
+    // ---- 4 x 4 diagonal block: A = L L^T, W = L^-1 (both lower), every thread
+    T A[4][4], L[4][4], W[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = Lm[(p + i) * LS + p + j];
+    bool bad = false;
+    T inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      T dd = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+      if (!(dd > T(0))) { bad = true; dd = T(1); }
+      T y = fs_rsqrt(dd), l = dd * y;
+      l = fma(T(0.5) * y, fma(-l, l, dd), l);        // one residual step each, as in k_fs_factor
+      y = fma(y, fma(-l, y, T(1)), y);
+      L[j][j] = l; inv[j] = y;
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) {
+        T v = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+        L[i][j] = v * y;
+      }
+    }
+    if (bad && tid == 0) *flag = 1;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = c; r < 4; r++) {
+        T sacc = (r == c) ? T(1) : T(0);
+#pragma unroll
+        for (int k = c; k < r; k++) sacc -= L[r][k] * W[k][c];
+        W[r][c] = sacc * inv[r];
+      }
+    if (tid == 0) {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Ld[(p >> 2) * 10 + q++] = L[i][j];
+    }
+    // ---- rows below: L[i][p..p+3] = A[i][p..p+3] W^T;  the four rows of X: X[p..p+3][c] = W X[p..p+3][c]
+    const int m2 = NB - p - 4;
+    for (int t = tid; t < m2 + NX; t += nt) {
+      if (t < m2) {
+        T *row = Lm + (p + 4 + t) * LS + p;
+        const T a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+        row[0] = a0 * W[0][0];
+        row[1] = a0 * W[1][0] + a1 * W[1][1];
+        row[2] = a0 * W[2][0] + a1 * W[2][1] + a2 * W[2][2];
+        row[3] = a0 * W[3][0] + a1 * W[3][1] + a2 * W[3][2] + a3 * W[3][3];
+      } else {
+        T *cp = X + p * XS + (t - m2);
+        const T b0 = cp[0], b1 = cp[XS], b2 = cp[2 * XS], b3 = cp[3 * XS];
+        cp[0] = W[0][0] * b0;
+        cp[XS] = W[1][0] * b0 + W[1][1] * b1;
+        cp[2 * XS] = W[2][0] * b0 + W[2][1] * b1 + W[2][2] * b2;
+        cp[3 * XS] = W[3][0] * b0 + W[3][1] * b1 + W[3][2] * b2 + W[3][3] * b3;
+      }
+    }
     __syncthreads();
-    for (int i = p + tid; i < NB; i += nt) Lm[i * LS + p] = (i == p) ? l : Lm[i * LS + p] * inv;
-    __syncthreads();
-    const int m2 = NB - p - 1;
-    for (int idx = tid; idx < m2 * m2; idx += nt) {
-      const int i = p + 1 + idx / m2, j = p + 1 + idx % m2;
-      if (j <= i) Lm[i * LS + j] -= Lm[i * LS + p] * Lm[j * LS + p];
+    // ---- rank-4 update of the trailing triangle and of the rows of X below
+    for (int i = p + 4 + ty; i < NB; i += nty) {
+      const T *li = Lm + i * LS + p;
+      const T l0 = li[0], l1 = li[1], l2 = li[2], l3 = li[3];
+      for (int cc = tx; cc < m2 + NX; cc += 64) {
+        if (cc < m2) {
+          const int j = p + 4 + cc;
+          if (j <= i) {
+            const T *lj = Lm + j * LS + p;
+            Lm[i * LS + j] -= l0 * lj[0] + l1 * lj[1] + l2 * lj[2] + l3 * lj[3];
+          }
+        } else {
+          const T *xp = X + p * XS + (cc - m2);
+          X[i * XS + (cc - m2)] -= l0 * xp[0] + l1 * xp[XS] + l2 * xp[2 * XS] + l3 * xp[3 * XS];
+        }
+      }
     }
     __syncthreads();
   }
+}
+// entry (i, j), j <= i, of the factor after fat_factor_panel4
+template <typename T> __device__ __forceinline__ T fat_l_entry(const T *Lm, const T *Ld, int LS, int i, int j) {
+  if ((i >> 2) != (j >> 2)) return Lm[i * LS + j];
+  const int a = i & 3, b = j & 3;
+  return Ld[(i >> 2) * 10 + a * (a + 1) / 2 + b];
 }
 
 template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T, TR> a, FatLevel lv) {
@@ -526,6 +610,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   const int NB = a.NB, LS = NB + 1, XS = 2 * NB + 1, NB2 = NB * NB;
   T *Lm = reinterpret_cast<T *>(fat_smem);
   T *X = Lm + NB * LS;
+  __shared__ T Ld[(kFatMax / 4) * 10];
   const int *e = lv.elim + 6 * blockIdx.x;
   const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -537,18 +622,10 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
   for (int i = tid; i < NB; i += nt) X[i * XS + 2 * NB] = a.gfat[(size_t)m * NB + i];
   __syncthreads();
-  fat_chol_lds(Lm, NB, LS, a.flag);
-  for (int c = tid; c < XS; c += nt) {      // forward substitution, one column per thread
-    for (int i = 0; i < NB; i++) {
-      T s = X[i * XS + c];
-      for (int k = 0; k < i; k++) s -= Lm[i * LS + k] * X[k * XS + c];
-      X[i * XS + c] = s / Lm[i * LS + i];
-    }
-  }
-  __syncthreads();
+  fat_factor_panel4(Lm, X, Ld, NB, LS, XS, XS, a.flag);
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
-    a.Dfat[(size_t)m * NB2 + idx] = Lm[i * LS + j];
+    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);
     a.link[(size_t)lk_lm * NB2 + idx] = X[i * XS + j];           // P
     a.Qbuf[(size_t)m * NB2 + idx] = X[i * XS + NB + j];          // Q
     T s1 = T(0), s2 = T(0), s3 = T(0);
@@ -595,22 +672,20 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   const int NB = a.NB, LS = NB + 1;
   T *Lm = reinterpret_cast<T *>(fat_smem);
   T *y = Lm + NB * LS;
+  __shared__ T Ld[(kFatMax / 4) * 10];
   for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lm[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)top * NB * NB + idx];
   for (int i = threadIdx.x; i < NB; i += blockDim.x) y[i] = a.gfat[(size_t)top * NB + i];
   __syncthreads();
-  fat_chol_lds(Lm, NB, LS, a.flag);
-  if (threadIdx.x == 0) {
-    for (int i = 0; i < NB; i++) {
-      T s = y[i];
-      for (int k = 0; k < i; k++) s -= Lm[i * LS + k] * y[k];
-      y[i] = s / Lm[i * LS + i];
-    }
+  fat_factor_panel4(Lm, y, Ld, NB, LS, 1, 1, a.flag);          // y <- L^-1 g
+  if (threadIdx.x < 64) {                                        // x = L^-T y, right-looking, one wave
+    const int lane = threadIdx.x;
     for (int i = NB - 1; i >= 0; i--) {
-      T s = y[i];
-      for (int k = i + 1; k < NB; k++) s -= Lm[k * LS + i] * y[k];
-      y[i] = s / Lm[i * LS + i];
-      a.xfat[(size_t)top * NB + i] = y[i];
+      const T xi = y[i] / fat_l_entry(Lm, Ld, LS, i, i);
+      if (lane == 0) y[i] = xi;
+      for (int k = lane; k < i; k += 64) y[k] -= fat_l_entry(Lm, Ld, LS, i, k) * xi;
+      fs_wave_sync();
     }
+    for (int i = lane; i < NB; i += 64) a.xfat[(size_t)top * NB + i] = y[i];
   }
 }
 
