@@ -323,7 +323,14 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
   extern __shared__ __align__(16) unsigned char syrk_smem[];
   double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x LSP
   const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int NCP = a.NCP, T16 = NCP / 16, ntiles = T16 * (T16 + 1) / 2;
+  const int NCP = a.NCP;
+  // When the right-hand side column (index 2 NB) sits alone in the last 16-column tile (NB a multiple of 8: 40 at config 4's
+  // landmark density), the matrix cores only see the 2 NB fat columns -- 15 tiles of the lower triangle instead of 21 -- and
+  // the row of the Schur complement that belongs to the right-hand side (2 NB dot products over the chunk rows) is summed on
+  // the vector ALU by two of the four waves out of the same LDS chunk; the fetch then skips the padding columns as well.
+  const bool rhs_alone = ((2 * a.NB) % 16) == 0;
+  const int T16 = rhs_alone ? (2 * a.NB) / 16 : NCP / 16, ntiles = T16 * (T16 + 1) / 2;
+  const int NCF = rhs_alone ? 2 * a.NB + 2 : NCP;           // columns fetched per chunk row (even: 16-byte pieces)
   // LDS row stride: a multiple of 32 doubles plus 16, so that the four chunk rows an MFMA operand load touches (16 lanes x
   // 8 bytes each) fall into different bank groups; with the plain stride NCP = 96 they all hit the same banks (4-way
   // conflict on every operand load: the kernel was LDS-bandwidth bound at 0.40 of the matrix peak)
@@ -336,14 +343,15 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
     acc[q] = fs_d4{0.0, 0.0, 0.0, 0.0};
-    const int pidx = wv + 4 * q;                            // tile p of the lower triangle, row-major: (ti, tj <= ti)
+    const int pidx = (3 - wv) + 4 * q;                      // tile p of the lower triangle, row-major: (ti, tj <= ti); the
+                                                            // low waves get one tile fewer (they also sum the rhs row)
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= pidx) ti++;
     tti[q] = ti;
     ttj[q] = pidx - ti * (ti + 1) / 2;
   }
   typedef double V2 __attribute__((ext_vector_type(2)));
-  const int chunk_v2 = KC * NCP / 2;                        // 16-byte pieces per chunk
+  const int chunk_v2 = KC * NCF / 2;                        // 16-byte pieces per chunk
   constexpr int PV = (KC * 144 / 2 + 255) / 256;            // pieces per thread at the widest NCP (144)
   V2 pre[PV];
   auto fetch = [&](int c) {                                 // global -> registers (in flight under the MFMAs)
@@ -352,7 +360,8 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
     for (int u = 0; u < PV; u++) {
       const int v = tid + u * 256;
       pre[u] = V2{0.0, 0.0};
-      if (v < chunk_v2 && k0 + (2 * v) / NCP < kdim) pre[u] = *reinterpret_cast<const V2 *>(Yb + (size_t)k0 * NCP + 2 * v);
+      const int row = (2 * v) / NCF, col = 2 * v - row * NCF;
+      if (v < chunk_v2 && k0 + row < kdim) pre[u] = *reinterpret_cast<const V2 *>(Yb + (size_t)(k0 + row) * NCP + col);
     }
   };
   auto commit = [&](int which) {                            // registers -> LDS
@@ -360,7 +369,7 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
     for (int u = 0; u < PV; u++) {
       const int v = tid + u * 256;
       if (v < chunk_v2) {
-        const int row = (2 * v) / NCP, col = 2 * v - row * NCP;
+        const int row = (2 * v) / NCF, col = 2 * v - row * NCF;
         *reinterpret_cast<V2 *>(buf + (size_t)which * KC * LSP + (size_t)row * LSP + col) = pre[u];
       }
     }
@@ -369,6 +378,7 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
   if (nchunks > 0) { fetch(0); commit(0); }
   __syncthreads();
   const int kl = lane >> 4, cl = lane & 15;
+  double racc = 0.0;
   for (int c = 0; c < nchunks; c++) {
     if (c + 1 < nchunks) fetch(c + 1);
     const double *bb = buf + (size_t)(c & 1) * KC * LSP;
@@ -377,19 +387,25 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
       const double *yr = bb + (size_t)(k4 + kl) * LSP;
 #pragma unroll
       for (int q = 0; q < TPW; q++) {
-        if (wv + 4 * q < ntiles) {
+        if ((3 - wv) + 4 * q < ntiles) {
           const double av = yr[tti[q] * 16 + cl], bv = yr[ttj[q] * 16 + cl];
           acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
         }
       }
     }
+    if (rhs_alone && wv < 2) {                               // row 2 NB of Y^T Y: column jr against the rhs column
+      const int jr = min(lane + 64 * wv, 2 * a.NB);
+#pragma unroll
+      for (int k = 0; k < KC; k++) racc += bb[(size_t)k * LSP + jr] * bb[(size_t)k * LSP + 2 * a.NB];
+    }
     if (c + 1 < nchunks) commit((c + 1) & 1);
     __syncthreads();
   }
   double *out = a.Aseg + (size_t)seg * NCP * NCP;
+  if (rhs_alone && wv < 2 && lane + 64 * wv <= 2 * a.NB) out[(size_t)(2 * a.NB) * NCP + lane + 64 * wv] = racc;
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
-    if (wv + 4 * q < ntiles) {
+    if ((3 - wv) + 4 * q < ntiles) {
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) out[(size_t)(tti[q] * 16 + kl + 4 * rg) * NCP + ttj[q] * 16 + cl] = acc[q][rg];
     }
