@@ -2,7 +2,8 @@
 # mean PMC counters per launch of the kernels matching a pattern:  bash scripts/pmc_kernel.sh <pattern> "<counters>" <command...>
 PAT=$1; CNT=$2; shift 2
 ROOT=$(pwd); OUT=/tmp/pmc_$$; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
-(cd $ROOT && rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/log.txt 2>&1)
+# always under a timeout: a pass with seven TCC_* counters at once did not come back within ten minutes on this pool
+(cd $ROOT && timeout ${PMC_TIMEOUT:-120} rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- "$@" > $OUT/log.txt 2>&1)
 python - "$OUT" "$PAT" <<'PY'
 import csv, glob, sys, collections
 f = glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True)
