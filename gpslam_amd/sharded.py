@@ -403,7 +403,10 @@ class SplitSolver:
 
     def exchange(self):
         if self.dist is None:
-            self.recv.view(self.nranks, -1)[self.rank].copy_(self.send)
+            if self.nranks > 1:
+                raise RuntimeError("SplitSolver without a process group holds one piece of %d: drive the pieces of one process "
+                                   "with iterate_pieces / iterate_pieces_lm" % self.nranks)
+            self.recv.copy_(self.send)
             return
         chunks = list(self.recv.view(self.nranks, -1).unbind(0))
         self.dist.all_gather(chunks, self.send, group=self.group)
