@@ -151,7 +151,7 @@ def test_split_chain_one_process_per_gpu_over_rccl():
     import sys
     import torch
     world = max(1, min(torch.cuda.device_count(), 8))
-    port = 29500 + os.getpid() % 90
+    port = 29300 + os.getpid() % 90
     worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_split_worker.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, worker, str(r), str(world), str(port), str(3000 * world)], env=env,
