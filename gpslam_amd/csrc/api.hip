@@ -819,7 +819,6 @@ int gpslam_hip_fs_set_split(gpslam_hip_handle *h, int32_t rank, int32_t nranks, 
   if (nranks < 1 || rank < 0 || rank >= nranks || n_first < 0 || n_last < 0 || (n_first && !first_lm) || (n_last && !last_lm))
     return fail(h, GPSLAM_E_INVALID, "fs_set_split: bad rank / nranks / landmark lists");
   if (sharded(h)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: create the handle with nranks = 1 (the pieces overlap in their shared cut states, there is no halo)");
-  if (h->cfg.precision == GPSLAM_FP32) return fail(h, GPSLAM_E_UNSUPPORTED, "fs_set_split: fp64 handles only");
   if ((rank == 0 && n_first) || (rank == nranks - 1 && n_last)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: the two ends of the whole chain share nothing");
   h->fs.split = true;
   h->fs.rank = rank; h->fs.nranks = nranks; h->fs.nb_top = 0;

@@ -10,13 +10,14 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _pieces(problem, P, segment_length=0):
+def _pieces(problem, P, segment_length=0, precision=0):
     import gpslam_amd
     from gpslam_amd import sharded
     locals_, pieces = [], []
     for r in range(P):
         lp = sharded.split_local_problem(problem, r, P)
-        s = gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=segment_length)
+        s = gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=segment_length,
+                                   precision=precision)
         sharded.apply_split(lp, s, r, P)
         locals_.append(lp)
         pieces.append(sharded.SplitSolver(s, r, P))
@@ -110,6 +111,36 @@ def test_split_levenberg_marquardt_follows_the_unsplit_lambda_schedule(P):
     for sv in pieces:
         sv.backend.close()
     ref.close()
+
+
+def test_segmented_and_split_chains_with_fp32_jacobian_rows():
+    """GPSLAM_FP32 (fp32 row tables; residual, normal equations, Schur complements and fat solve stay fp64: DESIGN.md section 4b)
+    on the segmented landmark path, unsplit and cut in three: the split run follows the unsplit fp32 run (same rows, another
+    summation order), and both land within fp32-row accuracy of the fp64 solve."""
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(3000, L=150, window=200)
+    kw = dict(chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True)
+    ref64 = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, **kw))
+    ref32 = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, precision=gpslam_amd.FP32, **kw))
+    locals_, pieces = _pieces(problem, 3, precision=gpslam_amd.FP32)
+    for it in range(8):
+        got = sharded.iterate_pieces(pieces)
+        _, s32 = ref32.iterate_gn()
+        _, s64 = ref64.iterate_gn()
+        assert abs(got["error_after"] - s32.error_after) <= 1e-7 * max(1.0, s32.error_after)
+    assert abs(s32.error_after - s64.error_after) <= 1e-5 * max(1.0, s64.error_after)      # at convergence
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p32, v32 = ref32.get_states()
+    p64, v64 = ref64.get_states()
+    assert np.abs(pose - p32).max() <= 1e-7 * max(1.0, np.abs(p32).max())
+    assert np.abs(lmk - ref32.get_landmarks()).max() <= 1e-7 * max(1.0, np.abs(lmk).max())
+    assert np.abs(p32 - p64).max() <= 1e-5 * max(1.0, np.abs(p64).max())          # north_star's fp32 tolerance
+    assert np.abs(ref32.get_landmarks() - ref64.get_landmarks()).max() <= 1e-5 * max(1.0, np.abs(lmk).max())
+    for sv in pieces:
+        sv.backend.close()
+    ref32.close()
+    ref64.close()
 
 
 def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
