@@ -33,7 +33,7 @@ def _merged(problem, locals_, pieces):
 
 
 @pytest.mark.parametrize("P,N,L,window,C", [(1, 700, 35, 200, 0), (2, 2000, 100, 200, 0), (3, 3000, 150, 200, 0), (4, 3001, 150, 120, 128),
-                                            (5, 6000, 300, 200, 256), (8, 12000, 600, 200, 0), (4, 200000, 10000, 200, 0)])
+                                            (5, 6000, 300, 200, 256), (8, 12000, 600, 200, 0), (4, 200000, 10000, 200, 0), (4, 1000000, 50000, 200, 0)])   # the last one: BASELINE config 4 at full size
 def test_split_chain_equals_the_unsplit_segmented_solve(P, N, L, window, C):
     import gpslam_amd
     from gpslam_amd import sharded, synthetic as S
