@@ -155,7 +155,7 @@ __device__ __forceinline__ void wave_store_part(const T *st, const int *srow, in
     const int r0 = srow[fl];
     if (r0 >= 0) {
       const V2 v = *reinterpret_cast<const V2 *>(st + fl * LS + piece * 2);
-      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + coloff + piece * 2) = v;
+      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + coloff + piece * 2) = v;   // (nontemporal: K1 0.17 instead of 0.09 ms)
     }
   }
 }
