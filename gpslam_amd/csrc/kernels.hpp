@@ -2571,7 +2571,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
 #pragma unroll
       for (int q = 0; q < NV; q++) {
         const int idx = q * 16 + r;
-        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);
+        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);   // (nontemporal: 0.181 vs 0.184 ms, inside the noise)
       }
     }
     double Dn[B], Fn[B], gn;
