@@ -867,7 +867,8 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
   __shared__ T outb[FL * B];
   const int nb = (n + FL - 1) / FL;
   const int r = lane < B ? lane : 0;                       // lanes >= B compute row 0 again (harmless, keeps the code branch-free)
-  T pre[PF], prer;
+  constexpr int PR = (FL * B + 63) / 64;                   // right-hand-side values per lane and burst (2 for B = 12)
+  T pre[PF], prer[PR];
   // fetch burst `bi` of a sweep over the states j0 + lo .. j0 + lo + FL - 1 (clamped to the segment)
   auto fetch = [&](int lo) {
 #pragma unroll
@@ -876,9 +877,10 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       const int st = min(max(lo + f, 0), n - 1);
       pre[u] = (k < FL * FW) ? a.fac[(size_t)(j0 + st) * FW + (k - f * FW)] : T(0);
     }
-    {
-      const int f = lane / B, st = min(max(lo + f, 0), n - 1);
-      prer = (lane < FL * B) ? a.rhs[(size_t)(j0 + st) * B + (lane - f * B)] : T(0);
+#pragma unroll
+    for (int u = 0; u < PR; u++) {
+      const int k = lane + 64 * u, f = k / B, st = min(max(lo + f, 0), n - 1);
+      prer[u] = (k < FL * B) ? a.rhs[(size_t)(j0 + st) * B + (k - f * B)] : T(0);
     }
   };
   auto commit = [&](int w) {
@@ -887,7 +889,11 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       const int k = lane + 64 * u, f = k / FW;
       if (k < FL * FW) buf[w][f * SL + (k - f * FW)] = pre[u];
     }
-    if (lane < FL * B) { const int f = lane / B; buf[w][f * SL + FW + (lane - f * B)] = prer; }
+#pragma unroll
+    for (int u = 0; u < PR; u++) {
+      const int k = lane + 64 * u, f = k / B;
+      if (k < FL * B) buf[w][f * SL + FW + (k - f * B)] = prer[u];
+    }
   };
   // ---- forward
   T y = T(0), ep[B];                                       // ep[k] = E_{s-1}[k][r]
@@ -916,7 +922,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       if (lane < B) outb[f * B + lane] = y;
     }
     fs_wave_sync();
-    if (lane < cnt * B) a.rhs[(size_t)(j0 + base) * B + lane] = outb[lane];       // y~ of the burst, read back by the backward sweep
+    for (int k = lane; k < cnt * B; k += 64) a.rhs[(size_t)(j0 + base) * B + k] = outb[k];   // y~ of the burst, read back by the backward sweep
     commit((bi + 1) & 1);
     fs_wave_sync();
   }
@@ -946,7 +952,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       if (lane < B) outb[f * B + lane] = x;
     }
     fs_wave_sync();
-    if (lane < cnt * B) a.x[(size_t)(j0 + base) * B + lane] = outb[lane];
+    for (int k = lane; k < cnt * B; k += 64) a.x[(size_t)(j0 + base) * B + k] = outb[k];
     commit((it + 1) & 1);
     fs_wave_sync();
   }

@@ -112,3 +112,32 @@ def test_c4_full_size_properties():
     dx, dv, dl = np.abs(xa - xc).max(), np.abs(va - vc).max(), np.abs(la - c.get_landmarks()).max()
     print("two segmentations: max |dx| %.3e |dv| %.3e |dl| %.3e" % (dx, dv, dl))
     assert dx <= 1e-7 and dv <= 1e-7 and dl <= 1e-7, (dx, dv, dl)
+
+
+@pytest.mark.parametrize("kind,sensor,N,seg", [(O.POSE3, True, 61, 32), (O.POSE3, False, 130, 64), (O.LINEAR3, False, 61, 32), (O.POSE2, True, 97, 48)],
+                         ids=["pose3+sensor", "pose3", "linear3", "pose2+sensor"])
+def test_segmented_path_on_every_block_size_and_measurement_mix(kind, sensor, N, seg):
+    """The segmented landmark elimination is compiled for the chain block sizes 4 (planar linear), 6 (SE(2)) and 12 (SE(3)) and
+    walks generic Jacobian rows: the measurement mixes of tests/test_gpu_measurements.py (interpolated and plain ranges,
+    bearing-range, GPS / attitude rows without landmarks, body_P_sensor, velocity priors) recorded once and replayed onto a
+    handle that is forced onto the segmented path -- two or three segments, every landmark in the fat separator between them --
+    next to the dense-border solve of the same graph."""
+    import gpslam_amd
+    from gpslam_amd import sharded
+    from test_gpu_measurements import build_meas_pair, LD
+    orc, ref, c, (rec,) = build_meas_pair(kind, N=N, seed=11, sensor=sensor, extra_makers=(sharded.GraphRecorder,))
+    chart = O.CHART_FIRST_ORDER if kind == O.POSE2 else O.CHART_EXPMAP
+    s = gpslam_amd.ChainSolver(kind, chart, LD[kind], force_segmented=True, segment_length=seg)
+    rec.replay(s)
+    assert s.segment_plan()["active"] == 1
+    for it in range(5):
+        _, a = s.iterate_gn()
+        _, b = ref.iterate_gn()
+        assert abs(a.error_before - b.error_before) <= 1e-9 * max(1.0, b.error_before), it
+        assert abs(a.error_after - b.error_after) <= 1e-7 * max(1.0, b.error_after), it
+    pa, va = s.get_states()
+    pb, vb = ref.get_states()
+    assert np.abs(pa - pb).max() <= 1e-8 * max(1.0, np.abs(pb).max())
+    assert np.abs(va - vb).max() <= 1e-8 * max(1.0, np.abs(vb).max())
+    assert np.abs(s.get_landmarks() - ref.get_landmarks()).max() <= 1e-8
+    s.close()
