@@ -39,6 +39,12 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   const int *lm_fat, *lm_slot;       // L
   const int *lmrow_ptr, *lmrow, *lmrow_state;   // rows touching each landmark, sorted by left state
   const int *lmpri_ptr, *lmpri;      // L + 1, prior ids per landmark
+  // what a landmark's rows put on the right-hand side of the border columns, grouped by the interior state it lands on
+  // (row rho's left half at its own state, its right half at the next one): groups per landmark sorted by state, members
+  // (rho << 1 | half) per group; Gev[(g * ld + q) * B + r] = sum over the members of J[rho][half][r] * m[rho][q] (k_fs_gev)
+  const int *lg_ptr, *lg_state, *lg_mptr, *lg_m;
+  int ngroups;
+  T *Gev;
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
   const int *rowptr, *rowLm;
@@ -193,12 +199,35 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
   }
 }
 
+// ---- right-hand sides of the landmark border columns, one thread per (group, landmark component): the row tables are
+// gathered HERE, fully parallel, so that k_fs_sweep's sequential steps read a dense, prefetchable stream instead of chasing
+// lmrow_state -> lmrow -> rowM / rowLR (three dependent round trips per step: 5 us per step, 2.0 ms per iteration at 1e6 states)
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(256) k_fs_gev(FsArgs<T, TR> a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.ngroups * a.ld) return;
+  const int g = t / a.ld, q = t - g * a.ld;
+  T G[B];
+#pragma unroll
+  for (int r = 0; r < B; r++) G[r] = T(0);
+  for (int k = a.lg_mptr[g]; k < a.lg_mptr[g + 1]; k++) {
+    const int mm = a.lg_m[k], rho = mm >> 1, half = mm & 1;
+    const T m = a.rowM[(size_t)rho * a.ld + q];
+    const TR *row = a.rowLR + (size_t)rho * 2 * B + half * B;
+#pragma unroll
+    for (int r = 0; r < B; r++) G[r] += row[r] * m;
+  }
+#pragma unroll
+  for (int r = 0; r < B; r++) a.Gev[(size_t)t * B + r] = G[r];
+}
+
 // ---- forward substitution of the border columns.  One thread per (segment, column):
 // G~_j = G_j - E_{j-1}^T Y_{j-1},  Y_j = W_j G~_j.  Columns: [0, NB) left fat block, [NB, 2 NB) right fat block, 2 NB rhs.
 template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, c = threadIdx.x;
   const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
   const int j0 = cutL + 1, n = cutR - cutL - 1;
+  if (n <= 0) return;
+  const int slast = j0 + n - 1;
   const bool is_rhs = (c == 2 * a.NB);
   const bool right = (!is_rhs && c >= a.NB);
   const int cc = is_rhs ? 0 : (right ? c - a.NB : c);
@@ -212,69 +241,100 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
     if (a.fat_lm_ptr[kf] + li < a.fat_lm_ptr[kf + 1]) lm = a.fat_lm[a.fat_lm_ptr[kf] + li];
     if (lm < 0) active = false;     // padding column: Y stays zero (cleared once at compile time)
   }
-  int cur = 0, end = 0;
-  if (lm >= 0) { cur = a.lmrow_ptr[lm]; end = a.lmrow_ptr[lm + 1]; }
-  // rows of other segments come first in the landmark's list: skip them once, then keep the state of the next row in a
-  // register so that a step without a row of this landmark (most steps) issues no dependent load at all
-  while (cur < end && a.lmrow_state[cur] < j0 - 1) cur++;
-  int nxt = (cur < end) ? a.lmrow_state[cur] : 0x7fffffff;
+  // ---- the column's right-hand sides.  Landmark columns: the groups of k_fs_gev, walked in order: the state of the next
+  // group and its B values sit in registers one group ahead (gs, gn), so a step never waits for an index before it can ask
+  // for data.  Groups of other segments (and of the cut states) come first in the landmark's list: skipped once.
+  int gcur = 0, gend = 0;
+  if (lm >= 0) { gcur = a.lg_ptr[lm]; gend = a.lg_ptr[lm + 1]; }
+  while (gcur < gend && a.lg_state[gcur] < j0) gcur++;
+  const int glast = max(a.ngroups - 1, 0);
+  int gs = (gcur < gend) ? a.lg_state[gcur] : 0x7fffffff;
+  T gn[B];
+  {
+    const T *gp = a.Gev + ((size_t)min(gcur, glast) * a.ld + q) * B;
+#pragma unroll
+    for (int r = 0; r < B; r++) gn[r] = gp[r];
+  }
   T y[B];
 #pragma unroll
   for (int r = 0; r < B; r++) y[r] = T(0);
+  bool started = false;
   // [W_s | E_{s-1}] of the current state are the same for every column: staged through LDS, the next state's being
-  // fetched (one value per thread) while the current step computes
+  // fetched (one value per thread, from a clamped address and without a branch around the load: the compiler waits for a
+  // load under a branch right where it is issued) while the current step computes.  The same goes for the right-hand side
+  // of the rhs column (every lane fetches the six values of the next state; one lane uses them).
   constexpr int FW = 2 * B * B;
   __shared__ T Fs[2][FW];
   const int tid = threadIdx.x;
-  auto fac_at = [&](int s, int k) -> T {     // k < B*B: W_s[k]; else E_{s-1}[k - B*B] (zero for the first interior state)
-    if (k < B * B) return a.fac[(size_t)s * FW + k];
-    return (s > j0) ? a.fac[(size_t)(s - 1) * FW + k] : T(0);
-  };
   constexpr int PF = (FW + 63) / 64;          // values per thread (the block has at least 64 threads)
   const int nt = blockDim.x;
-  if (n > 0)
-    for (int k = tid; k < FW; k += nt) Fs[0][k] = fac_at(j0, k);
+  for (int k = tid; k < FW; k += nt)
+    Fs[0][k] = (k < B * B) ? a.fac[(size_t)j0 * FW + k] : T(0);       // E_{j0 - 1} = 0: the first interior state
+  T rn[B];
+  {
+    const T *gp = a.blk + (size_t)j0 * a.BS + 2 * B * B;
+#pragma unroll
+    for (int r = 0; r < B; r++) rn[r] = gp[r];
+  }
   __syncthreads();
   for (int jj = 0; jj < n; jj++) {
     const int s = j0 + jj;
     const T *fw = Fs[jj & 1], *fep = Fs[jj & 1] + B * B;
-    T pre[PF];
+    // ---- this step's right-hand side (registers only, except the two cut-state couplings at the segment's ends)
+    T G[B];
 #pragma unroll
-    for (int u = 0; u < PF; u++) pre[u] = (jj + 1 < n && tid + u * nt < FW) ? fac_at(s + 1, tid + u * nt) : T(0);
+    for (int r = 0; r < B; r++) G[r] = T(0);
+    bool consume = false;
     if (active) {
-      T G[B];
-#pragma unroll
-      for (int r = 0; r < B; r++) G[r] = T(0);
       if (is_rhs) {
-        const T *gp = a.blk + (size_t)s * a.BS + 2 * B * B;
+        started = true;
 #pragma unroll
-        for (int r = 0; r < B; r++) G[r] = gp[r];
+        for (int r = 0; r < B; r++) G[r] = rn[r];
       } else if (is_state) {
         if (!right && jj == 0) {            // H[cutL + 1, cutL] = O_cutL
+          started = true;
           const T *op = a.blk + (size_t)cutL * a.BS + B * B;
 #pragma unroll
           for (int r = 0; r < B; r++) G[r] = op[r * B + cc];
         } else if (right && jj == n - 1) {  // H[cutR - 1, cutR] = O_{cutR-1}^T
+          started = true;
           const T *op = a.blk + (size_t)s * a.BS + B * B;
 #pragma unroll
           for (int r = 0; r < B; r++) G[r] = op[cc * B + r];
         }
-      } else if (nxt <= s) {
-        while (cur < end && a.lmrow_state[cur] < s - 1) cur++;
-        int t = cur;
-        for (; t < end && a.lmrow_state[t] <= s; t++) {
-          const int rho = a.lmrow[t];
-          const T m = a.rowM[(size_t)rho * a.ld + q];
-          const TR *row = a.rowLR + (size_t)rho * 2 * B + (a.lmrow_state[t] == s ? 0 : B);   // left half for its own state
+      } else if (gs == s) {
+        started = true;
+        consume = true;
 #pragma unroll
-          for (int r = 0; r < B; r++) G[r] += row[r] * m;
-        }
-        // next step that needs a look: rows of state s contribute again at s + 1 (their right halves), later rows at
-        // their own state
-        int t2 = cur;
-        while (t2 < end && a.lmrow_state[t2] < s) t2++;
-        nxt = (t2 < end) ? max(a.lmrow_state[t2], s + 1) : 0x7fffffff;
+        for (int r = 0; r < B; r++) G[r] = gn[r];
       }
+    }
+    // ---- requests for the next step, all issued before this step's arithmetic: the next group of a column that has just
+    // used one, the next state's factors, the next state's rhs.  (Y is identically zero until a column's first group /
+    // coupling -- structurally, so nothing is computed or stored before that: the rows of Y were zeroed at compile time.)
+    if (consume) gcur++;
+    const int gidx = min(gcur, glast);
+    const int gs_new = a.lg_state[gidx];
+    T gnew[B];
+    {
+      const T *gp = a.Gev + ((size_t)gidx * a.ld + q) * B;
+#pragma unroll
+      for (int r = 0; r < B; r++) gnew[r] = gp[r];
+    }
+    const int sn = min(s + 1, slast);
+    T pre[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int k = min(tid + u * nt, FW - 1);
+      pre[u] = a.fac[(size_t)(k < B * B ? sn : sn - 1) * FW + k];      // W_{s+1}[k] or E_s[k - B*B]
+    }
+    T rnew[B];
+    {
+      const T *gp = a.blk + (size_t)sn * a.BS + 2 * B * B;
+#pragma unroll
+      for (int r = 0; r < B; r++) rnew[r] = gp[r];
+    }
+    if (active && started) {
       if (jj > 0) {
 #pragma unroll
         for (int k = 0; k < B; k++)
@@ -288,17 +348,27 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
         for (int k = 0; k <= r; k++) acc += fw[r * B + k] * G[k];
         y[r] = acc;
       }
-      T *yp = a.Y + (size_t)s * B * a.NCP + c;
-#pragma unroll
-      for (int r = 0; r < B; r++) {
-        // Y is written once and read once, 2 ms later, by k_fs_syrk: a streaming (nontemporal) store -- 2.21 -> 1.98 ms
-        __builtin_nontemporal_store(y[r], yp + (size_t)r * a.NCP);
-      }
     }
+    // ---- hand the prefetched values over (this is where the step waits for memory), then store
+    if (consume) {
+      gs = (gcur < gend) ? gs_new : 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < B; r++) gn[r] = gnew[r];
+    }
+#pragma unroll
+    for (int r = 0; r < B; r++) rn[r] = rnew[r];
     if (jj + 1 < n) {
 #pragma unroll
       for (int u = 0; u < PF; u++)
         if (tid + u * nt < FW) Fs[(jj + 1) & 1][tid + u * nt] = pre[u];
+    }
+    if (active && started) {
+      T *yp = a.Y + (size_t)s * B * a.NCP + c;
+#pragma unroll
+      for (int r = 0; r < B; r++) {
+        // Y is written once and read once, 2 ms later, by k_fs_syrk: a streaming (nontemporal) store
+        __builtin_nontemporal_store(y[r], yp + (size_t)r * a.NCP);
+      }
     }
     __syncthreads();
   }
@@ -1019,11 +1089,16 @@ struct FatSepPlan {
   std::vector<int> first_lm, last_lm;
   std::vector<LevelHost> tlevels;
   DevBuf send, recv, tD, tlink, tg, tQ, tS1, tS2, tsv, tx, d_telim, d_tupd, d_lm_own, lm_tmp;
+  // right-hand-side groups of the landmark border columns (FsArgs::lg_*)
+  DevBuf d_lg_ptr, d_lg_state, d_lg_mptr, d_lg_m, Gev;
+  int ngroups = 0;
+  std::vector<int> h_lmrow, h_lmstate, h_lmptr;     // compile(): rows per landmark, sorted by left state
 
   void release() {
     for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
                       &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
-                      &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp})
+                      &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp,
+                      &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev})
       b->release();
     active = false;
   }
