@@ -142,3 +142,94 @@ def cyclic_reduction(Dfat, Ofat, gfat):
             t -= Q @ x[r]
         x[m] = np.linalg.solve(Lc.T, t)
     return np.stack([x[k] for k in range(K)])
+
+
+def build_levels(K, keep_last):
+    """Level sets of the block cyclic reduction as FatSepPlan::build_levels (gpslam_amd/csrc/fatsep.hpp) forms them: every
+    level eliminates every other active block; keep_last: the last block is never eliminated (a piece of a split chain
+    stops at its two end blocks).  Returns (levels, survivors): levels = list of lists of (m, l, r) with r = None when the
+    eliminated block has no right neighbour."""
+    active = list(range(K))
+    levels = []
+    while len(active) > (2 if keep_last else 1):
+        n = len(active)
+        elim = lambda q: 0 <= q < n and (q & 1) == 1 and not (keep_last and q == n - 1)
+        lv = [(active[q], active[q - 1], active[q + 1] if q + 1 < n else None) for q in range(1, n, 2) if elim(q)]
+        levels.append(lv)
+        active = [active[i] for i in range(n) if not elim(i)]
+    return levels, active
+
+
+def reduce_piece(Dfat, Ofat, gfat, keep_last=True):
+    """Forward half of the cyclic reduction over the given level sets.  Returns (ends, D, g, link, trail): what is left on
+    the surviving blocks (`ends`: their indices) and the trail for the back-substitution."""
+    K, NB = gfat.shape
+    Dm = {k: Dfat[k].copy() for k in range(K)}
+    gm = {k: gfat[k].copy() for k in range(K)}
+    link = {(k, k + 1): Ofat[k].copy() for k in range(K - 1)}    # link[(l, r)] = H[r, l]
+    levels, ends = build_levels(K, keep_last)
+    trail = []
+    for lv in levels:
+        for m, l, r in lv:
+            Lc = np.linalg.cholesky(Dm[m])
+            P = np.linalg.solve(Lc, link[(l, m)])
+            z = np.linalg.solve(Lc, gm[m])
+            Dm[l] -= P.T @ P
+            gm[l] -= P.T @ z
+            Q = None
+            if r is not None:
+                Q = np.linalg.solve(Lc, link[(m, r)].T)
+                Dm[r] -= Q.T @ Q
+                gm[r] -= Q.T @ z
+                link[(l, r)] = -Q.T @ P
+            trail.append((m, l, r, Lc, P, Q, z))
+    return ends, Dm, gm, link, trail
+
+
+def back_substitute(trail, x):
+    for m, l, r, Lc, P, Q, z in reversed(trail):
+        t = z - P @ x[l]
+        if r is not None:
+            t -= Q @ x[r]
+        x[m] = np.linalg.solve(Lc.T, t)
+    return x
+
+
+def split_solve(Dfat, Ofat, gfat, bounds, share=0.5):
+    """The fat block-tridiagonal system cut into pieces at the blocks `bounds` (first and last block included): piece r holds
+    the blocks bounds[r] .. bounds[r + 1]; a shared block's diagonal / right-hand side is split between its two pieces
+    (`share` to the left one -- any split is exact).  Every piece is reduced to its two end blocks (interface record), the
+    records are joined into the (P + 1)-block system of the shared separators, solved, and every piece back-substitutes:
+    the scheme of gpslam_hip_fs_phase1 / fs_phase2.  Returns x (K x NB)."""
+    K, NB = gfat.shape
+    P = len(bounds) - 1
+    recs, pieces = [], []
+    for r in range(P):
+        lo, hi = bounds[r], bounds[r + 1]
+        Dp, gp = Dfat[lo:hi + 1].copy(), gfat[lo:hi + 1].copy()
+        if r > 0:
+            Dp[0] *= (1.0 - share); gp[0] *= (1.0 - share)
+        if r < P - 1:
+            Dp[-1] *= share; gp[-1] *= share
+        ends, Dm, gm, link, trail = reduce_piece(Dp, Ofat[lo:hi].copy(), gp, keep_last=True)
+        assert ends == [0, hi - lo]
+        recs.append((Dm[0], link[(0, hi - lo)], Dm[hi - lo], gm[0], gm[hi - lo]))
+        pieces.append((lo, hi, trail))
+    T = np.zeros(((P + 1) * NB, (P + 1) * NB))
+    tr = np.zeros((P + 1) * NB)
+    for j in range(P + 1):
+        sl = slice(j * NB, (j + 1) * NB)
+        if j > 0:
+            T[sl, sl] += recs[j - 1][2]; tr[sl] += recs[j - 1][4]
+        if j < P:
+            T[sl, sl] += recs[j][0]; tr[sl] += recs[j][3]
+            nx = slice((j + 1) * NB, (j + 2) * NB)
+            T[nx, sl] = recs[j][1]; T[sl, nx] = recs[j][1].T
+    xt = np.linalg.solve(T, tr).reshape(P + 1, NB)
+    x = np.zeros((K, NB))
+    for r, (lo, hi, trail) in enumerate(pieces):
+        xl = {0: xt[r], hi - lo: xt[r + 1]}
+        back_substitute(trail, xl)
+        for k, v in xl.items():
+            x[lo + k] = v
+    return x

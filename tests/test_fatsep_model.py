@@ -61,3 +61,33 @@ def test_fat_elimination_and_cyclic_reduction_equal_dense_solve():
             for l in range(L):
                 got = xfat[fat_of[l], b + slot_of[l] * ld: b + (slot_of[l] + 1) * ld]
                 np.testing.assert_allclose(got, xd[N * b + l * ld: N * b + (l + 1) * ld], rtol=1e-8, atol=1e-10)
+
+
+def test_level_sets_keep_the_last_block_of_a_piece():
+    for K in range(2, 40):
+        levels, ends = FM.build_levels(K, keep_last=True)
+        assert ends == [0, K - 1]
+        gone = [m for lv in levels for m, _, _ in lv]
+        assert sorted(gone) == list(range(1, K - 1))                   # every interior block exactly once
+        for lv in levels:
+            for m, l, r in lv:
+                assert l < m and r is not None and m < r               # with the last block kept there is always a right neighbour
+        levels1, top = FM.build_levels(K, keep_last=False)
+        assert top == [0] and sorted(m for lv in levels1 for m, _, _ in lv) == list(range(1, K))
+    assert len(FM.build_levels(3908, True)[0]) == 12                   # BASELINE config 4 on one GPU: 12 levels either way
+
+
+def test_split_fat_chain_equals_the_unsplit_solve():
+    """The algebra of gpslam_hip_fs_phase1 / fs_phase2 on CPU: pieces reduced to their end blocks, records joined, top system
+    solved, pieces back-substituted -- against the dense solve of the whole bordered system."""
+    b, ld = 4, 2
+    D, O, g, B, HLL, gL, touch = _random_problem(120, 24, b, ld, 6, 5)
+    cuts, fat_of, slot_of, counts = FM.plan(120, 24, touch, 10)
+    K, NB = len(cuts), b + ld * max(counts)
+    Dfat, Ofat, gfat, (H, rhs) = FM.fat_system(D, O, g, B, HLL, gL, ld, cuts, fat_of, slot_of, NB, 0.2)
+    xd = np.linalg.solve(H, rhs)
+    for bounds, share in (([0, K - 1], 0.5), ([0, 5, K - 1], 0.5), ([0, 3, 4, 9, K - 1], 0.25), ([0, 1, 2, K - 1], 1.0)):
+        x = FM.split_solve(Dfat, Ofat, gfat, bounds, share)
+        np.testing.assert_allclose(x, FM.cyclic_reduction(Dfat, Ofat, gfat), rtol=1e-8, atol=1e-9)
+        for k, c in enumerate(cuts):
+            np.testing.assert_allclose(x[k, :b], xd[c * b:(c + 1) * b], rtol=1e-7, atol=1e-9)
