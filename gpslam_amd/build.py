@@ -12,9 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgpslam_hip.so")
-SOURCES = ["api.hip"]
-HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "api_impl.inc", os.path.join("..", "..", "include", "gpslam_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=fast"]
+SOURCES = ["api.hip", "upper.hip"]     # one object each, compiled side by side, linked into the one library
+HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "dpp.hpp", "upper.hpp", "api_impl.inc",
+           os.path.join("..", "..", "include", "gpslam_hip.h")]
+# what each translation unit includes (an edit to upper.hip does not recompile the two-minute api.hip)
+DEPS = {"api.hip": HEADERS, "upper.hip": ["dpp.hpp", "upper.hpp"]}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
+OBJDIR = os.path.join(LIBDIR, "obj")
 
 
 def _hipcc():
@@ -24,23 +28,49 @@ def _hipcc():
     raise RuntimeError("hipcc not found: the HIP library cannot be built (there is no CPU fallback)")
 
 
+def _obj(src):
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _src_deps(src):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in DEPS[src]] + [os.path.abspath(__file__)]
+
+
 def up_to_date():
-    if not os.path.exists(LIB):
+    if any(_stale(_obj(s), _src_deps(s)) for s in SOURCES):
         return False
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return all(os.path.getmtime(d) <= t for d in deps)
+    return not _stale(LIB, [_obj(s) for s in SOURCES])
 
 
 def build(force=False, verbose=False):
+    extra = os.environ.get("GPSLAM_HIPCC_FLAGS", "").split()      # e.g. -DGPS_ABLATE_ASM for the timing ablations of DESIGN.md
+    if extra:
+        force = True
     if not force and up_to_date():
         return LIB
-    os.makedirs(LIBDIR, exist_ok=True)
-    extra = os.environ.get("GPSLAM_HIPCC_FLAGS", "").split()      # e.g. -DGPS_ABLATE_ASM for the timing ablations of DESIGN.md
-    cmd = [_hipcc()] + FLAGS + extra + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJDIR, exist_ok=True)
+    procs = []
+    for src in SOURCES:
+        if not force and not _stale(_obj(src), _src_deps(src)):
+            continue
+        cmd = [_hipcc()] + FLAGS + extra + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, cmd)
+    link = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd, cwd=CSRC)
+        print(" ".join(link))
+    subprocess.check_call(link, cwd=CSRC)
     return LIB
 
 

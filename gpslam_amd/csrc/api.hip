@@ -17,6 +17,7 @@
 #include "devbuf.hpp"
 #include "kernels.hpp"
 #include "fatsep.hpp"
+#include "upper.hpp"
 
 using namespace gps;
 
@@ -91,6 +92,7 @@ struct gpslam_hip_handle {
   // landmark elimination at scale (fatsep.hpp): segments + fat separators instead of the dense border
   FatSepPlan fs;
   DevBuf lm_gL;             // undamped landmark gradient of the segmented path (the dense path keeps it behind lm_S)
+  bool upper_ok = false;    // the levels above level 0 run as LDS-resident cyclic reduction (upper.hip)
   bool fuse_ok = false;     // k_fused_level0 applies to this graph (compile())
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
