@@ -13,10 +13,10 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libgpslam_hip.so")
 SOURCES = ["api.hip", "upper.hip"]     # one object each, compiled side by side, linked into the one library
-HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "dpp.hpp", "upper.hpp", "api_impl.inc",
+HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "dpp.hpp", "cr_step.hpp", "upper.hpp", "api_impl.inc",
            os.path.join("..", "..", "include", "gpslam_hip.h")]
 # what each translation unit includes (an edit to upper.hip does not recompile the two-minute api.hip)
-DEPS = {"api.hip": HEADERS, "upper.hip": ["dpp.hpp", "upper.hpp"]}
+DEPS = {"api.hip": HEADERS, "upper.hip": ["dpp.hpp", "cr_step.hpp", "upper.hpp"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 OBJDIR = os.path.join(LIBDIR, "obj")
 

@@ -25,6 +25,7 @@
 
 #include "factors.hpp"
 #include "dpp.hpp"
+#include "cr_step.hpp"
 #include <type_traits>
 
 namespace gps {
@@ -87,8 +88,11 @@ template <typename T> __global__ void __launch_bounds__(256) k_final_reduce(cons
 // first pose IN FP64, so that a Jacobian computed 1e5 m from the origin is as accurate as one computed at the origin
 // (a float holds 1e5 m to 8 mm: the 0.1 m step between consecutive states would carry 4 digits).  The fp64
 // instantiations do not re-centre: their results stay bit-identical to what the oracle parity tests pinned.
+// (LINEAR3 is (x, y, theta) for OdometryFactor2DLinear / RangeBearingFactor2DLinear, whose Jacobians are evaluated AT theta:
+//  only x and y are re-centred -- ADVICE r2; a plain GaussianProcessPriorLinear<3> chain loses nothing by that, its Jacobians
+//  are constants.)
 template <int MF> struct TransPart {
-  static constexpr int n = (MF == POSE3) ? 3 : (MF == POSE2 ? 2 : ((MF == ROT3 || MF == ROT3_BIAS) ? 0 : MTraits<MF>::pd));
+  static constexpr int n = (MF == POSE3) ? 3 : ((MF == POSE2 || MF == LINEAR3) ? 2 : ((MF == ROT3 || MF == ROT3_BIAS) ? 0 : MTraits<MF>::pd));
   static constexpr int off = (MF == POSE3) ? 9 : 0;
 };
 template <typename T> struct IsF64 { static constexpr bool v = false; };
@@ -1525,6 +1529,12 @@ template <typename T> struct FwdArgs {
   const T *remote_add; // [RD | Rg] already owed to that outside separator by lower levels / the assembly, or null
   T lambda;          // LM damping added to the diagonal of D while loading (level 0 only)
   int *flag;         // set to 1 if a pivot is not positive
+  // k_fused_level0 only.  tail = 1: the wave's four chunk separators are reduced to the first of them at the end of the
+  // kernel (two sub-levels of cyclic reduction, cr_step.hpp) -- the level of groups of four that upper.hip would otherwise
+  // run as a launch of its own.  up_blk / up_add then belong to the level ABOVE that one (one record per workgroup), and
+  // the factor records of the three eliminated separators go to l1_blk (the records of the level in between).
+  T *l1_blk;
+  int tail;
 };
 
 // One wave per chunk.  Panel columns: [ D~ (B) | O^T (B) | F (B) | rhs (R) ], one column per lane.
@@ -2085,7 +2095,12 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
   const bool rowlane = r < B;
   const int rr = rowlane ? r : 0;
   const bool right_exists = (e < a.n) || (a.last_has_right != 0);
-  const bool has_int = valid && j0 < e;
+  // tail: the chain's last chunk is padded to full length with decoupled identity blocks (D = I, O = 0, g = 0: their
+  // elimination changes nothing and their records are never stored), so that the four chunks of a wave end in the same
+  // block step and their separator data is still in registers when the tail starts
+  const bool tail = a.tail != 0;
+  const int ep = (valid && tail) ? s + a.m : e;
+  const bool has_int = valid && j0 < ep;
   const double lambda = a.lambda;
   __shared__ __attribute__((aligned(16))) double IMG[2 * 4 * BS];    // two rotating record images per chunk
   __shared__ __attribute__((aligned(16))) double OUTR[4 * BS];       // the factor record on its way out
@@ -2093,7 +2108,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
   int co = grp * BS + rr;         // column r:             IMG[... + co + k * B]
   int po = grp * BS + 2 * r;      // 16-byte piece q * 16 + r of OUTR
   asm volatile("" : "+v"(ro), "+v"(co), "+v"(po));
-  const int steps = __builtin_amdgcn_readfirstlane(max(e - j0, 0));   // lane 0: the wave's first (never shorter) chunk
+  const int steps = __builtin_amdgcn_readfirstlane(max(ep - j0, 0));   // lane 0: the wave's first (never shorter) chunk
 
   if (role == 1) {
     // ================================================================ ASM: images 0 .. steps + 1
@@ -2255,9 +2270,14 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
           __builtin_amdgcn_sched_barrier(0);
         }
       }
-      if (live) {   // Levenberg-Marquardt damping on the diagonal of a real state's D
+      {   // Levenberg-Marquardt damping on the diagonal of a real state's D; the padding blocks behind the chain's last state
+          // (tail) are identities
+        const bool pad = valid && (s + kimg) >= e && (s + kimg) < ep;
+        const double dg = live ? lambda : (pad ? 1.0 : 0.0);
+        if (live || pad) {
 #pragma unroll
-        for (int k = 0; k < B; k++) Dacc[k] += (k == r) ? lambda : 0.0;
+          for (int k = 0; k < B; k++) Dacc[k] += (k == r) ? dg : 0.0;
+        }
       }
 #pragma unroll
       for (int k = 0; k < B; k++) carry[k] = RRacc[k];
@@ -2425,7 +2445,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     gr = gn;
     wave_lds_sync();
     __builtin_amdgcn_sched_barrier(0);
-    if (live && lastb && rowlane) {
+    if (!tail && live && lastb && rowlane) {
       double *ub = a.up_blk + (size_t)c * BS;
 #pragma unroll
       for (int k = 0; k < B; k++) {
@@ -2440,6 +2460,79 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
         ua[B * B + r] = gr;
       }
     }
+  }
+  if (!tail) return;
+
+  // ================================================================== the level of groups of four, in place
+  // All four chunks ended in the same block step (padding above); row grp holds what the in-loop branch above would have
+  // sent to memory: the separator's record [Ar | Fr | as_] and the addend [Dr | gr] it owes the next separator.  Both
+  // images are dead (the assembly wave is past its last write), they now hold the group: REC[0..3] the records, REC[4] the
+  // virtual block beyond the group, TA[0..3] the addends.
+  {
+    constexpr int G4 = 4;
+    double *REC = IMG, *TA = IMG + (G4 + 1) * BS;
+    const int c0 = blockIdx.x * 4;
+    const int cnt = min(G4, nch - c0);
+    wave_lds_sync();
+    if (valid && rowlane) {
+      double *rc = REC + grp * BS, *ta = TA + grp * AS;
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        rc[r * B + k] = Ar[k];
+        rc[B * B + r * B + k] = right_exists ? Fr[k] : 0.0;
+        ta[r * B + k] = Dr[k];
+      }
+      rc[2 * B * B + r] = as_;
+      ta[B * B + r] = gr;
+    }
+    wave_lds_sync();
+    if (valid && rowlane && grp >= 1) {          // block i >= 1 of the group receives what chunk i - 1 owes it
+      double *rc = REC + grp * BS;
+      const double *ta = TA + (grp - 1) * AS;
+#pragma unroll
+      for (int k = 0; k < B; k++) rc[r * B + k] += ta[r * B + k];
+      rc[2 * B * B + r] += ta[B * B + r];
+    }
+    if (grp == 0 && rowlane) {                   // the block beyond the group is owed the last chunk's addend
+      const bool have = (c0 + cnt < nch);
+      double *rc = REC + G4 * BS;
+      const double *ta = TA + (cnt - 1) * AS;
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        rc[r * B + k] = have ? ta[r * B + k] : 0.0;
+        rc[B * B + r * B + k] = 0.0;
+      }
+      rc[2 * B * B + r] = have ? ta[B * B + r] : 0.0;
+    }
+    wave_lds_sync();
+    CrStep<B> st;
+#pragma unroll 1
+    for (int q = 0; q < 2; q++) {
+      const int h = 1 << q, np = G4 >> (q + 1);
+      const int sq = grp * 2 * h, jq = sq + h;
+      const bool act = (grp < np) && (jq < cnt);
+      const int nq = (jq + h < cnt) ? jq + h : G4;
+      if (__ballot(act) != 0ull) {               // (idle DPP rows recompute block 0; they never store)
+        const bool bad = st.compute(REC, act ? sq : 0, act ? jq : 0, r, rr);
+        if (bad && act && r == 0) *a.flag = 1;
+      }
+      wave_lds_sync();
+      if (act && rowlane) st.store_own(REC, sq, jq, r);
+      wave_lds_sync();
+      if (act && rowlane) st.add_right(REC, nq, r);
+      if (act) {                                 // the factor record of the eliminated separator: level 1's back-substitution reads it
+        V2 *dst = reinterpret_cast<V2 *>(a.l1_blk + (size_t)(c0 + jq) * BS);
+        const V2 *src = reinterpret_cast<const V2 *>(REC + jq * BS);
+        for (int t = r; t < NPC; t += 16) dst[t] = src[t];
+      }
+      wave_lds_sync();
+    }
+    V2 *ub = reinterpret_cast<V2 *>(a.up_blk + (size_t)blockIdx.x * BS);
+    const V2 *s0 = reinterpret_cast<const V2 *>(REC);
+    for (int t = lane; t < NPC; t += 64) ub[t] = s0[t];
+    V2 *ua = reinterpret_cast<V2 *>(a.up_add + (size_t)(blockIdx.x + 1) * AS);
+    const V2 *s4 = reinterpret_cast<const V2 *>(REC + G4 * BS);
+    for (int t = lane; t < B * B / 2 + B / 2; t += 64) ua[t] = s4[t < B * B / 2 ? t : t + B * B / 2];
   }
 }
 

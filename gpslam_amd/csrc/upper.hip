@@ -1,179 +1,119 @@
-// upper.hip -- the solver levels above level 0: LDS-resident block cyclic reduction, 32 blocks per workgroup and launch.
-// See upper.hpp for the scheme.  The arithmetic of one elimination is the row-layout block step of
-// k_chunk_forward_rows (kernels.hpp): lane r of a 16-lane DPP row holds ROW r of the panel [D~_j | O_j^T | F | g~_j],
-// Gauss-Jordan multipliers are lane-local, the pivot / source rows travel fused into the multiply-adds
-// (v_fmac_f64_dpp row_newbcast, dpp.hpp).
-//
-// One elimination (pair (s, j), n = the block 2^q to the right of j, possibly the virtual block G beyond the group):
-//   D_j x_j + O_j^T x_n + F x_s = g_j,  F = O_s          (O_i = H[right neighbour of i, i])
-//   U = D_j^-1 O_j^T,  V = D_j^-1 F,  Y = D_j^-1 g_j        -> record j becomes [V | U | Y] (column-major, as level 0 stores it)
-//   D_s -= F^T V,  g_s -= F^T Y,  O_s <- -O_j V             (s now couples to n)
-//   D_n -= O_j U,  g_n -= O_j Y                             (added after a barrier: n is the s of the next pair)
+// upper.hip -- the solver levels above level 0: LDS-resident block cyclic reduction, G blocks per workgroup and launch.
+// See upper.hpp for the scheme and cr_step.hpp for one elimination (the row-layout block step of k_chunk_forward_rows:
+// lane r of a 16-lane DPP row holds ROW r of the panel [D~_j | O_j^T | F | g~_j], Gauss-Jordan multipliers are lane-local,
+// the pivot / source rows travel fused into the multiply-adds -- v_fmac_f64_dpp row_newbcast, dpp.hpp).
 // Back-substitution: x_j = Y_j - U_j x_n - V_j x_s, sub-levels in reverse.
 #include "upper.hpp"
-#include "dpp.hpp"
+#include "cr_step.hpp"
+
+#include <cstdio>
+#include <cstdlib>
 
 namespace gps {
 
 namespace {
 
-template <int B> struct UpDims {
+template <int B, int G> struct UpDims {
+  static_assert(G == 32 || G == 4, "group sizes: 32 (a launch of its own), 4 (the level the row-layout level-0 kernels fold into their tail)");
   static constexpr int BS = 2 * B * B + B, AS = B * B + B;
   static constexpr int DP = B * B / 2, GP = B / 2, NPC = BS / 2;     // 16-byte pieces of D (or O), of g, of a record
-  static constexpr size_t lds_fwd(bool top) { return ((size_t)(kUpG + 1) * BS + (top ? (size_t)(kUpG + 1) * B : 0)) * sizeof(double); }
-  static constexpr size_t lds_bwd() { return ((size_t)kUpG * BS + (size_t)(kUpG + 1) * B) * sizeof(double); }
+  static constexpr int Q = (G == 32) ? 5 : 2;                         // sub-levels
+  static constexpr int NT = (G == 32) ? 256 : 64, NW = NT / 64;       // threads, waves: G / 2 pairs on NW * 4 DPP rows
+  static constexpr int UF = (G * NPC + NT - 1) / NT;                  // 16-byte pieces per thread of a group's records
+  static constexpr size_t lds_fwd(bool top) { return ((size_t)(G + 1) * BS + (top ? (size_t)(G + 1) * B : 0)) * sizeof(double); }
+  static constexpr size_t lds_bwd() { return ((size_t)G * BS + (size_t)(G + 1) * B) * sizeof(double); }
 };
 
 typedef double V2 __attribute__((ext_vector_type(2)));
 
-// x_j = Y_j - U_j x_n - V_j x_s for every eliminated block of the group, sub-levels in reverse; 16 lanes per pair.
-// XS[0] (the group's first block) and XS[G] (the block beyond the group, or zero) are given.
-template <int B>
-__device__ __forceinline__ void group_backward(const double *REC, double *XS, int cnt, int tid) {
-  constexpr int BS = UpDims<B>::BS, G = kUpG;
-  const int p = tid >> 4, r = tid & 15;
-#pragma unroll 1
-  for (int q = kUpQ - 1; q >= 0; q--) {
-    const int h = 1 << q, np = G >> (q + 1);
-    const int s = p * 2 * h, j = s + h;
-    if (p < np && j < cnt && r < B) {
-      const int n = (j + h < cnt) ? j + h : G;
-      const double *Rj = REC + j * BS;
-      double v = Rj[2 * B * B + r];
-#pragma unroll
-      for (int k = 0; k < B; k++) v = fma(-Rj[B * B + k * B + r], XS[n * B + k], v);
-#pragma unroll
-      for (int k = 0; k < B; k++) v = fma(-Rj[k * B + r], XS[s * B + k], v);
-      XS[j * B + r] = v;
-    }
-    lds_barrier();
-  }
-}
-
-template <int B, bool TOP>
-__global__ void __launch_bounds__(256) k_multi_forward(UpFwdArgs a) {
-  constexpr int BS = UpDims<B>::BS, AS = UpDims<B>::AS, DP = UpDims<B>::DP, GP = UpDims<B>::GP, NPC = UpDims<B>::NPC, G = kUpG;
+template <int B, int G, bool TOP>
+__global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs a) {
+  typedef UpDims<B, G> DM;
+  constexpr int BS = DM::BS, AS = DM::AS, DP = DM::DP, GP = DM::GP, NPC = DM::NPC, Q = DM::Q, NT = DM::NT, NW = DM::NW, UF = DM::UF;
   extern __shared__ __attribute__((aligned(16))) double REC[];   // (G + 1) records; TOP: + (G + 1) solutions
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, row = lane >> 4, r = lane & 15;
   const int g = blockIdx.x, base = g * G;
   const int cnt = min(G, a.n - base);
   const bool rowlane = r < B;
   const int rr = rowlane ? r : 0;            // idle lanes shadow row 0 (they never store)
+  int pi = 0;
+  auto probe = [&]() {                        // GPSLAM_UPPER_PROBE=1: shader-clock stamps of workgroup 0 (diagnostics)
+    if (a.probe != nullptr && blockIdx.x == 0 && tid == 0) { a.probe[pi] = (long long)__builtin_readcyclecounter(); a.probe[pi == 0 ? 62 : 63] = (long long)wall_clock64(); }
+    pi++;
+  };
+  probe();
 
-  // ---- the group's records (+ the addends the level below sent them) into LDS, as 16-byte pieces.  The group's first
-  // block keeps its addend out: the previous group carries it upward (TOP: there is no level above, it joins here).
-  for (int idx = tid; idx < cnt * NPC; idx += 256) {
-    const int i = idx / NPC, t = idx - i * NPC;
-    V2 v = reinterpret_cast<const V2 *>(a.blk + (size_t)(base + i) * BS)[t];
-    if (a.add != nullptr && (i >= 1 || TOP) && (t < DP || t >= 2 * DP)) {
-      const V2 w = reinterpret_cast<const V2 *>(a.add + (size_t)(base + i) * AS)[t < DP ? t : t - DP];
-      v.x += w.x; v.y += w.y;
+  // ---- the group's records (+ the addends the level below sent them) into LDS, as 16-byte pieces; every load of the
+  // thread is issued before the first one is consumed (a load per loop iteration had exposed a memory round trip each:
+  // 17 500 of the kernel's 79 000 cycles).  The group's first block keeps its addend out: the previous group carries it
+  // upward (TOP: there is no level above, it joins here).
+  {
+    V2 v[UF], w[UF];
+    const V2 *blk2 = reinterpret_cast<const V2 *>(a.blk + (size_t)base * BS);
+    const V2 *add2 = reinterpret_cast<const V2 *>(a.add != nullptr ? a.add + (size_t)base * AS : a.blk + (size_t)base * BS);
+#pragma unroll
+    for (int u = 0; u < UF; u++) {
+      const int idx = min(tid + NT * u, cnt * NPC - 1);
+      const int i = idx / NPC, t = idx - i * NPC;
+      v[u] = blk2[idx];
+      w[u] = add2[i * (AS / 2) + (t < DP ? t : (t >= 2 * DP ? t - DP : 0))];
     }
-    reinterpret_cast<V2 *>(REC + i * BS)[t] = v;
+#pragma unroll
+    for (int u = 0; u < UF; u++) {
+      const int idx = tid + NT * u;
+      const int i = idx / NPC, t = idx - i * NPC;
+      const bool joins = a.add != nullptr && (i >= 1 || TOP) && (t < DP || t >= 2 * DP);
+      V2 x = v[u];
+      if (joins) { x.x += w[u].x; x.y += w[u].y; }
+      if (idx < cnt * NPC) reinterpret_cast<V2 *>(REC)[idx] = x;
+    }
   }
   {   // the virtual block G: what is already owed to the block beyond the group
     const int xi = base + cnt;
     const bool have = a.add != nullptr && ((xi < a.n) || (a.ext != 0));
-    for (int t = tid; t < NPC; t += 256) {
+    for (int t = tid; t < NPC; t += NT) {
       V2 v = {0.0, 0.0};
       if (have && (t < DP || t >= 2 * DP)) v = reinterpret_cast<const V2 *>(a.add + (size_t)xi * AS)[t < DP ? t : t - DP];
       reinterpret_cast<V2 *>(REC + G * BS)[t] = v;
     }
   }
   __syncthreads();
+  probe();
 
+  CrStep<B> st;
 #pragma unroll 1
-  for (int q = 0; q < kUpQ; q++) {
+  for (int q = 0; q < Q; q++) {
     const int h = 1 << q, np = G >> (q + 1);
-    const int p = row * 4 + wave;            // the pairs of a sub-level spread over the waves first, then over DPP rows
+    const int p = row * NW + wave;           // the pairs of a sub-level spread over the waves first, then over DPP rows
     const int s = p * 2 * h, j = s + h;
     const bool act = (p < np) && (j < cnt);
     const int n = (j + h < cnt) ? j + h : G;
-    const bool wact = __ballot(act) != 0ull;
-    double Or[B], Fr[B], Ar[B], Dn[B], Fn[B];
-    double gr = 0.0, as_ = 0.0, gn = 0.0;
-    if (wact) {
-      const double *Rj = REC + (act ? j : 0) * BS, *Rs = REC + (act ? s : 0) * BS;   // idle rows recompute block 0 (never stored)
-      double Dr[B], Gr[B], Ol[B];
-#pragma unroll
-      for (int k = 0; k < B; k++) {
-        Dr[k] = Rj[rr * B + k];                    // row r of D_j
-        Or[k] = Rj[B * B + k * B + rr];            // row r of O_j^T
-        Ol[k] = Rj[B * B + rr * B + k];            // row r of O_j
-        Ar[k] = Rs[rr * B + k];                    // row r of D_s
-        Fr[k] = Rs[B * B + rr * B + k];            // row r of F = O_s
-        Gr[k] = Rs[B * B + k * B + rr];            // row r of F^T
-      }
-      gr = Rj[2 * B * B + rr];
-      as_ = Rs[2 * B * B + rr];
-      __builtin_amdgcn_sched_barrier(0);
-      // Gauss-Jordan on D_j by row operations; the pivot row stays unscaled until the end (scaling commutes)
-      double invs = 1.0;
-      bool bad = false;
-      static_for<0, B>([&](auto kk) {
-        constexpr int k = decltype(kk)::value;
-        const double piv = row_bcast<k>(Dr[k]);
-        bad = bad || !(piv > 0.0);
-        const double inv = fast_rcp(piv);
-        const bool isk = (r == k);
-        invs = isk ? inv : invs;
-        const double nmp = isk ? 0.0 : -(Dr[k] * inv);
-        fmac_self_n<k, B>(Dr, nmp);              // (entries at or left of the pivot become garbage that nothing reads again)
-        fmac_self_n<k, B>(Or, nmp);
-        fmac_self_n<k, B>(Fr, nmp);
-        fmac_self1<k>(gr, nmp);
-      });
+    if (__ballot(act) != 0ull) {             // (idle DPP rows of a working wave recompute block 0; they never store)
+      const bool bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr);
       if (bad && act && r == 0) *a.flag = 1;
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; Dn[k] = 0.0; Fn[k] = 0.0; }   // U_j, V_j: row r
-      gr *= invs;                                                                                  // Y_j
-      __builtin_amdgcn_sched_barrier(0);
-      static_for<0, B>([&](auto ii) {
-        constexpr int i = decltype(ii)::value;
-        const double nol = -Ol[i], ngg = -Gr[i];
-        fmac_bcast_n<i, B>(Dn, Or, nol);         // -O_j U_j: row r
-        fmac_bcast2<i>(gn, as_, gr, nol, ngg);   // -O_j Y_j,  g_s -= F^T Y_j
-        fmac_bcast_n<i, B>(Fn, Fr, nol);         // -O_j V_j: the coupling of s to n
-        fmac_bcast_n<i, B>(Ar, Fr, ngg);         // D_s -= F^T V_j
-      });
-      __builtin_amdgcn_sched_barrier(0);
     }
+    probe();
     lds_barrier();                            // every pair has read its operands
-    if (act && rowlane) {
-      double *Ws = REC + s * BS, *Wj = REC + j * BS;
-#pragma unroll
-      for (int k = 0; k < B; k++) {
-        Ws[r * B + k] = Ar[k];
-        Ws[B * B + r * B + k] = Fn[k];
-        Wj[k * B + r] = Fr[k];                  // the factor record is column-major [V | U | Y]
-        Wj[B * B + k * B + r] = Or[k];
-      }
-      Ws[2 * B * B + r] = as_;
-      Wj[2 * B * B + r] = gr;
-    }
+    if (act && rowlane) st.store_own(REC, s, j, r);
     lds_barrier();                            // the pairs' own blocks are in place: now the right neighbours' shares
-    if (act && rowlane) {
-      double *Wn = REC + n * BS;
-#pragma unroll
-      for (int k = 0; k < B; k++) Wn[r * B + k] += Dn[k];
-      Wn[2 * B * B + r] += gn;
-    }
+    probe();
+    if (act && rowlane) st.add_right(REC, n, r);
     if (!TOP) {   // this sub-level's factor records leave for the back-substitution launch
-      for (int idx = tid; idx < np * NPC; idx += 256) {
+      for (int idx = tid; idx < np * NPC; idx += NT) {
         const int pp = idx / NPC, t = idx - pp * NPC;
         const int jj = pp * 2 * h + h;
         if (jj < cnt) reinterpret_cast<V2 *>(a.blk + (size_t)(base + jj) * BS)[t] = reinterpret_cast<const V2 *>(REC + jj * BS)[t];
       }
     }
     lds_barrier();
+    probe();
   }
 
   if (!TOP) {
     // what is left of the group: its first block (now coupled to the block beyond the group) and what that block is owed
-    for (int t = tid; t < NPC; t += 256)
+    for (int t = tid; t < NPC; t += NT)
       reinterpret_cast<V2 *>(a.up_blk + (size_t)g * BS)[t] = reinterpret_cast<const V2 *>(REC)[t];
-    for (int t = tid; t < DP + GP; t += 256)
+    for (int t = tid; t < DP + GP; t += NT)
       reinterpret_cast<V2 *>(a.up_add + (size_t)(g + 1) * AS)[t] = reinterpret_cast<const V2 *>(REC + G * BS)[t < DP ? t : t + DP];
     return;
   }
@@ -203,21 +143,27 @@ __global__ void __launch_bounds__(256) k_multi_forward(UpFwdArgs a) {
   }
   if (tid < B) XS[G * B + tid] = 0.0;          // nothing beyond the top level
   lds_barrier();
-  group_backward<B>(REC, XS, cnt, tid);
-  for (int idx = tid; idx < cnt * B; idx += 256) a.x[(size_t)base * B + idx] = XS[idx];
+  cr_group_backward<B, G, Q>(REC, XS, cnt, tid, [] { lds_barrier(); });
+  for (int idx = tid; idx < cnt * B; idx += NT) a.x[(size_t)base * B + idx] = XS[idx];
 }
 
-template <int B>
-__global__ void __launch_bounds__(256) k_multi_backward(UpBwdArgs a) {
-  constexpr int BS = UpDims<B>::BS, NPC = UpDims<B>::NPC, G = kUpG;
+template <int B, int G>
+__global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_backward(UpBwdArgs a) {
+  typedef UpDims<B, G> DM;
+  constexpr int BS = DM::BS, NPC = DM::NPC, Q = DM::Q, NT = DM::NT, UF = DM::UF;
   extern __shared__ __attribute__((aligned(16))) double REC[];   // G records, then (G + 1) solutions
   double *XS = REC + G * BS;
   const int tid = threadIdx.x;
   const int g = blockIdx.x, base = g * G;
   const int cnt = min(G, a.n - base);
-  for (int idx = tid + NPC; idx < cnt * NPC; idx += 256) {       // (the group's first block was not eliminated here)
-    const int i = idx / NPC, t = idx - i * NPC;
-    reinterpret_cast<V2 *>(REC + i * BS)[t] = reinterpret_cast<const V2 *>(a.blk + (size_t)(base + i) * BS)[t];
+  {   // (all loads first, as in the forward launch; the group's first block was not eliminated here but comes along)
+    V2 v[UF];
+    const V2 *blk2 = reinterpret_cast<const V2 *>(a.blk + (size_t)base * BS);
+#pragma unroll
+    for (int u = 0; u < UF; u++) v[u] = blk2[min(tid + NT * u, cnt * NPC - 1)];
+#pragma unroll
+    for (int u = 0; u < UF; u++)
+      if (tid + NT * u < cnt * NPC) reinterpret_cast<V2 *>(REC)[tid + NT * u] = v[u];
   }
   const bool have = (base + cnt < a.n) || (a.ext != 0);
   if (tid < B) {
@@ -225,8 +171,8 @@ __global__ void __launch_bounds__(256) k_multi_backward(UpBwdArgs a) {
     XS[G * B + tid] = have ? a.xup[(size_t)(g + 1) * B + tid] : 0.0;
   }
   __syncthreads();
-  group_backward<B>(REC, XS, cnt, tid);
-  for (int idx = tid; idx < cnt * B; idx += 256) a.x[(size_t)base * B + idx] = XS[idx];
+  cr_group_backward<B, G, Q>(REC, XS, cnt, tid, [] { lds_barrier(); });
+  for (int idx = tid; idx < cnt * B; idx += NT) a.x[(size_t)base * B + idx] = XS[idx];
   // the block beyond the level lives on the next rank: park its solution in the extra slot, where the level below
   // expects the solution of "block n"
   if (a.ext != 0 && base + cnt == a.n && tid < B) a.x[(size_t)a.n * B + tid] = XS[G * B + tid];
@@ -236,48 +182,63 @@ template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-template <int B> int fwd_b(bool top, const UpFwdArgs &a, hipStream_t st) {
+template <int B, int G> int fwd_b(bool top, const UpFwdArgs &a0, hipStream_t st) {
+  typedef UpDims<B, G> DM;
   static bool ready = false;                  // (the attribute is per kernel and process-wide: set once, to the one size)
   hipError_t e;
+  UpFwdArgs a = a0;
+  static long long *dprobe = nullptr;
+  static const bool want_probe = getenv("GPSLAM_UPPER_PROBE") && atoi(getenv("GPSLAM_UPPER_PROBE")) != 0;
+  if (want_probe && !dprobe) (void)hipMalloc((void **)&dprobe, 64 * sizeof(long long));
+  a.probe = want_probe ? dprobe : nullptr;
   if (!ready) {
-    if ((e = allow_lds(&k_multi_forward<B, true>, UpDims<B>::lds_fwd(true))) != hipSuccess) return (int)e;
-    if ((e = allow_lds(&k_multi_forward<B, false>, UpDims<B>::lds_fwd(false))) != hipSuccess) return (int)e;
+    if ((e = allow_lds(&k_multi_forward<B, G, true>, DM::lds_fwd(true))) != hipSuccess) return (int)e;
+    if ((e = allow_lds(&k_multi_forward<B, G, false>, DM::lds_fwd(false))) != hipSuccess) return (int)e;
     ready = true;
   }
-  const int groups = (a.n + kUpG - 1) / kUpG;
-  if (top) k_multi_forward<B, true><<<dim3(1), dim3(256), UpDims<B>::lds_fwd(true), st>>>(a);
-  else k_multi_forward<B, false><<<dim3(groups), dim3(256), UpDims<B>::lds_fwd(false), st>>>(a);
+  const int groups = (a.n + G - 1) / G;
+  if (top) k_multi_forward<B, G, true><<<dim3(1), dim3(DM::NT), DM::lds_fwd(true), st>>>(a);
+  else k_multi_forward<B, G, false><<<dim3(groups), dim3(DM::NT), DM::lds_fwd(false), st>>>(a);
+  if (a.probe) {   // diagnostics only: synchronous
+    long long hp[64];
+    (void)hipStreamSynchronize(st);
+    (void)hipMemcpy(hp, dprobe, sizeof(hp), hipMemcpyDeviceToHost);
+    fprintf(stderr, "[upper probe] B=%d G=%d top=%d n=%d groups=%d cycles:", B, G, (int)top, a.n, groups);
+    for (int i = 1; i < 2 + 3 * DM::Q; i++) fprintf(stderr, "%s%lld", (i >= 2 && (i - 2) % 3 == 0) ? " | " : " ", hp[i] - hp[i - 1]);
+    fprintf(stderr, " | total %lld cycles, %lld wall ticks (100 MHz)\n", hp[1 + 3 * DM::Q] - hp[0], hp[63] - hp[62]);
+  }
   return (int)hipGetLastError();
 }
-template <int B> int bwd_b(const UpBwdArgs &a, hipStream_t st) {
+template <int B, int G> int bwd_b(const UpBwdArgs &a, hipStream_t st) {
+  typedef UpDims<B, G> DM;
   static bool ready = false;
   hipError_t e;
   if (!ready) {
-    if ((e = allow_lds(&k_multi_backward<B>, UpDims<B>::lds_bwd())) != hipSuccess) return (int)e;
+    if ((e = allow_lds(&k_multi_backward<B, G>, DM::lds_bwd())) != hipSuccess) return (int)e;
     ready = true;
   }
-  const int groups = (a.n + kUpG - 1) / kUpG;
-  k_multi_backward<B><<<dim3(groups), dim3(256), UpDims<B>::lds_bwd(), st>>>(a);
+  const int groups = (a.n + G - 1) / G;
+  k_multi_backward<B, G><<<dim3(groups), dim3(DM::NT), DM::lds_bwd(), st>>>(a);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-int upper_forward(int B, bool top, const UpFwdArgs &a, hipStream_t st) {
-  if (a.n <= 0 || (top && a.n > kUpG)) return (int)hipErrorInvalidValue;
+int upper_forward(int B, int G, bool top, const UpFwdArgs &a, hipStream_t st) {
+  if (a.n <= 0 || (top && a.n > G) || (G != 32 && G != 4)) return (int)hipErrorInvalidValue;
   switch (B) {
-    case 4: return fwd_b<4>(top, a, st);
-    case 6: return fwd_b<6>(top, a, st);
-    case 12: return fwd_b<12>(top, a, st);
+    case 4: return G == 32 ? fwd_b<4, 32>(top, a, st) : fwd_b<4, 4>(top, a, st);
+    case 6: return G == 32 ? fwd_b<6, 32>(top, a, st) : fwd_b<6, 4>(top, a, st);
+    case 12: return G == 32 ? fwd_b<12, 32>(top, a, st) : fwd_b<12, 4>(top, a, st);
   }
   return (int)hipErrorInvalidValue;
 }
-int upper_backward(int B, const UpBwdArgs &a, hipStream_t st) {
-  if (a.n <= 0) return (int)hipErrorInvalidValue;
+int upper_backward(int B, int G, const UpBwdArgs &a, hipStream_t st) {
+  if (a.n <= 0 || (G != 32 && G != 4)) return (int)hipErrorInvalidValue;
   switch (B) {
-    case 4: return bwd_b<4>(a, st);
-    case 6: return bwd_b<6>(a, st);
-    case 12: return bwd_b<12>(a, st);
+    case 4: return G == 32 ? bwd_b<4, 32>(a, st) : bwd_b<4, 4>(a, st);
+    case 6: return G == 32 ? bwd_b<6, 32>(a, st) : bwd_b<6, 4>(a, st);
+    case 12: return G == 32 ? bwd_b<12, 32>(a, st) : bwd_b<12, 4>(a, st);
   }
   return (int)hipErrorInvalidValue;
 }

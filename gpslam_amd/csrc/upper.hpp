@@ -28,6 +28,7 @@ struct UpFwdArgs {
   int n;
   int ext;            // a block exists beyond the level's last one (sharded chains: the next rank's separator)
   int *flag;          // set to 1 when a pivot is not positive
+  long long *probe;   // diagnostics (GPSLAM_UPPER_PROBE=1): shader-clock stamps of workgroup 0, or null
 };
 
 struct UpBwdArgs {
@@ -38,8 +39,10 @@ struct UpBwdArgs {
   int ext;
 };
 
-// B in {4, 6, 12}.  Return a hipError_t (as int); the launches are asynchronous on `st`.
-int upper_forward(int B, bool top, const UpFwdArgs &a, hipStream_t st);
-int upper_backward(int B, const UpBwdArgs &a, hipStream_t st);
+// B in {4, 6, 12}; G = blocks per group: kUpG, or 4 for the level that the row-layout level-0 kernels fold into their tail
+// (then only its back-substitution, and the forward launch of the unfused path, come through here).
+// Return a hipError_t (as int); the launches are asynchronous on `st`.
+int upper_forward(int B, int G, bool top, const UpFwdArgs &a, hipStream_t st);
+int upper_backward(int B, int G, const UpBwdArgs &a, hipStream_t st);
 
 }  // namespace gps

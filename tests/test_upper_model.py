@@ -6,9 +6,10 @@ import upper_model as M
 
 
 @pytest.mark.parametrize("n,B,m0", [(9, 4, 3), (40, 6, 3), (200, 6, 4), (700, 4, 5), (1500, 6, 1), (3000, 4, 2), (1030, 12, 1), (33 * 32 + 1, 4, 1)])
-def test_hierarchy_matches_the_dense_solve(n, B, m0):
+@pytest.mark.parametrize("tail", [False, True])
+def test_hierarchy_matches_the_dense_solve(n, B, m0, tail):
     D, O, g = M.random_chain(n, B, seed=n + B)
-    x = M.solve_chain(D, O, g, m0)
+    x = M.solve_chain(D, O, g, m0, tail=tail)
     ref = M.dense_solve(D, O, g) if n * B <= 9000 else None
     if ref is None:
         # too large for a dense factorisation: check the residual of the block-tridiagonal system instead

@@ -57,7 +57,7 @@ def level0_back(rec, x1, n, m0, B):
     return x
 
 
-def multi_forward(blk, add, top, ext=False):
+def multi_forward(blk, add, top, ext=False, G=G, Q=Q):
     """one launch of k_multi_forward over a level.  blk = (D, O, g) arrays of n blocks, add = (RD, Rg) of n + 1 entries.
     Returns (factor records, up_blk, up_add) or, for TOP, (records, x)."""
     D, O, g = (a.copy() for a in blk)
@@ -107,14 +107,14 @@ def multi_forward(blk, add, top, ext=False):
         else:
             XS = np.zeros((G + 1, B))
             XS[0] = np.linalg.solve(RD[0], Rg[0])
-            group_backward(fac, XS, cnt)
+            group_backward(fac, XS, cnt, G, Q)
             xs_top = XS[:cnt].copy()
     if top:
         return rec, xs_top
     return rec, (up_D, up_O, up_g), (up_aD, up_ag)
 
 
-def group_backward(fac, XS, cnt):
+def group_backward(fac, XS, cnt, G=G, Q=Q):
     for q in range(Q - 1, -1, -1):
         h, npairs = 1 << q, G >> (q + 1)
         for p in range(npairs):
@@ -126,7 +126,7 @@ def group_backward(fac, XS, cnt):
             XS[j] = Y - U @ XS[nn] - V @ XS[s]
 
 
-def multi_backward(rec, xup, n, B, ext=False):
+def multi_backward(rec, xup, n, B, ext=False, G=G, Q=Q):
     x = np.zeros((n + 1, B))
     ngroups = (n + G - 1) // G
     for gi in range(ngroups):
@@ -137,25 +137,29 @@ def multi_backward(rec, xup, n, B, ext=False):
         if base + cnt < n or ext:
             XS[G] = xup[gi + 1]
         fac = {j: rec[base + j] for j in range(1, cnt)}
-        group_backward(fac, XS, cnt)
+        group_backward(fac, XS, cnt, G, Q)
         x[base:base + cnt] = XS[:cnt]
         if ext and base + cnt == n:
             x[n] = XS[G]
     return x
 
 
-def solve_chain(D, O, g, m0):
-    """the whole hierarchy: level 0 in chunks of m0, then groups of G until one group is left (TOP)."""
+def solve_chain(D, O, g, m0, tail=False):
+    """the whole hierarchy: level 0 in chunks of m0, then groups of G until one group is left (TOP).  tail: level 1 in
+    groups of four (what k_fused_level0 folds into its own tail) when it has more than G blocks."""
     n, B = g.shape
     rec0, blk, add = level0(D, O, g, m0)
     levels = []
+    first = True
     while blk[2].shape[0] > G:
-        rec, ublk, uadd = multi_forward(blk, add, top=False)
-        levels.append((rec, blk[2].shape[0]))
+        gq = (4, 2) if (tail and first) else (G, Q)
+        first = False
+        rec, ublk, uadd = multi_forward(blk, add, top=False, G=gq[0], Q=gq[1])
+        levels.append((rec, blk[2].shape[0], gq))
         blk, add = ublk, uadd
     _, x = multi_forward(blk, add, top=True)
-    for rec, nl in reversed(levels):
-        x = multi_backward(rec, x, nl, B)[:nl]
+    for rec, nl, gq in reversed(levels):
+        x = multi_backward(rec, x, nl, B, G=gq[0], Q=gq[1])[:nl]
     return level0_back(rec0, x, n, m0, B)
 
 
