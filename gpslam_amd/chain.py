@@ -33,7 +33,8 @@ ABI_SYMBOLS = [
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
     "gpslam_hip_add_ahrs", "gpslam_hip_plan_info", "gpslam_hip_fs_set_split", "gpslam_hip_fs_split_info", "gpslam_hip_fs_set_top",
     "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
-    "gpslam_hip_fs_lm_trial_phase2",
+    "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
+    "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity",
 ]
 
 
@@ -159,6 +160,17 @@ class ChainSolver:
         left, dt = _i32(left), _f64(dt)
         self.n_gp += len(left)
         return self._chk(self.lib.gpslam_hip_add_gp_priors(self._h, len(left), _p(left), _p(dt)), "add_gp_priors")
+
+    def add_gp_priors_qc(self, left, dt, Qc):
+        """GP priors with one Qc_model per factor (count x d x d), as the reference's constructors take it."""
+        left, dt, Qc = _i32(left), _f64(dt), _f64(Qc)
+        self.n_gp += len(left)
+        return self._chk(self.lib.gpslam_hip_add_gp_priors_qc(self._h, len(left), _p(left), _p(dt), _p(Qc)), "add_gp_priors_qc")
+
+    def set_meas_covariance(self, kind, cov):
+        """noiseModel::Gaussian::Covariance (count x rows x rows) on the most recently added factors of one MEAS_* kind."""
+        cov = _f64(cov)
+        return self._chk(self.lib.gpslam_hip_set_meas_covariance(self._h, int(kind), cov.shape[0], _p(cov)), "set_meas_covariance")
 
     def add_pose_priors(self, idx, prior, sigmas):
         idx, prior, sigmas = _i32(idx), _f64(prior), _f64(sigmas)
@@ -332,6 +344,24 @@ class ChainSolver:
         out = np.zeros((len(left), self.pd))
         self._chk(self.lib.gpslam_hip_interpolate_poses(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out)),
                   "interpolate_poses")
+        return out
+
+    def interpolate_velocities(self, left, dt, tau, jac=False):
+        """Batched GaussianProcessInterpolatorLinear::interpolateVelocity of the current estimate: (count, d) [, H (count, 4, d, d)]."""
+        left, dt, tau = _i32(left), _f64(dt), _f64(tau)
+        out = np.zeros((len(left), self.d))
+        H = np.zeros((len(left), 4, self.d, self.d)) if jac else None
+        self._chk(self.lib.gpslam_hip_interpolate_velocities(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out), _p(H)),
+                  "interpolate_velocities")
+        return (out, H) if jac else out
+
+    def body_centric_velocity(self, pose1, pose2, dt, spatial=False):
+        """getBodyCentricVb (spatial=False) / getBodyCentricVs of pose pairs (count x 12 each): (count, 6)."""
+        pose1, pose2 = _f64(pose1).reshape(-1, 12), _f64(pose2).reshape(-1, 12)
+        dt = _f64(np.broadcast_to(np.asarray(dt, dtype=np.float64), (len(pose1),)))
+        out = np.zeros((len(pose1), 6))
+        self._chk(self.lib.gpslam_hip_body_centric_velocity(self._h, 1 if spatial else 0, len(pose1), _p(pose1), _p(pose2), _p(dt), _p(out)),
+                  "body_centric_velocity")
         return out
 
     def plan_info(self):

@@ -46,9 +46,12 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
   std::vector<double> aux;
   std::vector<int32_t> aidx;
   bool any_aux = false;                // some factor of this kind carries a sensor transform or a calibration
-  DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0, d_aux, d_aidx;
+  // noiseModel::Gaussian on factors of this kind (gpslam_hip_set_meas_covariance): rows x rows square-root information per
+  // factor, diag(1 / sigma) for those that kept their diagonal model; empty: every factor is diagonal
+  std::vector<double> sqi;
+  DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0, d_aux, d_aidx, d_sqi;
   int count() const { return (int)idx.size(); }
-  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); d_aux.release(); d_aidx.release(); }
+  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); d_aux.release(); d_aidx.release(); d_sqi.release(); }
 };
 
 }  // namespace
@@ -70,6 +73,14 @@ struct gpslam_hip_handle {
   std::vector<int32_t> gp_left;
   std::vector<double> gp_dt;
   DevBuf d_gp_left, d_gp_dt, d_gp_row0;
+  // one Qc_model per GP prior (gpslam_hip_add_gp_priors_qc; GaussianProcessPriorPose3.h:43-49): gp_q[f] = 0: the handle's
+  // shared Qc (set_qc), k >= 1: entry k - 1 of gp_Utab (36 doubles each, chol_upper(Qc^-1)).  With more than one distinct
+  // Qc, compile() orders the device-side factor arrays by Qc (gp_perm: device position -> position in the order added)
+  // and the linearisation runs one launch per group (gp_groups: {q, first, count}), each with its U as a kernel argument.
+  std::vector<int32_t> gp_q;
+  std::vector<double> gp_Utab;
+  std::vector<int32_t> gp_perm;
+  std::vector<int32_t> gp_groups;
   SimpleSet pri, vpri, btw, lpri;
   MeasSet ms[kNumMeasKinds];
   // row table
@@ -284,6 +295,11 @@ int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool hasl
   if (haslm) s.lm.insert(s.lm.end(), lm, lm + count);
   s.meas.insert(s.meas.end(), meas, meas + (size_t)count * mw);
   s.sig.insert(s.sig.end(), sig, sig + (size_t)count * rows);
+  if (!s.sqi.empty()) {   // the kind already has Gaussian factors: the newcomers' diagonal models as matrices
+    for (int k = 0; k < count; k++)
+      for (int r = 0; r < rows; r++)
+        for (int q = 0; q < rows; q++) s.sqi.push_back(r == q ? 1.0 / sig[(size_t)k * rows + r] : 0.0);
+  }
   if (interp) { s.dt.insert(s.dt.end(), dt, dt + count); s.tau.insert(s.tau.end(), tau, tau + count); }
   {   // this call's body_P_sensor / calibration: find it in (or append it to) the kind's table
     double ent[kMeasAux] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
@@ -554,6 +570,68 @@ int gpslam_hip_add_gp_priors(gpslam_hip_handle *h, int32_t count, const int32_t 
   }
   h->gp_left.insert(h->gp_left.end(), left, left + count);
   h->gp_dt.insert(h->gp_dt.end(), dt, dt + count);
+  h->gp_q.insert(h->gp_q.end(), (size_t)count, 0);
+  h->compiled = false;
+  return 0;
+}
+int gpslam_hip_add_gp_priors_qc(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt, const double *Qc) {
+  if (!h || count < 0 || (count > 0 && (!left || !dt || !Qc))) return GPSLAM_E_INVALID;
+  const int dq = (h->mf == ROT3_BIAS) ? 3 : h->d;
+  std::vector<int32_t> q((size_t)count);
+  std::vector<double> tab = h->gp_Utab;
+  for (int k = 0; k < count; k++) {
+    if (left[k] < 0 || left[k] > max_left(h)) return fail(h, GPSLAM_E_INVALID, "gp prior index out of range");
+    if (!(dt[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "gp prior delta_t must be positive");
+    double U[36], Qpad[36];
+    const double *qc = Qc + (size_t)k * dq * dq;
+    if (h->mf == ROT3_BIAS) {   // as in set_qc: bias and pad components are identities
+      std::memset(Qpad, 0, sizeof(Qpad));
+      for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Qpad[i * 6 + j] = qc[i * 3 + j];
+        Qpad[(3 + i) * 6 + 3 + i] = 1.0;
+      }
+      qc = Qpad;
+    }
+    std::memset(U, 0, sizeof(U));
+    if (!make_U(h->d, qc, U)) return fail(h, GPSLAM_E_NOT_SPD, "Qc is not positive definite");
+    int slot = -1;
+    const int nent = (int)(tab.size() / 36);
+    for (int e = 0; e < nent && slot < 0; e++)
+      if (std::memcmp(&tab[(size_t)e * 36], U, sizeof(U)) == 0) slot = e;
+    if (slot < 0) { slot = nent; tab.insert(tab.end(), U, U + 36); }
+    q[k] = slot + 1;
+  }
+  h->gp_Utab.swap(tab);
+  h->gp_left.insert(h->gp_left.end(), left, left + count);
+  h->gp_dt.insert(h->gp_dt.end(), dt, dt + count);
+  h->gp_q.insert(h->gp_q.end(), q.begin(), q.end());
+  h->compiled = false;
+  return 0;
+}
+int gpslam_hip_set_meas_covariance(gpslam_hip_handle *h, int32_t kind, int32_t count, const double *cov) {
+  if (!h || kind < 0 || kind >= kNumMeasKinds || count < 0 || (count > 0 && !cov)) return GPSLAM_E_INVALID;
+  if (kind == FK_AHRS) return fail(h, GPSLAM_E_INVALID, "AHRSFactor takes its covariance in gpslam_hip_add_ahrs");
+  MeasSet &s = h->ms[kind];
+  if (count > s.count()) return fail(h, GPSLAM_E_INVALID, "set_meas_covariance: more covariances than factors of this kind");
+  const int rows = s.rows, n = s.count();
+  if (count == 0) return 0;
+  if (rows == 1) {   // a 1 x 1 Gaussian is a sigma
+    for (int k = 0; k < count; k++) {
+      if (!(cov[k] > 0.0)) return fail(h, GPSLAM_E_NOT_SPD, "covariance is not positive definite");
+      s.sig[(size_t)(n - count + k)] = std::sqrt(cov[k]);
+    }
+    h->compiled = false;
+    return 0;
+  }
+  std::vector<double> R((size_t)count * rows * rows, 0.0);
+  for (int k = 0; k < count; k++)
+    if (!make_U(rows, cov + (size_t)k * rows * rows, &R[(size_t)k * rows * rows])) return fail(h, GPSLAM_E_NOT_SPD, "covariance is not positive definite");
+  if (s.sqi.empty()) {
+    s.sqi.assign((size_t)n * rows * rows, 0.0);
+    for (int f = 0; f < n; f++)
+      for (int r = 0; r < rows; r++) s.sqi[((size_t)f * rows + r) * rows + r] = 1.0 / s.sig[(size_t)f * rows + r];
+  }
+  std::memcpy(&s.sqi[(size_t)(n - count) * rows * rows], R.data(), R.size() * sizeof(double));
   h->compiled = false;
   return 0;
 }
@@ -651,10 +729,10 @@ int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int3
 
 int gpslam_hip_clear_factors(gpslam_hip_handle *h) {
   if (!h) return GPSLAM_E_INVALID;
-  h->gp_left.clear(); h->gp_dt.clear();
+  h->gp_left.clear(); h->gp_dt.clear(); h->gp_q.clear(); h->gp_Utab.clear(); h->gp_perm.clear(); h->gp_groups.clear();
   for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) { s->idx.clear(); s->meas.clear(); s->sig.clear(); }
   for (MeasSet &s : h->ms) {
-    s.idx.clear(); s.lm.clear(); s.meas.clear(); s.sig.clear(); s.dt.clear(); s.tau.clear(); s.aux.clear(); s.aidx.clear();
+    s.idx.clear(); s.lm.clear(); s.meas.clear(); s.sig.clear(); s.dt.clear(); s.tau.clear(); s.aux.clear(); s.aidx.clear(); s.sqi.clear();
     s.any_aux = false;
   }
   h->compiled = false;
@@ -736,6 +814,84 @@ int gpslam_hip_interpolate_poses_jac(gpslam_hip_handle *h, int32_t count, const 
                                      const double *tau, double *out_pose, double *out_H) {
   if (!out_H) return GPSLAM_E_INVALID;
   return interpolate_impl(h, count, left, dt, tau, out_pose, out_H);
+}
+
+// GaussianProcessInterpolatorLinear<D>::interpolateVelocity (gpslam.h:193, GaussianProcessInterpolatorLinear.h:106-126) of the
+// current estimate, batched.  Bottom block rows of Lambda(tau) / Psi(tau): l21 = -p21, l22 = 1 - p21 dt - p22 with
+// (p21, p22) = second row of A(tau) Phi2(dt - tau)^T Ainv(dt) (Qc cancels, as in interp_coef).
+int gpslam_hip_interpolate_velocities(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                      const double *tau, double *out_vel, double *out_H) {
+  if (!h || count < 0 || (count > 0 && (!left || !dt || !tau || !out_vel))) return GPSLAM_E_INVALID;
+  if (h->mf != LINEAR2 && h->mf != LINEAR3)
+    return fail(h, GPSLAM_E_UNSUPPORTED, "interpolateVelocity exists for GaussianProcessInterpolatorLinear only: the reference declares it for the "
+                                         "Lie-group interpolators without implementing it (GaussianProcessInterpolatorPose3.h:118-123)");
+  if (h->N < 2) return fail(h, GPSLAM_E_INVALID, "interpolation needs at least two states");
+  const int mx = max_left(h);
+  for (int q = 0; q < count; q++) {
+    if (left[q] < 0 || left[q] > mx) return fail(h, GPSLAM_E_INVALID, "query interval out of range");
+    if (!(dt[q] > 0.0)) return fail(h, GPSLAM_E_INVALID, "delta_t must be positive");
+  }
+  if (count == 0) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  const int d = h->d;
+  std::vector<double> coef((size_t)count * 4);
+  for (int q = 0; q < count; q++) {
+    const double T = dt[q], t = tau[q], sft = T - t;
+    const double a21 = t * t / 2.0 + t * sft, a22 = t;            // second row of A(tau) Phi2(dt - tau)^T
+    const double p21 = a21 * (12.0 / (T * T * T)) + a22 * (-6.0 / (T * T));
+    const double p22 = a21 * (-6.0 / (T * T)) + a22 * (4.0 / T);
+    coef[4 * (size_t)q] = -p21;
+    coef[4 * (size_t)q + 1] = 1.0 - p21 * T - p22;
+    coef[4 * (size_t)q + 2] = p21;
+    coef[4 * (size_t)q + 3] = p22;
+  }
+  std::vector<int> li(left, left + count);
+  struct Scratch {
+    DevBuf left, coef, out, outH;
+    ~Scratch() { left.release(); coef.release(); out.release(); outH.release(); }
+  } sc;
+  int rc;
+  if ((rc = upload(h, sc.left, li))) return rc;
+  if ((rc = upload(h, sc.coef, coef))) return rc;
+  HIPCHK(sc.out.reserve((size_t)count * d * sizeof(double)));
+  if (out_H) HIPCHK(sc.outH.reserve((size_t)count * 4 * d * d * sizeof(double)));
+  QueryArgs<double> a;
+  a.pose = h->pose.as<double>(); a.vel = h->vel.as<double>(); a.stride = h->stride; a.count = count;
+  a.left = sc.left.as<int>(); a.coef = sc.coef.as<double>(); a.out = sc.out.as<double>(); a.out_H = out_H ? sc.outH.as<double>() : nullptr;
+  a.vw = 0;
+  if (h->mf == LINEAR2) k_interp_velocity<double, LINEAR2><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
+  else k_interp_velocity<double, LINEAR3><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(a);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out_vel, sc.out.p, (size_t)count * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  if (out_H) HIPCHK(hipMemcpyAsync(out_H, sc.outH.p, (size_t)count * 4 * d * d * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+// getBodyCentricVb / getBodyCentricVs (gpslam.h:161-164, gpslam/gp/Pose3utils.cpp:17-24), batched over pose pairs; any handle
+// (its device and stream are used, its graph is not touched)
+int gpslam_hip_body_centric_velocity(gpslam_hip_handle *h, int32_t which, int32_t count, const double *pose1, const double *pose2,
+                                     const double *dt, double *out) {
+  if (!h || count < 0 || (which != 0 && which != 1) || (count > 0 && (!pose1 || !pose2 || !dt || !out))) return GPSLAM_E_INVALID;
+  for (int q = 0; q < count; q++)
+    if (!(dt[q] != 0.0)) return fail(h, GPSLAM_E_INVALID, "delta_t must not be zero");
+  if (count == 0) return 0;
+  (void)hipSetDevice(h->cfg.device);
+  struct Scratch {
+    DevBuf a, b, t, o;
+    ~Scratch() { a.release(); b.release(); t.release(); o.release(); }
+  } sc;
+  const size_t np = (size_t)count * 12 * sizeof(double);
+  HIPCHK(sc.a.reserve(np)); HIPCHK(sc.b.reserve(np));
+  HIPCHK(sc.t.reserve((size_t)count * sizeof(double))); HIPCHK(sc.o.reserve((size_t)count * 6 * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(sc.a.p, pose1, np, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(sc.b.p, pose2, np, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(sc.t.p, dt, (size_t)count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  k_body_velocity<double><<<dim3(nblocks(count, 128)), dim3(128), 0, h->stream>>>(sc.a.as<double>(), sc.b.as<double>(), sc.t.as<double>(), count, which, sc.o.as<double>());
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, sc.o.p, (size_t)count * 6 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
 }
 
 // ---- precision dispatch: the handle was created GPSLAM_FP64 or GPSLAM_FP32

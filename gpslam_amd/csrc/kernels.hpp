@@ -630,6 +630,8 @@ template <typename T> struct MeasArgs {
   const double *aux;       // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
   const int *aidx;     // count: entry of each factor (one body_P_sensor / calibration PER FACTOR, as in the reference:
                        // GPInterpolatedRangeFactorPose3.h:46-54), or null: no sensor transform anywhere
+  const double *sqi;   // count x rows x rows square-root information R (upper triangular, R^T R = cov^-1) of factors with a
+                       // noiseModel::Gaussian instead of diagonal sigmas (multi-row kinds; `sig` is then ignored), or null
   int vw;              // Pose3 only: velocities are world-frame [v; w]
   const int *row0;
   T *rowLR, *rowE, *rowM;
@@ -931,9 +933,38 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       }
       const int row0 = (JAC || a.rowE32) ? a.row0[f] : 0;
       row0v = row0;
+      constexpr bool kFullNoise = rows > 1 && FK != FK_AHRS;     // (AHRSFactor whitens by its pre-integrated covariance above)
+      if constexpr (kFullNoise) {
+        if (a.sqi) {   // noiseModel::Gaussian: rows <- R rows; R is upper triangular, so ascending in place
+          const double *Rw = a.sqi + (size_t)f * rows * rows;
+#pragma unroll
+          for (int r = 0; r < rows; r++) {
+            T acc = T(0);
+#pragma unroll
+            for (int q = r; q < rows; q++) acc += T(Rw[r * rows + q]) * e[q];
+            e[r] = acc;
+            if (JAC) {
+#pragma unroll
+              for (int c = 0; c < b; c++) {
+                T aL = T(0), aR = T(0);
+#pragma unroll
+                for (int q = r; q < rows; q++) { aL += T(Rw[r * rows + q]) * JL[q * b + c]; aR += T(Rw[r * rows + q]) * JR[q * b + c]; }
+                JL[r * b + c] = aL; JR[r * b + c] = aR;
+              }
+#pragma unroll
+              for (int c = 0; c < 3; c++) {
+                T am = T(0);
+#pragma unroll
+                for (int q = r; q < rows; q++) am += T(Rw[r * rows + q]) * Jm[q * 3 + c];
+                Jm[r * 3 + c] = am;
+              }
+            }
+          }
+        }
+      }
 #pragma unroll
       for (int r = 0; r < rows; r++) {
-        const T w = T(1) / T(a.sig[(size_t)f * rows + r]);
+        const T w = (kFullNoise && a.sqi) ? T(1) : T(1) / T(a.sig[(size_t)f * rows + r]);
         const T we = e[r] * w;
         err += we * we;
         wgt[r] = w;
@@ -1511,6 +1542,51 @@ __global__ void __launch_bounds__(128) k_interp_query(QueryArgs<T> a) {
       }
     }
   }
+}
+
+// Batched GaussianProcessInterpolatorLinear<D>::interpolateVelocity (GaussianProcessInterpolatorLinear.h:106-126): the bottom
+// block rows of Lambda and Psi.  coef = (l21, l22, p21, p22) per query; H_k = those scalars times I (:117-120).
+template <typename T, int MF>
+__global__ void __launch_bounds__(128) k_interp_velocity(QueryArgs<T> a) {
+  constexpr int d = MTraits<MF>::d;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.count) return;
+  if constexpr (MF == LINEAR2 || MF == LINEAR3) {
+    const int i = a.left[q];
+    const T cf[4] = {T(a.coef[4 * (size_t)q]), T(a.coef[4 * (size_t)q + 1]), T(a.coef[4 * (size_t)q + 2]), T(a.coef[4 * (size_t)q + 3])};
+#pragma unroll
+    for (int c = 0; c < d; c++) {
+      const T p1 = a.pose[(size_t)c * a.stride + i], p2 = a.pose[(size_t)c * a.stride + i + 1];
+      const T v1 = a.vel[(size_t)c * a.stride + i], v2 = a.vel[(size_t)c * a.stride + i + 1];
+      a.out[(size_t)q * d + c] = cf[0] * p1 + cf[1] * v1 + cf[2] * p2 + cf[3] * v2;
+    }
+    if (a.out_H) {
+      T *oh = a.out_H + (size_t)q * 4 * d * d;
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < d; r++)
+#pragma unroll
+          for (int c = 0; c < d; c++) oh[(m * d + r) * d + c] = (r == c) ? cf[m] : T(0);
+    }
+  }
+}
+
+// getBodyCentricVb / getBodyCentricVs (gpslam/gp/Pose3utils.cpp:17-24; Barfoot14tro eq. 25), batched: thread per pose pair.
+//   which 0: Vb = Logmap(pose1^-1 pose2) / dt      which 1: Vs = Logmap(pose2 pose1^-1) / dt
+template <typename T>
+__global__ void __launch_bounds__(128) k_body_velocity(const double *p1, const double *p2, const double *dt, int count, int which, double *out) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= count) return;
+  T a[12], b[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) { a[k] = T(p1[(size_t)q * 12 + k]); b[k] = T(p2[(size_t)q * 12 + k]); }
+  const SE3<T> A = as_se3(a), Bm = as_se3(b);
+  const SE3<T> h = which ? se3_compose(Bm, se3_inverse(A)) : se3_between(A, Bm);
+  const V6<T> r = se3_log(h);
+  const T s = T(1) / T(dt[q]);
+  double *o = out + (size_t)q * 6;
+  o[0] = s * r.w.x; o[1] = s * r.w.y; o[2] = s * r.w.z; o[3] = s * r.v.x; o[4] = s * r.v.y; o[5] = s * r.v.z;
 }
 
 // ------------------------------------------------------------------ K4: partitioned block Gauss-Jordan

@@ -22,8 +22,9 @@
  *  - State i is the pair (pose_i, vel_i); the variable ordering is the explicit chain order
  *    [x0, v0, x1, v1, ..., l0, l1, ...].  Factors that couple two states couple i and i+1 only
  *    (the GP Markov property, gpslam/gp/GaussianProcessPriorPose3.h:43-47).
- *  - Noise models: the GP prior uses Q(dt) built from the shared Qc (gpslam/gp/GPutils.h:24-41);
- *    every other factor takes diagonal sigmas.
+ *  - Noise models: the GP prior uses Q(dt) built from Qc (gpslam/gp/GPutils.h:24-41) -- the handle's shared one or one per
+ *    factor (add_gp_priors_qc); every other factor takes diagonal sigmas, or a full Gaussian covariance through
+ *    gpslam_hip_set_meas_covariance.
  */
 #ifndef GPSLAM_HIP_H
 #define GPSLAM_HIP_H
@@ -71,7 +72,8 @@ enum {
 
 typedef struct {
   int32_t manifold;      /* GPSLAM_LINEAR2 .. GPSLAM_ROT3 */
-  int32_t precision;     /* GPSLAM_FP64 (GPSLAM_FP32: reserved) */
+  int32_t precision;     /* GPSLAM_FP64, or GPSLAM_FP32: fp32 Jacobian rows (evaluated re-centred, with the exact derivative in place of the
+                          * h = 1e-6 difference), fp64 residual, normal equations and solver */
   int32_t device;        /* HIP device ordinal */
   int32_t chart;         /* GPSLAM_CHART_* */
   int32_t landmark_dim;  /* 0 (no landmarks), 2 or 3 */
@@ -134,6 +136,14 @@ int gpslam_hip_set_qc(gpslam_hip_handle *h, const double *Qc);
 /* GaussianProcessPrior{Linear,Pose2,Pose3,Rot3}(key_i, vel_i, key_i+1, vel_i+1, dt, Qc_model)
  * gpslam/gp/GaussianProcessPriorPose3.h:43-49 and siblings */
 int gpslam_hip_add_gp_priors(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt);
+/* ... with ONE Qc_model PER FACTOR, as the reference's constructors take it (gpslam/gp/GaussianProcessPriorPose3.h:43-49,
+ * GaussianProcessPriorLinear.h:45-52): Qc = count x d x d (GPSLAM_ROT3_BIAS: 3 x 3), each SPD.  Factors added through
+ * gpslam_hip_add_gp_priors use the handle's shared Qc (set_qc).  A graph with several distinct Qc is linearised with one
+ * launch per distinct Qc.  (The interpolated measurement factors do not need their Qc_model at all: in
+ * Psi = Q(tau) Phi(dt - tau)^T Q^-1(dt) = (A(tau) Phi2^T A^-1(dt)) (x) (Qc Qc^-1) and Lambda = Phi(tau) - Psi Phi(dt)
+ * -- gpslam/gp/GPutils.h:54-71 -- Qc cancels for every SPD Qc, so their constructors' Qc_model argument has no effect
+ * on evaluateError; GPInterpolatedRangeFactorPose2.h:46-54.) */
+int gpslam_hip_add_gp_priors_qc(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt, const double *Qc);
 /* gtsam::PriorFactor<Pose> on x_idx, diagonal sigmas (count x d) */
 int gpslam_hip_add_pose_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                                const double *sigmas);
@@ -186,6 +196,14 @@ int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t
 /* RangeBearingFactor2DLinear(x, l, range, bearing) -- gpslam/slam/RangeBearingFactor2DLinear.h:33-37 */
 int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const int32_t *landmark,
                                  const double *bearing, const double *range, const double *sigmas);
+
+/* noiseModel::Gaussian::Covariance on measurement factors.  The reference's constructors take any gtsam::SharedNoiseModel
+ * (gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54, GPInterpolatedRangeFactorPose3.h:46-54, OdometryFactor2DLinear.h:38-40);
+ * the add_* calls above take diagonal sigmas.  This call replaces the noise model of the `count` most recently added factors
+ * of `kind` (GPSLAM_MEAS_*, not AHRS: that one takes its covariance itself) by full covariances, cov = count x rows x rows
+ * (rows = residual dimension of the kind), each SPD: the rows are whitened by R = chol_upper(cov^-1), R^T R = cov^-1, as
+ * gtsam::noiseModel::Gaussian does. */
+int gpslam_hip_set_meas_covariance(gpslam_hip_handle *h, int32_t kind, int32_t count, const double *cov);
 
 /* drop every factor added so far (states, landmarks and Qc stay); the handle needs a new compile() */
 int gpslam_hip_clear_factors(gpslam_hip_handle *h);
@@ -243,6 +261,18 @@ int gpslam_hip_interpolate_poses(gpslam_hip_handle *h, int32_t count, const int3
  * out_H count x 4 x d x d = H1..H4 of interpolatePose (gpslam/gp/GaussianProcessInterpolatorPose3.h:82-98, gpslam.h:57-86) */
 int gpslam_hip_interpolate_poses_jac(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
                                      const double *tau, double *out_pose, double *out_H);
+/* GaussianProcessInterpolatorLinear<D>::interpolateVelocity (gpslam.h:193, gpslam/gp/GaussianProcessInterpolatorLinear.h:106-126)
+ * of the current estimate, batched like interpolate_poses: out_vel count x d; out_H (may be NULL) count x 4 x d x d = H1..H4
+ * (:117-120, the lower blocks of Lambda and Psi).  GPSLAM_LINEAR2 / GPSLAM_LINEAR3 handles; the reference declares the method
+ * for its Lie-group interpolators without implementing it (GaussianProcessInterpolatorPose3.h:118-123): GPSLAM_E_UNSUPPORTED. */
+int gpslam_hip_interpolate_velocities(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *dt,
+                                      const double *tau, double *out_vel, double *out_H);
+/* getBodyCentricVb / getBodyCentricVs (gpslam.h:161-164, gpslam/gp/Pose3utils.cpp:17-24), batched: the MATLAB scripts
+ * initialise the velocity of every state with them.  which = 0: Vb = Logmap(pose1^-1 pose2) / dt, 1: Vs = Logmap(pose2
+ * pose1^-1) / dt;  pose1, pose2: count x 12 (R row-major, t), dt: count, out: count x 6 (omega, v).  Any handle: its device
+ * and stream are used, its graph is not touched. */
+int gpslam_hip_body_centric_velocity(gpslam_hip_handle *h, int32_t which, int32_t count, const double *pose1,
+                                     const double *pose2, const double *dt, double *out);
 /* What compile() chose for the chain solver (introspection for tests and tuning; no reference counterpart):
  * out8 = {levels of the hierarchy, level-0 chunk length, upper chunk length, assembly fused into the level-0 elimination
  * (k_fused_level0) 0/1, GP priors handed to it as structured records instead of Jacobian rows 0/1, rows in the

@@ -232,6 +232,10 @@ int orc_chain_get_states(const orc_chain *c, double *pose, double *vel);
 int orc_chain_set_landmarks(orc_chain *c, int L, const double *pts);
 int orc_chain_get_landmarks(const orc_chain *c, double *pts);
 int orc_chain_add_gp_priors(orc_chain *c, int count, const int32_t *left, const double *dt);
+/* one Qc_model per factor (GaussianProcessPriorPose3.h:43-49): Qc count x d x d */
+int orc_chain_add_gp_priors_qc(orc_chain *c, int count, const int32_t *left, const double *dt, const double *Qc);
+/* noiseModel::Gaussian::Covariance on the `count` most recently added measurement factors of `type` (cov count x rows x rows) */
+int orc_chain_set_meas_covariance(orc_chain *c, int type, int count, int rows, const double *cov);
 int orc_chain_add_pose_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
 int orc_chain_add_vel_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
 int orc_chain_add_between(orc_chain *c, int count, const int32_t *left, const double *measured, const double *sigmas);

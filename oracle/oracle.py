@@ -280,6 +280,17 @@ class Chain:
         self.n_gp += len(left)
         return call("orc_chain_add_gp_priors", self._h, len(left), left, A(dt))
 
+    def add_gp_priors_qc(self, left, dt, Qc):
+        """one Qc per factor (count x d x d)"""
+        left, _ = _i(left)
+        self.n_gp += len(left)
+        return call("orc_chain_add_gp_priors_qc", self._h, len(left), left, A(dt), A(Qc))
+
+    def set_meas_covariance(self, kind, cov):
+        """full Gaussian covariances (count x rows x rows) for the most recently added factors of one GPSLAM_MEAS_* kind"""
+        cov = A(cov)
+        return call("orc_chain_set_meas_covariance", self._h, 5 + int(kind), cov.shape[0], self.MEAS_ROWS[kind], cov)
+
     def add_pose_priors(self, idx, prior, sigmas):
         idx, _ = _i(idx)
         return call("orc_chain_add_pose_priors", self._h, len(idx), idx, A(prior), A(sigmas))

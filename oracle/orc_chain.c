@@ -38,6 +38,10 @@ typedef struct {
   int has_sensor;
   double sensor[12];
   double ahrs[34];  /* F_AHRS: the 25 parameters of orc_ahrs_factor + square-root information R (3 x 3 upper triangular) */
+  int has_qc;       /* F_GP: this factor's own Qc_model (GaussianProcessPriorPose3.h:43-49 takes one per factor) */
+  double qc[36];
+  int has_cov;      /* measurement factors: noiseModel::Gaussian::Covariance instead of diagonal sigmas */
+  double sqi[9];    /* ... its square-root information R, R^T R = cov^-1 (rows x rows, upper triangular) */
 } orc_factor;
 
 struct orc_chain {
@@ -143,6 +147,44 @@ static orc_factor *new_factor(orc_chain *c, int type) {
 int orc_chain_add_gp_priors(orc_chain *c, int count, const int32_t *left, const double *dt) {
   for (int k = 0; k < count; k++) { orc_factor *f = new_factor(c, F_GP); f->idx = left[k]; f->dt = dt[k]; }
   return 0;
+}
+/* GaussianProcessPrior*(key1 .. key4, delta_t, Qc_model): one Qc per factor, as the reference's constructors take it
+ * (gpslam/gp/GaussianProcessPriorPose3.h:43-49).  Qc: count x d x d (ROT3_BIAS: 3 x 3, padded as in orc_chain_set_qc). */
+int orc_chain_add_gp_priors_qc(orc_chain *c, int count, const int32_t *left, const double *dt, const double *Qc) {
+  const int dq = (c->kind == ORC_ROT3_BIAS) ? 3 : c->d;
+  for (int k = 0; k < count; k++) {
+    orc_factor *f = new_factor(c, F_GP);
+    f->idx = left[k];
+    f->dt = dt[k];
+    f->has_qc = 1;
+    const double *q = Qc + (size_t)k * dq * dq;
+    if (c->kind == ORC_ROT3_BIAS) {
+      orc_eye(6, f->qc);
+      for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) f->qc[i * 6 + j] = q[i * 3 + j];
+    } else {
+      orc_copy(c->d * c->d, q, f->qc);
+    }
+  }
+  return 0;
+}
+/* noiseModel::Gaussian::Covariance on the `count` most recently added factors of one measurement type (the reference's
+ * constructors take any gtsam::SharedNoiseModel, e.g. GPInterpolatedGPSFactorPose3.h:46-54): whitening by
+ * R = chol_upper(cov^-1), as gtsam::noiseModel::Gaussian does.  cov: count x rows x rows. */
+int orc_chain_set_meas_covariance(orc_chain *c, int type, int count, int rows, const double *cov) {
+  if (rows < 1 || rows > 3 || type < F_INTERP_RANGE || type == F_AHRS) return -2;
+  int k = count;
+  for (int i = c->nf - 1; i >= 0 && k > 0; i--) {
+    orc_factor *f = &c->f[i];
+    if (f->type != type) continue;
+    k--;
+    double inv[9];
+    if (orc_inv(rows, cov + (size_t)k * rows * rows, inv)) return -1;
+    orc_copy(rows * rows, inv, f->sqi);
+    if (orc_chol_upper(rows, f->sqi)) return -1;
+    f->has_cov = 1;
+  }
+  return k == 0 ? 0 : -2;
 }
 int orc_chain_add_pose_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas) {
   for (int k = 0; k < count; k++) {
@@ -349,7 +391,7 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
       gp_eval(c, f, e, H1, H2, H3, H4);
       *uses_right = 1;
       double R[144], t[MAXR];
-      if (orc_gp_whitening(d, c->Qc, f->dt, R)) return -1;
+      if (orc_gp_whitening(d, f->has_qc ? f->qc : c->Qc, f->dt, R)) return -1;
       orc_mm(b, b, 1, R, e, t);
       orc_copy(b, t, we);
       if (want_jac) {
@@ -483,6 +525,27 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
     default: return -2;
   }
 #undef PUT
+  if (f->has_cov) {   /* Gaussian noise model: rows <- R rows (R upper triangular: row r needs rows >= r, so ascending in place) */
+    const double *Rw = f->sqi;
+    for (int r = 0; r < rows; r++) {
+      double acc = 0.0;
+      for (int q = r; q < rows; q++) acc += Rw[r * rows + q] * e[q];
+      we[r] = acc;
+      if (want_jac) {
+        for (int col = 0; col < b; col++) {
+          double aL = 0.0, aR = 0.0;
+          for (int q = r; q < rows; q++) { aL += Rw[r * rows + q] * JL[q * b + col]; aR += Rw[r * rows + q] * JR[q * b + col]; }
+          JL[r * b + col] = aL; JR[r * b + col] = aR;
+        }
+        for (int col = 0; col < ld; col++) {
+          double am = 0.0;
+          for (int q = r; q < rows; q++) am += Rw[r * rows + q] * Jm[q * ld + col];
+          Jm[r * ld + col] = am;
+        }
+      }
+    }
+    return rows;
+  }
   /* diagonal noise model: R = diag(1/sigma) */
   for (int r = 0; r < rows; r++) {
     double w = 1.0 / f->sig[r];
@@ -547,8 +610,26 @@ int orc_chain_linearize_meas(const orc_chain *c, int type, double *errors, doubl
       for (int r = 0; r < 3; r++)
         for (int q = 0; q < 3; q++) { JL[r * b + q] = A[r * 3 + q]; JL[r * b + 3 + q] = C3[r * 3 + q]; JR[r * b + q] = B[r * 3 + q]; }
     }
+    if (f->has_cov) {   /* undo the full whitening: solve R x = (whitened) from the last row up */
+      const double *Rw = f->sqi;
+      for (int r = rows - 1; r >= 0; r--) {
+        double acc = we[r];
+        for (int q = r + 1; q < rows; q++) acc -= Rw[r * rows + q] * we[q];
+        we[r] = acc / Rw[r * rows + r];
+        for (int col = 0; col < b; col++) {
+          double aL = JL[r * b + col], aR = JR[r * b + col];
+          for (int q = r + 1; q < rows; q++) { aL -= Rw[r * rows + q] * JL[q * b + col]; aR -= Rw[r * rows + q] * JR[q * b + col]; }
+          JL[r * b + col] = aL / Rw[r * rows + r]; JR[r * b + col] = aR / Rw[r * rows + r];
+        }
+        for (int col = 0; col < ld; col++) {
+          double am = Jm[r * ld + col];
+          for (int q = r + 1; q < rows; q++) am -= Rw[r * rows + q] * Jm[q * ld + col];
+          Jm[r * ld + col] = am / Rw[r * rows + r];
+        }
+      }
+    }
     for (int r = 0; r < rows; r++) {
-      const double sg = f->sig[r];
+      const double sg = f->has_cov ? 1.0 : f->sig[r];
       errors[k * rows + r] = we[r] * sg;
       double *o = jac + (k * rows + r) * W;
       for (int q = 0; q < W; q++) o[q] = 0.0;

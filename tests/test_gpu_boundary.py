@@ -1,0 +1,210 @@
+"""GPU: the round-3 additions to the drop-in boundary (VERDICT r2 "what's missing" 2-5), each against the oracle through the C ABI:
+per-factor Qc_model of the GP priors, noiseModel::Gaussian (full covariance) on the measurement factors,
+GaussianProcessInterpolatorLinear::interpolateVelocity, getBodyCentricVb / getBodyCentricVs."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from test_gpu_parity import gpu, random_chain
+from test_gpu_measurements import build_meas_pair
+
+pytestmark = pytest.mark.gpu
+
+MEAS_ROWS = {0: 1, 1: 1, 2: 2, 3: 3, 4: 3, 5: 2, 6: 2}
+
+
+def _spd(rng, n, scale):
+    A = rng.standard_normal((n, n))
+    return scale * (A @ A.T + n * np.eye(n))
+
+
+# ------------------------------------------------------------------ one Qc_model per GP prior
+
+@pytest.mark.parametrize("kind", [O.LINEAR3, O.POSE2, O.POSE3, O.ROT3], ids=["linear3", "pose2", "pose3", "rot3"])
+def test_per_factor_qc_matches_oracle(kind):
+    """GaussianProcessPrior*(keys, delta_t, Qc_model) takes one Qc per factor (GaussianProcessPriorPose3.h:43-49): three
+    distinct Qc interleaved along the chain + some factors on the handle's shared Qc."""
+    gp = gpu()
+    N, d = 61, O.TANGENT_DIM[kind]
+    rng = np.random.default_rng(17 + kind)
+    c = random_chain(kind, N, seed=23 + kind)
+    chart = O.CHART_FIRST_ORDER if kind == O.POSE2 else O.CHART_EXPMAP
+    Qs = [_spd(rng, d, 0.004), np.diag(0.01 + 0.02 * rng.random(d)), _spd(rng, d, 0.02)]
+    shared = np.diag(0.02 + 0.01 * rng.random(d))
+    own = np.arange(N - 1) % 4 != 3                      # every fourth factor uses the shared Qc
+    which = np.arange(N - 1) % 3
+    left_own = np.arange(N - 1)[own]
+    Qc_own = np.stack([Qs[w] for w in which[own]])
+    left_sh = np.arange(N - 1)[~own]
+    pair = []
+    for s in (O.Chain(kind, chart, 0), gp.ChainSolver(kind, chart)):
+        s.set_qc(shared)
+        s.set_states(c["pose"], c["vel"])
+        s.add_gp_priors_qc(left_own, c["dt"][left_own], Qc_own)
+        s.add_gp_priors(left_sh, c["dt"][left_sh])
+        fix = np.arange(0, N, 15)
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.02))
+        s.add_vel_priors([0], c["truth_vel"][[0]], np.full((1, d), 0.05))
+        s.compile()
+        pair.append(s)
+    orc, dev = pair
+    assert abs(orc.error() - dev.error()) <= 1e-10 * max(1.0, orc.error())
+    e0, H0 = orc.linearize_gp()
+    e1, H1 = dev.linearize_gp()                          # unwhitened, in the order the factors were added
+    assert np.abs(e0 - e1).max() <= 1e-10 * max(1.0, np.abs(e0).max())
+    assert np.abs(H0 - H1).max() <= 2e-7 * max(1.0, np.abs(H0).max())
+    D0, O0, g0 = orc.normal_equations()[:3]
+    D1, O1, g1 = dev.normal_equations()[:3]
+    for a, b in ((D0, D1), (O0, O1), (g0, g1)):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max())
+    for _ in range(6):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-6 * max(1.0, s0.error_after)
+    p0, v0 = orc.get_states()
+    p1, v1 = dev.get_states()
+    assert np.abs(p0 - p1).max() <= 1e-9 * max(1.0, np.abs(p0).max())
+    assert np.abs(v0 - v1).max() <= 1e-9 * max(1.0, np.abs(v0).max())
+
+
+def test_one_per_factor_qc_equals_the_shared_qc_path():
+    """every factor added through add_gp_priors_qc with the SAME Qc: one group, the fused / structured-free path -- and the
+    result of a handle that got that Qc through set_qc"""
+    gp = gpu()
+    N, kind = 400, O.POSE3
+    c = random_chain(kind, N, seed=5)
+    Qc = np.diag([0.01, 0.012, 0.014, 0.02, 0.018, 0.016])
+    out = []
+    for per_factor in (False, True):
+        s = gp.ChainSolver(kind)
+        s.set_states(c["pose"], c["vel"])
+        if per_factor:
+            s.add_gp_priors_qc(np.arange(N - 1), c["dt"], np.tile(Qc, (N - 1, 1, 1)))
+        else:
+            s.set_qc(Qc)
+            s.add_gp_priors(np.arange(N - 1), c["dt"])
+        fix = np.arange(0, N, 40)
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), 6), 0.02))
+        s.compile()
+        for _ in range(5):
+            s.iterate_gn()
+        out.append(s.get_states())
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-10
+    assert np.abs(out[0][1] - out[1][1]).max() <= 1e-10
+
+
+# ------------------------------------------------------------------ noiseModel::Gaussian on measurement factors
+
+@pytest.mark.parametrize("kind,meas", [(O.POSE3, (0, 1, 3)), (O.ROT3, (2,)), (O.LINEAR3, (0, 1, 4, 5)), (O.POSE2, (0, 1))],
+                         ids=["pose3-range+gps", "rot3-attitude", "linear3-range+odometry+bearing-range", "pose2-range"])
+def test_full_covariance_noise_matches_oracle(kind, meas):
+    """the reference's constructors take any SharedNoiseModel (GPInterpolatedGPSFactorPose3.h:46-54): full covariances on
+    half of the factors of every kind (the rest keep their diagonal sigmas)"""
+    covs = {}
+
+    def hook(s, k, n):
+        if k not in meas:
+            return
+        rows, m = MEAS_ROWS[k], n // 2
+        if (k, n) not in covs:
+            rng = np.random.default_rng(100 + k)
+            covs[(k, n)] = np.stack([_spd(rng, rows, 0.0008) for _ in range(m)])
+        s.set_meas_covariance(k, covs[(k, n)])
+
+    orc, dev, _ = build_meas_pair(kind, cov_hook=hook)
+    assert abs(orc.error() - dev.error()) <= 1e-10 * max(1.0, orc.error())
+    D0, O0, g0, B0, _, _ = orc.normal_equations()
+    D1, O1, g1, B1 = dev.normal_equations()
+    for a, b in ((D0, D1), (O0, O1), (g0, g1)):
+        assert np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(a).max())
+    if B0 is not None:
+        assert np.abs(B0 - B1).max() <= 1e-9 * max(1.0, np.abs(B0).max())
+    for k in meas:                                       # evaluateError + H stay unwhitened whatever the noise model
+        cnt = [kk for kk in covs if kk[0] == k][0][1]
+        e0, J0 = orc.linearize_meas(k, cnt)
+        e1, J1 = dev.linearize_meas(k, cnt)
+        assert np.abs(e0 - e1).max() <= 1e-10 * max(1.0, np.abs(e0).max())
+        assert np.abs(J0 - J1).max() <= 1e-7 * max(1.0, np.abs(J0).max())
+    for _ in range(8):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-6 * max(1.0, s0.error_after)
+    p0, v0 = orc.get_states()
+    p1, v1 = dev.get_states()
+    assert np.abs(p0 - p1).max() <= 1e-8 * max(1.0, np.abs(p0).max())
+    assert np.abs(v0 - v1).max() <= 1e-8 * max(1.0, np.abs(v0).max())
+
+
+def test_a_diagonal_covariance_is_the_diagonal_model():
+    """Gaussian::Covariance(diag(sigma^2)) must reproduce the sigmas path bit for bit up to rounding of 1 / sigma"""
+    def hook(s, k, n):
+        if k == 3 and not isinstance(s, O.Chain):
+            s.set_meas_covariance(3, np.tile(np.diag([0.05 ** 2] * 3), (n, 1, 1)))
+    orc, dev, _ = build_meas_pair(O.POSE3, cov_hook=hook)
+    assert abs(orc.error() - dev.error()) <= 1e-10 * max(1.0, orc.error())
+
+
+# ------------------------------------------------------------------ interpolateVelocity
+
+@pytest.mark.parametrize("kind", [O.LINEAR2, O.LINEAR3], ids=["linear2", "linear3"])
+def test_interpolate_velocities_match_oracle(kind):
+    gp = gpu()
+    N, d = 40, O.TANGENT_DIM[kind]
+    rng = np.random.default_rng(4 + kind)
+    c = random_chain(kind, N, seed=9)
+    Qc = _spd(rng, d, 0.01)                               # (the result does not depend on Qc: it cancels in Lambda, Psi)
+    s = gp.ChainSolver(kind)
+    s.set_qc(Qc)
+    s.set_states(c["pose"], c["vel"])
+    left = rng.integers(0, N - 1, size=200).astype(np.int32)
+    dt = c["dt"][left]
+    tau = dt * rng.uniform(-0.3, 1.3, size=len(left))
+    v, H = s.interpolate_velocities(left, dt, tau, jac=True)
+    for q in range(len(left)):
+        Lam, Psi = O.lambda_psi(d, Qc, dt[q], tau[q])
+        ref = np.zeros(d)
+        i = left[q]
+        O.call("orc_interp_linear_velocity", d, O.A(Lam), O.A(Psi), O.A(c["pose"][i]), O.A(c["vel"][i]), O.A(c["pose"][i + 1]),
+               O.A(c["vel"][i + 1]), ref)
+        assert np.abs(ref - v[q]).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+        for m, blk in enumerate((Lam[d:, :d], Lam[d:, d:], Psi[d:, :d], Psi[d:, d:])):   # H1..H4 (:117-120)
+            assert np.abs(blk - H[q, m]).max() <= 1e-11 * max(1.0, np.abs(blk).max())
+    assert np.array_equal(v, s.interpolate_velocities(left, dt, tau))
+
+
+def test_interpolate_velocities_is_refused_where_the_reference_has_no_implementation():
+    gp = gpu()
+    c = random_chain(O.POSE3, 5, seed=1)
+    s = gp.ChainSolver(O.POSE3)
+    s.set_states(c["pose"], c["vel"])
+    with pytest.raises(gp.GpslamHipError):
+        s.interpolate_velocities([0], [0.1], [0.05])
+
+
+# ------------------------------------------------------------------ getBodyCentricVb / Vs
+
+def test_body_centric_velocities_match_oracle(golden):
+    gp = gpu()
+    rng = np.random.default_rng(8)
+    n = 300
+    p1 = np.stack([O.pose3(rng.uniform(-2, 2, 3), rng.uniform(-5, 5, 3)) for _ in range(n)])
+    p2 = np.stack([O.pose3(rng.uniform(-2, 2, 3), rng.uniform(-5, 5, 3)) for _ in range(n)])
+    dt = rng.uniform(0.05, 2.0, n)
+    s = gp.ChainSolver(O.POSE3)
+    vb, vs = s.body_centric_velocity(p1, p2, dt), s.body_centric_velocity(p1, p2, dt, spatial=True)
+    for q in range(n):
+        rb, rs = np.zeros(6), np.zeros(6)
+        O.call("orc_getBodyCentricVb", O.A(p1[q]), O.A(p2[q]), float(dt[q]), rb)
+        O.call("orc_getBodyCentricVs", O.A(p1[q]), O.A(p2[q]), float(dt[q]), rs)
+        assert np.abs(rb - vb[q]).max() <= 1e-11 * max(1.0, np.abs(rb).max())
+        assert np.abs(rs - vs[q]).max() <= 1e-11 * max(1.0, np.abs(rs).max())
+    # the reference's own vectors (testPose3Utils.cpp, transcribed into tests/golden/reference_tests.json)
+    from helpers import dec_pose
+    g1 = np.stack([dec_pose("pose3", cse["p1"]) for cse in golden["body_centric_velocity"]])
+    g2 = np.stack([dec_pose("pose3", cse["p2"]) for cse in golden["body_centric_velocity"]])
+    gb, gs = s.body_centric_velocity(g1, g2, 0.1), s.body_centric_velocity(g1, g2, 0.1, spatial=True)
+    for q, cse in enumerate(golden["body_centric_velocity"]):
+        assert np.abs(gb[q] - np.array(cse["vb"])).max() <= 1e-6, cse["src"]
+        assert np.abs(gs[q] - np.array(cse["vs"])).max() <= 1e-6, cse["src"]

@@ -118,3 +118,20 @@ def test_fp32_c5_mix_matches_the_oracle():
     rel = _rel_state_diff(O.POSE3, orc, dev)
     print("C5 pose3+gps mix fp32 (LM): relative state difference %.3e, errors %.9e / %.9e, last |delta| %.1e / %.1e" % (rel, h0[-1][0], h1[-1][0], h0[-1][1], h1[-1][1]))
     assert rel <= 1e-5, rel
+
+
+def test_fp32_2dlinear_factors_with_nonzero_headings():
+    """OdometryFactor2DLinear / RangeBearingFactor2DLinear evaluate their Jacobians AT theta; the fp32 re-centring
+    must leave the heading alone (it shifts x, y only).  A LINEAR3 chain with headings far from zero: the fp32 handle's
+    Gauss-Newton must reach the oracle's fp64 fixed point."""
+    from test_gpu_measurements import build_meas_pair
+    gp = gpu()
+    orc, dev64, c, (dev32,) = build_meas_pair(O.LINEAR3, extra_makers=(lambda: gp.ChainSolver(O.LINEAR3, O.CHART_EXPMAP, 2, precision=gp.FP32),))
+    assert np.abs(c["truth_pose"][:, 2]).max() > 0.05         # the headings really are away from zero
+    assert abs(dev32.error() - orc.error()) <= 1e-10 * max(1.0, orc.error())
+    for _ in range(12):
+        orc.iterate_gn()
+    h = _converge(dev32, 12)
+    rel = _rel_state_diff(O.LINEAR3, orc, dev32)
+    print("fp32 2D-linear factors: relative state difference %.3e, |delta| history %s" % (rel, ["%.1e" % x for x in h]))
+    assert rel <= 1e-5, rel

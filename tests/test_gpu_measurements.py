@@ -41,7 +41,9 @@ def true_range(kind, pose, land, sensor=None):
     return float(np.hypot(land[0] - pose[0], land[1] - pose[1]))
 
 
-def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=()):
+def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=(), cov_hook=None):
+    """cov_hook(solver, MEAS kind, count): called after each batch of measurement factors (e.g. to give them full covariances)"""
+    hook = cov_hook if cov_hook is not None else (lambda s, k, n: None)
     rng = np.random.default_rng(seed + 1000)
     d, ld = O.TANGENT_DIM[kind], LD[kind]
     if chart is None:
@@ -83,7 +85,9 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=(
         if L:
             s.add_landmark_priors(np.arange(L), lands_true + 0.05, np.full((L, ld), 0.5))
             s.add_interp_range(left, specs["lm"], specs["z"], np.full(len(left), 0.05), specs["dts"], tau, S)
+            hook(s, 0, len(left))
             s.add_range(specs["uidx"], specs["ulm"], specs["uz"], np.full(len(specs["uidx"]), 0.05))
+            hook(s, 1, len(specs["uidx"]))
         if kind == O.ROT3:
             nZ = np.tile([0.0, 0.0, 1.0], (len(left), 1))
             bref = []
@@ -92,6 +96,7 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=(
                 bref.append(R.T @ np.array([0.0, 0.0, 1.0]) + 0.01 * rng.standard_normal(3))
             specs.setdefault("bref", np.array(bref))
             s.add_interp_attitude(left, nZ, specs["bref"], np.full((len(left), 2), 0.05), specs["dts"], tau)
+            hook(s, 2, len(left))
         if kind == O.POSE3:
             gl = left[::3]
             gt = tau[::3]
@@ -102,6 +107,7 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=(
                     gm.append(p[9:12] + 0.01 * rng.standard_normal(3))
                 specs["gps"] = np.array(gm)
             s.add_interp_gps(gl, specs["gps"], np.full((len(gl), 3), 0.05), c["dt"][gl], gt)
+            hook(s, 3, len(gl))
         if kind == O.LINEAR3:
             if "odo" not in specs:
                 odo = []
@@ -123,7 +129,9 @@ def build_meas_pair(kind, N=48, seed=3, sensor=False, chart=None, extra_makers=(
                 specs.update(bidx=bidx, blm=blm, bear=np.array(bear) + 0.01 * rng.standard_normal(len(bear)),
                              brng=np.array(brng) + 0.01 * rng.standard_normal(len(brng)))
             s.add_odometry2d(np.arange(N - 1), specs["odo"], np.full((N - 1, 3), 0.02))
+            hook(s, 4, N - 1)
             s.add_bearing_range(specs["bidx"], specs["blm"], specs["bear"], specs["brng"], np.full((len(specs["bidx"]), 2), 0.05))
+            hook(s, 5, len(specs["bidx"]))
         s.compile()
         solvers.append(s)
     if extra_makers:
