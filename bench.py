@@ -105,9 +105,10 @@ def reference_baseline(problem):
 
 
 def extras(gpslam_amd, S, device):
-    """Driver-visible measurements beyond the headline line: the north-star 1e6-state run, the other
-    BASELINE configs on one GPU, the fp32 / fp64 tolerance sweep of config 5.  Everything here runs AFTER the contract's
-    timed region, on rank 0 of a single-GPU run only."""
+    """Driver-visible measurements beyond the headline line: the north-star 1e6-state run, the other BASELINE configs on one
+    GPU (config 5 AT ITS SIZE, 1e6 states, fp32 and fp64), the per-rank cost of the 1e6-state chain cut 2 / 4 / 8 ways.
+    Everything here runs AFTER the contract's timed region, on rank 0 of a single-GPU run only, and every section is
+    guarded: a failure is recorded in its place and never takes the headline line down."""
     out = {}
     tols = [1e-3, 1e-4, 1e-5, 1e-6, 1e-7, 1e-8, 1e-9]
 
@@ -131,108 +132,164 @@ def extras(gpslam_amd, S, device):
                 break
         return first, hist, time.perf_counter() - t0, st.error_after
 
-    # ---- north star: 1e6 Pose3 GP states converged (|delta|_inf < 1e-6) on ONE GPU
-    p = S.pose3_chain(1000000)
-    s = S.apply(p, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=device))
-    first, hist, wall, err = converge(s, use_lm=False, max_it=15)
-    s.set_states(p["pose"], p["vel"])
-    _st, ph = s.run_gn(5, timed=True)
-    ms = float(ph[4]) / 5
-    it6 = first[1e-6]
-    out["north_star_1e6_pose3_1gpu"] = {
-        "states": 1000000, "ms_per_iteration_device": ms,
-        "phase_ms": {k: float(v) / 5 for k, v in zip(["linearize", "assemble", "solve", "retract+error", "total"], ph)},
-        "iterations_to_delta_inf_below_1e-6": it6, "delta_inf_history": hist,
-        "seconds_to_convergence_wall_incl_host_sync": wall,
-        "seconds_to_convergence_device": (it6 * ms * 1e-3) if it6 else None,
-        "states_converged_per_sec": (1000000 / (it6 * ms * 1e-3)) if it6 else None,
-        "hbm_roofline_frac_whole_iteration": 7.8e3 * 1000000 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-        "note": "target: >= 1e6 Pose3 GP states converged in < 1 s (BASELINE north_star names 8 GPUs; this is one)"}
-    s.close()
+    def section(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:      # an extra: never take the headline line down with it
+            out[name] = {"failed": repr(e)}
 
-    # ---- config 2 (linear GP chain) and config 4 (1e6 SE(2) poses + 5e4 locally visible range landmarks), one GPU
-    p = S.linear_chain(100000)
-    s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], device=device))
-    _st, ph = s.run_gn(5, timed=True)
-    out["config2_linear3_1e5"] = {"ms_per_iteration_device": float(ph[4]) / 5, "state_iterations_per_sec": 100000 / (float(ph[4]) / 5 * 1e-3)}
-    s.close()
-    p = S.pose2_local_landmarks_chain(1000000)
-    s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device))
-    first, hist, wall, err = converge(s, use_lm=False, max_it=15)
-    s.set_states(p["pose"], p["vel"])
-    s.set_landmarks(p["landmarks"])
-    _st, ph = s.run_gn(3, timed=True)
-    ms = float(ph[4]) / 3
-    out["config4_pose2_1e6_landmarks_5e4_1gpu"] = {
-        "states": 1000000, "landmarks": len(p["landmarks"]), "range_factors": len(p["range_left"]), "plan": s.segment_plan(),
-        "ms_per_iteration_device": ms, "phase_ms": {k: float(v) / 3 for k, v in zip(["linearize", "assemble", "solve", "retract+error", "total"], ph)},
-        "iterations_to_delta_inf_below_1e-6": first[1e-6], "seconds_to_convergence_wall_incl_host_sync": wall,
-        "state_iterations_per_sec": 1000000 / (ms * 1e-3),
-        "landmark_elimination": "segments + fat separators, segment Schur complements on v_mfma_f64_16x16x4_f64 (fatsep.hpp)"}
-    s.close()
-    # the same graph across GPUs = pieces joined at shared fat separators (gpslam_amd/sharded.py: SplitSolver).  Here both
-    # pieces of a 2-way cut live on this one GPU and run one after the other: per-rank work of a 2-GPU run without its
-    # all-gather (2 records of ~40 KB).
-    try:
+    # ---- north star: 1e6 Pose3 GP states converged (|delta|_inf < 1e-6) on ONE GPU
+    def north_star():
+        p = S.pose3_chain(1000000)
+        s = S.apply(p, gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=device))
+        first, hist, wall, err = converge(s, use_lm=False, max_it=15)
+        s.set_states(p["pose"], p["vel"])
+        _st, ph = s.run_gn(5, timed=True)
+        ms = float(ph[4]) / 5
+        it6 = first[1e-6]
+        r = {"states": 1000000, "ms_per_iteration_device": ms,
+             "phase_ms": {k: float(v) / 5 for k, v in zip(["linearize", "assemble", "solve", "retract+error", "total"], ph)},
+             "level0_forward_ms_in_iteration": s.last_level0_ms() / 5,
+             "iterations_to_delta_inf_below_1e-6": it6, "delta_inf_history": hist,
+             "seconds_to_convergence_wall_incl_host_sync": wall,
+             "seconds_to_convergence_device": (it6 * ms * 1e-3) if it6 else None,
+             "states_converged_per_sec": (1000000 / (it6 * ms * 1e-3)) if it6 else None,
+             "hbm_roofline_frac_whole_iteration": 7.8e3 * 1000000 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "note": "target: >= 1e6 Pose3 GP states converged in < 1 s (BASELINE north_star names 8 GPUs; this is one)"}
+        s.close()
+        return r
+    section("north_star_1e6_pose3_1gpu", north_star)
+
+    # ---- the 1e6-state chain cut P ways: what ONE rank of a P-GPU run does per iteration (forced sharded code path on this
+    # GPU, the all-gather of the P interface records replaced by a device copy), so that the first real multi-GPU run has a
+    # prediction to be checked against
+    def projected():
         import torch
         from gpslam_amd import sharded
-        pieces, locals_ = [], []
-        for r in range(2):
-            lp = sharded.split_local_problem(p, r, 2)
-            sp = gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device)
-            sharded.apply_split(lp, sp, r, 2)
-            locals_.append(lp)
-            pieces.append(sharded.SplitSolver(sp, r, 2))
-        nb_top = max(sv.nb_local for sv in pieces)
-        for sv in pieces:
-            sv.set_top(nb_top)
-        hist = [sharded.iterate_pieces(pieces) for _ in range(2)]
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-        for _ in range(3):
-            for sv in pieces:
-                sv.backend.fs_phase1(0.0)
-            for sv in pieces:
-                rv = sv.recv.view(2, -1)
-                for k in range(2):
-                    rv[k].copy_(pieces[k].send)
-            for sv in pieces:
-                sv.backend.fs_phase2(False)
-        ev1.record()
-        torch.cuda.synchronize()
-        out["config4_pose2_1e6_landmarks_5e4_1gpu"]["split_in_2_pieces_on_this_gpu"] = {
-            "ms_per_rank_and_iteration": ev0.elapsed_time(ev1) / 3 / 2, "states_per_piece": [lp["N"] for lp in locals_],
-            "interface_record_bytes": int(pieces[0].send.numel() * 8), "error_after_2_iterations": hist[-1]["error_after"],
-            "note": "unsplit: ms_per_iteration_device above (1e6 states on one GPU); a piece holds 5e5"}
-        for sv in pieces:
-            sv.backend.close()
-    except Exception as e:      # an extra: never take the headline line down with it
-        out["config4_pose2_1e6_landmarks_5e4_1gpu"]["split_in_2_pieces_on_this_gpu"] = {"failed": repr(e)}
+        p = S.pose3_chain(1000000)
+        res = {"total_states": 1000000, "note": "per-rank device + launch time of the sharded code path without its collective; the "
+               "collective is one all-gather of a 3.6 KB record per rank (latency-sized)", "ranks": {}}
+        for P in (2, 4, 8):
+            lp = sharded.local_problem(p, 0, P)             # rank 0's segment (every rank holds N / P states)
+            sv_ = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=device, rank=0, nranks=P)
+            sv_.set_stream(torch.cuda.current_stream().cuda_stream)
+            sharded.apply_local(lp, sv_)
+            send, recv = sharded.device_tensors(sv_)
+            rv = recv.view(P, -1)
 
-    # ---- config 5: fp32 vs fp64 tolerance sweep.  fp32 = fp32 Jacobian rows (the dominant HBM traffic) + fp64 residual,
-    # normal equations and solver: the update cannot fall below cond(H) * eps32 * |whitened residual|, so
-    # each mix has a tolerance below which the fp32 handle never gets; above it both take the same iterations.
-    sweep = {}
-    for name, make, kind in (("rot3_gp_prior+interp_attitude_x4_(acc+mag)_1e5", lambda: S.rot3_attitude_chain(100000, refs=2), gpslam_amd.ROT3),
-                             ("pose3_gp_prior+odometry+interp_gps_x4_1e5", lambda: S.pose3_gps_chain(100000, keep_odometry=True), gpslam_amd.POSE3)):
-        p = make()
-        res = {}
-        finals = {}
-        for prec_name, prec in (("fp64", gpslam_amd.FP64), ("fp32", gpslam_amd.FP32)):
-            s = S.apply(p, gpslam_amd.ChainSolver(kind, device=device, precision=prec))
-            first, hist, wall, err = converge(s, use_lm=False, max_it=16)
-            finals[prec_name] = s.get_states()
-            s.set_states(p["pose"], p["vel"])
-            _st, ph = s.run_gn(3, timed=True)
-            res[prec_name] = {"gn_iterations_to_delta_inf_below": {("%.0e" % t): first[t] for t in tols},
-                              "final_error": err, "delta_inf_floor": min(hist), "iterations_run": len(hist),
-                              "ms_per_iteration_device": float(ph[4]) / 3}
-            s.close()
-        (x64, v64), (x32, v32) = finals["fp64"], finals["fp32"]
-        scale = max(1.0, float(np.abs(x64).max()), float(np.abs(v64).max()))
-        res["fp32_vs_fp64_final_state_rel_diff"] = float(max(np.abs(x64 - x32).max(), np.abs(v64 - v32).max()) / scale)
-        sweep[name] = res
-    out["config5_fp32_vs_fp64_tolerance_sweep"] = sweep
+            def one():
+                sv_.iterate_phase1(0.0)
+                for k in range(P):                          # stand-in for the all-gather: every slot gets this rank's record
+                    rv[k].copy_(send)
+                sv_.iterate_phase2(False)
+            for _ in range(3):
+                one()
+            sv_.set_states(lp["pose"], lp["vel"])
+            if "halo_pose" in lp:
+                sv_.set_halo_state(lp["halo_pose"], lp["halo_vel"])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                one()
+            torch.cuda.synchronize()
+            res["ranks"][str(P)] = {"states_per_rank": int(lp["N"]), "ms_per_rank_and_iteration": (time.perf_counter() - t0) / 20 * 1e3,
+                                    "record_bytes": int(send.numel() * send.element_size())}
+            sv_.close()
+        return res
+    section("projected_sharded_1e6_pose3", projected)
+
+    # ---- config 2 (linear GP chain) and config 4 (1e6 SE(2) poses + 5e4 locally visible range landmarks), one GPU
+    def config2():
+        p = S.linear_chain(100000)
+        s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], device=device))
+        s.run_gn(2)
+        _st, ph = s.run_gn(5, timed=True)
+        s.close()
+        return {"ms_per_iteration_device": float(ph[4]) / 5, "state_iterations_per_sec": 100000 / (float(ph[4]) / 5 * 1e-3)}
+    section("config2_linear3_1e5", config2)
+
+    def config4():
+        p = S.pose2_local_landmarks_chain(1000000)
+        s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device))
+        first, hist, wall, err = converge(s, use_lm=False, max_it=15)
+        s.set_states(p["pose"], p["vel"])
+        s.set_landmarks(p["landmarks"])
+        _st, ph = s.run_gn(3, timed=True)
+        ms = float(ph[4]) / 3
+        r = {"states": 1000000, "landmarks": len(p["landmarks"]), "range_factors": len(p["range_left"]), "plan": s.segment_plan(),
+             "ms_per_iteration_device": ms, "phase_ms": {k: float(v) / 3 for k, v in zip(["linearize", "assemble", "solve", "retract+error", "total"], ph)},
+             "iterations_to_delta_inf_below_1e-6": first[1e-6], "seconds_to_convergence_wall_incl_host_sync": wall,
+             "state_iterations_per_sec": 1000000 / (ms * 1e-3),
+             "landmark_elimination": "segments + fat separators, segment Schur complements on v_mfma_f64_16x16x4_f64 (fatsep.hpp)"}
+        s.close()
+        # the same graph across GPUs = pieces joined at shared fat separators (gpslam_amd/sharded.py: SplitSolver).  Here both
+        # pieces of a 2-way cut live on this one GPU and run one after the other: per-rank work of a 2-GPU run without its
+        # all-gather (2 records of ~40 KB).
+        try:
+            import torch
+            from gpslam_amd import sharded
+            pieces, locals_ = [], []
+            for rk in range(2):
+                lp = sharded.split_local_problem(p, rk, 2)
+                sp = gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device)
+                sharded.apply_split(lp, sp, rk, 2)
+                locals_.append(lp)
+                pieces.append(sharded.SplitSolver(sp, rk, 2))
+            nb_top = max(sv.nb_local for sv in pieces)
+            for sv in pieces:
+                sv.set_top(nb_top)
+            hist2 = [sharded.iterate_pieces(pieces) for _ in range(2)]
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+            for _ in range(3):
+                for sv in pieces:
+                    sv.backend.fs_phase1(0.0)
+                for sv in pieces:
+                    rv = sv.recv.view(2, -1)
+                    for k in range(2):
+                        rv[k].copy_(pieces[k].send)
+                for sv in pieces:
+                    sv.backend.fs_phase2(False)
+            ev1.record()
+            torch.cuda.synchronize()
+            r["split_in_2_pieces_on_this_gpu"] = {
+                "ms_per_rank_and_iteration": ev0.elapsed_time(ev1) / 3 / 2, "states_per_piece": [lp["N"] for lp in locals_],
+                "interface_record_bytes": int(pieces[0].send.numel() * 8), "error_after_2_iterations": hist2[-1]["error_after"],
+                "note": "unsplit: ms_per_iteration_device above (1e6 states on one GPU); a piece holds 5e5"}
+            for sv in pieces:
+                sv.backend.close()
+        except Exception as e:
+            r["split_in_2_pieces_on_this_gpu"] = {"failed": repr(e)}
+        return r
+    section("config4_pose2_1e6_landmarks_5e4_1gpu", config4)
+
+    # ---- config 5 AT ITS SIZE (1e6 states): fp32 vs fp64 tolerance sweep.  fp32 = fp32 Jacobian rows (the dominant HBM traffic)
+    # + fp64 residual, normal equations and solver: the update cannot fall below cond(H) * eps32 * |whitened
+    # residual|, so each mix has a tolerance below which the fp32 handle never gets; above it both take the same iterations.
+    def config5():
+        sweep = {}
+        for name, make, kind in (("rot3_gp_prior+interp_attitude_x4_(acc+mag)_1e6", lambda: S.rot3_attitude_chain(1000000, refs=2), gpslam_amd.ROT3),
+                                 ("pose3_gp_prior+odometry+interp_gps_x4_1e6", lambda: S.pose3_gps_chain(1000000, keep_odometry=True), gpslam_amd.POSE3)):
+            p = make()
+            res = {"states": 1000000}
+            finals = {}
+            for prec_name, prec in (("fp64", gpslam_amd.FP64), ("fp32", gpslam_amd.FP32)):
+                s = S.apply(p, gpslam_amd.ChainSolver(kind, device=device, precision=prec))
+                first, hist, wall, err = converge(s, use_lm=False, max_it=16)
+                finals[prec_name] = s.get_states()
+                s.set_states(p["pose"], p["vel"])
+                _st, ph = s.run_gn(3, timed=True)
+                res[prec_name] = {"gn_iterations_to_delta_inf_below": {("%.0e" % t): first[t] for t in tols},
+                                  "final_error": err, "delta_inf_floor": min(hist), "iterations_run": len(hist),
+                                  "ms_per_iteration_device": float(ph[4]) / 3,
+                                  "phase_ms": {k: float(v) / 3 for k, v in zip(["linearize", "assemble", "solve", "retract+error", "total"], ph)}}
+                s.close()
+            (x64, v64), (x32, v32) = finals["fp64"], finals["fp32"]
+            scale = max(1.0, float(np.abs(x64).max()), float(np.abs(v64).max()))
+            res["fp32_vs_fp64_final_state_rel_diff"] = float(max(np.abs(x64 - x32).max(), np.abs(v64 - v32).max()) / scale)
+            sweep[name] = res
+        return sweep
+    section("config5_fp32_vs_fp64_tolerance_sweep_1e6", config5)
     return out
 
 
@@ -260,6 +317,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # one process per GPU over RCCL, exactly as many as asked for
+        assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
+    elif args.gpus != 1:
+        raise SystemExit("bench.py --gpus %d: launch with python -m torch.distributed.run --nproc-per-node %d (WORLD_SIZE is 1)" % (args.gpus, args.gpus))
 
     def barrier():
         if dist is not None:
@@ -370,8 +431,17 @@ def main():
         live = [i for i in range(5) if not (fused and i == 1)]    # no k_assemble launch exists when the assembly is fused
         dom = live[int(np.argmax([kms[i] for i in live]))]
         achieved = alg[dom] / (kms[dom] * 1e-3) / 1e9
-        _st, phase = probe.run_gn(3, timed=True)
+        probe.run_gn(2)
+        _st, phase = probe.run_gn(6, timed=True)
+        phase = phase / 2                               # (the keys below divide by 3, as before)
+        l0_in_iter = probe.last_level0_ms() / 6         # the level-0 forward launch as it runs INSIDE an iteration
+        if dom == 2 and l0_in_iter > 0:
+            achieved = alg[dom] / (l0_in_iter * 1e-3) / 1e9
         ms_per_step = elapsed / args.steps * 1e3
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            rccl = None
         out = {
             "metric": "GN state-iterations/sec (states x Gauss-Newton iters/sec), Pose3 GP chain",
             "value": total_states * args.steps / elapsed,
@@ -391,6 +461,7 @@ def main():
                        "factors": "N-1 GaussianProcessPriorPose3 + N-1 BetweenFactor<Pose3> + 1 PriorFactor<Pose3>",
                        "parallelism": "1 chain in %d contiguous segments, 1 all-gather of interface records per "
                                       "iteration" % world if world > 1 else "single GPU"},
+            "ranks": world, "rccl_version": rccl,
             "gn_iters_per_sec": args.steps / elapsed,
             "iters_to_convergence": conv_iters,
             "delta_inf_at_convergence": conv_delta,
@@ -409,11 +480,15 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N),
                          "traffic_source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum, "
                                            "profiles/latest_pmc.json (bytes per launch, same workload)",
-                         "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": kms[dom],
+                         "algorithmic_bytes_per_launch": alg[dom],
+                         "avg_launch_ms": l0_in_iter if (dom == 2 and l0_in_iter > 0) else kms[dom],
+                         "timing": ("hipEvents around the launch INSIDE 6 consecutive Gauss-Newton iterations (gpslam_hip_last_level0_ms); the "
+                                    "isolated launches of kernel_ms are faster" if (dom == 2 and l0_in_iter > 0) else "isolated launches (time_kernel)"),
                          # what actually limits the kernel the HBM fraction is quoted for
                          "note": ("arithmetic and data path of equal length (timing ablations, DESIGN.md section 4): two-wave workgroups "
                                   "(assembly + elimination), ~2100 fp64 VALU instructions per workgroup block step; measured traffic is below "
-                                  "the SURVEY 8(d) figure because the GP priors arrive as structured records (196 instead of 312 doubles)"
+                                  "the SURVEY 8(d) figure because the GP priors arrive as structured records (196 instead of 312 doubles); "
+                                  "round 3: the launch also reduces its four chunk separators (a solver level of its own before)"
                                   if fused and dom == 2 else None)},
         }
         # K1 (batched evaluateError + Jacobians of the GP priors) standalone and inside an iteration, where it shares the

@@ -34,7 +34,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_add_ahrs", "gpslam_hip_plan_info", "gpslam_hip_fs_set_split", "gpslam_hip_fs_split_info", "gpslam_hip_fs_set_top",
     "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
-    "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity",
+    "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
 ]
 
 
@@ -384,6 +384,12 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_interpolate_poses_jac(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out), _p(H)),
                   "interpolate_poses_jac")
         return out, H
+
+    def last_level0_ms(self):
+        """device ms of the level-0 forward launch, summed over the iterations of the last timed run_gn / iterate_gn"""
+        out = C.c_double(0.0)
+        self._chk(self.lib.gpslam_hip_last_level0_ms(self._h, C.byref(out)), "last_level0_ms")
+        return out.value
 
     def last_timing(self):
         t = np.zeros(5)

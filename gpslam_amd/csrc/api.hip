@@ -113,6 +113,8 @@ struct gpslam_hip_handle {
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
+  bool time_l0 = false;       // a timed iteration also stamps the end of the level-0 forward launch (ev[5])
+  double l0_ms = 0.0;         // ... accumulated over the last timed run: the dominant kernel INSIDE an iteration
   double ph_lambda = 0.0;
   std::string err;
 };
@@ -248,6 +250,10 @@ int collect_timing(gpslam_hip_handle *h, double *acc) {
   }
   HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
   acc[4] += ms;
+  if (h->time_l0) {            // the level-0 forward launch of this iteration (ev[2] = start of the solve phase)
+    HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[5]));
+    h->l0_ms += ms;
+  }
   return 0;
 }
 
@@ -351,14 +357,25 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // kernels that exist for fp64 only (hand-written 64-bit DPP row layout, v_mfma_f64): the fp32 instantiation of the
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
-inline void launch_fused_k(const FusedArgs<double> &u, int grid, hipStream_t st) {
+inline void launch_fused_k(const FusedArgs<double, double> &u, int grid, hipStream_t st) {
   if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
   else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);
 }
-inline void launch_fused_k(const FusedArgs<float> &, int, hipStream_t) {}
+// fp32 handles: fp32 row tables straight into the fused kernel's fp64 accumulation (round 3: the unfused assembly had cost the
+// fp32 mode more than its halved row traffic saved)
+inline void launch_fused_k(const FusedArgs<double, float> &u, int grid, hipStream_t st) { k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u); }
 inline void launch_rows_k(const FwdArgs<double> &a, int grid, hipStream_t st) { k_chunk_forward_rows<<<dim3(grid), dim3(64), 0, st>>>(a); }
 inline void launch_rows_k(const FwdArgs<float> &, int, hipStream_t) {}
+// segment interiors of the segmented landmark elimination: planar fp64 chains take the cooperative row-layout kernel (four
+// segments per wave); GPSLAM_FS_FACTOR_ROWS=0 keeps the wave-per-segment kernel, for A/B measurements
+template <int BB, typename T, typename TR> inline void fs_launch_factor(const FsArgs<T, TR> &a, int nseg, hipStream_t st) {
+  if constexpr (BB == 6 && std::is_same<T, double>::value && std::is_same<TR, double>::value) {
+    static const bool off = getenv("GPSLAM_FS_FACTOR_ROWS") && atoi(getenv("GPSLAM_FS_FACTOR_ROWS")) == 0;
+    if (!off) { k_fs_factor_rows6<<<dim3((nseg + 3) / 4), dim3(64), 0, st>>>(a); return; }
+  }
+  k_fs_factor<T, BB, TR><<<dim3(nseg), dim3(64), 0, st>>>(a);
+}
 }  // namespace
 
 // =================================================================== the precision-dependent half, once per precision
@@ -760,6 +777,11 @@ int gpslam_hip_segment_plan(gpslam_hip_handle *h, int32_t out8[8]) {
   return 0;
 }
 
+int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms) {
+  if (!h || !ms) return GPSLAM_E_INVALID;
+  *ms = h->l0_ms;
+  return 0;
+}
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5) {
   if (!h || !out5) return GPSLAM_E_INVALID;
   for (int i = 0; i < 5; i++) out5[i] = h->last_ms[i];
@@ -978,6 +1000,14 @@ int gpslam_hip_fs_set_split(gpslam_hip_handle *h, int32_t rank, int32_t nranks, 
     return fail(h, GPSLAM_E_INVALID, "fs_set_split: bad rank / nranks / landmark lists");
   if (sharded(h)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: create the handle with nranks = 1 (the pieces overlap in their shared cut states, there is no halo)");
   if ((rank == 0 && n_first) || (rank == nranks - 1 && n_last)) return fail(h, GPSLAM_E_INVALID, "fs_set_split: the two ends of the whole chain share nothing");
+  {   // a landmark listed twice, or in both lists, would corrupt the slot bookkeeping of the shared end blocks
+    std::vector<int32_t> all(first_lm, first_lm + n_first);
+    all.insert(all.end(), last_lm, last_lm + n_last);
+    std::sort(all.begin(), all.end());
+    if (std::adjacent_find(all.begin(), all.end()) != all.end())
+      return fail(h, GPSLAM_E_INVALID, "fs_set_split: a landmark is listed twice (the first / last lists must be duplicate-free and disjoint)");
+    if (!all.empty() && all.front() < 0) return fail(h, GPSLAM_E_INVALID, "fs_set_split: negative landmark index");
+  }
   h->fs.split = true;
   h->fs.rank = rank; h->fs.nranks = nranks; h->fs.nb_top = 0;
   h->fs.first_lm.assign(first_lm, first_lm + n_first);

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "devbuf.hpp"
+#include "dpp.hpp"
 
 namespace gps {
 
@@ -196,6 +197,111 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
       fs_wave_sync();
     }
    }
+  }
+}
+
+// ---- the same factorisation in the ROW LAYOUT of the chain solver (round 3; planar chains, B = 6, fp64): FOUR segments per wave,
+// one per 16-lane DPP row; lane r < 6 of a row holds ROW r of the state's block.  The wave-per-segment kernel above lets every
+// lane factor the whole 6 x 6 block redundantly (~700 VALU instructions per state and segment: 0.91 ms at config 4, VALU
+// bound); here the block is factored cooperatively without a single barrier -- what a lane needs from another row arrives
+// fused into the multiply-add (v_fmac_f64_dpp row_newbcast, dpp.hpp):
+//   Cholesky, pivot p:  dd = A[p][p] broadcast;  every lane forms 1 / sqrt(dd);  L[r][p] = A[r][p] / l_pp;
+//                       A[r][k] -= L[k][p] L[r][p] for all k at once (gather form: one source register, six lanes)
+//   W = L^-1 by rows:   W_r = (e_r - sum_{k < r} L[r][k] W_k) / l_rr, row k broadcast as soon as it is final
+//   E = W O^T:          E_r += W[r][m] (column m of O, held by lane m)
+//   next block:         A' = D' + lambda I - E^T E,  (E^T E)[r][c] = sum_k E[k][r] E_k[c]; column r of E through a 288-byte LDS transpose
+// ~370 instructions per state for four segments.  Records are fetched three states ahead (the only memory latency of a
+// step); with that distance the in-order vmcnt counter never makes a step wait for its own stores.
+__global__ void __launch_bounds__(64) k_fs_factor_rows6(FsArgs<double, double> a) {
+  constexpr int B = 6, DEPTH = 3;
+  const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
+  const int nseg = a.K - 1;
+  const int seg = min((int)blockIdx.x * 4 + row, nseg - 1);
+  const bool segok = ((int)blockIdx.x * 4 + row) < nseg;
+  const bool rowlane = r < B;
+  const int rr = rowlane ? r : 0;
+  const int j0 = a.cuts[seg] + 1, n = segok ? a.cuts[seg + 1] - a.cuts[seg] - 1 : 0;
+  int nmax = n;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+  nmax = __builtin_amdgcn_readfirstlane(nmax);
+  __shared__ double ET[4][B * B];
+  const double lambda = a.lambda;
+  double pD[DEPTH][B], pO[DEPTH][B];              // row r of D, column r of O of the states in flight
+  auto fetch = [&](int slot, int jj) {            // unconditional (clamped): a load under a branch is waited for at once
+    const double *bp = a.blk + (size_t)(j0 + min(jj, max(n - 1, 0))) * a.BS;
+#pragma unroll
+    for (int c = 0; c < B; c++) { pD[slot][c] = bp[rr * B + c]; pO[slot][c] = bp[B * B + c * B + rr]; }
+  };
+#pragma unroll
+  for (int q = 0; q < DEPTH; q++) fetch(q, q);
+  double Ecol[B], Er[B];
+#pragma unroll
+  for (int c = 0; c < B; c++) { Ecol[c] = 0.0; Er[c] = 0.0; }
+  for (int j3 = 0; j3 < nmax; j3 += DEPTH) {
+#pragma unroll
+    for (int q = 0; q < DEPTH; q++) {
+      const int jj = j3 + q;
+      if (jj >= nmax) break;
+      const bool live = jj < n;
+      // ---- A = D + lambda I - E_{j-1}^T E_{j-1}
+      double Ar[B], OT[B];
+#pragma unroll
+      for (int c = 0; c < B; c++) { Ar[c] = pD[q][c] + ((c == r) ? lambda : 0.0); OT[c] = pO[q][c]; }
+      fetch(q, jj + DEPTH);
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, B>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        fmac_bcast6<k>(Ar, Er, -Ecol[k]);
+      });
+      // ---- Cholesky by rows
+      double Lr[B], inv[B];
+      bool bad = false;
+      static_for<0, B>([&](auto pp) {
+        constexpr int p = decltype(pp)::value;
+        double dd = row_bcast<p>(Ar[p]);
+        if (!(dd > 0.0)) { bad = true; dd = 1.0; }
+        double y = fs_rsqrt(dd), l = dd * y;
+        l = fma(0.5 * y, fma(-l, l, dd), l);        // one residual step each, as in k_fs_factor
+        y = fma(y, fma(-l, y, 1.0), y);
+        inv[p] = y;
+        Lr[p] = (r > p) ? Ar[p] * y : ((r == p) ? l : 0.0);
+        fmac_gather<6>(Ar, Lr[p], (r > p) ? -Lr[p] : 0.0);
+      });
+      if (bad && live && rowlane) *a.flag = 1;
+      // ---- W = L^-1 by rows
+      double Wr[B];
+#pragma unroll
+      for (int c = 0; c < B; c++) Wr[c] = (c == r) ? 1.0 : 0.0;
+      static_for<0, B>([&](auto kk) {
+        constexpr int k = decltype(kk)::value;
+        const double sc = (r == k) ? inv[k] : 1.0;
+#pragma unroll
+        for (int c = 0; c < B; c++) Wr[c] *= sc;
+        fmac_self6<k>(Wr, (r > k) ? -Lr[k] : 0.0);
+      });
+      // ---- E = W O^T
+#pragma unroll
+      for (int c = 0; c < B; c++) Er[c] = 0.0;
+      static_for<0, B>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
+        fmac_bcast6<m>(Er, OT, Wr[m]);
+      });
+      // ---- out: [W | E] of this state; column r of E for the next state's E^T E
+      if (rowlane) {
+#pragma unroll
+        for (int c = 0; c < B; c++) ET[row][r * B + c] = Er[c];
+      }
+      if (live && rowlane) {
+        double *fp = a.fac + (size_t)(j0 + jj) * 2 * B * B;
+#pragma unroll
+        for (int c = 0; c < B; c++) { fp[r * B + c] = Wr[c]; fp[B * B + r * B + c] = Er[c]; }
+      }
+      fs_wave_sync();
+#pragma unroll
+      for (int k = 0; k < B; k++) Ecol[k] = ET[row][k * B + rr];
+      fs_wave_sync();
+    }
   }
 }
 
@@ -391,7 +497,13 @@ __host__ __device__ inline int fs_lds_stride(int ncp) { return ((ncp + 31) / 32)
 // (12 accumulator tiles + the sweep's state) leave two workgroups per CU, and per 24-row chunk the workgroup then pays the
 // sweep's four dependent steps (LDS-fed 6 x 6 products on two of its four waves), the gather of the next chunk's right-hand
 // sides and the MFMAs one after the other: 10 us per chunk instead of 4.3.
-template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) k_fs_syrk(FsArgs<double, TR> a) {
+// Round 3: two instantiations (TPW accumulator tiles per wave, NCM = widest staged chunk row): <7, 112> serves borders up to 112
+// columns (config 4: 80) and is 0.4 ms per iteration faster there than the <12, 144> that serves everything wider.  A variant
+// that requested chunks two iterations ahead (two register sets, loop unrolled by two, LDS-only barriers) was measured at the
+// same time as the one-ahead loop: the kernel is not waiting for its prefetch -- its 1600 VALU instructions per wave and chunk
+// (index arithmetic of the runtime tile / piece geometry around 24 MFMAs) are what it spends its time on
+// (SQ_INSTS_VALU / SQ_WAVES / chunks, profiles/round3_c4_kernel_stats.md).
+template <int TPW, int NCM, typename TR = double> __global__ void __launch_bounds__(256) k_fs_syrk(FsArgs<double, TR> a) {
   constexpr int KC = 24;                                   // rows per chunk: 4 states of 6, 2 of 12, 6 of 4
   extern __shared__ __align__(16) unsigned char syrk_smem[];
   double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x LSP
@@ -425,7 +537,7 @@ template <int TPW, typename TR = double> __global__ void __launch_bounds__(256) 
   }
   typedef double V2 __attribute__((ext_vector_type(2)));
   const int chunk_v2 = KC * NCF / 2;                        // 16-byte pieces per chunk
-  constexpr int PV = (KC * 144 / 2 + 255) / 256;            // pieces per thread at the widest NCP (144)
+  constexpr int PV = (KC * NCM / 2 + 255) / 256;            // pieces per thread at the widest chunk row of this instantiation
   V2 pre[PV];
   auto fetch = [&](int c) {                                 // global -> registers (in flight under the MFMAs)
     const int k0 = c * KC;
@@ -1188,6 +1300,11 @@ struct FatSepPlan {
           forced[l] = K - 1; fat_of[l] = K - 1; slot_of[l] = counts[K - 1]++;
         }
       }
+      // The fat block size is set by the FULLEST cut (NB = B + ld * max count; the border of every segment, the Y buffer and
+      // the cubic cost of the fat chain all scale with it), so the landmarks are balanced: those with a single admissible
+      // cut first, then the others to the emptier of their cuts, then single moves off the fullest cuts while that lowers
+      // the maximum (round 3: 17 -> 14 landmarks per cut on the config-4 graph, NB 40 -> 36).
+      std::vector<int> lo_of(L, 0), hi_of(L, -1);
       for (int l = 0; l < L && ok; l++) {
         if (forced[l] >= 0) continue;
         int lo, hi;
@@ -1202,10 +1319,44 @@ struct FatSepPlan {
         if (lsh && lo == 0) lo = 1;
         if (rsh && hi == K - 1) hi = K - 2;
         if (lo > hi) { ok = false; break; }
-        int best = lo;
-        for (int k = lo + 1; k <= hi; k++) if (counts[k] < counts[best]) best = k;
-        fat_of[l] = best;
-        slot_of[l] = counts[best]++;
+        lo_of[l] = lo; hi_of[l] = hi;
+      }
+      if (ok) {
+        for (int pass = 0; pass < 2; pass++)          // pass 0: no choice; pass 1: the emptier admissible cut
+          for (int l = 0; l < L; l++) {
+            if (forced[l] >= 0 || (pass == 0) != (lo_of[l] == hi_of[l])) continue;
+            int best = lo_of[l];
+            for (int k = lo_of[l] + 1; k <= hi_of[l]; k++) if (counts[k] < counts[best]) best = k;
+            fat_of[l] = best;
+            counts[best]++;
+          }
+        std::vector<std::vector<int>> members(K);
+        for (int l = 0; l < L; l++) if (forced[l] < 0) members[fat_of[l]].push_back(l);
+        for (int round = 0; round < 64; round++) {    // move a landmark off a fullest cut to a cut at least two emptier
+          int mxc = 0;
+          for (int k = 0; k < K; k++) mxc = std::max(mxc, counts[k]);
+          bool moved = false;
+          for (int k = 0; k < K; k++) {
+            if (counts[k] != mxc) continue;
+            for (size_t q = 0; q < members[k].size(); q++) {
+              const int l = members[k][q];
+              int to = -1;
+              for (int k2 = lo_of[l]; k2 <= hi_of[l]; k2++) if (k2 != k && counts[k2] + 1 < counts[k] && (to < 0 || counts[k2] < counts[to])) to = k2;
+              if (to < 0) continue;
+              members[k].erase(members[k].begin() + (long)q);
+              members[to].push_back(l);
+              fat_of[l] = to; counts[k]--; counts[to]++;
+              moved = true;
+              break;
+            }
+          }
+          if (!moved) break;
+        }
+        // slots: forced landmarks keep theirs (the shared end blocks' order is the caller's); the rest in landmark order
+        std::vector<int> next(K, 0);
+        for (int k = 0; k < K; k++) next[k] = 0;
+        for (int l = 0; l < L; l++) if (forced[l] >= 0) next[forced[l]]++;
+        for (int l = 0; l < L; l++) if (forced[l] < 0) slot_of[l] = next[fat_of[l]]++;
       }
       int mx = 0;
       for (int k = 0; k < K; k++) mx = std::max(mx, counts[k]);

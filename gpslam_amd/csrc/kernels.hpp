@@ -2135,12 +2135,14 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
 // Conventions that differ from the unfused pair: a separator's own record holds only its rows' L^T L part -- the
 // R^T R of the rows of the state before it (the previous chunk's last state) reaches it as part of the addend that
 // chunk sends to the upper level anyway (the "virtual" record after a chunk's last state is [carry | 0 | carry_g]).
-template <typename T> struct FusedArgs {
+// TR: type of the Jacobian row tables (float on fp32 handles -- GPSLAM_FP32 --, whose accumulation, normal equations and
+// elimination stay fp64: the rows are widened as they leave the ring)
+template <typename T, typename TR = T> struct FusedArgs {
   FwdArgs<T> f;           // level-0 arguments of the elimination (blk: where the factors [V | U | Y] go)
   const int *rowptr;      // full-width rows of left state s: [rowptr[s], rowptr[s+1])
-  const T *rowLR, *rowE;  // M x 24, M
+  const TR *rowLR, *rowE; // M x 24, M
   const int *crowptr;     // compact rows
-  const T *rowC, *rowCE;  // Mc x 12, Mc
+  const TR *rowC, *rowCE; // Mc x 12, Mc
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
   int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
@@ -2154,8 +2156,9 @@ template <typename T> struct FusedArgs {
 // full-width row ring is replaced by the record ring (a kernel with both spills: 256 VGPRs + 176 B of scratch, 0.34 ms).
 // SV = 2: a structured chain that also has a few other full-width rows (a velocity prior or two): those are fetched where
 // they are used, without a ring (the pure variant stays free of that loop's registers: with it the kernel spills again).
-template <int SV>
-__global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
+template <int SV, typename TR = double>
+__global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
+  static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
   constexpr bool ST = SV != 0, ODD = SV == 2;
   const FwdArgs<double> &a = u.f;
   constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
@@ -2227,20 +2230,20 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double> u) {
     };
     auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = rp + min(i, max(nf - 1, 0));
-      const double *row = u.rowLR + (size_t)rho * 2 * B;
+      const TR *row = u.rowLR + (size_t)rho * 2 * B;
 #ifdef GPS_ABLATE_LOAD   /* timing ablation only: no row traffic */
       Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
 #else
-      Lv = row[rr]; Rv = row[B + rr]; ev = u.rowE[rho];
+      Lv = (double)row[rr]; Rv = (double)row[B + rr]; ev = (double)u.rowE[rho];
 #endif
     };
     auto ldc = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = cp + min(i, max(nc - 1, 0));
-      const double *row = u.rowC + (size_t)rho * B;
+      const TR *row = u.rowC + (size_t)rho * B;
 #ifdef GPS_ABLATE_LOAD
       Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
 #else
-      Lv = row[rc]; Rv = row[Dh + rc]; ev = u.rowCE[rho];
+      Lv = (double)row[rc]; Rv = (double)row[Dh + rc]; ev = (double)u.rowCE[rho];
 #endif
     };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads

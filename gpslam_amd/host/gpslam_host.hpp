@@ -217,6 +217,7 @@ struct Desc {   // what a factor hands to the graph compiler
   Key kw[2] = {0, 0};                // omega1, omega2 of the *Pose3VW factors
   bool vw = false;                   // world-frame (v, w) velocity family
   std::vector<double> meas, sig, sensor, aux;
+  std::vector<double> cov;           // measurement factors with a noiseModel::Gaussian (full covariance): rows x rows, else empty
   double dt = 0, tau = 0;
   Matrix Qc;
 };
@@ -232,8 +233,17 @@ class NonlinearFactor {
 };
 
 inline std::vector<double> sigmas_of(const SharedNoiseModel &m) {
-  if (!m || !m->diagonal_) throw std::invalid_argument("measurement noise models must be diagonal (Isotropic / Diagonal)");
+  if (!m || !m->diagonal_) throw std::invalid_argument("the noise model of PriorFactor / BetweenFactor must be diagonal (Isotropic / Diagonal)");
   return m->sigmas_;
+}
+// the measurement factors take any Gaussian model, as the reference's constructors do (GPInterpolatedGPSFactorPose3.h:46-54):
+// a full covariance travels in Desc::cov and reaches the device through gpslam_hip_set_meas_covariance
+inline void noise_of(const SharedNoiseModel &m, detail::Desc &d) {
+  if (!m) throw std::invalid_argument("null noise model");
+  if (m->diagonal_) { d.sig = m->sigmas_; d.cov.clear(); return; }
+  d.cov = m->cov_.a;
+  d.sig.resize(m->dim_);
+  for (int i = 0; i < m->dim_; i++) d.sig[i] = std::sqrt(m->cov_(i, i));
 }
 
 #define GPSLAM_FACTOR_BOILERPLATE(CLS, NKEYS)                                                           \
@@ -416,8 +426,12 @@ struct Session {
         throw std::invalid_argument("factor type does not match the pose type in the Values");
       auto set_qc = [&](const Matrix &Qc) {
         if (Qc.rows != (bias ? 3 : d)) throw std::invalid_argument("Qc_model dimension does not match the manifold");
+        // (the handle's shared Qc serves the interpolation queries; GP priors carry their own Qc_model -- below --, and
+        //  the interpolated measurement factors do not depend on theirs: Qc cancels in Lambda and Psi)
         if (!qc_set) { check(gpslam_hip_set_qc(h, Qc.a.data()), h, "set_qc"); qc_set = true; qc_used = Qc.a; }
-        else if (Qc.a != qc_used) throw std::invalid_argument("all GP factors of one graph must share one Qc_model (one Qc per handle)");
+      };
+      auto gaussian = [&](int kind) {   // noiseModel::Gaussian::Covariance on the factor just added
+        if (!f.cov.empty()) check(gpslam_hip_set_meas_covariance(h, kind, 1, f.cov.data()), h, "set_meas_covariance");
       };
       auto adjacent = [&](Key k1, Key k2) {
         const int s1 = state_of(k1), s2 = state_of(k2);
@@ -432,7 +446,7 @@ struct Session {
               (f.vw && (symbolIndex(f.kw[0]) != symbolIndex(f.k[0]) || symbolIndex(f.kw[1]) != symbolIndex(f.k[2]))))
             throw std::invalid_argument("GP prior: pose and velocity keys of a state must share their index");
           int32_t l = adjacent(f.k[0], f.k[2]);
-          check(gpslam_hip_add_gp_priors(h, 1, &l, &f.dt), h, "add_gp_priors");
+          check(gpslam_hip_add_gp_priors_qc(h, 1, &l, &f.dt, f.Qc.a.data()), h, "add_gp_priors_qc");   // one Qc_model per factor
         } break;
         case F_POSE_PRIOR: {
           int32_t s = state_of(f.k[0]);
@@ -472,6 +486,7 @@ struct Session {
           const double one = 1.0, tau = st > 0 ? 1.0 : 0.0;
           if (N < 2) throw std::invalid_argument("Rot3AttitudeFactor needs a chain of at least two states");
           check(gpslam_hip_add_interp_attitude(h, 1, &l, f.aux.data(), f.aux.data() + 3, f.sig.data(), &one, &tau), h, "add_interp_attitude");
+          gaussian(GPSLAM_MEAS_INTERP_ATTITUDE);
         } break;
         case F_VEL_PRIOR: { if (vw) throw std::invalid_argument("PriorFactor<Vector3> on a 'v' / 'w' key of a Pose3VW graph is not supported yet");
           int32_t s = state_of(f.k[0]);
@@ -491,18 +506,18 @@ struct Session {
           }
         } break;
         case F_INTERP_RANGE: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
-          check(gpslam_hip_add_interp_range(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_range"); } break;
-        case F_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]); check(gpslam_hip_add_range(h, 1, &s, &m, f.meas.data(), f.sig.data()), h, "add_range"); } break;
+          check(gpslam_hip_add_interp_range(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_range"); gaussian(GPSLAM_MEAS_INTERP_RANGE); } break;
+        case F_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]); check(gpslam_hip_add_range(h, 1, &s, &m, f.meas.data(), f.sig.data()), h, "add_range"); gaussian(GPSLAM_MEAS_RANGE); } break;
         case F_INTERP_ATT: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]);
-          check(gpslam_hip_add_interp_attitude(h, 1, &l, f.aux.data(), f.aux.data() + 3, f.sig.data(), &f.dt, &f.tau), h, "add_interp_attitude"); } break;
+          check(gpslam_hip_add_interp_attitude(h, 1, &l, f.aux.data(), f.aux.data() + 3, f.sig.data(), &f.dt, &f.tau), h, "add_interp_attitude"); gaussian(GPSLAM_MEAS_INTERP_ATTITUDE); } break;
         case F_INTERP_GPS: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]);
-          check(gpslam_hip_add_interp_gps(h, 1, &l, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_gps"); } break;
-        case F_ODOM2D: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_odometry2d(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_odometry2d"); } break;
+          check(gpslam_hip_add_interp_gps(h, 1, &l, f.meas.data(), f.sig.data(), &f.dt, &f.tau, sens), h, "add_interp_gps"); gaussian(GPSLAM_MEAS_INTERP_GPS); } break;
+        case F_ODOM2D: { int32_t l = adjacent(f.k[0], f.k[2]); check(gpslam_hip_add_odometry2d(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_odometry2d"); gaussian(GPSLAM_MEAS_ODOMETRY2D); } break;
         case F_BEARING_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]);
-          check(gpslam_hip_add_bearing_range(h, 1, &s, &m, &f.meas[0], &f.meas[1], f.sig.data()), h, "add_bearing_range"); } break;
+          check(gpslam_hip_add_bearing_range(h, 1, &s, &m, &f.meas[0], &f.meas[1], f.sig.data()), h, "add_bearing_range"); gaussian(GPSLAM_MEAS_BEARING_RANGE); } break;
         case F_INTERP_PROJ: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
           check(gpslam_hip_add_interp_projection(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), h,
-                "add_interp_projection"); } break;
+                "add_interp_projection"); gaussian(GPSLAM_MEAS_INTERP_PROJECTION); } break;
       }
     }
     // states whose velocity is not a variable of the user's graph: pin a zero velocity (decoupled, zero error)
@@ -727,7 +742,7 @@ class Rot3AttitudeFactor : public NonlinearFactor {
   Rot3AttitudeFactor(Key key, const Unit3 &nZ, const SharedNoiseModel &model, const Unit3 &bRef = Unit3(0, 0, 1)) {
     d_.type = detail::F_ATTITUDE; d_.k[0] = key;
     d_.aux = {nZ.p[0], nZ.p[1], nZ.p[2], bRef.p[0], bRef.p[1], bRef.p[2]};
-    d_.sig = sigmas_of(model);
+    noise_of(model, d_);
   }
   GPSLAM_FACTOR_BOILERPLATE(Rot3AttitudeFactor, 1)
 };
@@ -914,7 +929,7 @@ class GPInterpolatedRangeFactorPose2 : public gtsam::NonlinearFactor {
                                  double delta_t, double tau, const gtsam::Pose2 *body_P_sensor = nullptr) {
     d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_POSE2;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
-    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    d_.meas = {measured}; gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = {body_P_sensor->x, body_P_sensor->y, body_P_sensor->theta};
   }
   /// gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98
@@ -935,7 +950,7 @@ class GPInterpolatedRangeFactorPose3 : public gtsam::NonlinearFactor {
                                  double delta_t, double tau, const gtsam::Pose3 *body_P_sensor = nullptr) {
     d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_POSE3;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
-    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    d_.meas = {measured}; gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
   /// gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
@@ -956,7 +971,7 @@ class GPInterpolatedRangeFactor2DLinear : public gtsam::NonlinearFactor {
                                     const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau) {
     d_.type = gtsam::detail::F_INTERP_RANGE; d_.manifold = GPSLAM_LINEAR3;
     d_.k[0] = pose1Key; d_.k[1] = vel1Key; d_.k[2] = pose2Key; d_.k[3] = vel2Key; d_.k[4] = pointKey;
-    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    d_.meas = {measured}; gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
   }
   /// gpslam/slam/GPInterpolatedRangeFactor2DLinear.h:60-88
   gtsam::Vector evaluateError(const gtsam::Vector3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Vector3 &pose2, const gtsam::Vector3 &vel2, const gtsam::Point2 &point,
@@ -977,7 +992,7 @@ class GPInterpolatedAttitudeFactorRot3 : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_INTERP_ATT; d_.manifold = GPSLAM_ROT3;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2;
     d_.aux = {nZ.p[0], nZ.p[1], nZ.p[2], bRef.p[0], bRef.p[1], bRef.p[2]};
-    d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
+    gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance(); d_.dt = delta_t; d_.tau = tau;
   }
   /// gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:61-83
   gtsam::Vector evaluateError(const gtsam::Rot3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Rot3 &pose2, const gtsam::Vector3 &vel2,
@@ -996,7 +1011,7 @@ class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
                                const gtsam::Pose3 *body_P_sensor = nullptr) {
     d_.type = gtsam::detail::F_INTERP_GPS; d_.manifold = GPSLAM_POSE3;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2;
-    d_.meas = {measured.x, measured.y, measured.z}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance();
+    d_.meas = {measured.x, measured.y, measured.z}; gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance();
     d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
@@ -1029,7 +1044,7 @@ class GPInterpolatedGPSFactorPose3VW : public gtsam::NonlinearFactor {
                                  const gtsam::Pose3 *body_P_sensor = nullptr) {
     d_.type = gtsam::detail::F_INTERP_GPS; d_.manifold = GPSLAM_POSE3; d_.vw = true;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.kw[0] = omegaKey1; d_.kw[1] = omegaKey2;
-    d_.meas = {measured.x, measured.y, measured.z}; d_.sig = gtsam::sigmas_of(meas_model); d_.Qc = Qc_model->covariance();
+    d_.meas = {measured.x, measured.y, measured.z}; gtsam::noise_of(meas_model, d_); d_.Qc = Qc_model->covariance();
     d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
@@ -1047,7 +1062,7 @@ class GPInterpolatedProjectionFactorPose3 : public gtsam::NonlinearFactor {
                                       const std::shared_ptr<CALIBRATION> &K, const gtsam::Pose3 *body_P_sensor = nullptr) {
     d_.type = gtsam::detail::F_INTERP_PROJ; d_.manifold = GPSLAM_POSE3;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
-    d_.meas = {measured.x, measured.y}; d_.sig = gtsam::sigmas_of(cam_model); d_.Qc = Qc_model->covariance();
+    d_.meas = {measured.x, measured.y}; gtsam::noise_of(cam_model, d_); d_.Qc = Qc_model->covariance();
     d_.dt = delta_t; d_.tau = tau; d_.aux = {K->fx(), K->fy(), K->skew(), K->px(), K->py()};
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
@@ -1059,7 +1074,7 @@ class RangeFactor2DLinear : public gtsam::NonlinearFactor {
  public:
   RangeFactor2DLinear(gtsam::Key poseKey, gtsam::Key pointKey, double measured, const gtsam::SharedNoiseModel &model) {
     d_.type = gtsam::detail::F_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
-    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(model);
+    d_.meas = {measured}; gtsam::noise_of(model, d_);
   }
   GPSLAM_FACTOR_BOILERPLATE(RangeFactor2DLinear, 2)
 };
@@ -1068,7 +1083,7 @@ class RangeFactorPose2 : public gtsam::NonlinearFactor {
  public:
   RangeFactorPose2(gtsam::Key poseKey, gtsam::Key pointKey, double measured, const gtsam::SharedNoiseModel &model) {
     d_.type = gtsam::detail::F_RANGE; d_.manifold = GPSLAM_POSE2; d_.k[0] = poseKey; d_.k[4] = pointKey;
-    d_.meas = {measured}; d_.sig = gtsam::sigmas_of(model);
+    d_.meas = {measured}; gtsam::noise_of(model, d_);
   }
   GPSLAM_FACTOR_BOILERPLATE(RangeFactorPose2, 2)
 };
@@ -1077,7 +1092,7 @@ class RangeBearingFactor2DLinear : public gtsam::NonlinearFactor {
  public:
   RangeBearingFactor2DLinear(gtsam::Key poseKey, gtsam::Key pointKey, double range, double bearing, const gtsam::SharedNoiseModel &model) {
     d_.type = gtsam::detail::F_BEARING_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
-    d_.meas = {bearing, range}; d_.sig = gtsam::sigmas_of(model);
+    d_.meas = {bearing, range}; gtsam::noise_of(model, d_);
   }
   GPSLAM_FACTOR_BOILERPLATE(RangeBearingFactor2DLinear, 2)
 };
@@ -1086,7 +1101,7 @@ class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
  public:
   OdometryFactor2DLinear(gtsam::Key pose1Key, gtsam::Key pose2Key, const gtsam::Vector3 &betweenMeasured, const gtsam::SharedNoiseModel &model) {
     d_.type = gtsam::detail::F_ODOM2D; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = pose1Key; d_.k[2] = pose2Key;
-    d_.meas = {betweenMeasured[0], betweenMeasured[1], betweenMeasured[2]}; d_.sig = gtsam::sigmas_of(model);
+    d_.meas = {betweenMeasured[0], betweenMeasured[1], betweenMeasured[2]}; gtsam::noise_of(model, d_);
   }
   GPSLAM_FACTOR_BOILERPLATE(OdometryFactor2DLinear, 2)
 };
@@ -1123,9 +1138,66 @@ template <int Dim> class GaussianProcessInterpolatorLinear {
     return detail_g::interpolate_one<gtsam::VectorN<Dim>, gtsam::VectorN<Dim>>(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, Qc_, delta_t_, tau_,
                                                                                pose1, vel1, pose2, vel2, H1, H2, H3, H4);
   }
+  /// interpolate velocity with Jacobians -- gpslam/gp/GaussianProcessInterpolatorLinear.h:106-126 (gpslam.h:193); evaluated on the
+  /// device like interpolatePose (gpslam_hip_interpolate_velocities on a two-state session)
+  gtsam::VectorN<Dim> interpolateVelocity(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
+                                          const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
+                                          gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+    typedef gtsam::VectorN<Dim> V;
+    detail_g::Single s(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, 0, gtsam::detail::VT<V>::pack(pose1), gtsam::detail::VT<V>::pack(vel1),
+                       gtsam::detail::VT<V>::pack(pose2), gtsam::detail::VT<V>::pack(vel2), &Qc_, nullptr);
+    const int32_t left = 0;
+    std::vector<double> out(Dim), H((size_t)4 * Dim * Dim);
+    gtsam::detail::check(gpslam_hip_interpolate_velocities(s.h, 1, &left, &delta_t_, &tau_, out.data(), H.data()), s.h, "interpolate_velocities");
+    gtsam::Matrix *Hs[4] = {H1, H2, H3, H4};
+    for (int m = 0; m < 4; m++) detail_g::fill(Hs[m], Dim, Dim, H.data() + (size_t)m * Dim * Dim, Dim);
+    return gtsam::detail::VT<V>::un(out);
+  }
  private:
   gtsam::Matrix Qc_;
   double delta_t_, tau_;
 };
+
+// ---- getBodyCentricVb / getBodyCentricVs (gpslam.h:161-164, gpslam/gp/Pose3utils.cpp:17-24; Barfoot14tro eq. 25): the MATLAB
+// scripts initialise every velocity with them.  Evaluated on the device (gpslam_hip_body_centric_velocity); the batched
+// overloads take all pose pairs of a trajectory in one call.
+namespace detail_g {
+inline std::vector<gtsam::Vector6> body_centric(int which, const std::vector<gtsam::Pose3> &pose1, const std::vector<gtsam::Pose3> &pose2,
+                                                const std::vector<double> &delta_t) {
+  if (pose1.size() != pose2.size() || pose1.size() != delta_t.size()) throw std::invalid_argument("getBodyCentricV*: argument lengths differ");
+  const size_t n = pose1.size();
+  std::vector<gtsam::Vector6> out(n);
+  if (n == 0) return out;
+  gpslam_hip_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.manifold = GPSLAM_POSE3; cfg.nranks = 1;
+  gpslam_hip_handle *h = nullptr;
+  if (gpslam_hip_create(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+  std::vector<double> p1(n * 12), p2(n * 12), o(n * 6);
+  for (size_t i = 0; i < n; i++) {
+    const std::vector<double> a = gtsam::detail::VT<gtsam::Pose3>::pack(pose1[i]), b = gtsam::detail::VT<gtsam::Pose3>::pack(pose2[i]);
+    std::memcpy(&p1[i * 12], a.data(), sizeof(double) * 12);
+    std::memcpy(&p2[i * 12], b.data(), sizeof(double) * 12);
+  }
+  const int rc = gpslam_hip_body_centric_velocity(h, which, (int32_t)n, p1.data(), p2.data(), delta_t.data(), o.data());
+  const std::string msg = rc < 0 ? gpslam_hip_last_error(h) : "";
+  gpslam_hip_destroy(h);
+  if (rc < 0) throw std::invalid_argument("getBodyCentricV*: " + msg);
+  for (size_t i = 0; i < n; i++) for (int k = 0; k < 6; k++) out[i][k] = o[i * 6 + k];
+  return out;
+}
+}  // namespace detail_g
+inline gtsam::Vector6 getBodyCentricVb(const gtsam::Pose3 &pose1, const gtsam::Pose3 &pose2, double delta_t) {
+  return detail_g::body_centric(0, {pose1}, {pose2}, {delta_t})[0];
+}
+inline gtsam::Vector6 getBodyCentricVs(const gtsam::Pose3 &pose1, const gtsam::Pose3 &pose2, double delta_t) {
+  return detail_g::body_centric(1, {pose1}, {pose2}, {delta_t})[0];
+}
+inline std::vector<gtsam::Vector6> getBodyCentricVb(const std::vector<gtsam::Pose3> &pose1, const std::vector<gtsam::Pose3> &pose2, const std::vector<double> &delta_t) {
+  return detail_g::body_centric(0, pose1, pose2, delta_t);
+}
+inline std::vector<gtsam::Vector6> getBodyCentricVs(const std::vector<gtsam::Pose3> &pose1, const std::vector<gtsam::Pose3> &pose2, const std::vector<double> &delta_t) {
+  return detail_g::body_centric(1, pose1, pose2, delta_t);
+}
 
 }  // namespace gpslam

@@ -14,7 +14,9 @@
 //                gpslam_hip::HipChainOptimizerPose3 opt(graph, init, params);   (…Pose2 for SE(2) graphs)
 //      iterate() / optimize() / error() / values() / iterations() / lambda() keep GTSAM's meaning
 //      (call sites: matlab/PlazaPose2.m:208-228, gpslam/gp/tests/testGaussianProcessPriorPose3.cpp:185-188).
-// Graph requirements are those of the C ABI (include/gpslam_hip.h): keys Symbol('x'|'v'|'l', i), chain order, one Qc.
+// Graph requirements are those of the C ABI (include/gpslam_hip.h): keys Symbol('x'|'v'|'l', i), chain order (a factor couples
+// state i with state i + 1 only; checked, not assumed).  Every GP prior keeps its own Qc_model (gpslam_hip_add_gp_priors_qc).
+// CI without GTSAM type-checks this header against the declaration-only stand-ins of tests/cpp/gtsam_decl/ (-fsyntax-only).
 #pragma once
 
 #if defined(__has_include)
@@ -43,6 +45,7 @@
 
 #include <cstring>
 #include <map>
+#include <memory>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -99,10 +102,11 @@ GPSLAM_HIP_RECORDING_RANGE(GPInterpolatedRangeFactorPose2, gtsam::Pose2)
 namespace detail {
 inline std::vector<double> sigmas(const gtsam::SharedNoiseModel &m) {
   auto diag = boost::dynamic_pointer_cast<gtsam::noiseModel::Diagonal>(m);
-  if (!diag) throw std::invalid_argument("HipChainOptimizer: measurement noise models must be diagonal");
+  if (!diag) throw std::invalid_argument("HipChainOptimizer: the noise models of priors, odometry and range factors must be diagonal");
   const gtsam::Vector s = diag->sigmas();
   return std::vector<double>(s.data(), s.data() + s.size());
 }
+struct HandleDeleter { void operator()(gpslam_hip_handle *h) const { if (h) gpslam_hip_destroy(h); } };
 inline void pack(const gtsam::Pose3 &p, double *o) {
   const gtsam::Matrix3 R = p.rotation().matrix();
   for (int i = 0; i < 3; i++)
@@ -170,21 +174,30 @@ template <typename POSE> class HipChainOptimizerT {
     gpslam_hip_config cfg;
     std::memset(&cfg, 0, sizeof(cfg));
     cfg.manifold = TR::manifold; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.nranks = 1;
-    cfg.chart = (TR::manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;
+    cfg.chart = ((int)TR::manifold == (int)GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;
     cfg.landmark_dim = L > 0 ? TR::ld : 0;
-    if (gpslam_hip_create(&cfg, &h_) != 0) throw std::runtime_error("HipChainOptimizer: no usable HIP device");
+    {   // (owned from here on: whatever throws below, the handle is destroyed -- ADVICE r2)
+      gpslam_hip_handle *raw = nullptr;
+      if (gpslam_hip_create(&cfg, &raw) != 0) throw std::runtime_error("HipChainOptimizer: no usable HIP device");
+      hh_.reset(raw);
+      h_ = raw;
+    }
     check(gpslam_hip_set_states(h_, N, P.data(), V.data()), "set_states");
     if (L > 0) check(gpslam_hip_set_landmarks(h_, L, LM.data()), "set_landmarks");
     bool qc_set = false;
     for (const auto &f : graph) {
       if (!f) continue;
       if (auto gp = boost::dynamic_pointer_cast<typename TR::Prior>(f)) {
-        if (!qc_set) { set_qc(gp->gp.Qc); qc_set = true; }
-        const int32_t left = state_of(gp->key1());
-        check(gpslam_hip_add_gp_priors(h_, 1, &left, &gp->gp.delta_t), "add_gp_priors");
+        // the chain solver takes (x_i, v_i, x_i+1, v_i+1) only: verify it instead of reading key1() alone
+        const int32_t left = chain_left(gp->key1(), gp->key2(), gp->key3(), gp->key4());
+        if (!qc_set) { set_qc(gp->gp.Qc); qc_set = true; }      // (the shared Qc only serves interpolation queries)
+        std::vector<double> q((size_t)TR::d * TR::d);
+        for (int i2 = 0; i2 < TR::d; i2++)
+          for (int j2 = 0; j2 < TR::d; j2++) q[(size_t)i2 * TR::d + j2] = gp->gp.Qc(i2, j2);
+        check(gpslam_hip_add_gp_priors_qc(h_, 1, &left, &gp->gp.delta_t, q.data()), "add_gp_priors_qc");   // its own Qc_model
       } else if (auto rg = boost::dynamic_pointer_cast<typename TR::Range>(f)) {
-        if (!qc_set) { set_qc(rg->gp.Qc); qc_set = true; }
-        const int32_t left = state_of(rg->key1()), lm = lm_of(rg->key5());
+        // (an interpolated factor's Qc_model has no effect on its error or Jacobians: Qc cancels in Lambda and Psi)
+        const int32_t left = chain_left(rg->key1(), rg->key2(), rg->key3(), rg->key4()), lm = lm_of(rg->key5());
         const std::vector<double> sg = detail::sigmas(rg->noiseModel());
         double sensor[12];
         if (rg->sensor) detail::pack(*rg->sensor, sensor);
@@ -234,7 +247,6 @@ template <typename POSE> class HipChainOptimizerT {
     lambda_ = p_.lambda_initial;
     check(gpslam_hip_error(h_, &error_), "error");
   }
-  ~HipChainOptimizerT() { if (h_) gpslam_hip_destroy(h_); }
   HipChainOptimizerT(const HipChainOptimizerT &) = delete;
   HipChainOptimizerT &operator=(const HipChainOptimizerT &) = delete;
 
@@ -297,11 +309,23 @@ template <typename POSE> class HipChainOptimizerT {
     if (it == states_.end()) throw std::invalid_argument("HipChainOptimizer: factor refers to an unknown state");
     return (int32_t)it->second;
   }
+  /// left state of a factor on (pose1, vel1, pose2, vel2): 'x' / 'v' symbols, matching indices, consecutive states
+  int32_t chain_left(gtsam::Key pose1, gtsam::Key vel1, gtsam::Key pose2, gtsam::Key vel2) const {
+    const gtsam::Symbol p1(pose1), v1(vel1), p2(pose2), v2(vel2);
+    if (p1.chr() != 'x' || p2.chr() != 'x' || v1.chr() != 'v' || v2.chr() != 'v')
+      throw std::invalid_argument("HipChainOptimizer: GP factors take keys (x_i, v_i, x_j, v_j) in this order");
+    if (v1.index() != p1.index() || v2.index() != p2.index())
+      throw std::invalid_argument("HipChainOptimizer: the velocity keys of a GP factor must carry the indices of its pose keys");
+    const int32_t left = state_of(pose1);
+    if (state_of(pose2) != left + 1) throw std::invalid_argument("HipChainOptimizer: GP factors must join consecutive states (chain structure)");
+    return left;
+  }
   int32_t lm_of(gtsam::Key k) const {
     auto it = lms_.find(gtsam::Symbol(k).index());
     if (it == lms_.end()) throw std::invalid_argument("HipChainOptimizer: factor refers to an unknown landmark");
     return (int32_t)it->second;
   }
+  std::unique_ptr<gpslam_hip_handle, detail::HandleDeleter> hh_;   // owns the handle, also when the constructor throws
   gpslam_hip_handle *h_ = nullptr;
   gpslam_hip_params p_;
   std::map<uint64_t, int> states_, lms_;

@@ -285,6 +285,11 @@ int gpslam_hip_segment_plan(gpslam_hip_handle *h, int32_t out8[8]);
 /* time (ms) of the last iterate call's phases measured with hipEvents on the handle's stream:
  * out[0] linearize, out[1] assemble, out[2] solve, out[3] retract+error, out[4] total */
 int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
+/* device time (ms) of the LEVEL-0 FORWARD launch -- on Pose3 chains k_fused_level0, the dominant kernel -- summed over the
+ * iterations of the last timed run_gn / iterate_gn: the kernel as it runs INSIDE an iteration (behind the linearisation,
+ * caches as an iteration leaves them), which is what bench.py's roofline fraction is computed from (time_kernel's isolated
+ * launches are faster).  0 on the segmented landmark path. */
+int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms);
 /* run `iters` Gauss-Newton iterations back to back with no host synchronisation in between (the benchmark
  * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL.
  * The error of the state an iteration produces is the error the next iteration's linearisation evaluates, so

@@ -526,6 +526,74 @@ static void test_ahrs_graph_with_bias_states() {
   gpslam_hip_destroy(h);
 }
 
+// Round 3: what the reference's constructors accept and the ABI could not yet express -- one Qc_model per GP prior
+// (GaussianProcessPriorPose2.h:42-48), a full Gaussian noise model on a measurement factor (GPInterpolatedGPSFactorPose3.h:46-54),
+// GaussianProcessInterpolatorLinear::interpolateVelocity (GaussianProcessInterpolatorLinear.h:106-126) and getBodyCentricVb / Vs
+// (Pose3utils.cpp:17-24; values of testPose3Utils.cpp's scenario: a pure translation and a pure rotation).
+static void test_round3_boundary_additions() {
+  {   // two GP priors with DIFFERENT Qc_models in one graph: zero-error fixed point, and a stiffer Qc pulls harder
+    auto prior = noiseModel::Isotropic::Sigma(3, 0.001);
+    auto QcA = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    Matrix qb = 0.5 * Matrix::Identity(3); qb(0, 1) = qb(1, 0) = 0.1;
+    auto QcB = noiseModel::Gaussian::Covariance(qb);
+    Vector3 v = {1, 0, 0};
+    NonlinearFactorGraph graph;
+    graph.add(PriorFactor<Pose2>(Symbol('x', 1), Pose2(0, 0, 0), prior));
+    graph.add(PriorFactor<Pose2>(Symbol('x', 3), Pose2(2, 0, 0), prior));
+    graph.add(GaussianProcessPriorPose2(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 1.0, QcA));
+    graph.add(GaussianProcessPriorPose2(Symbol('x', 2), Symbol('v', 2), Symbol('x', 3), Symbol('v', 3), 1.0, QcB));
+    Values init;
+    init.insert(Symbol('x', 1), Pose2(0.1, 0.05, 0.02)); init.insert(Symbol('v', 1), Vector3{0.8, 0.1, 0.0});
+    init.insert(Symbol('x', 2), Pose2(0.9, -0.1, 0.05)); init.insert(Symbol('v', 2), Vector3{1.2, 0.0, 0.1});
+    init.insert(Symbol('x', 3), Pose2(2.1, 0.1, -0.03)); init.insert(Symbol('v', 3), Vector3{0.9, -0.1, 0.0});
+    LevenbergMarquardtOptimizer opt(graph, init);
+    opt.optimize();
+    Values r = opt.values();
+    EXPECT_NEAR(0, graph.error(r), 1e-6);
+    EXPECT_NEAR(1.0, r.at<Pose2>(Symbol('x', 2)).x, 1e-4);
+    EXPECT(nearV(v, r.at<Vector3>(Symbol('v', 2)), 1e-4));
+  }
+  {   // a GPS fix with a full covariance: the optimum of  prior + gps  on one coordinate pair is the covariance-weighted mean
+    auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+    Matrix cov = 0.04 * Matrix::Identity(3); cov(0, 1) = cov(1, 0) = 0.02;
+    auto gps_model = noiseModel::Gaussian::Covariance(cov);
+    auto diag_model = noiseModel::Isotropic::Sigma(3, 0.2);
+    Pose3 p1, p2(Rot3(), Point3(0.1, 0, 0));
+    Vector6 v = {0, 0, 0, 1, 0, 0};
+    for (int full = 0; full < 2; full++) {
+      GPInterpolatedGPSFactorPose3 f(Point3(0.05, 0.01, 0), full ? gps_model : diag_model, Qc_model, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, 0.05);
+      NonlinearFactorGraph g;
+      g.add(f);
+      Values vals;
+      vals.insert(Symbol('x', 1), p1); vals.insert(Symbol('v', 1), v); vals.insert(Symbol('x', 2), p2); vals.insert(Symbol('v', 2), v);
+      // e = (0, -0.01, 0): error = 0.5 e^T cov^-1 e
+      const double e1 = -0.01;
+      const double expect = full ? 0.5 * e1 * e1 * (0.04 / (0.04 * 0.04 - 0.02 * 0.02)) : 0.5 * e1 * e1 / 0.04;
+      EXPECT_NEAR(expect, g.error(vals), 1e-12);
+    }
+  }
+  {   // interpolateVelocity: constant velocity in, the same velocity out; H2 + H4 blocks at tau = 0 are [I, 0]
+    auto Qc3 = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
+    GaussianProcessInterpolatorLinear<3> lin(Qc3, 0.1, 0.03), at0(Qc3, 0.1, 0.0);
+    Vector3 a = {0, 0, 0}, va = {1, 2, 3}, b = {0.1, 0.2, 0.3};
+    Vector3 qv = lin.interpolateVelocity(a, va, b, va);
+    EXPECT(nearV(va, qv, 1e-12));
+    Matrix H1, H2, H3, H4;
+    Vector3 q0 = at0.interpolateVelocity(a, va, b, Vector3{4, 5, 6}, &H1, &H2, &H3, &H4);
+    EXPECT(nearV(va, q0, 1e-12));
+    for (int i = 0; i < 3; i++) { EXPECT_NEAR(1.0, H2(i, i), 1e-12); EXPECT_NEAR(0.0, H1(i, i), 1e-12); EXPECT_NEAR(0.0, H3(i, i), 1e-12); EXPECT_NEAR(0.0, H4(i, i), 1e-12); }
+  }
+  {   // body-centric velocities: a pure translation along x in 0.1 s, then a yaw of 0.1 rad in 0.1 s
+    Pose3 a, b(Rot3(), Point3(0.1, 0, 0)), c(Rot3::Ypr(0.1, 0, 0), Point3(0, 0, 0));
+    Vector6 vb = getBodyCentricVb(a, b, 0.1), vs = getBodyCentricVs(a, b, 0.1);
+    EXPECT(nearV(Vector6{0, 0, 0, 1, 0, 0}, vb, 1e-12) && nearV(Vector6{0, 0, 0, 1, 0, 0}, vs, 1e-12));
+    Vector6 wb = getBodyCentricVb(a, c, 0.1);
+    EXPECT(nearV(Vector6{0, 0, 1, 0, 0, 0}, wb, 1e-12));
+    std::vector<Vector6> many = getBodyCentricVb(std::vector<Pose3>{a, a}, std::vector<Pose3>{b, c}, std::vector<double>{0.1, 0.1});
+    EXPECT(many.size() == 2 && nearV(vb, many[0], 0) && nearV(wb, many[1], 0));
+  }
+}
+
 int main() {
   test_gp_prior_pose3_optimization();
   test_gp_prior_pose2_rot3_linear_optimization();
@@ -537,6 +605,7 @@ int main() {
   test_evaluate_error_and_interpolators();
   test_error_conventions();
   test_ahrs_graph_with_bias_states();
+  test_round3_boundary_additions();
   if (failures == 0) std::printf("host_api_tests: all tests passed\n");
   return failures == 0 ? 0 : 1;
 }

@@ -107,3 +107,24 @@ def test_cpp_split_host_runs_config4_pieces():
     out = subprocess.run([_build_split_exe()], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def test_gtsam_only_files_type_check_against_declaration_headers():
+    """gtsam_adapter.hpp and bench/gtsam_reference.cpp have no compiler anywhere this project is built (no GTSAM, no Boost, no
+    reference install).  tests/cpp/gtsam_decl/ declares -- bodies none, behaviour none -- the GTSAM / gpslam names they use,
+    so that both translation units are at least type-checked: both optimizer instantiations of the
+    adapter, and the reference benchmark's live branch."""
+    decl = os.path.join(ROOT, "tests", "cpp", "gtsam_decl")
+    src = os.path.join(ROOT, "tests", "cpp", "_adapter_live_tu.cpp")
+    with open(src, "w") as f:
+        f.write('#include "../../gpslam_amd/host/gtsam_adapter.hpp"\n#ifndef GPSLAM_HIP_HAVE_GTSAM\n#error "declaration headers not found"\n#endif\n'
+                'template class gpslam_hip::HipChainOptimizerT<gtsam::Pose3>;\ntemplate class gpslam_hip::HipChainOptimizerT<gtsam::Pose2>;\n'
+                'int main() { return 0; }\n')
+    try:
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", decl, src])
+    finally:
+        os.remove(src)
+    ref = os.path.join(ROOT, "bench", "gtsam_reference.cpp")
+    pre = subprocess.run(["g++", "-std=c++17", "-E", "-dM", "-I", decl, ref], capture_output=True, text=True, check=True).stdout
+    assert "HAVE_REFERENCE" in pre                       # the live branch is the one being checked
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", decl, ref])
