@@ -4,7 +4,7 @@
 // A dense landmark border (kernels.hpp k_lm_*) carries every landmark column through the whole chain: R = 1 + L ld
 // right-hand sides, impossible for L = 5e4.  Here the chain is cut by nested dissection instead:
 //   * CUT states every C states; every landmark is attached to ONE cut such that all states its factors touch lie in the
-//     two segments next to that cut.  A cut state plus its landmarks is a FAT SEPARATOR (NB = 2d + ld * landmarks <= 64
+//     two segments next to that cut.  A cut state plus its landmarks is a FAT SEPARATOR (NB = 2d + ld * landmarks <= 80
 //     columns).  compile() picks the smallest C for which every landmark fits (a landmark seen from more than two
 //     segments does not; the segment length is doubled until all do).
 //   * every segment interior (a plain block-tridiagonal chain) is eliminated against its NC = 2 NB + 1 border columns
@@ -29,7 +29,9 @@
 
 namespace gps {
 
-constexpr int kFatMax = 64;   // largest fat block (cut state + landmark columns)
+constexpr int kFatMax = 80;   // largest fat block (cut state + landmark columns).  Round 3: 64 -> 80, what one workgroup's LDS
+                              // holds of the three NB x NB operands of k_fat_elim (155 KB of 160); config 4's graph needs 36, twice
+                              // its landmark density 62.  Beyond 80 the fat-block elimination would have to be tiled.
 
 template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jacobian row tables (kernels.hpp, LmArgs)
   int N, B, ld, L, K, NB, NC, NCP;   // K cuts / fat blocks; NC = 2 NB + 1 border columns; NCP = NC rounded up to 16
@@ -484,7 +486,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 // cores.  One wave per (segment, 16-row tile): v_mfma_f64_16x16x4_f64, A[i][k] = Y[k][i0 + i], B[k][j] = Y[k][j0 + j]
 // (lane l holds A[l & 15][l >> 4] and B[l >> 4][l & 15]); C: col = lane & 15, row = (lane >> 4) + 4 * reg.
 typedef double fs_d4 __attribute__((ext_vector_type(4)));
-__host__ __device__ inline int fs_lds_stride(int ncp) { return ((ncp + 31) / 32) * 32 + 16; }
+__host__ __device__ inline int fs_lds_stride(int ncp) { return ((ncp + 31) / 32) * 32 + 16; }   // (k_fs_syrk: of the instantiation's NCM)
 // Y^T Y is symmetric: only the tiles on and below the diagonal (tile column <= tile row) are formed; readers use fs_sym.
 // One 4-wave workgroup per segment.  The K dimension is walked in chunks of KC rows that the workgroup stages ONCE in
 // LDS (coalesced 16-byte loads into registers while the matrix cores work on the current chunk, committed to the other
@@ -497,83 +499,92 @@ __host__ __device__ inline int fs_lds_stride(int ncp) { return ((ncp + 31) / 32)
 // (12 accumulator tiles + the sweep's state) leave two workgroups per CU, and per 24-row chunk the workgroup then pays the
 // sweep's four dependent steps (LDS-fed 6 x 6 products on two of its four waves), the gather of the next chunk's right-hand
 // sides and the MFMAs one after the other: 10 us per chunk instead of 4.3.
-// Round 3: two instantiations (TPW accumulator tiles per wave, NCM = widest staged chunk row): <7, 112> serves borders up to 112
-// columns (config 4: 80) and is 0.4 ms per iteration faster there than the <12, 144> that serves everything wider.  A variant
-// that requested chunks two iterations ahead (two register sets, loop unrolled by two, LDS-only barriers) was measured at the
-// same time as the one-ahead loop: the kernel is not waiting for its prefetch -- its 1600 VALU instructions per wave and chunk
-// (index arithmetic of the runtime tile / piece geometry around 24 MFMAs) are what it spends its time on
-// (SQ_INSTS_VALU / SQ_WAVES / chunks, profiles/round3_c4_kernel_stats.md).
+// Round 3: two instantiations (TPW accumulator tiles per wave, NCM = widest staged chunk row = LDS row stride): <7, 112> serves
+// borders up to 112 columns (config 4: 80), <12, 144> everything wider.  Also measured: chunks requested two iterations ahead
+// (two register sets, LDS-only barriers) -- no change, the kernel does not wait for its prefetch; piece / tile offsets formed
+// once before the chunk loop with a compile-time stride (kept) -- 2 %.  SQ_INSTS_VALU / SQ_WAVES: ~1600 VALU instructions per
+// wave and chunk around 24 MFMAs (profiles/round3_c4_kernel_stats.md).
 template <int TPW, int NCM, typename TR = double> __global__ void __launch_bounds__(256) k_fs_syrk(FsArgs<double, TR> a) {
   constexpr int KC = 24;                                   // rows per chunk: 4 states of 6, 2 of 12, 6 of 4
+  // LDS row stride: a multiple of 32 doubles plus 16, so that the four chunk rows an MFMA operand load touches (16 lanes x
+  // 8 bytes each) fall into different bank groups; with the plain stride NCP = 96 they all hit the same banks (4-way
+  // conflict on every operand load: the kernel was LDS-bandwidth bound at 0.40 of the matrix peak).  Round 3: the stride is
+  // a COMPILE-TIME constant (that of the widest border the instantiation serves) and every per-thread piece / tile offset is
+  // formed once, before the chunk loop: the loop had spent ~1600 VALU instructions per wave and chunk on the index
+  // arithmetic of its runtime geometry (integer divisions by the row width, tile origins) around 24 MFMAs.
+  constexpr int LSP = ((NCM + 31) / 32) * 32 + 16;
   extern __shared__ __align__(16) unsigned char syrk_smem[];
   double *buf = reinterpret_cast<double *>(syrk_smem);      // 2 x KC x LSP
   const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int NCP = a.NCP;
   // When the right-hand side column (index 2 NB) sits alone in the last 16-column tile (NB a multiple of 8: 40 at config 4's
-  // landmark density), the matrix cores only see the 2 NB fat columns -- 15 tiles of the lower triangle instead of 21 -- and
-  // the row of the Schur complement that belongs to the right-hand side (2 NB dot products over the chunk rows) is summed on
-  // the vector ALU by two of the four waves out of the same LDS chunk; the fetch then skips the padding columns as well.
+  // round-2 landmark density), the matrix cores only see the 2 NB fat columns and the row of the Schur complement that belongs
+  // to the right-hand side (2 NB dot products over the chunk rows) is summed on the vector ALU by two of the four waves out
+  // of the same LDS chunk; the fetch then skips the padding columns as well.
   const bool rhs_alone = ((2 * a.NB) % 16) == 0;
   const int T16 = rhs_alone ? (2 * a.NB) / 16 : NCP / 16, ntiles = T16 * (T16 + 1) / 2;
   const int NCF = rhs_alone ? 2 * a.NB + 2 : NCP;           // columns fetched per chunk row (even: 16-byte pieces)
-  // LDS row stride: a multiple of 32 doubles plus 16, so that the four chunk rows an MFMA operand load touches (16 lanes x
-  // 8 bytes each) fall into different bank groups; with the plain stride NCP = 96 they all hit the same banks (4-way
-  // conflict on every operand load: the kernel was LDS-bandwidth bound at 0.40 of the matrix peak)
-  const int LSP = fs_lds_stride(NCP);
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   const int kdim = n * a.B;
   const double *Yb = a.Y + (size_t)j0 * a.B * NCP;
+  const int kl = lane >> 4, cl = lane & 15;
   fs_d4 acc[TPW];
-  int tti[TPW], ttj[TPW];
+  int aoff[TPW], boff[TPW], ooff[TPW];                     // operand offsets inside a chunk (row kl), output offset of the tile
+  int nq = 0;                                               // tiles of this wave: p = (3 - wv) + 4 q of the lower triangle, row-major
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
     acc[q] = fs_d4{0.0, 0.0, 0.0, 0.0};
-    const int pidx = (3 - wv) + 4 * q;                      // tile p of the lower triangle, row-major: (ti, tj <= ti); the
-                                                            // low waves get one tile fewer (they also sum the rhs row)
+    const int pidx = (3 - wv) + 4 * q;                      // (the low waves get one tile fewer: they also sum the rhs row)
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= pidx) ti++;
-    tti[q] = ti;
-    ttj[q] = pidx - ti * (ti + 1) / 2;
+    const int tj = pidx - ti * (ti + 1) / 2;
+    aoff[q] = kl * LSP + ti * 16 + cl;
+    boff[q] = kl * LSP + tj * 16 + cl;
+    ooff[q] = (ti * 16 + kl) * NCP + tj * 16 + cl;
+    if (pidx < ntiles) nq = q + 1;
   }
+  nq = __builtin_amdgcn_readfirstlane(nq);
   typedef double V2 __attribute__((ext_vector_type(2)));
   const int chunk_v2 = KC * NCF / 2;                        // 16-byte pieces per chunk
   constexpr int PV = (KC * NCM / 2 + 255) / 256;            // pieces per thread at the widest chunk row of this instantiation
   V2 pre[PV];
+  int prow[PV], goff[PV], loff[PV];                         // chunk row, offset in Y, offset in the LDS chunk of the thread's pieces
+#pragma unroll
+  for (int u = 0; u < PV; u++) {
+    const int v = min(tid + u * 256, chunk_v2 - 1);
+    const int row = (2 * v) / NCF, col = 2 * v - row * NCF;
+    prow[u] = (tid + u * 256 < chunk_v2) ? row : 0x3fffffff;   // pieces beyond the chunk: never valid
+    goff[u] = row * NCP + col;
+    loff[u] = row * LSP + col;
+  }
   auto fetch = [&](int c) {                                 // global -> registers (in flight under the MFMAs)
     const int k0 = c * KC;
+    const double *yc = Yb + (size_t)k0 * NCP;
 #pragma unroll
     for (int u = 0; u < PV; u++) {
-      const int v = tid + u * 256;
       pre[u] = V2{0.0, 0.0};
-      const int row = (2 * v) / NCF, col = 2 * v - row * NCF;
-      if (v < chunk_v2 && k0 + row < kdim) pre[u] = *reinterpret_cast<const V2 *>(Yb + (size_t)(k0 + row) * NCP + col);   // (a nontemporal load: no change)
+      if (k0 + prow[u] < kdim) pre[u] = *reinterpret_cast<const V2 *>(yc + goff[u]);   // (a nontemporal load: no change)
     }
   };
   auto commit = [&](int which) {                            // registers -> LDS
+    double *bc = buf + (size_t)which * KC * LSP;
 #pragma unroll
-    for (int u = 0; u < PV; u++) {
-      const int v = tid + u * 256;
-      if (v < chunk_v2) {
-        const int row = (2 * v) / NCF, col = 2 * v - row * NCF;
-        *reinterpret_cast<V2 *>(buf + (size_t)which * KC * LSP + (size_t)row * LSP + col) = pre[u];
-      }
-    }
+    for (int u = 0; u < PV; u++)
+      if (prow[u] < KC) *reinterpret_cast<V2 *>(bc + loff[u]) = pre[u];
   };
   const int nchunks = (kdim + KC - 1) / KC;
   if (nchunks > 0) { fetch(0); commit(0); }
   __syncthreads();
-  const int kl = lane >> 4, cl = lane & 15;
   double racc = 0.0;
   for (int c = 0; c < nchunks; c++) {
     if (c + 1 < nchunks) fetch(c + 1);
     const double *bb = buf + (size_t)(c & 1) * KC * LSP;
 #pragma unroll
     for (int k4 = 0; k4 < KC; k4 += 4) {
-      const double *yr = bb + (size_t)(k4 + kl) * LSP;
 #pragma unroll
       for (int q = 0; q < TPW; q++) {
-        if ((3 - wv) + 4 * q < ntiles) {
-          const double av = yr[tti[q] * 16 + cl], bv = yr[ttj[q] * 16 + cl];
+        if (q < nq) {                                       // (wave-uniform)
+          const double av = bb[aoff[q] + k4 * LSP], bv = bb[boff[q] + k4 * LSP];
           acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[q], 0, 0, 0);
         }
       }
@@ -581,7 +592,7 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
     if (rhs_alone && wv < 2) {                               // row 2 NB of Y^T Y: column jr against the rhs column
       const int jr = min(lane + 64 * wv, 2 * a.NB);
 #pragma unroll
-      for (int k = 0; k < KC; k++) racc += bb[(size_t)k * LSP + jr] * bb[(size_t)k * LSP + 2 * a.NB];
+      for (int k = 0; k < KC; k++) racc += bb[k * LSP + jr] * bb[k * LSP + 2 * a.NB];
     }
     if (c + 1 < nchunks) commit((c + 1) & 1);
     __syncthreads();
@@ -590,9 +601,9 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
   if (rhs_alone && wv < 2 && lane + 64 * wv <= 2 * a.NB) out[(size_t)(2 * a.NB) * NCP + lane + 64 * wv] = racc;
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
-    if ((3 - wv) + 4 * q < ntiles) {
+    if (q < nq) {
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) out[(size_t)(tti[q] * 16 + kl + 4 * rg) * NCP + ttj[q] * 16 + cl] = acc[q][rg];
+      for (int rg = 0; rg < 4; rg++) out[ooff[q] + 4 * rg * NCP] = acc[q][rg];
     }
   }
 }
@@ -1363,14 +1374,14 @@ struct FatSepPlan {
       const int nb = B + ld * mx;
       if (ok && nb <= kFatMax) { C = Ctry; NB = (nb + 3) & ~3; if (NB > kFatMax) NB = kFatMax; break; }
       if (c_forced > 0 || K <= 2) {
-        err = ok ? "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 64)"
+        err = ok ? "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)"
                  : (split ? "no segmentation of this piece keeps its private landmarks off the shared end blocks and the shared ones inside the "
                             "end segments: the piece is too short for the landmarks' windows of visibility (use fewer, longer pieces)"
                           : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists");
         return false;
       }
       if (ok && nb > kFatMax) {   // longer segments only add landmarks per cut
-        err = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 64)";
+        err = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)";
         return false;
       }
     }

@@ -17,7 +17,7 @@ the tests and in bench.py's cpu_baseline leg), so both sides see bit-identical i
 """
 import numpy as np
 
-LINEAR2, LINEAR3, POSE2, POSE3, ROT3 = 0, 1, 2, 3, 4
+LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 SEED_BASE = 0x6770736C616D  # "gpslam"
 
 
@@ -285,6 +285,59 @@ def pose3_gps_chain(N, per_interval=4, seed=0, dt=0.1, keep_odometry=False):
     return p
 
 
+def _so3_right_jacobian(w):
+    """Rot3::ExpmapDerivative, batched (GTSAM's closed form; series near zero)"""
+    th2 = np.sum(w * w, -1)
+    th = np.sqrt(np.maximum(th2, 1e-300))
+    W = _skew(w)
+    a = np.where(th2 > 1e-16, (1.0 - np.cos(th)) / np.maximum(th2, 1e-300), 0.5 - th2 / 24.0)
+    b = np.where(th2 > 1e-16, (th - np.sin(th)) / np.maximum(th2 * th, 1e-300), 1.0 / 6.0 - th2 / 120.0)
+    return np.eye(3) - a[..., None, None] * W + b[..., None, None] * (W @ W)
+
+
+def rot3_bias_ahrs_chain(N, seed=0, dt=0.1, qc_sigma=1.0, gyro_sigma=0.03, acc_sigma=0.1, acc_every=4, bias_walk=1e-4):
+    """C5 as matlab/GPAHRSexample.m:69-209 builds it, at any size: one (rotation, gyroscope bias | angular velocity) state per
+    time stamp (GPSLAM_ROT3_BIAS), per interval one gtsam::AHRSFactor of a single pre-integrated gyroscope sample
+    (PreintegratedAhrsMeasurements::integrateMeasurement, biasHat = 0) + BetweenFactorVector on the bias +
+    GaussianProcessPriorRot3; a Rot3AttitudeFactor (accelerometer, = the interpolated factor at tau = dt) on every
+    acc_every-th state, alternating between the body z and x axes so that the heading is observable; priors on the first state."""
+    rng = np.random.default_rng(SEED_BASE + 7 + seed)
+    i = np.arange(N - 1)
+    omega = np.stack([0.3 * np.sin(0.004 * i), 0.2 * np.cos(0.006 * i + 0.5), 0.4 + 0.1 * np.sin(0.002 * i)], -1)
+    R = np.zeros((N, 3, 3))
+    R[0] = np.eye(3)
+    R[1:], _ = se3_prefix(so3_exp(dt * omega), np.zeros((N - 1, 3)))
+    bias_true = np.array([0.02, -0.01, 0.015]) + bias_walk * np.cumsum(rng.standard_normal((N, 3)), axis=0)
+    # one gyroscope sample per interval: omega_m = omega + bias + noise;  incrR = Exp(omega_m dt), D = Jr(omega_m dt)
+    wm = omega + bias_true[:-1] + gyro_sigma * rng.standard_normal((N - 1, 3))
+    dR = so3_exp(wm * dt)
+    dRdb = -dt * _so3_right_jacobian(wm * dt)
+    cov = np.tile(gyro_sigma ** 2 * dt * np.eye(3), (N - 1, 1, 1))
+    pose = np.zeros((N, 12))
+    pose[:, :9] = (R @ so3_exp(0.03 * rng.standard_normal((N, 3)))).reshape(N, 9)          # noisy initial attitudes, zero bias
+    vel = np.zeros((N, 6))
+    vel[:-1, :3] = wm
+    vel[-1, :3] = wm[-1]
+    truth = np.zeros((N, 12))
+    truth[:, :9], truth[:, 9:] = R.reshape(N, 9), bias_true
+    right = np.arange(acc_every, N, acc_every)                                              # states with an accelerometer sample
+    M = len(right)
+    bref = np.tile([0.0, 0.0, 1.0], (M, 1))
+    bref[1::2] = [1.0, 0.0, 0.0]
+    nz = np.einsum("nij,nj->ni", R[right], bref) + acc_sigma * rng.standard_normal((M, 3))
+    nz /= np.linalg.norm(nz, axis=1, keepdims=True)
+    ident_bias0 = np.concatenate([np.eye(3).reshape(9), np.zeros(3)])
+    return dict(kind=ROT3_BIAS, name="C5 AHRS: rot3 + gyroscope bias chain", N=N, qc=qc_sigma ** 2 * np.eye(3), pose=pose, vel=vel, truth=truth,
+                gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=np.full(N - 1, dt),
+                prior_idx=np.array([0], dtype=np.int32), prior_pose=truth[:1].copy(), prior_sig=np.array([[0.1, 0.1, 0.1, 1e-2, 1e-2, 1e-2]]),
+                between_left=np.arange(N - 1, dtype=np.int32), between_meas=np.tile(ident_bias0, (N - 1, 1)),
+                between_sig=np.tile([np.inf] * 3 + [10 * bias_walk] * 3, (N - 1, 1)),
+                ahrs_left=np.arange(N - 1, dtype=np.int32), ahrs_dR=dR.reshape(-1, 9), ahrs_dRdb=dRdb.reshape(-1, 9), ahrs_bias_hat=np.zeros((N - 1, 3)),
+                ahrs_dt=np.full(N - 1, dt), ahrs_cov=cov.reshape(-1, 9),
+                att_left=(right - 1).astype(np.int32), att_nz=nz, att_bref=bref, att_sigma=np.full((M, 2), acc_sigma),
+                att_dt=np.full(M, dt), att_tau=np.full(M, dt))
+
+
 def apply(problem, solver):
     """Feed a problem description to a solver (ChainSolver or oracle.Chain) and compile it."""
     p = problem
@@ -305,6 +358,8 @@ def apply(problem, solver):
             solver.add_interp_range(p["range_left"], p["range_lm"], p["range_z"], p["range_sigma"], p["range_dt"], p["range_tau"])
     if "gps_left" in p:
         solver.add_interp_gps(p["gps_left"], p["gps_meas"], p["gps_sigma"], p["gps_dt"], p["gps_tau"])
+    if "ahrs_left" in p:
+        solver.add_ahrs(p["ahrs_left"], p["ahrs_dR"], p["ahrs_dRdb"], p["ahrs_bias_hat"], p["ahrs_dt"], p["ahrs_cov"], None)
     if "att_left" in p:
         solver.add_interp_attitude(p["att_left"], p["att_nz"], p["att_bref"], p["att_sigma"], p["att_dt"], p["att_tau"])
     solver.compile()

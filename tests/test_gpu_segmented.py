@@ -34,6 +34,26 @@ def test_c4_local_landmarks_gauss_newton_matches_oracle(N, seglen):
     assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
 
 
+def test_twice_config4_landmark_density_matches_oracle():
+    """config 4 sat at NB = 40 of 64 and 1.6x its landmark density did not compile.  Round 3: balanced landmark-to-cut
+    assignment (config 4: NB = 36) and fat blocks up to 80 columns.  Here L = N / 10 (twice config 4's density, ~28 landmarks
+    per cut: NB above the old limit of 64) against the oracle's dense bordered solve."""
+    N = 2600
+    p = S.pose2_local_landmarks_chain(N, L=N // 10, window=200)
+    orc, dev = _pair(p)
+    plan = dev.segment_plan()
+    assert plan["active"] == 1 and plan["NB"] > 48, plan
+    assert abs(orc.error() - dev.error()) <= 1e-10 * orc.error()
+    for it in range(4):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (it, s0.error_after, s1.error_after)
+    states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
+    l0, l1 = orc.get_landmarks(), dev.get_landmarks()
+    assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
+
+
 def test_segmented_path_equals_dense_border_on_a_small_graph():
     """The same small graph (8 landmarks seen from everywhere would not segment; 6 local ones do) through both landmark
     paths of the library."""
