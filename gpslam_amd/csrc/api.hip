@@ -113,6 +113,13 @@ struct gpslam_hip_handle {
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;
   double last_ms[5] = {0, 0, 0, 0, 0};
+  // deferred reductions inside run_gn / iterate_gn (chains without landmarks, unsharded): the error partial sums of the
+  // linearisation are summed by an extra workgroup of k_retract, the |delta|_inf partial maxima of the retraction by an
+  // extra workgroup of the NEXT iteration's k_lin -- two launches (+ their gaps) less per iteration, same values, same order
+  DevBuf partial2;            // the retraction's per-block maxima (its own buffer: the linearisation reuses `partial`)
+  bool defer_err = false, defer_dmax = false;   // what the call being enqueued may defer (enqueue_gn)
+  int pend_err_n = 0, pend_err_slot = 0;        // pending: error partials in `partial`
+  int pend_dmax_n = 0, pend_dmax_slot = 0;      // pending: maxima in `partial2`
   bool time_l0 = false;       // a timed iteration also stamps the end of the level-0 forward launch (ev[5])
   double l0_ms = 0.0;         // ... accumulated over the last timed run: the dominant kernel INSIDE an iteration
   double ph_lambda = 0.0;
@@ -462,7 +469,7 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
                     &h->d_gp_row0, &h->rowLR, &h->rowE, &h->rowC, &h->rowCE, &h->crowptr, &h->rowM, &h->rowLm, &h->rowptr, &h->partial, &h->lmrow,
                     &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
-                    &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU, &h->gsave2};
+                    &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU, &h->gsave2, &h->partial2};
   for (DevBuf *b : bufs) b->release();
   for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
   for (MeasSet &s : h->ms) s.release();

@@ -197,6 +197,77 @@ template <> __device__ __forceinline__ void lane_gather<6>(double v, double *d) 
       : "v"(v));
 }
 
+// ---- d[i] += M(m0 + i * S) * m for i < N, where matrix element e lives in lane (e & 15) of every 16-lane row of register
+// Mr[e >> 4] (wave-uniform matrices held ONCE per DPP row instead of being re-read from LDS as broadcast operands: k_fs_sweep_syrk).
+// The registers Mr come from memory loads, not from VALU writes, but the block still opens with s_nop 1 (a register copy the
+// allocator might place in front of the block would be a VALU write of a DPP source).
+template <int M0, int S> __device__ __forceinline__ void fmac_mat1(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15));
+}
+template <int M0, int S> __device__ __forceinline__ void fmac_mat2(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%5 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(Mr[(M0 + 1 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15), "n"((M0 + 1 * S) & 15));
+}
+template <int M0, int S> __device__ __forceinline__ void fmac_mat3(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%7 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%8 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(Mr[(M0 + 1 * S) >> 4]), "v"(Mr[(M0 + 2 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15), "n"((M0 + 1 * S) & 15), "n"((M0 + 2 * S) & 15));
+}
+template <int M0, int S> __device__ __forceinline__ void fmac_mat4(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%10 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%11 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%12 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(Mr[(M0 + 1 * S) >> 4]), "v"(Mr[(M0 + 2 * S) >> 4]), "v"(Mr[(M0 + 3 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15), "n"((M0 + 1 * S) & 15), "n"((M0 + 2 * S) & 15), "n"((M0 + 3 * S) & 15));
+}
+template <int M0, int S> __device__ __forceinline__ void fmac_mat5(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %5, %10 row_newbcast:%11 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %1, %6, %10 row_newbcast:%12 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %7, %10 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %3, %8, %10 row_newbcast:%14 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %9, %10 row_newbcast:%15 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(Mr[(M0 + 1 * S) >> 4]), "v"(Mr[(M0 + 2 * S) >> 4]), "v"(Mr[(M0 + 3 * S) >> 4]), "v"(Mr[(M0 + 4 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15), "n"((M0 + 1 * S) & 15), "n"((M0 + 2 * S) & 15), "n"((M0 + 3 * S) & 15), "n"((M0 + 4 * S) & 15));
+}
+template <int M0, int S> __device__ __forceinline__ void fmac_mat6(double *d, const double *Mr, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %6, %12 row_newbcast:%13 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %1, %7, %12 row_newbcast:%14 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%15 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %3, %9, %12 row_newbcast:%16 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %4, %10, %12 row_newbcast:%17 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %5, %11, %12 row_newbcast:%18 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+      : "v"(Mr[(M0 + 0 * S) >> 4]), "v"(Mr[(M0 + 1 * S) >> 4]), "v"(Mr[(M0 + 2 * S) >> 4]), "v"(Mr[(M0 + 3 * S) >> 4]), "v"(Mr[(M0 + 4 * S) >> 4]), "v"(Mr[(M0 + 5 * S) >> 4]), "v"(m), "n"((M0 + 0 * S) & 15), "n"((M0 + 1 * S) & 15), "n"((M0 + 2 * S) & 15), "n"((M0 + 3 * S) & 15), "n"((M0 + 4 * S) & 15), "n"((M0 + 5 * S) & 15));
+}
+template <int N, int M0, int S> __device__ __forceinline__ void fmac_mat(double *d, const double *Mr, double m) {
+  if constexpr (N == 1) fmac_mat1<M0, S>(d, Mr, m);
+  else if constexpr (N == 2) fmac_mat2<M0, S>(d, Mr, m);
+  else if constexpr (N == 3) fmac_mat3<M0, S>(d, Mr, m);
+  else if constexpr (N == 4) fmac_mat4<M0, S>(d, Mr, m);
+  else if constexpr (N == 5) fmac_mat5<M0, S>(d, Mr, m);
+  else fmac_mat6<M0, S>(d, Mr, m);
+}
+
+
 // LDS-only workgroup barrier: the two waves exchange nothing but LDS, so neither the factor stores nor the row loads
 // in flight are drained (which __syncthreads() would do)
 __device__ __forceinline__ void lds_barrier() {

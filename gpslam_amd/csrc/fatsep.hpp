@@ -48,6 +48,11 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   const int *lg_ptr, *lg_state, *lg_mptr, *lg_m;
   int ngroups;
   T *Gev;
+  // the same right-hand sides as ENTRIES per chunk of a segment (k_fs_sweep_syrk): chunk ci = sc_base[seg] + (state - first interior
+  // state) / (24 / B) holds entries [sc_ptr[ci], sc_ptr[ci + 1]); entry = (se_pk: (state - first interior state) << 8 | border
+  // column,  se_src: g * ld + q, the B values at Gev + se_src * B)
+  const int *sc_base, *sc_ptr, *se_pk, *se_src;
+  int dbg;                           // timing ablations of k_fs_sweep_syrk (builds with -DGPS_FSY_DBG only; GPSLAM_FSY_DBG bits: 1 no MFMA, 2 no steps, 4 no requests after the first chunk)
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
   const int *rowptr, *rowLm;
@@ -607,6 +612,311 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
     }
   }
 }
+// ---- round 3: sweep and Schur complement in ONE launch, the border columns never reach memory.
+// k_fs_sweep writes Y (N x B x NCP doubles: 3.84 GB at config 4) with streaming stores at 2.4 TB/s -- 1.6 ms -- and k_fs_syrk
+// reads it back in 1.2 ms; together 2.8 of the iteration's 6.0 ms.  The round-2 fusion (every wave sweeps four steps, then
+// multiplies: 5.0 ms against 4.45) serialised two latency chains in each wave.  Here the workgroup's waves are SPECIALISED, as
+// in k_fused_level0: waves 4 and 5 are the sweep (one thread per border column, 64 columns each, state after state), waves
+// 0..3 the matrix cores (tiles p = wave + 4 q of the lower triangle).  The sweep waves fill one half of a two-chunk LDS ring
+// with the 24 rows of Y of the next chunk while the MFMA waves multiply the other half; one LDS-only barrier per chunk.
+// What a step needs arrives a chunk ahead:
+//   * the chunk's factors [W_s | E_{s-1}] and right-hand sides g_s: 24 / B states x (2 B^2 + B) doubles, one to five values per
+//     lane, committed to a wave-private LDS copy (so the two sweep waves never have to meet);
+//   * the landmark columns' right-hand sides as ENTRIES (FsArgs::sc_*, se_*): lane e of a sweep wave fetches entry e of the
+//     chunk (descriptor two chunks ahead, its B values one chunk ahead) and drops it into the ring at (row, column) -- the
+//     ring slot is zeroed by the column's own thread first; DS operations of one wave execute in order.  k_fs_sweep walked a
+//     per-column list of groups instead: one dependent index -> data round trip per step and column.
+// A step then is LDS and registers only: G = ring[row][c], G -= E^T y, y = W G, ring[row][c] = y (in place) -- the same
+// expressions in the same order as k_fs_sweep, and the MFMA waves accumulate chunk after chunk in k_fs_syrk's order: the
+// Schur complements are bit-identical to the two-launch path (test_gpu_segmented.py).
+constexpr int fs_tri_row(int p) { int t = 0; while ((t + 1) * (t + 2) / 2 <= p) t++; return t; }
+// Which of the workgroup's four waves owns tile p of the lower triangle.  Waves 0 and 1 are the sweep; a chunk of it costs what
+// kFsSweepTiles tiles cost on the matrix cores (measured: ~2700 cycles against 6 x 64 per tile -- on MI355X the fp64 MFMA and
+// the fp64 vector multiply-adds of one SIMD do not overlap, the matrix peak equals the vector peak), so the tiles are dealt
+// greedily to the least loaded wave with that head start: every wave, hence every SIMD, carries the same work.
+constexpr int kFsSweepTiles = 7;
+constexpr int fs_tile_owner(int T16, int p) {
+  const int NT = T16 * (T16 + 1) / 2;
+  int load[4] = {kFsSweepTiles, kFsSweepTiles, 0, 0};
+  int owner = 3;
+  for (int q = 0; q <= p && q < NT; q++) {
+    owner = 3;
+    for (int w = 2; w >= 0; w--) if (load[w] < load[owner]) owner = w;
+    load[owner]++;
+  }
+  return owner;
+}
+constexpr int fs_tile_rank(int T16, int p) {       // index of tile p among its owner's tiles
+  const int o = fs_tile_owner(T16, p);
+  int r = 0;
+  for (int q = 0; q < p; q++) if (fs_tile_owner(T16, q) == o) r++;
+  return r;
+}
+constexpr int fs_tile_count(int T16, int w) {
+  int r = 0;
+  for (int q = 0; q < T16 * (T16 + 1) / 2; q++) if (fs_tile_owner(T16, q) == w) r++;
+  return r;
+}
+
+template <int T16, int WV, int LSP> struct FsTiles {
+  static constexpr int NT = T16 * (T16 + 1) / 2, KC = 24, CNT = fs_tile_count(T16, WV), NA = CNT > 0 ? CNT : 1;
+  fs_d4 acc[NA];
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int q = 0; q < NA; q++) acc[q] = fs_d4{0.0, 0.0, 0.0, 0.0};
+  }
+  // one chunk: slot = the 24 x LSP rows of Y in LDS.  Every 16-column panel is fetched once per four rows in operand layout
+  // (lane l: row l >> 4, column l & 15) and serves as A and as B operand of the tiles that touch it.
+  __device__ __forceinline__ void chunk(const double *slot, int lane) {
+    if constexpr (CNT > 0) {
+      const double *bb = slot + (lane >> 4) * LSP + (lane & 15);
+#pragma unroll
+      for (int k4 = 0; k4 < KC; k4 += 4) {
+        double pn[T16];
+#pragma unroll
+        for (int t = 0; t < T16; t++) pn[t] = bb[k4 * LSP + 16 * t];
+        static_for<0, NT>([&](auto pp) {
+          constexpr int p = decltype(pp)::value;
+          if constexpr (fs_tile_owner(T16, p) == WV) {
+            constexpr int ti = fs_tri_row(p), tj = p - ti * (ti + 1) / 2, q = fs_tile_rank(T16, p);
+            acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pn[ti], pn[tj], acc[q], 0, 0, 0);
+          }
+        });
+      }
+    }
+  }
+  __device__ __forceinline__ void store(double *out, int NCP, int lane) const {
+    const int kl = lane >> 4, cl = lane & 15;
+    static_for<0, NT>([&](auto pp) {
+      constexpr int p = decltype(pp)::value;
+      if constexpr (fs_tile_owner(T16, p) == WV) {
+        constexpr int ti = fs_tri_row(p), tj = p - ti * (ti + 1) / 2, q = fs_tile_rank(T16, p);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) out[(size_t)(ti * 16 + kl + 4 * rg) * NCP + tj * 16 + cl] = acc[q][rg];
+      }
+    });
+  }
+};
+
+template <int T16, int WV, int LSP>
+__device__ __forceinline__ void fs_mfma_role(const double *ring, int nchunks, int lane, double *out, int NCP, int dbg = 0) {
+  constexpr int KC = 24;
+  FsTiles<T16, WV, LSP> tl;
+  tl.init();
+#pragma unroll 1
+  for (int i = 0; i <= nchunks; i++) {
+#ifdef GPS_FSY_DBG
+    if (i >= 1 && !(dbg & 1)) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
+#else
+    if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
+#endif
+    lds_barrier();
+  }
+  tl.store(out, NCP, lane);
+}
+
+// the sweep wave SWV (0 / 1: border columns 64 SWV ..) of k_fs_sweep_syrk, including the few tiles fs_tile_owner deals to it
+template <int B, int T16, int SWV, typename TR>
+__device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, double *ring, double *FsAll, int seg, int lane, int cutL, int j0, int n,
+                                              int nchunks, double *out) {
+  constexpr int KC = 24, SPC = KC / B;
+  constexpr int NCP = 16 * T16;
+  constexpr int LSP = ((NCP + 31) / 32) * 32 + 16;
+  constexpr int FW = 2 * B * B, SW = FW + B;                // staged per state: W_s | E_{s-1} | g_s
+  constexpr int MP = ((FW + 15) / 16) * 16, MQ = MP / 16;   // the matrices of a state in LDS: FW elements padded to whole 16-lane rows
+  constexpr int PF = (SPC * SW + 63) / 64;
+  FsTiles<T16, SWV, LSP> tl;
+  tl.init();
+  constexpr int sw = SWV;
+  const int c = sw * 64 + lane;                             // border column
+  const int NB = a.NB;
+  double *Fs = FsAll + sw * SPC * MP;
+  const bool colok = c < NCP;
+  const bool own_rhs = ((2 * NB) >> 6) == sw;               // (wave-uniform) this wave's columns include the right-hand side
+  const bool lstate = c < B, rstate = (c >= NB && c < NB + B);
+  const int slast = j0 + max(n, 1) - 1;
+  const double *opL = a.blk + (size_t)cutL * a.BS + B * B, *opR = a.blk + (size_t)slast * a.BS + B * B;
+  const int cb = a.sc_base[seg];
+  double y[B];
+#pragma unroll
+  for (int r = 0; r < B; r++) y[r] = 0.0;
+  double pre[PF], val[B];
+  const int clast = max(nchunks - 1, 0);
+  // every staged value of a lane has a fixed place in the chunk: (state t of the chunk, element k of [W | E | g]) -> base
+  // pointer, stride per state and LDS destination are formed once
+  const double *sbase[PF];
+  int sstr[PF], sst[PF], sdst[PF];                          // sdst: >= 0 offset in Fs, -1 - r: rhs element r (ring), INT_MIN: nothing
+  bool szero[PF];
+#pragma unroll
+  for (int u = 0; u < PF; u++) {
+    const int v = min(lane + 64 * u, SPC * SW - 1);
+    const int t = v / SW, k = v - t * SW;
+    sst[u] = t;
+    sbase[u] = (k < B * B) ? a.fac + k : (k < FW) ? a.fac + k - FW : a.blk + FW + (k - FW);
+    sstr[u] = (k < FW) ? FW : a.BS;
+    sdst[u] = (lane + 64 * u >= SPC * SW) ? (int)0x80000000 : (k < FW ? t * MP + k : -1 - (t * B + (k - FW)));
+    szero[u] = (k >= B * B && k < FW && t == 0);            // E_{j0 - 1} = 0 (first chunk only): the first interior state
+  }
+  auto stage = [&](int i) {                                 // factors + rhs of chunk i -> pre (clamped: never out of the segment)
+    const int s0 = j0 + min(i, clast) * SPC;
+#pragma unroll
+    for (int u = 0; u < PF; u++) pre[u] = sbase[u][(size_t)min(s0 + sst[u], slast) * sstr[u]];
+  };
+  auto ent_range = [&](int i, int &e0, int &e1) {
+    const int ci = cb + min(i, clast);
+    e0 = a.sc_ptr[ci]; e1 = a.sc_ptr[ci + 1];
+    if (i >= nchunks) e1 = e0;
+  };
+  auto ent_desc = [&](int e0, int e1, int &pk, int &src) {  // (the entry arrays carry 64 entries of slack)
+    const int e = e0 + lane;
+    pk = a.se_pk[e]; src = a.se_src[e];
+    if (e >= e1) { pk = -1; src = 0; }
+  };
+  auto ent_vals = [&](int src) {
+    const double *gp = a.Gev + (size_t)src * B;
+#pragma unroll
+    for (int r = 0; r < B; r++) val[r] = gp[r];
+  };
+  // the pipeline: ranges three chunks ahead, descriptors two, values one -- no request waits for one of the same chunk
+  int pk_cur = -1, pk_n1 = -1, src_n1 = 0;
+  int e0c = 0, e1c = 0, e0n1 = 0, e1n1 = 0, e0n2 = 0, e1n2 = 0;
+  if (nchunks > 0) {
+    stage(0);
+    ent_range(0, e0c, e1c);
+    ent_range(1, e0n1, e1n1);
+    ent_range(2, e0n2, e1n2);
+    int src0;
+    ent_desc(e0c, e1c, pk_cur, src0);
+    ent_desc(e0n1, e1n1, pk_n1, src_n1);
+    ent_vals(src0);
+  }
+#pragma unroll 1
+  for (int i = 0; i <= nchunks; i++) {
+    if (i < nchunks) {
+      double *slot = ring + (i & 1) * KC * LSP;
+      // ---- the chunk's right-hand sides: zero the column, then the staged values and the entries
+      if (colok) {
+#pragma unroll
+        for (int row = 0; row < KC; row++) slot[row * LSP + c] = 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        if (sdst[u] >= 0) Fs[sdst[u]] = (szero[u] && i == 0) ? 0.0 : (((sdst[u] % MP) >= B * B) ? -pre[u] : pre[u]);   // W, -E
+        else if (sdst[u] != (int)0x80000000 && own_rhs && i * SPC + sst[u] < n) slot[(-1 - sdst[u]) * LSP + 2 * NB] = pre[u];
+      }
+      if (pk_cur >= 0) {
+        const int col = pk_cur & 255, row = ((pk_cur >> 8) - i * SPC) * B;
+        if ((col >> 6) == sw) {
+#pragma unroll
+          for (int r = 0; r < B; r++) slot[(row + r) * LSP + col] = val[r];
+        }
+      }
+      // the cut states' couplings, twice per segment.  HERE, where the wave waits for its staged values anyway: a load under
+      // a branch costs every lane a full vmcnt(0) at the join, taken or not -- inside the steps that drained the requests
+      // of the chunks ahead four times per chunk (4.0 ms instead of 2.8 for the two launches)
+      if (i == 0 && lstate) {
+#pragma unroll
+        for (int r = 0; r < B; r++) slot[r * LSP + c] = opL[r * B + c];                                    // H[cutL + 1, cutL] = O_cutL
+      }
+      if (i == nchunks - 1 && rstate) {
+        const int row = (n - 1 - i * SPC) * B;
+#pragma unroll
+        for (int r = 0; r < B; r++) slot[(row + r) * LSP + c] = opR[(c - NB) * B + r];                     // H[cutR - 1, cutR] = O_{cutR-1}^T
+      }
+      for (int e = e0c + 64 + lane; e < e1c; e += 64) {     // more than 64 entries in one chunk: the rest, synchronously
+        const int pk = a.se_pk[e];
+        const double *gp = a.Gev + (size_t)a.se_src[e] * B;
+        const int col = pk & 255, row = ((pk >> 8) - i * SPC) * B;
+        if ((col >> 6) == sw) {
+#pragma unroll
+          for (int r = 0; r < B; r++) slot[(row + r) * LSP + col] = gp[r];
+        }
+      }
+      fs_wave_sync();
+      // ---- requests of the chunks ahead (in flight under this chunk's steps)
+#ifdef GPS_FSY_DBG
+      if (!(a.dbg & 4)) {
+#endif
+      stage(i + 1);
+      pk_cur = pk_n1; e0c = e0n1; e1c = e1n1;
+      ent_vals(src_n1);
+      e0n1 = e0n2; e1n1 = e1n2;
+      ent_desc(e0n1, e1n1, pk_n1, src_n1);
+      ent_range(i + 3, e0n2, e1n2);
+#ifdef GPS_FSY_DBG
+      }
+#endif
+      // ---- the steps.  The matrices are the same for every column: lane j of each 16-lane row holds elements j, 16 + j, ...
+      // of [W_s | -E_{s-1}] (MQ registers) and every multiply-add takes its matrix element by DPP row broadcast
+      // (v_fmac_f64_dpp, dpp.hpp fmac_mat).  The first version read them from LDS as broadcast operands, two per ds_read_b128
+      // right in front of the multiply-adds that use them: ~30 exposed LDS round trips per step, 12 800 cycles per chunk.
+#pragma unroll
+      for (int t = 0; t < SPC; t++) {
+        const int jj = i * SPC + t;
+#ifdef GPS_FSY_DBG
+        if (jj < n && !(a.dbg & 2)) {
+#else
+        if (jj < n) {
+#endif
+          double Mr[MQ];
+#pragma unroll
+          for (int q = 0; q < MQ; q++) Mr[q] = Fs[t * MP + q * 16 + (lane & 15)];
+          double G[B], yn[B];
+#pragma unroll
+          for (int r = 0; r < B; r++) { G[r] = colok ? slot[(t * B + r) * LSP + c] : 0.0; yn[r] = 0.0; }
+          static_for<0, B>([&](auto kk) {                  // G -= E^T y  (E_{j0-1} is staged as zero)
+            constexpr int k = decltype(kk)::value;
+            fmac_mat<B, B * B + k * B, 1>(G, Mr, y[k]);
+          });
+          static_for<0, B>([&](auto kk) {                  // y = W G, W lower triangular: column k serves rows k .. B - 1
+            constexpr int k = decltype(kk)::value;
+            fmac_mat<B - k, k * B + k, B>(yn + k, Mr, G[k]);
+          });
+#pragma unroll
+          for (int r = 0; r < B; r++) y[r] = yn[r];
+          if (colok) {
+#pragma unroll
+            for (int r = 0; r < B; r++) slot[(t * B + r) * LSP + c] = y[r];
+          }
+        }
+      }
+    }
+#ifdef GPS_FSY_DBG
+    if (i >= 1 && !(a.dbg & 1)) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
+#else
+    if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
+#endif
+    lds_barrier();
+  }
+  tl.store(out, NCP, lane);
+}
+
+// NCP == 16 * T16 exactly (the caller picks the instantiation); 2 NB + 1 <= 128 columns; 256 threads: waves 0, 1 sweep, 2, 3 multiply
+template <int B, int T16, typename TR = double> __global__ void __launch_bounds__(256, 3) k_fs_sweep_syrk(FsArgs<double, TR> a) {
+  constexpr int KC = 24, SPC = KC / B;                      // rows / states per chunk
+  constexpr int NCP = 16 * T16;
+  constexpr int LSP = ((NCP + 31) / 32) * 32 + 16;          // (see k_fs_syrk)
+  static_assert(B <= 6, "fmac_mat blocks hold up to six multiply-adds");
+  extern __shared__ __align__(16) unsigned char fsy_smem[];
+  double *ring = reinterpret_cast<double *>(fsy_smem);      // 2 x KC x LSP
+  double *FsAll = ring + 2 * KC * LSP;                      // 2 sweep waves x SPC x MP: [W_s | -E_{s-1}] per state of the chunk
+  const int seg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
+  const int j0 = cutL + 1, n = cutR - cutL - 1;
+  const int nchunks = n > 0 ? (n + SPC - 1) / SPC : 0;
+  double *out = a.Aseg + (size_t)seg * NCP * NCP;
+  switch (wv) {
+    case 0: fs_sweep_role<B, T16, 0, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out); break;
+    case 1: fs_sweep_role<B, T16, 1, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out); break;
+    case 2: fs_mfma_role<T16, 2, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
+    default: fs_mfma_role<T16, 3, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
+  }
+}
+
+// dynamic LDS of k_fs_sweep_syrk<B, NCP / 16>: the two-chunk ring + the two sweep waves' factor copies
+inline size_t fs_fused_smem(int b, int ncp) {
+  return ((size_t)2 * 24 * fs_lds_stride(ncp) + (size_t)2 * (24 / b) * ((2 * b * b + 15) / 16 * 16)) * sizeof(double);
+}
 // entry (i, j) of a segment's symmetric Schur complement, stored by its lower tile triangle
 template <typename T> __device__ __forceinline__ T fs_sym(const T *A, int ncp, int i, int j) {
   return (i >= j) ? A[(size_t)i * ncp + j] : A[(size_t)j * ncp + i];
@@ -834,7 +1144,13 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
   for (int i = tid; i < NB; i += nt) X[i * XS + 2 * NB] = a.gfat[(size_t)m * NB + i];
   __syncthreads();
+#ifdef GPS_FSY_DBG
+  if (!(a.dbg & 8))
+#endif
   fat_factor_panel4(Lm, X, Ld, NB, LS, XS, XS, a.flag);
+#ifdef GPS_FSY_DBG
+  if (a.dbg & 16) return;
+#endif
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
     a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);
@@ -1214,6 +1530,8 @@ struct FatSepPlan {
   DevBuf send, recv, tD, tlink, tg, tQ, tS1, tS2, tsv, tx, d_telim, d_tupd, d_lm_own, lm_tmp;
   // right-hand-side groups of the landmark border columns (FsArgs::lg_*)
   DevBuf d_lg_ptr, d_lg_state, d_lg_mptr, d_lg_m, Gev;
+  DevBuf d_sc_base, d_sc_ptr, d_se_pk, d_se_src;    // the same as entries per chunk (k_fs_sweep_syrk)
+  bool fused_sweep = false;                         // k_fs_sweep_syrk serves this plan (else k_fs_sweep + k_fs_syrk through Y)
   int ngroups = 0;
   std::vector<int> h_lmrow, h_lmstate, h_lmptr;     // compile(): rows per landmark, sorted by left state
 
@@ -1221,7 +1539,7 @@ struct FatSepPlan {
     for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
                       &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
                       &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp,
-                      &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev})
+                      &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev, &d_sc_base, &d_sc_ptr, &d_se_pk, &d_se_src})
       b->release();
     active = false;
   }

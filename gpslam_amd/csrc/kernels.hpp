@@ -579,6 +579,12 @@ template <typename T> struct LinArgs {
   FacArgs<T> fac[3];      // pose priors, velocity priors, between factors
   int nb_gp, nb[3];       // blocks per type (0: type absent)
   int interleave;         // 1: GP and between blocks alternate; 0: all GP blocks first
+  // deferred reduction (round 3): the per-block |delta|_inf maxima the PREVIOUS iteration's k_retract left behind are
+  // reduced here, by one extra workgroup at the end of the grid, instead of by a launch of their own (fixed order:
+  // deterministic; nothing is skipped, the value lands in *red_out one launch later).  red_in == null: nothing pending.
+  const double *red_in = nullptr;
+  int red_n = 0;
+  double *red_out = nullptr;
 };
 // VP: the launch contains velocity priors (full-width rows).  Without them a Pose3 launch stages half rows only (the GP
 // prior writes its rows in halves, pose priors / between factors have compact rows): 14 KB of LDS instead of 27 KB, so that
@@ -589,6 +595,13 @@ __global__ void __launch_bounds__(128, GPS_KLIN_WAVES) k_lin(LinArgs<T> a) {
   __shared__ T stage[2 * 64 * LS];
   __shared__ int srow[128];
   int bid = blockIdx.x;
+  if (a.red_in != nullptr && bid == (int)gridDim.x - 1) {     // the extra workgroup: pending maximum of the previous retraction
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < a.red_n; i += 128) acc = fmax(acc, a.red_in[i]);
+    const double r = block_max(acc);
+    if (threadIdx.x == 0) *a.red_out = r;
+    return;
+  }
   const int pair = a.interleave ? min(a.nb_gp, a.nb[2]) : 0;
   if (bid < 2 * pair) {                                    // interleaved part: even = GP, odd = between
     if (bid & 1) simple_block<T, MF, 2, true>(a.fac[2], bid >> 1, stage, srow);
@@ -2735,11 +2748,23 @@ template <typename T> struct RetractArgs {
   T *partial;       // per-block max |delta|
   const int *flag;  // non-SPD flag of the elimination: when set the states are left untouched (GTSAM throws
                     // IndeterminantLinearSystemException before Values::retract), only |delta|_inf is reported
+  // deferred reduction (round 3): the per-block error sums of this iteration's linearisation, summed by one extra
+  // workgroup at the end of the grid instead of by a launch of their own right behind the linearisation
+  const double *red_in = nullptr;
+  int red_n = 0;
+  double *red_out = nullptr;
 };
 
 template <typename T, int MF>
 __global__ void __launch_bounds__(128) k_retract(RetractArgs<T> a) {
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
+  if (a.red_in != nullptr && blockIdx.x == gridDim.x - 1) {     // the extra workgroup: pending error sum, fixed order
+    double acc = 0.0;
+    for (int k = threadIdx.x; k < a.red_n; k += 128) acc += a.red_in[k];
+    const double r = block_sum(acc);
+    if (threadIdx.x == 0) *a.red_out = r;
+    return;
+  }
   const int li = blockIdx.x * blockDim.x + threadIdx.x;
   const int i = a.first + li;
   T mx = T(0);
