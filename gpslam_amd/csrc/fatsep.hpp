@@ -1176,6 +1176,121 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
 }
 
+// ---- round 3: the same elimination with the whole factorisation in REGISTERS (fat blocks up to 48 columns, fp64).
+// k_fat_elim above takes 37-40 us for ONE 36-column block whatever the level's size (ablations: load 6, the blocked
+// factorisation + L^-1 [H | H | g] through LDS 22, the five products 10) and the cyclic reduction has twelve levels of it, nine
+// of them smaller than the chip.  Here lane i < NBP of a wave holds ROW i of the block D_m (NBP = NB rounded up to 8, padded with
+// the identity) and the remaining 64 - NBP lanes hold rows of [H(m,l) | H(m,r) | g]^T: the right-looking Cholesky's row
+// operations turn the stacked matrix [D; X^T] into [L; (L^-1 X)^T] -- the triangular solves ride along as extra rows.  Column
+// j's pivot row entries reach the other lanes through v_readlane (scalar operands of the multiply-adds); no LDS, no barrier.
+// Every wave factors the block redundantly (they run on different SIMDs) and carries its own 64 - NBP columns of X, so the
+// waves never meet before the products.  Those -- P^T P, Q^T Q, Q^T P, P^T z, Q^T z, all of them blocks of X'^T X' with
+// X' = L^-1 X -- are 16 x 16 tiles on v_mfma_f64_16x16x4_f64 over the rows X'^T left in LDS.
+template <int NBP, typename TR = double>
+__global__ void __launch_bounds__(NBP <= 40 ? 256 : 512) k_fat_elim_rows(FsArgs<double, TR> a, FatLevel lv) {
+  constexpr int NBL = 64 - NBP;                       // rows of X^T per wave
+  constexpr int KS = NBP + 1;                         // LDS row stride of X'^T (odd: operand loads spread over the banks)
+  constexpr int CTM = (2 * NBP + 1 + 15) / 16;        // 16-column panels of X at the largest NB this instantiation serves
+  __shared__ double PT[16 * CTM * KS];
+  const int NB = a.NB, NB2 = NB * NB, NX = 2 * NB + 1;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
+  const bool isA = lane < NBP;
+  const int c = wv * NBL + (lane - NBP);              // column of X of a lane behind the block rows
+  // ---- loads: one row per lane, element k at base[min(k, NB - 1) * stride]
+  const double *base = a.Dfat + (size_t)m * NB2;      // (a valid address for the lanes that hold padding)
+  int stride = 0;
+  bool valid = false;
+  if (isA) {
+    if (lane < NB) { base = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB; stride = 1; valid = true; }
+  } else if (c < NB) { base = a.link + (size_t)lk_lm * NB2 + c; stride = NB; valid = true; }                       // H[m, l][k][c]
+  else if (c < 2 * NB) { if (r >= 0) { base = a.link + (size_t)lk_mr * NB2 + (size_t)(c - NB) * NB; stride = 1; valid = true; } }   // H[r, m][c - NB][k]
+  else if (c == 2 * NB) { base = a.gfat + (size_t)m * NB; stride = 1; valid = true; }
+  double av[NBP];
+#pragma unroll
+  for (int k = 0; k < NBP; k++) av[k] = base[(size_t)min(k, NB - 1) * stride];
+#pragma unroll
+  for (int k = 0; k < NBP; k++) {
+    const double pad = (isA && lane == k) ? 1.0 : 0.0;
+    av[k] = (valid && k < NB) ? av[k] : pad;
+  }
+  // ---- [D; X^T] -> [L; X'^T]
+  bool bad = false;
+  static_for<0, NBP>([&](auto jj) {
+    constexpr int j = decltype(jj)::value;
+    double dd = lane_bcast(av[j], j);
+    if (!(dd > 0.0)) { bad = true; dd = 1.0; }
+    double y = fs_rsqrt(dd), l = dd * y;
+    l = fma(0.5 * y, fma(-l, l, dd), l);              // one residual step each, as in fat_factor_panel4
+    y = fma(y, fma(-l, y, 1.0), y);
+    const double lj = (lane == j) ? l : av[j] * y;
+    av[j] = lj;
+    static_for<j + 1, NBP>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      av[k] = fma(-lj, lane_bcast(lj, k), av[k]);
+    });
+  });
+  if (bad && tid == 0) *a.flag = 1;
+  // ---- results: L (wave 0), P / Q / z (the lanes that own the columns), X'^T rows to LDS for the products
+  if (isA) {
+    if (wv == 0 && lane < NB) {
+      double *dp = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB;
+#pragma unroll
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[k] = (k <= lane) ? av[k] : 0.0;
+    }
+  } else {
+    if (c < 16 * CTM) {
+#pragma unroll
+      for (int k = 0; k < NBP; k++) PT[c * KS + k] = av[k];
+    }
+    if (c < NB) {
+      double *dp = a.link + (size_t)lk_lm * NB2 + c;                                  // P
+#pragma unroll
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[(size_t)k * NB] = av[k];
+    } else if (c < 2 * NB) {
+      double *dp = a.Qbuf + (size_t)m * NB2 + (c - NB);                               // Q
+#pragma unroll
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[(size_t)k * NB] = av[k];
+    } else if (c == 2 * NB) {
+      double *dp = a.gfat + (size_t)m * NB;                                           // z
+#pragma unroll
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[k] = av[k];
+    }
+  }
+  __syncthreads();
+  // ---- products: tile (ti, tj), tj <= ti, of X'^T X' (rows / columns = columns of X: P | Q | z)
+  const int CT = (NX + 15) / 16, ntiles = CT * (CT + 1) / 2;
+  const int kl = lane >> 4, cl = lane & 15;
+  for (int p = wv; p < ntiles; p += nw) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= p) ti++;
+    const int tj = p - ti * (ti + 1) / 2;
+    const double *pa = PT + (ti * 16 + cl) * KS + kl, *pb = PT + (tj * 16 + cl) * KS + kl;
+    fs_d4 acc = fs_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k4 = 0; k4 < NBP; k4 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k4], pb[k4], acc, 0, 0, 0);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int ci = ti * 16 + kl + 4 * rg, cj = tj * 16 + cl;      // entry (ci, cj) of X'^T X'
+      const double v = acc[rg];
+      if (ci >= NX || cj > ci) continue;                            // padding; the upper half of a diagonal tile
+      if (ci < NB) {                                                // P^T P (cj < NB as well)
+        a.S1[(size_t)m * NB2 + (size_t)ci * NB + cj] = v;
+        a.S1[(size_t)m * NB2 + (size_t)cj * NB + ci] = v;
+      } else if (ci < 2 * NB) {
+        if (cj < NB) { if (r >= 0) a.link[(size_t)lk_new * NB2 + (size_t)(ci - NB) * NB + cj] = -v; }   // H[r, l] = -(Q^T P)
+        else {                                                      // Q^T Q
+          a.S2[(size_t)m * NB2 + (size_t)(ci - NB) * NB + (cj - NB)] = v;
+          a.S2[(size_t)m * NB2 + (size_t)(cj - NB) * NB + (ci - NB)] = v;
+        }
+      } else if (cj < 2 * NB) {                                     // ci == 2 NB: P^T z | Q^T z
+        a.sv[(size_t)m * 2 * NB + cj] = v;
+      }
+    }
+  }
+}
+
 template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T, TR> a, FatLevel lv) {
   const int NB = a.NB, NB2 = NB * NB;
   const int *u = lv.upd + 3 * blockIdx.x;

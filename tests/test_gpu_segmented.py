@@ -168,7 +168,7 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 import gpslam_amd
 from gpslam_amd import synthetic as S
-p = S.pose2_local_landmarks_chain(%d, window=200)
+p = S.pose2_local_landmarks_chain(%d, window=%d)
 s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=%d))
 for _ in range(3):
     s.iterate_gn()
@@ -177,7 +177,7 @@ np.savez(sys.argv[1], pose=pose, vel=vel, lmk=s.get_landmarks(), plan=np.array([
 """
 
 
-@pytest.mark.parametrize("N,seglen", [(20000, 0), (3000, 96), (777, 250)])
+@pytest.mark.parametrize("N,seglen", [(20000, 0), (3000, 256), (777, 250)])
 def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_bit(N, seglen, tmp_path):
     """k_fs_sweep_syrk (sweep and MFMA waves sharing an LDS ring, no Y buffer) against k_fs_sweep + k_fs_syrk through the Y
     buffer (GPSLAM_FS_FUSED=0, read once per process: two child processes): same expressions in the same order -> the
@@ -188,7 +188,7 @@ def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_
     for fused in ("1", "0"):
         out = str(tmp_path / ("fused%s.npz" % fused))
         env = dict(os.environ, GPSLAM_FS_FUSED=fused)
-        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, seglen), out], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, 100 if N < 1000 else 200, seglen), out], check=True, env=env, timeout=600)
         outs.append(np.load(out))
     a, b = outs
     assert a["plan"][1] <= 112, "the fused kernel serves borders up to 112 columns: this case would not exercise it"
