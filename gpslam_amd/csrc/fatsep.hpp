@@ -1363,6 +1363,52 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_f
   for (int i = lane; i < NB; i += 64) a.xfat[(size_t)m * NB + i] = ts[i];
 }
 
+// ---- round 3: the same back-substitution without LDS (fat blocks up to 64 columns, fp64).  Lane k holds COLUMN k of L
+// (L[i][k] for all i: coalesced loads) and entry k of t = z - P x_l - Q x_r; step i broadcasts x_i = t_i / L_ii from lane i
+// (v_readlane) and every lane k < i takes L[i][k] x_i off its entry.  k_fat_back above spends 12-13 us per block (one wave,
+// 2 NB wave-level syncs around LDS round trips); this is one dependent multiply-add + broadcast per step.
+template <int NBP, typename TR = double> __global__ void __launch_bounds__(64) k_fat_back_rows(FsArgs<double, TR> a, FatLevel lv) {
+  const int NB = a.NB, NB2 = NB * NB, lane = threadIdx.x;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], l = e[1], r = e[2], lk_lm = e[3];
+  const int kc = min(lane, NB - 1);
+  const bool on = lane < NB;
+  double Lc[NBP];                                   // column `lane` of L
+  const double *dp = a.Dfat + (size_t)m * NB2 + kc;
+#pragma unroll
+  for (int i = 0; i < NBP; i++) Lc[i] = dp[(size_t)min(i, NB - 1) * NB];
+  // t = z - P x_l - Q x_r: row `lane` of P and Q against the neighbours' solutions, broadcast entry by entry
+  const double xl = a.xfat[(size_t)l * NB + kc], xr = (r >= 0) ? a.xfat[(size_t)r * NB + kc] : 0.0;
+  double t = a.gfat[(size_t)m * NB + kc];
+  const double *P = a.link + (size_t)lk_lm * NB2 + (size_t)kc * NB, *Q = a.Qbuf + (size_t)m * NB2 + (size_t)kc * NB;
+  static_for<0, NBP / 8>([&](auto cc) {             // eight columns at a time (all of P and Q at once would not fit the registers)
+    constexpr int j0 = 8 * decltype(cc)::value;
+    double pr[8], qr[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { pr[j] = P[min(j0 + j, NB - 1)]; qr[j] = Q[min(j0 + j, NB - 1)]; }
+    static_for<0, 8>([&](auto jj) {
+      constexpr int j = j0 + decltype(jj)::value;
+      if (j < NB) {                                 // (uniform)
+        t = fma(-pr[j - j0], lane_bcast(xl, j), t);
+        t = fma(-qr[j - j0], lane_bcast(xr, j), t);
+      }
+    });
+  });
+  double dinv = 1.0;
+  static_for<0, NBP>([&](auto ii) {                 // lane i keeps 1 / L_ii
+    constexpr int i = decltype(ii)::value;
+    if (lane == i) dinv = 1.0 / Lc[i];
+  });
+  static_for<0, NBP>([&](auto ii) {
+    constexpr int i = NBP - 1 - decltype(ii)::value;
+    if (i < NB) {                                   // (uniform)
+      const double xi = lane_bcast(t * dinv, i);
+      t = (lane == i) ? xi : ((lane < i) ? fma(-Lc[i], xi, t) : t);
+    }
+  });
+  if (on) a.xfat[(size_t)m * NB + lane] = t;
+}
+
 // ---- a chain split across GPUs (every piece runs from one shared cut state to the next; the shared cut and the landmarks
 // seen from both sides form a fat separator both neighbours hold).  The cyclic reduction of a piece stops at its two end
 // blocks; what is left of it is the interface record  [Dff | H(last, first) | Dll | g_first | g_last]  in blocks of NT
