@@ -2,6 +2,8 @@
 """Turn gpurun_out/<tag> (scripts/collect_profiles.sh) into profiles/<name>_kernel_stats.md and profiles/<name>_pmc.json.
 
   python scripts/summarise_profiles.py gpurun_out/r1v2 round1_v2
+  python scripts/summarise_profiles.py gpurun_out/r3_1e6 round3_1e6 1000000     (scripts/collect_profiles_1e6.sh: the north-star size;
+                                                                                 profiles/latest_pmc.json -- bench.py's traffic source -- is left alone)
 """
 import collections
 import csv
@@ -11,6 +13,7 @@ import os
 import sys
 
 src, name = sys.argv[1], sys.argv[2]
+states = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -24,7 +27,7 @@ def find(pattern):
     return g[0] if g else None
 
 
-out = ["# %s -- rocprofv3 --kernel-trace --stats of `python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline`" % name, ""]
+out = ["# %s -- rocprofv3 --kernel-trace --stats of %s" % (name, "`python bench.py --gpus 1 --steps 20 --warmup 3 --no-cpu-baseline`" if states == 100000 else "`python scripts/profile_iter.py %d` (Pose3 chain of %d states, 2 + 5 Gauss-Newton iterations)" % (states, states)), ""]
 kt = find("trace/**/t_kernel_trace.csv")
 per = collections.OrderedDict()
 if kt:
@@ -97,10 +100,10 @@ if pmc:
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 open(os.path.join(root, "profiles", name + "_kernel_stats.md"), "w").write("\n".join(out) + "\n")
 for c in pmc.values():
-    c["states"] = 100000          # scripts/profile_iter.py default workload (BASELINE config 3)
+    c["states"] = states          # scripts/profile_iter.py workload (default: BASELINE config 3, 1e5 Pose3 states)
 blob = dict(source="rocprofv3 --pmc passes over scripts/profile_iter.py (scripts/collect_profiles.sh), mean per launch",
             fetch_size_correction=2.0, unit="FETCH_SIZE/WRITE_SIZE in KB, ea_*_bytes in bytes", kernels=pmc, kernel_trace=per)
-for fn in (name + "_pmc.json", "latest_pmc.json"):
+for fn in ((name + "_pmc.json", "latest_pmc.json") if states == 100000 else (name + "_pmc.json",)):
     json.dump(blob, open(os.path.join(root, "profiles", fn), "w"), indent=1, sort_keys=True)
 bj = os.path.join(src, "bench.json")
 if os.path.exists(bj):
