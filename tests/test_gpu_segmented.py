@@ -194,3 +194,26 @@ def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_
     assert a["plan"][1] <= 112, "the fused kernel serves borders up to 112 columns: this case would not exercise it"
     for k in ("pose", "vel", "lmk"):
         assert np.array_equal(a[k], b[k]), k
+
+
+def test_register_resident_fat_kernels_at_every_block_width():
+    """k_fat_elim_rows<NBP> / k_fat_back_rows<NBP> (round 3: the fat blocks' factorisation and back-substitution in registers)
+    are instantiated for NBP = 8 .. 48 in steps of 8; blocks beyond 48 columns keep the LDS kernels.  Landmark densities from a
+    quarter to 1.6x config 4's put NB into most of those classes: each against the oracle's dense bordered solve, 1e-9."""
+    seen = set()
+    for div in (80, 40, 27, 20, 16, 13):
+        N = 2400
+        p = S.pose2_local_landmarks_chain(N, L=N // div, window=200)
+        orc, dev = _pair(p)
+        plan = dev.segment_plan()
+        assert plan["active"] == 1, plan
+        seen.add((plan["NB"] + 7) // 8 * 8)
+        for it in range(3):
+            rc0, s0 = orc.iterate_gn()
+            rc1, s1 = dev.iterate_gn()
+            assert rc0 == 0 and rc1 == 0
+            assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (div, plan, it, s0.error_after, s1.error_after)
+        states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
+        l0, l1 = orc.get_landmarks(), dev.get_landmarks()
+        assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max()), (div, plan)
+    assert len(seen) >= 4 and min(seen) <= 24 and max(seen) >= 48, seen
