@@ -18,7 +18,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def short(k):
-    k = k.replace("void gps::", "").replace("gps::", "")
+    k = k.replace("(anonymous namespace)::", "").replace("void gps::", "").replace("gps::", "")
     return k.split("(")[0][:70]
 
 
