@@ -372,8 +372,12 @@ inline void launch_fused_k(const FusedArgs<double, double> &u, int grid, hipStre
 // fp32 handles: fp32 row tables straight into the fused kernel's fp64 accumulation (round 3: the unfused assembly had cost the
 // fp32 mode more than its halved row traffic saved)
 inline void launch_fused_k(const FusedArgs<double, float> &u, int grid, hipStream_t st) { k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u); }
-inline void launch_rows_k(const FwdArgs<double> &a, int grid, hipStream_t st) { k_chunk_forward_rows<<<dim3(grid), dim3(64), 0, st>>>(a); }
-inline void launch_rows_k(const FwdArgs<float> &, int, hipStream_t) {}
+inline void launch_rows_k(int b, const FwdArgs<double> &a, int grid, hipStream_t st) {
+  if (b == 12) k_chunk_forward_rows<12><<<dim3(grid), dim3(64), 0, st>>>(a);
+  else if (b == 6) k_chunk_forward_rows<6><<<dim3(grid), dim3(64), 0, st>>>(a);
+  else k_chunk_forward_rows<4><<<dim3(grid), dim3(64), 0, st>>>(a);
+}
+inline void launch_rows_k(int, const FwdArgs<float> &, int, hipStream_t) {}
 // segment interiors of the segmented landmark elimination: planar fp64 chains take the cooperative row-layout kernel (four
 // segments per wave); GPSLAM_FS_FACTOR_ROWS=0 keeps the wave-per-segment kernel, for A/B measurements
 template <int BB, typename T, typename TR> inline void fs_launch_factor(const FsArgs<T, TR> &a, int nseg, hipStream_t st) {

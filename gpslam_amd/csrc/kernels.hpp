@@ -1925,8 +1925,12 @@ __global__ void __launch_bounds__(64, 4) k_chunk_forward(FwdArgs<T> a) {
 //   D_sep -= G_j V_j,  g_sep -= G_j Y_j.
 // Records enter and leave as contiguous 16-byte pieces through a per-row LDS image (which also provides the
 // transposed reads of O).  ~660 VALU instructions per chunk-step against ~830 (288 of them v_readlane) before.
+// Round 3: the block size is a template parameter (12: SE(3); 6: SE(2), SO(3), 3-D linear; 4: 2-D linear) -- the planar /
+// rotation chains had kept the column-layout kernel (k_chunk_forward), at 1.7 TB/s of record traffic where this one is bound
+// by it.
+template <int B>
 __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a) {
-  constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
+  constexpr int BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2;                                  // 16-byte pieces of a record
   constexpr int NV = (NPC + 15) / 16;                          // pieces per lane of a 16-lane row
   typedef double V2 __attribute__((ext_vector_type(2)));
@@ -2041,11 +2045,15 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
       // row r -= (D~[r][k] / pivot) * row k, the pivot row fused into the multiply-add (fmac_self*): of D~ only the columns
       // right of the pivot still matter, in blocks of four (entries at or left of the pivot inside a block become garbage
       // that nothing reads again)
-      if (k < 3) fmac_self4<k>(Dr, nmp);
-      if (k < 7) fmac_self4<k>(Dr + 4, nmp);
-      if (k < 11) fmac_self4<k>(Dr + 8, nmp);
-      fmac_self12<k>(Or, nmp);
-      fmac_self12<k>(Fr, nmp);
+      if constexpr (B == 12) {
+        if (k < 3) fmac_self4<k>(Dr, nmp);
+        if (k < 7) fmac_self4<k>(Dr + 4, nmp);
+        if (k < 11) fmac_self4<k>(Dr + 8, nmp);
+      } else {
+        fmac_self_n<k, B>(Dr, nmp);
+      }
+      fmac_self_n<k, B>(Or, nmp);
+      fmac_self_n<k, B>(Fr, nmp);
       fmac_self1<k>(gr, nmp);
     });
     if (bad && live && r == 0) *a.flag = 1;
@@ -2087,8 +2095,8 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast12<i>(Dn, Or, nol);        // D~_{j+1} -= O_j[r][i] * (row i of U_j)
-      fmac_bcast12<i>(Gn, Or, ngg);        // G_{j+1}  -= G_j[r][i] * (row i of U_j)
+      fmac_bcast_n<i, B>(Dn, Or, nol);     // D~_{j+1} -= O_j[r][i] * (row i of U_j)
+      fmac_bcast_n<i, B>(Gn, Or, ngg);     // G_{j+1}  -= G_j[r][i] * (row i of U_j)
       fmac_bcast2<i>(gn, as_, gr, nol, ngg);
     });
     // (pinned here: the compiler otherwise sinks the G_{j+1} sums below the output branch at the end of the step and
@@ -2102,8 +2110,8 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast12<i>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
-      fmac_bcast12<i>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B>(Fn, Fr, nol);     // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B>(Ar, Fr, ngg);     // D_sep   -= G_j[r][i] * (row i of V_j)
     });
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
