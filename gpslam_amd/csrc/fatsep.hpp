@@ -52,6 +52,11 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   // state) / (24 / B) holds entries [sc_ptr[ci], sc_ptr[ci + 1]); entry = (se_pk: (state - first interior state) << 8 | border
   // column,  se_src: g * ld + q, the B values at Gev + se_src * B)
   const int *sc_base, *sc_ptr, *se_pk, *se_src;
+  // rows of each landmark that touch a cut state, by POSITION p of the landmark in fat_lm (k_fs_fat_assemble): items rho * 2 +
+  // half (half 0: the row's left state is the cut, 1: its right state is), in the order of the landmark's row list.
+  // fa: the landmark's own cut, fb: the next cut, fc: the previous one.  Null: walk the landmark's whole row list (fs_state_lm)
+  const int *fa_ptr, *fa_it, *fb_ptr, *fb_it, *fc_ptr, *fc_it;
+  T *lmMM;                           // L x ld x ld: sum over a landmark's rows of m m^T (+ its priors' weights on the diagonal), k_fs_lm_terms
   int dbg;                           // timing ablations of k_fs_sweep_syrk (builds with -DGPS_FSY_DBG only; GPSLAM_FSY_DBG bits: 1 no MFMA, 2 no steps, 4 no requests after the first chunk)
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
@@ -946,8 +951,57 @@ template <typename T, typename TR> __device__ __forceinline__ T fs_state_lm(cons
   }
   return v;
 }
+// ---- per landmark: its own block of the normal equations, sum_rows m m^T (+ prior weights), and its gradient -sum_rows m e
+// (- prior terms).  One thread per landmark, the sums in the order k_fs_fat_assemble used to form them in (round 3: that kernel
+// re-walked the landmark's row list for each of its ld x ld + ld entries, two dependent loads per row, inside the fat block's
+// workgroup).
+template <typename T, typename TR = T> __global__ void __launch_bounds__(128) k_fs_lm_terms(FsArgs<T, TR> a) {
+  const int lm = blockIdx.x * blockDim.x + threadIdx.x;
+  if (lm >= a.L) return;
+  const int ld = a.ld;
+  for (int q = 0; q < ld; q++) {
+    for (int q2 = 0; q2 < ld; q2++) {
+      T v = T(0);
+      for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
+        const int rho = a.lmrow[t];
+        v += a.rowM[(size_t)rho * ld + q] * a.rowM[(size_t)rho * ld + q2];
+      }
+      if (q == q2)
+        for (int t = a.lmpri_ptr[lm]; t < a.lmpri_ptr[lm + 1]; t++) {
+          const T w = T(1) / T(a.pri_sig[(size_t)a.lmpri[t] * ld + q]);
+          v += w * w;
+        }
+      a.lmMM[((size_t)lm * ld + q) * ld + q2] = v;
+    }
+    T g = T(0);
+    for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
+      const int rho = a.lmrow[t];
+      g -= a.rowM[(size_t)rho * ld + q] * a.rowE[rho];
+    }
+    for (int t = a.lmpri_ptr[lm]; t < a.lmpri_ptr[lm + 1]; t++) {
+      const int pk = a.lmpri[t];
+      const T w = T(1) / T(a.pri_sig[(size_t)pk * ld + q]);
+      g -= w * w * T(a.lmk[(size_t)lm * ld + q] - a.pri_meas[(size_t)pk * ld + q]);
+    }
+    a.gL[(size_t)lm * ld + q] = g;   // undamped gradient (LM model)
+  }
+}
+
+// the same sum from the precomputed items of the landmark at position p (round 3): fs_state_lm scans all ~9-18 rows of the landmark
+// through three dependent loads each to find the zero to two that touch the cut -- 720 such scans per fat block, 0.32 ms per
+// iteration at config 4; the items are found once, at compile() time.  Same rows in the same order: bit-identical.
+template <typename T, typename TR> __device__ __forceinline__ T fs_state_lm_items(const FsArgs<T, TR> &a, const int *ptr, const int *it, int p, int r, int q) {
+  T v = T(0);
+  for (int t = ptr[p]; t < ptr[p + 1]; t++) {
+    const int rho = it[t] >> 1, half = it[t] & 1;
+    v += a.rowLR[(size_t)rho * 2 * a.B + (half ? a.B : 0) + r] * a.rowM[(size_t)rho * a.ld + q];
+  }
+  return v;
+}
 template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fs_fat_assemble(FsArgs<T, TR> a) {
   const int k = blockIdx.x, NB = a.NB, B = a.B;
+  const bool items = a.fa_ptr != nullptr;
+  const int p0 = a.fat_lm_ptr[k], p1 = (k < a.K - 1) ? a.fat_lm_ptr[k + 1] : 0;     // positions of the landmarks of blocks k, k + 1
   const int cut = a.cuts[k];
   const T *AL = (k > 0) ? a.Aseg + (size_t)(k - 1) * a.NCP * a.NCP : nullptr;   // segment on the left: this block is its RIGHT fat
   const T *AR = (k < a.K - 1) ? a.Aseg + (size_t)k * a.NCP * a.NCP : nullptr;
@@ -960,8 +1014,9 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
       v = (r == c) ? T(1) : T(0);
     } else {
       if (vr.kind == 0 && vc.kind == 0) v = bp[r * B + c];
-      else if (vr.kind == 0) v = fs_state_lm(a, cut, r, vc.lm, vc.q);
-      else if (vc.kind == 0) v = fs_state_lm(a, cut, c, vr.lm, vr.q);
+      else if (vr.kind == 0) v = items ? fs_state_lm_items(a, a.fa_ptr, a.fa_it, p0 + (c - B) / a.ld, r, vc.q) : fs_state_lm(a, cut, r, vc.lm, vc.q);
+      else if (vc.kind == 0) v = items ? fs_state_lm_items(a, a.fa_ptr, a.fa_it, p0 + (r - B) / a.ld, c, vr.q) : fs_state_lm(a, cut, c, vr.lm, vr.q);
+      else if (vr.lm == vc.lm && items) v = a.lmMM[((size_t)vr.lm * a.ld + vr.q) * a.ld + vc.q];
       else if (vr.lm == vc.lm) {
         for (int t = a.lmrow_ptr[vr.lm]; t < a.lmrow_ptr[vr.lm + 1]; t++) {
           const int rho = a.lmrow[t];
@@ -984,8 +1039,8 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
       T o = T(0);
       if (wr.kind != 2 && vc.kind != 2) {
         if (wr.kind == 0 && vc.kind == 0) { if (cut1 == cut + 1) o = bp[B * B + r * B + c]; }
-        else if (wr.kind == 0 && vc.kind == 1) o = fs_state_lm(a, cut1, r, vc.lm, vc.q);
-        else if (wr.kind == 1 && vc.kind == 0) o = fs_state_lm(a, cut, c, wr.lm, wr.q);
+        else if (wr.kind == 0 && vc.kind == 1) o = items ? fs_state_lm_items(a, a.fb_ptr, a.fb_it, p0 + (c - B) / a.ld, r, vc.q) : fs_state_lm(a, cut1, r, vc.lm, vc.q);
+        else if (wr.kind == 1 && vc.kind == 0) o = items ? fs_state_lm_items(a, a.fc_ptr, a.fc_it, p1 + (r - B) / a.ld, c, wr.q) : fs_state_lm(a, cut, c, wr.lm, wr.q);
         o -= fs_sym(AR, a.NCP, NB + r, c);
       }
       a.link[(size_t)k * NB * NB + idx] = o;
@@ -995,6 +1050,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
     const FsVar<T> vr = fs_var(a, k, r);
     T g = T(0);
     if (vr.kind == 0) g = bp[2 * B * B + r];
+    else if (vr.kind == 1 && items) g = a.gL[(size_t)vr.lm * a.ld + vr.q];
     else if (vr.kind == 1) {
       for (int t = a.lmrow_ptr[vr.lm]; t < a.lmrow_ptr[vr.lm + 1]; t++) {
         const int rho = a.lmrow[t];
@@ -1692,6 +1748,8 @@ struct FatSepPlan {
   // right-hand-side groups of the landmark border columns (FsArgs::lg_*)
   DevBuf d_lg_ptr, d_lg_state, d_lg_mptr, d_lg_m, Gev;
   DevBuf d_sc_base, d_sc_ptr, d_se_pk, d_se_src;    // the same as entries per chunk (k_fs_sweep_syrk)
+  DevBuf d_fa_ptr, d_fa_it, d_fb_ptr, d_fb_it, d_fc_ptr, d_fc_it;   // rows of each landmark that touch a cut state (k_fs_fat_assemble)
+  DevBuf lmMM;
   bool fused_sweep = false;                         // k_fs_sweep_syrk serves this plan (else k_fs_sweep + k_fs_syrk through Y)
   int ngroups = 0;
   std::vector<int> h_lmrow, h_lmstate, h_lmptr;     // compile(): rows per landmark, sorted by left state
@@ -1700,7 +1758,8 @@ struct FatSepPlan {
     for (DevBuf *b : {&d_cuts, &d_segid, &d_fat_lm_ptr, &d_fat_lm, &d_lm_fat, &d_lm_slot, &d_lmpri_ptr, &d_lmpri, &d_elim, &d_upd,
                       &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
                       &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp,
-                      &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev, &d_sc_base, &d_sc_ptr, &d_se_pk, &d_se_src})
+                      &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev, &d_sc_base, &d_sc_ptr, &d_se_pk, &d_se_src,
+                      &d_fa_ptr, &d_fa_it, &d_fb_ptr, &d_fb_it, &d_fc_ptr, &d_fc_it, &lmMM})
       b->release();
     active = false;
   }
