@@ -364,14 +364,18 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // kernels that exist for fp64 only (hand-written 64-bit DPP row layout, v_mfma_f64): the fp32 instantiation of the
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
-inline void launch_fused_k(const FusedArgs<double, double> &u, int grid, hipStream_t st) {
+inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, hipStream_t st) {
+  if (b == 6) { k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u); return; }
   if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
   else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);
 }
 // fp32 handles: fp32 row tables straight into the fused kernel's fp64 accumulation (round 3: the unfused assembly had cost the
 // fp32 mode more than its halved row traffic saved)
-inline void launch_fused_k(const FusedArgs<double, float> &u, int grid, hipStream_t st) { k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u); }
+inline void launch_fused_k(int b, const FusedArgs<double, float> &u, int grid, hipStream_t st) {
+  if (b == 6) k_fused_level0<0, float, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
+  else k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u);
+}
 inline void launch_rows_k(int b, const FwdArgs<double> &a, int grid, hipStream_t st) {
   if (b == 12) k_chunk_forward_rows<12><<<dim3(grid), dim3(64), 0, st>>>(a);
   else if (b == 6) k_chunk_forward_rows<6><<<dim3(grid), dim3(64), 0, st>>>(a);

@@ -164,6 +164,15 @@ template <> __device__ __forceinline__ void fmac_gather<6>(double *d, double s, 
       : "v"(s), "v"(m));
 }
 
+template <> __device__ __forceinline__ void fmac_gather<3>(double *d, double s, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %3, %4 row_newbcast:0 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %3, %4 row_newbcast:1 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %3, %4 row_newbcast:2 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+      : "v"(s), "v"(m));
+}
+
 template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
 template <> __device__ __forceinline__ void lane_gather<12>(double v, double *d) {
   asm volatile(

@@ -2177,12 +2177,16 @@ template <typename T, typename TR = T> struct FusedArgs {
 // full-width row ring is replaced by the record ring (a kernel with both spills: 256 VGPRs + 176 B of scratch, 0.34 ms).
 // SV = 2: a structured chain that also has a few other full-width rows (a velocity prior or two): those are fetched where
 // they are used, without a ring (the pure variant stays free of that loop's registers: with it the kernel spills again).
-template <int SV, typename TR = double>
+// (round 3: the block size is a template parameter -- 12: SE(3), with or without structured GP records; 6: SE(2), SO(3), 3-D linear
+// chains, plain rows only)
+template <int SV, typename TR = double, int B = 12>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
   constexpr bool ST = SV != 0, ODD = SV == 2;
   const FwdArgs<double> &a = u.f;
-  constexpr int B = 12, BS = 2 * B * B + B, AS = B * B + B;   // R == 1
+  static_assert(B == 12 || B == 6, "block sizes with DPP gather blocks");
+  static_assert(SV == 0 || B == 12, "structured GP records are SE(3) records");
+  constexpr int BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
   typedef double V2 __attribute__((ext_vector_type(2)));
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15;
@@ -2309,9 +2313,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
             const double Rv = okg ? (lo6 ? gR[q] : kR * gR[q]) : 0.0;
             const double ev = okg ? gE[q] : 0.0;
 #ifndef GPS_ABLATE_ASM
-            fmac_gather<12>(Dacc, Lv, Lv);
-            fmac_gather<12>(Oacc, Lv, Rv);
-            fmac_gather<12>(RRacc, Rv, Rv);
+            fmac_gather<B>(Dacc, Lv, Lv);
+            fmac_gather<B>(Oacc, Lv, Rv);
+            fmac_gather<B>(RRacc, Rv, Rv);
 #endif
             gacc = fma(-Lv, ev, gacc);
             grr = fma(-Rv, ev, grr);
@@ -2329,9 +2333,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           const bool ok = i < nf;
           Lv = ok ? Lv : 0.0; Rv = ok ? Rv : 0.0; ev = ok ? ev : 0.0;
 #ifndef GPS_ABLATE_ASM
-          fmac_gather<12>(Dacc, Lv, Lv);
-          fmac_gather<12>(Oacc, Lv, Rv);
-          fmac_gather<12>(RRacc, Rv, Rv);
+          fmac_gather<B>(Dacc, Lv, Lv);
+          fmac_gather<B>(Oacc, Lv, Rv);
+          fmac_gather<B>(RRacc, Rv, Rv);
 #endif
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
@@ -2345,9 +2349,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           const bool ok = i < nf;
           const double Lv = ok ? fL[q] : 0.0, Rv = ok ? fR[q] : 0.0, ev = ok ? fE[q] : 0.0;
 #ifndef GPS_ABLATE_ASM   /* timing ablation only (wrong results): the assembly wave keeps its loads and barriers, skips the sums */
-          fmac_gather<12>(Dacc, Lv, Lv);     // D[r][k] += L[k] L[r]: the row's element of lane k fused into the multiply-add
-          fmac_gather<12>(Oacc, Lv, Rv);     // O[r][k] += L[k] R[r]
-          fmac_gather<12>(RRacc, Rv, Rv);    // carry[r][k] += R[k] R[r]
+          fmac_gather<B>(Dacc, Lv, Lv);     // D[r][k] += L[k] L[r]: the row's element of lane k fused into the multiply-add
+          fmac_gather<B>(Oacc, Lv, Rv);     // O[r][k] += L[k] R[r]
+          fmac_gather<B>(RRacc, Rv, Rv);    // carry[r][k] += R[k] R[r]
 #endif
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
@@ -2361,9 +2365,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           const int i = i0 + q;
           const bool ok = (i < nc) && (r < Dh);
           const double Lv = ok ? cL[q] : 0.0, Rv = ok ? cR[q] : 0.0, ev = (i < nc) ? cE[q] : 0.0;
-          fmac_gather<6>(Dacc, Lv, Lv);
-          fmac_gather<6>(Oacc, Lv, Rv);
-          fmac_gather<6>(RRacc, Rv, Rv);
+          fmac_gather<Dh>(Dacc, Lv, Lv);
+          fmac_gather<Dh>(Oacc, Lv, Rv);
+          fmac_gather<Dh>(RRacc, Rv, Rv);
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
           ldc(i + PC, cL[q], cR[q], cE[q]);
@@ -2464,11 +2468,15 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       // row r -= (D~[r][k] / pivot) * row k, the pivot row fused into the multiply-add (fmac_self*): of D~ only the columns
       // right of the pivot still matter, in blocks of four (entries at or left of the pivot inside a block become garbage
       // that nothing reads again)
-      if (k < 3) fmac_self4<k>(Dr, nmp);
-      if (k < 7) fmac_self4<k>(Dr + 4, nmp);
-      if (k < 11) fmac_self4<k>(Dr + 8, nmp);
-      fmac_self12<k>(Or, nmp);
-      fmac_self12<k>(Fr, nmp);
+      if constexpr (B == 12) {
+        if (k < 3) fmac_self4<k>(Dr, nmp);
+        if (k < 7) fmac_self4<k>(Dr + 4, nmp);
+        if (k < 11) fmac_self4<k>(Dr + 8, nmp);
+      } else {
+        fmac_self_n<k, B>(Dr, nmp);
+      }
+      fmac_self_n<k, B>(Or, nmp);
+      fmac_self_n<k, B>(Fr, nmp);
       fmac_self1<k>(gr, nmp);
     });
 #endif
@@ -2510,7 +2518,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast12<i>(Dn, Or, nol);
+      fmac_bcast_n<i, B>(Dn, Or, nol);
       fmac_bcast2<i>(gn, as_, gr, nol, ngg);
     });
 #endif
@@ -2523,8 +2531,8 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast12<i>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
-      fmac_bcast12<i>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
 #endif
     __builtin_amdgcn_sched_barrier(0);

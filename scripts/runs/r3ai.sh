@@ -1,0 +1,5 @@
+#!/bin/bash
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|Error|error" | tail -4
+python scripts/bench_configs.py 1000000 2>&1 | tail -4
+GPSLAM_FUSE_B6=0 python scripts/bench_configs.py 1000000 2>&1 | tail -4
+python scripts/bench_configs.py 100000 2>&1 | tail -4
