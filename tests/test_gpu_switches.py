@@ -21,7 +21,7 @@ def _rerun(env, files, k=None):
 
 
 def test_block6_chains_through_the_unfused_row_layout_kernels():
-    """Chains of block size 6 take k_fused_level0<.., 6> up to 262144 states and k_assemble_ghost + k_chunk_forward_rows<6> beyond
+    """Chains of block size 6 take k_fused_level0<.., 6> up to 131072 states and k_assemble_ghost + k_chunk_forward_rows<6> beyond
     (api_impl.inc: fused_kernel_applies); GPSLAM_FUSE_B6=0 sends the small parity cases through the latter."""
     _rerun({"GPSLAM_FUSE_B6": "0"}, ["test_gpu_parity.py", "test_gpu_upper.py"])
 
