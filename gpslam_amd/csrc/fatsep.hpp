@@ -657,6 +657,14 @@ constexpr int fs_tile_rank(int T16, int p) {       // index of tile p among its 
   for (int q = 0; q < p; q++) if (fs_tile_owner(T16, q) == o) r++;
   return r;
 }
+constexpr bool fs_panel_used(int T16, int w, int t) {   // does wave w touch the 16-column panel t?
+  for (int q = 0; q < T16 * (T16 + 1) / 2; q++) {
+    if (fs_tile_owner(T16, q) != w) continue;
+    const int ti = fs_tri_row(q), tj = q - ti * (ti + 1) / 2;
+    if (ti == t || tj == t) return true;
+  }
+  return false;
+}
 constexpr int fs_tile_count(int T16, int w) {
   int r = 0;
   for (int q = 0; q < T16 * (T16 + 1) / 2; q++) if (fs_tile_owner(T16, q) == w) r++;
@@ -678,8 +686,11 @@ template <int T16, int WV, int LSP> struct FsTiles {
 #pragma unroll
       for (int k4 = 0; k4 < KC; k4 += 4) {
         double pn[T16];
-#pragma unroll
-        for (int t = 0; t < T16; t++) pn[t] = bb[k4 * LSP + 16 * t];
+        static_for<0, T16>([&](auto tt) {                   // (only the panels this wave's tiles touch)
+          constexpr int t = decltype(tt)::value;
+          if constexpr (fs_panel_used(T16, WV, t)) pn[t] = bb[k4 * LSP + 16 * t];
+          else pn[t] = 0.0;
+        });
         static_for<0, NT>([&](auto pp) {
           constexpr int p = decltype(pp)::value;
           if constexpr (fs_tile_owner(T16, p) == WV) {
@@ -751,7 +762,8 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
   // pointer, stride per state and LDS destination are formed once
   const double *sbase[PF];
   int sstr[PF], sst[PF], sdst[PF];                          // sdst: >= 0 offset in Fs, -1 - r: rhs element r (ring), INT_MIN: nothing
-  bool szero[PF];
+  bool szero[PF], sneg[PF];
+  static_assert(MP > FW, "the matrices' last 16-lane row has a pad word");
 #pragma unroll
   for (int u = 0; u < PF; u++) {
     const int v = min(lane + 64 * u, SPC * SW - 1);
@@ -761,6 +773,7 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
     sstr[u] = (k < FW) ? FW : a.BS;
     sdst[u] = (lane + 64 * u >= SPC * SW) ? (int)0x80000000 : (k < FW ? t * MP + k : -1 - (t * B + (k - FW)));
     szero[u] = (k >= B * B && k < FW && t == 0);            // E_{j0 - 1} = 0 (first chunk only): the first interior state
+    sneg[u] = (k >= B * B && k < FW);
   }
   auto stage = [&](int i) {                                 // factors + rhs of chunk i -> pre (clamped: never out of the segment)
     const int s0 = j0 + min(i, clast) * SPC;
@@ -804,10 +817,20 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
 #pragma unroll
         for (int row = 0; row < KC; row++) slot[row * LSP + c] = 0.0;
       }
+      // (branch-free: a value that has no place goes to a word nobody reads -- the pad of the matrices' last 16-lane row, a
+      // ring column beyond NCP)
 #pragma unroll
       for (int u = 0; u < PF; u++) {
-        if (sdst[u] >= 0) Fs[sdst[u]] = (szero[u] && i == 0) ? 0.0 : (((sdst[u] % MP) >= B * B) ? -pre[u] : pre[u]);   // W, -E
-        else if (sdst[u] != (int)0x80000000 && own_rhs && i * SPC + sst[u] < n) slot[(-1 - sdst[u]) * LSP + 2 * NB] = pre[u];
+        const double v = (szero[u] && i == 0) ? 0.0 : (sneg[u] ? -pre[u] : pre[u]);                     // W, -E
+        Fs[sdst[u] >= 0 ? sdst[u] : MP - 1] = (sdst[u] >= 0) ? v : 0.0;
+      }
+      if (own_rhs) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+          const bool isg = sdst[u] < 0 && sdst[u] != (int)0x80000000 && i * SPC + sst[u] < n;
+          const int rw = isg ? -1 - sdst[u] : 0;
+          slot[rw * LSP + (isg ? 2 * NB : NCP + 8)] = pre[u];
+        }
       }
       if (pk_cur >= 0) {
         const int col = pk_cur & 255, row = ((pk_cur >> 8) - i * SPC) * B;
