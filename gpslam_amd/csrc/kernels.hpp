@@ -2667,7 +2667,7 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   const bool has_sep = !a.no_sep;
   const bool right_exists = has_sep && ((e < a.n) || (a.last_has_right != 0));
   constexpr int RG = 64 / B;
-  constexpr int PFB = 3;
+  constexpr int PFB = 4;   // records in flight (round 3: 3 -> 4 with the longer chunks of large chains: 485 -> 452 us at 1e6 states; 6: 510 us)
   const int rr = lane / B, k = lane - rr * B;
   const bool active = rr < RG;
   typedef T V2 __attribute__((ext_vector_type(2)));
