@@ -2410,8 +2410,10 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     assemble(0); write_img(0, 0);
     assemble(1); write_img(1, 1);
     lds_barrier();                       // P: images 0 and 1 are there
-    assemble(2);
     lds_barrier();                       // Q: ELIM has taken what it needs from image 0
+    // (round 3: image 2 is assembled AFTER Q, under the elimination of the first block -- ELIM only needs it at the barrier
+    //  of step 0.  Before, ELIM sat at Q through this assembly: one block step of every chunk, 3 % of the kernel)
+    assemble(2);
     write_img(0, 2);
     for (int t = 0; t < steps; t++) {
       lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
