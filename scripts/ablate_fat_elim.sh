@@ -1,10 +1,11 @@
 #!/bin/bash
-# where does k_fat_elim's 40 us per block go (library built with -DGPS_FSY_DBG; results are wrong on purpose)
+# where do the 40 us per block of k_fat_elim (the LDS kernel: GPSLAM_FAT_ELIM_ROWS=0) go -- library built with -DGPS_FSY_DBG,
+# bits 8: no factorisation, 16: no products; results are wrong on purpose
 ROOT=$(pwd)
 export TMPDIR=/tmp
 for d in 0 8 16 24; do
   OUT=$ROOT/gpurun_out/r3w/d$d; mkdir -p $OUT
-  (cd /tmp && GPSLAM_FSY_DBG=$d PYTHONPATH=$ROOT rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $ROOT/scripts/bench_c4.py 200000 > $OUT/run.log 2>&1)
+  (cd /tmp && GPSLAM_FAT_ELIM_ROWS=0 GPSLAM_FSY_DBG=$d PYTHONPATH=$ROOT rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python $ROOT/scripts/bench_c4.py 200000 > $OUT/run.log 2>&1)
   python - <<PY
 import csv, glob, collections
 f = glob.glob("$OUT/**/t_kernel_trace.csv", recursive=True)
