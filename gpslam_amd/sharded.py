@@ -204,6 +204,11 @@ class ShardedSolver:
         if self.dist is None:
             self.recv.copy_(self.send)
             return
+        if getattr(self.send, "is_cuda", False) and hasattr(self.dist, "all_gather_into_tensor"):
+            # one contiguous output: RCCL gathers straight into recv (a list of views makes torch gather into a temporary and
+            # copy it out chunk by chunk -- extra launches on a collective whose payload is a few KB)
+            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
+            return
         chunks = list(self.recv.view(self.nranks, -1).unbind(0))
         self.dist.all_gather(chunks, self.send, group=self.group)
 
@@ -407,6 +412,11 @@ class SplitSolver:
                 raise RuntimeError("SplitSolver without a process group holds one piece of %d: drive the pieces of one process "
                                    "with iterate_pieces / iterate_pieces_lm" % self.nranks)
             self.recv.copy_(self.send)
+            return
+        if getattr(self.send, "is_cuda", False) and hasattr(self.dist, "all_gather_into_tensor"):
+            # one contiguous output: RCCL gathers straight into recv (a list of views makes torch gather into a temporary and
+            # copy it out chunk by chunk -- extra launches on a collective whose payload is a few KB)
+            self.dist.all_gather_into_tensor(self.recv, self.send, group=self.group)
             return
         chunks = list(self.recv.view(self.nranks, -1).unbind(0))
         self.dist.all_gather(chunks, self.send, group=self.group)
