@@ -981,32 +981,44 @@ template <typename T, typename TR> __device__ __forceinline__ T fs_state_lm(cons
 template <typename T, typename TR = T> __global__ void __launch_bounds__(128) k_fs_lm_terms(FsArgs<T, TR> a) {
   const int lm = blockIdx.x * blockDim.x + threadIdx.x;
   if (lm >= a.L) return;
+  constexpr int LDM = 3;                       // landmark dimension <= 3 (Point2 / Point3)
   const int ld = a.ld;
-  for (int q = 0; q < ld; q++) {
-    for (int q2 = 0; q2 < ld; q2++) {
-      T v = T(0);
-      for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
-        const int rho = a.lmrow[t];
-        v += a.rowM[(size_t)rho * ld + q] * a.rowM[(size_t)rho * ld + q2];
-      }
-      if (q == q2)
-        for (int t = a.lmpri_ptr[lm]; t < a.lmpri_ptr[lm + 1]; t++) {
-          const T w = T(1) / T(a.pri_sig[(size_t)a.lmpri[t] * ld + q]);
-          v += w * w;
-        }
-      a.lmMM[((size_t)lm * ld + q) * ld + q2] = v;
+  T v[LDM][LDM], g[LDM];
+#pragma unroll
+  for (int q = 0; q < LDM; q++) {
+    g[q] = T(0);
+#pragma unroll
+    for (int q2 = 0; q2 < LDM; q2++) v[q][q2] = T(0);
+  }
+  for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {     // ONE pass over the rows; every sum keeps its row order
+    const int rho = a.lmrow[t];
+    TR m[LDM];                                 // (products in the row tables' type, as k_fs_fat_assemble formed them)
+#pragma unroll
+    for (int q = 0; q < LDM; q++) m[q] = (q < ld) ? a.rowM[(size_t)rho * ld + q] : TR(0);
+    const TR e = a.rowE[rho];
+#pragma unroll
+    for (int q = 0; q < LDM; q++) {
+#pragma unroll
+      for (int q2 = 0; q2 < LDM; q2++) v[q][q2] += m[q] * m[q2];
+      g[q] -= m[q] * e;
     }
-    T g = T(0);
-    for (int t = a.lmrow_ptr[lm]; t < a.lmrow_ptr[lm + 1]; t++) {
-      const int rho = a.lmrow[t];
-      g -= a.rowM[(size_t)rho * ld + q] * a.rowE[rho];
-    }
-    for (int t = a.lmpri_ptr[lm]; t < a.lmpri_ptr[lm + 1]; t++) {
-      const int pk = a.lmpri[t];
+  }
+  for (int t = a.lmpri_ptr[lm]; t < a.lmpri_ptr[lm + 1]; t++) {
+    const int pk = a.lmpri[t];
+#pragma unroll
+    for (int q = 0; q < LDM; q++) {
+      if (q >= ld) continue;
       const T w = T(1) / T(a.pri_sig[(size_t)pk * ld + q]);
-      g -= w * w * T(a.lmk[(size_t)lm * ld + q] - a.pri_meas[(size_t)pk * ld + q]);
+      v[q][q] += w * w;
+      g[q] -= w * w * T(a.lmk[(size_t)lm * ld + q] - a.pri_meas[(size_t)pk * ld + q]);
     }
-    a.gL[(size_t)lm * ld + q] = g;   // undamped gradient (LM model)
+  }
+#pragma unroll
+  for (int q = 0; q < LDM; q++) {
+    if (q >= ld) continue;
+#pragma unroll
+    for (int q2 = 0; q2 < LDM; q2++) if (q2 < ld) a.lmMM[((size_t)lm * ld + q) * ld + q2] = v[q][q2];
+    a.gL[(size_t)lm * ld + q] = g[q];          // undamped gradient (LM model)
   }
 }
 
