@@ -168,7 +168,7 @@ import sys, numpy as np
 sys.path.insert(0, %r)
 import gpslam_amd
 from gpslam_amd import synthetic as S
-p = S.pose2_local_landmarks_chain(%d, window=%d)
+p = S.pose2_local_landmarks_chain(%d, L=%d, window=%d)
 s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=%d))
 for _ in range(3):
     s.iterate_gn()
@@ -177,18 +177,20 @@ np.savez(sys.argv[1], pose=pose, vel=vel, lmk=s.get_landmarks(), plan=np.array([
 """
 
 
-@pytest.mark.parametrize("N,seglen", [(20000, 0), (3000, 256), (777, 250)])
-def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_bit(N, seglen, tmp_path):
+@pytest.mark.parametrize("N,seglen,div", [(20000, 0, 20), (3000, 256, 20), (777, 250, 20), (2400, 0, 80), (2400, 0, 40), (2400, 0, 27), (2400, 0, 16), (2400, 0, 13)])
+def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_bit(N, seglen, div, tmp_path):
     """k_fs_sweep_syrk (sweep and MFMA waves sharing an LDS ring, no Y buffer) against k_fs_sweep + k_fs_syrk through the Y
     buffer (GPSLAM_FS_FUSED=0, read once per process: two child processes): same expressions in the same order -> the
-    states after three Gauss-Newton iterations are IDENTICAL, including ragged last chunks and short last segments."""
+    states after three Gauss-Newton iterations are IDENTICAL, including ragged last chunks and short last segments.
+    div: landmarks = N / div -- a quarter to 1.6x config 4's density puts the border into every instantiation of the kernel
+    (NCP = 32 .. 112 columns)."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
     for fused in ("1", "0"):
         out = str(tmp_path / ("fused%s.npz" % fused))
         env = dict(os.environ, GPSLAM_FS_FUSED=fused)
-        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, 100 if N < 1000 else 200, seglen), out], check=True, env=env, timeout=600)
+        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, max(N // div, 1), 100 if N < 1000 else 200, seglen), out], check=True, env=env, timeout=600)
         outs.append(np.load(out))
     a, b = outs
     assert a["plan"][1] <= 112, "the fused kernel serves borders up to 112 columns: this case would not exercise it"
