@@ -1203,6 +1203,29 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(128) k_
 
 // ---- small utilities for Levenberg-Marquardt
 // partial[b] = sum over this block of a[i] * b[i]  (stride-aware: element i lives at a[i * sa], b[i * sb])
+// the three dot products of a Levenberg-Marquardt trial in one launch (round 3): x . y0, x . y1 (y1 may be null), x . x, each with
+// k_dot's partition into per-block partial sums -- partial[b], partial[nb + b], partial[2 nb + b] -- so that k_final_reduce3 adds
+// them up in k_final_reduce's order: the model-fidelity test sees bit-identical numbers
+template <typename T> __global__ void __launch_bounds__(256) k_dot3(const T *x, const T *y0, const T *y1, int n, T *partial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = gridDim.x;
+  const T xi = (i < n) ? x[i] : T(0);
+  const T t0 = block_sum((i < n) ? xi * y0[i] : T(0));
+  __syncthreads();
+  const T t1 = block_sum((i < n && y1 != nullptr) ? xi * y1[i] : T(0));
+  __syncthreads();
+  const T t2 = block_sum((i < n) ? xi * xi : T(0));
+  if (threadIdx.x == 0) { partial[blockIdx.x] = t0; partial[nb + blockIdx.x] = t1; partial[2 * nb + blockIdx.x] = t2; }
+}
+// block b: out[slot[b]] = sum of in[b * n .. b * n + n) in k_final_reduce's order
+template <typename T> __global__ void __launch_bounds__(256) k_final_reduce3(const T *in, int n, double *out, int s0, int s1, int s2) {
+  const T *p = in + (size_t)blockIdx.x * n;
+  T acc = T(0);
+  for (int i = threadIdx.x; i < n; i += 256) acc = acc + p[i];
+  const T r = block_sum(acc);
+  const int slot = blockIdx.x == 0 ? s0 : (blockIdx.x == 1 ? s1 : s2);
+  if (threadIdx.x == 0 && slot >= 0) out[slot] = (double)r;
+}
 template <typename T> __global__ void __launch_bounds__(256) k_dot(const T *x, const T *y, int n, T *partial) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const T v = (i < n) ? x[i] * y[i] : T(0);
