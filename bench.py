@@ -388,6 +388,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # a TIMED convergence run (outside the contract clock; VERDICT r2: the headline's states-to-convergence figure was derived
+    # from ms_per_step): from the initial values, the iterations the convergence run above needed, wall clock between barriers
+    reset()
+    barrier()
+    tc0 = time.perf_counter()
+    run(conv_iters)
+    barrier()
+    conv_seconds = time.perf_counter() - tc0
+    if dist is not None:
+        t = torch.tensor([conv_seconds], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        conv_seconds = float(t.item())
+
     # N > 1: what the one data-path collective of an iteration costs (all ranks take part; outside the contract clock):
     # device time of `reps` all-gathers of the 3.6 KB interface records between events on the stream RCCL is ordered against
     collective_ms = None
@@ -466,7 +479,9 @@ def main():
             "iters_to_convergence": conv_iters,
             "delta_inf_at_convergence": conv_delta,
             "final_error": final_error,
-            "states_to_convergence_per_sec": total_states / (conv_iters * ms_per_step * 1e-3),
+            "seconds_to_convergence": conv_seconds,
+            "states_to_convergence_per_sec": total_states / conv_seconds,
+            "states_to_convergence_per_sec_note": "timed: %d Gauss-Newton iterations from the initial values to |delta|_inf < 1e-6, wall clock between barriers" % conv_iters,
             "phase_ms_per_iter_1gpu": {k: float(v) / 3 for k, v in
                                        zip(["linearize", "assemble", "solve", "retract+error", "total"], phase)},
             "kernel_ms": {names[i]: float(kms[i]) for i in live},
