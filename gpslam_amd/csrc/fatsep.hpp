@@ -57,6 +57,7 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   // fa: the landmark's own cut, fb: the next cut, fc: the previous one.  Null: walk the landmark's whole row list (fs_state_lm)
   const int *fa_ptr, *fa_it, *fb_ptr, *fb_it, *fc_ptr, *fc_it;
   T *lmMM;                           // L x ld x ld: sum over a landmark's rows of m m^T (+ its priors' weights on the diagonal), k_fs_lm_terms
+  long long *probe;                  // (builds with -DGPS_FSY_DBG, GPSLAM_FSY_PROBE=1) cycle totals per phase of sweep wave 0 of segment 0
   int dbg;                           // timing ablations of k_fs_sweep_syrk (builds with -DGPS_FSY_DBG only; GPSLAM_FSY_DBG bits: 1 no MFMA, 2 no steps, 4 no requests after the first chunk)
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
@@ -639,7 +640,10 @@ constexpr int fs_tri_row(int p) { int t = 0; while ((t + 1) * (t + 2) / 2 <= p) 
 // kFsSweepTiles tiles cost on the matrix cores (measured: ~2700 cycles against 6 x 64 per tile -- on MI355X the fp64 MFMA and
 // the fp64 vector multiply-adds of one SIMD do not overlap, the matrix peak equals the vector peak), so the tiles are dealt
 // greedily to the least loaded wave with that head start: every wave, hence every SIMD, carries the same work.
-constexpr int kFsSweepTiles = 7;
+#ifndef GPS_FS_SWEEP_TILES
+#define GPS_FS_SWEEP_TILES 7
+#endif
+constexpr int kFsSweepTiles = GPS_FS_SWEEP_TILES;
 constexpr int fs_tile_owner(int T16, int p) {
   const int NT = T16 * (T16 + 1) / 2;
   int load[4] = {kFsSweepTiles, kFsSweepTiles, 0, 0};
@@ -808,6 +812,14 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
     ent_desc(e0n1, e1n1, pk_n1, src_n1);
     ent_vals(src0);
   }
+#ifdef GPS_FSY_DBG
+  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
+  const bool prb = a.probe != nullptr && seg == 0 && SWV == 0;
+#define FSY_STAMP(k) if (prb) { const long long tn = (long long)__builtin_readcyclecounter(); ph[k] += tn - tp; tp = tn; }
+  if (prb) tp = (long long)__builtin_readcyclecounter();
+#else
+#define FSY_STAMP(k)
+#endif
 #pragma unroll 1
   for (int i = 0; i <= nchunks; i++) {
     if (i < nchunks) {
@@ -860,7 +872,9 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
           for (int r = 0; r < B; r++) slot[(row + r) * LSP + col] = gp[r];
         }
       }
+      FSY_STAMP(0)
       fs_wave_sync();
+      FSY_STAMP(1)
       // ---- requests of the chunks ahead (in flight under this chunk's steps)
 #ifdef GPS_FSY_DBG
       if (!(a.dbg & 4)) {
@@ -874,6 +888,7 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
 #ifdef GPS_FSY_DBG
       }
 #endif
+      FSY_STAMP(2)
       // ---- the steps.  The matrices are the same for every column: lane j of each 16-lane row holds elements j, 16 + j, ...
       // of [W_s | -E_{s-1}] (MQ registers) and every multiply-add takes its matrix element by DPP row broadcast
       // (v_fmac_f64_dpp, dpp.hpp fmac_mat).  The first version read them from LDS as broadcast operands, two per ds_read_b128
@@ -909,14 +924,21 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
         }
       }
     }
+    FSY_STAMP(3)
 #ifdef GPS_FSY_DBG
     if (i >= 1 && !(a.dbg & 1)) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
 #else
     if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
 #endif
+    FSY_STAMP(4)
     lds_barrier();
+    FSY_STAMP(5)
   }
   tl.store(out, NCP, lane);
+#ifdef GPS_FSY_DBG
+  if (prb && lane == 0) { for (int k = 0; k < 6; k++) a.probe[k] = ph[k]; a.probe[6] = nchunks; }
+#endif
+#undef FSY_STAMP
 }
 
 // NCP == 16 * T16 exactly (the caller picks the instantiation); 2 NB + 1 <= 128 columns; 256 threads: waves 0, 1 sweep, 2, 3 multiply
