@@ -225,6 +225,7 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 //   next block:         A' = D' + lambda I - E^T E,  (E^T E)[r][c] = sum_k E[k][r] E_k[c]; column r of E through a 288-byte LDS transpose
 // ~370 instructions per state for four segments.  Records are fetched three states ahead (the only memory latency of a
 // step); with that distance the in-order vmcnt counter never makes a step wait for its own stores.
+template <int UNUSED = 0>   // (a template only so that the header may be included by several translation units)
 __global__ void __launch_bounds__(64) k_fs_factor_rows6(FsArgs<double, double> a) {
   constexpr int B = 6, DEPTH = 3;
   const int lane = threadIdx.x, row = lane >> 4, r = lane & 15;
