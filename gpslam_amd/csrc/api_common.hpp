@@ -84,6 +84,8 @@ struct gpslam_hip_handle {
   std::vector<double> gp_Utab;
   std::vector<int32_t> gp_perm;
   std::vector<int32_t> gp_groups;
+  int gp_single_q = 0;      // > 0: every GP prior came through add_gp_priors_qc with the SAME Qc (entry gp_single_q - 1 of gp_Utab):
+                            // one group, one launch, and the structured-record path of k_fused_level0 stays available
   SimpleSet pri, vpri, btw, lpri;
   MeasSet ms[kNumMeasKinds];
   // row table

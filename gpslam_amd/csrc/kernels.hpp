@@ -119,19 +119,27 @@ template <typename T> struct GpArgs {
 };
 
 // Structured record of one GaussianProcessPriorPose3 (what k_fused_level0's assembly wave reads when K1 feeds it directly).
-// Of the whitened 12 x 24 Jacobian [L | R] only the pose columns are data; the velocity columns are
-//   L[rho][6..11] = k2 U[rho]  (top rows),  -sc U[rho]  (bottom rows)          H2 = [-dt I; -I]      (GaussianProcessPriorPose3.h:86)
-//   R[rho][6..11] = sb WJ[rho] (top rows),   sc WJ[rho] (bottom rows), WJ = U Jr^-1(r)   H4 = [0; Jinv]   (:95)
-// with U = chol_upper(Qc^-1) the same for every factor: 196 doubles per factor instead of 312.
-//   [rho * 18 + 0..5]   R[rho][0..5]        rho = 0..5 (top rows)        written in K1's "right state" phase,
-//   [rho * 18 + 6..11]  WJ[rho][0..5]                                    144 contiguous bytes per rho
-//   [rho * 18 + 12..17] R[6 + rho][0..5]    (bottom rows)
-//   [108 + rho * 12 + 0..5] L[rho][0..5],  [.. + 6..11] L[6 + rho][0..5]  "left state" phase, 96 bytes per rho
-//   [180..191] whitened error,  [192] k2 = -(sa dt + sb), [193] sb, [194] sc, [195] pad
+// Round 4: the record holds what the whitened 12 x 24 Jacobian [L | R] is a FUNCTION of, not its columns.  With
+//   X = Jinv = Jr^-1(r) = [[XA, 0], [XC, XA]]                      (GaussianProcessPriorPose3.h:76; 18 distinct entries)
+//   J = Hlog Hcomp1 Hinv = -Jinv Ad(h^-1) = [[JA, 0], [JC, JA]]   (:79-84; the product of two such matrices is one again)
+//   F = FD = d(Jinv v2)/dr by central differences = [[FA, 0], [FC, FD]]     (:81, :90; Pose3utils.cpp:167-179; 27 entries)
+// the Jacobian is H1 = [J; F J], H2 = [-dt I; -I], H3 = [X; F X], H4 = [0; X] (:79-95), whitened by
+// R_w = [[sa U, sb U], [0, sc U]], U = chol_upper(Qc^-1) the same for every factor.  Column c of the whitened halves is
+//   L[:, c] = [U (sa J_c + sb F J_c); sc U F J_c]        c < 6 (pose)         [k2 U_c'; -sc U_c']           velocity column c'
+//   R[:, c] = [U (sa X_c + sb F X_c); sc U F X_c]                              [sb U X_c'; sc U X_c']
+// which the assembly wave forms lane by lane (lane c of a chunk's 16-lane DPP row holds column c): two 6 x 6 matrix-vector
+// products with F and four with U per lane and state, all as v_fmac_f64_dpp blocks.  80 doubles = five 128-byte lines per
+// factor instead of the 196 doubles of round 2/3's column records (and the 312 of plain rows + errors):
+//   [0..8] XA  [9..17] XC  [18..26] JA  [27..35] JC  [36..44] FA  [45..53] FC  [54..62] FD   (3 x 3 blocks, row-major)
+//   [63] 0 (the velocity lanes take their zero coefficients from here)
+//   [64..75] whitened error,  [76] k2 = -(sa dt + sb), [77] sb, [78] sc, [79] sa
+// K1 stages 16 doubles per lane and wave and writes whole 128-byte lines (wave_store_part): the order above is the order in
+// which it produces the blocks.  Record F (one past the last factor) is all zeros: states without a GP prior read it.
 #ifndef GPS_KLIN_WAVES
 #define GPS_KLIN_WAVES 2   /* two K1 waves per SIMD (<= 256 VGPRs): linearise phase 87.8 vs 93.3 us with structured records */
 #endif
-constexpr int kGpsLen = 196, kGpsL = 108, kGpsE = 180, kGpsS = 192;
+constexpr int kGpsLen = 80, kGpsXA = 0, kGpsXC = 9, kGpsJA = 18, kGpsJC = 27, kGpsFA = 36, kGpsFC = 45, kGpsFD = 54, kGpsZ = 63,
+              kGpsE = 64, kGpsS = 76;
 
 // Cooperative row store: every lane of a wave has deposited one row (W doubles, W even) of ITS factor in the wave's
 // LDS staging buffer; the wave then writes the 64 rows as 16-byte pieces, consecutive lanes on consecutive pieces of
@@ -195,12 +203,95 @@ __device__ __forceinline__ void utri_times_bl6_row(const T *U, const BL6<T> &M, 
 // [H1 H2] = [[J, -dt I], [FD J, -I]], J = -Jinv Ad(h^-1); whitening R = [[sa U, sb U], [0, sc U]] is applied as
 // U x (block lower-triangular) products row by row, skipping the structural zeros.  Peak live state is FD + two
 // 6x6 blocks instead of two 6 x 24 arrays, which is what lets two waves share a SIMD.
+// K1 for a chain whose GP priors reach the fused level-0 kernel as structured records (kGps* above): Log, Jr^-1, the
+// finite-difference block and J = -Jr^-1 Ad(h^-1) per factor, the whitened error -- and none of the products that turn them
+// into Jacobian columns (those moved to the consumer, where they are DPP row operations).
+template <typename T>
+__device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, int f, T *st, int *sr, int lane, T &err) {
+  T *mine = st + lane * 20;
+  sr[lane] = valid ? f : -1;                 // structured records are indexed by factor, not by row
+  const T *U = a.U.u;
+  T p1[12], p2[12], v1[6], v2[6];
+  T dt = T(1);
+#pragma unroll
+  for (int k = 0; k < 12; k++) { p1[k] = (k == 0 || k == 4 || k == 8) ? T(1) : T(0); p2[k] = p1[k]; }   // idle lane: identity
+#pragma unroll
+  for (int k = 0; k < 6; k++) { v1[k] = T(0); v2[k] = T(0); }
+  if (valid) {
+    const int i = a.left[f];
+    dt = a.dt[f];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { p1[k] = T(a.pose[(size_t)k * a.stride + i]); p2[k] = T(a.pose[(size_t)k * a.stride + i + 1]); }
+#pragma unroll
+    for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+  }
+  const SE3<T> h = se3_between(as_se3(p1), as_se3(p2));
+  const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
+  const JrK<T> k0 = jr_coefs(r.w);
+  const BL6<T> Jinv = se3_jrinv_k(k0, r);     // :76
+  const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+  const T sq = sqrt(dt);
+  const T sa = T(3.4641016151377545870548926830117) / (dt * sq);  // sqrt(12 / dt^3)
+  const T sb = T(-1.7320508075688772935274463415059) / sq;        // (-6 / dt^2) / sa
+  const T sc = T(1) / sq;                                          // sqrt(4/dt - sb^2)
+  {   // the whitened error and the scalars: line 4 of the record
+    const V6<T> top = r - dt * u1;            // :97
+    const V6<T> bot = Jinv * u2 - u1;
+    const T e[12] = {top.w.x, top.w.y, top.w.z, top.v.x, top.v.y, top.v.z, bot.w.x, bot.w.y, bot.w.z, bot.v.x, bot.v.y, bot.v.z};
+#pragma unroll
+    for (int rho = 0; rho < 6; rho++) {
+      T wt = T(0), wb = T(0);
+#pragma unroll
+      for (int q = rho; q < 6; q++) {
+        wt += U[rho * 6 + q] * (sa * e[q] + sb * e[6 + q]);
+        wb += U[rho * 6 + q] * e[6 + q];
+      }
+      wb *= sc;
+      err += wt * wt + wb * wb;
+      mine[rho] = wt;
+      mine[6 + rho] = wb;
+    }
+    mine[12] = -(sa * dt + sb); mine[13] = sb; mine[14] = sc; mine[15] = sa;
+    wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, kGpsE, a.gps);
+  }
+  // the matrix blocks in record order, 16 doubles (one 128-byte line) staged per lane at a time
+  auto put = [&](int idx, T v) {              // (idx is a compile-time constant once the loops below are unrolled)
+    mine[idx & 15] = v;
+    if ((idx & 15) == 15) wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, idx - 15, a.gps);
+  };
+#pragma unroll
+  for (int k = 0; k < 9; k++) put(kGpsXA + k, Jinv.A.m[k]);
+#pragma unroll
+  for (int k = 0; k < 9; k++) put(kGpsXC + k, Jinv.C.m[k]);
+  {
+    const SE3<T> hi = se3_inverse(h);
+    // J = -Jinv Ad(h^-1), Ad = [[R, 0], [t^ R, R]]: the diagonal blocks of J are equal (those of both factors are)
+    const M3<T> JA = neg(Jinv.A * hi.R);
+    const M3<T> JC = neg(Jinv.C * hi.R + Jinv.A * (skew(hi.t) * hi.R));
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kGpsJA + k, JA.m[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kGpsJC + k, JC.m[k]);
+  }
+  {   // last, with nothing but r, the coefficients and v2 alive next to it: the twelve evaluations of the difference quotient
+    // (the factor's error sum waits in a spare staging slot of the lane: across this block it was what the allocator spilled)
+    mine[16] = err;
+    const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90)
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kGpsFA + k, FD.A.m[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kGpsFC + k, FD.C.m[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kGpsFD + k, FD.D.m[k]);
+    put(kGpsZ, T(0));
+    err = mine[16];
+  }
+}
+
 template <typename T, bool VW>
 __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, int f, T *st, int *sr, int lane, T &err) {
   constexpr int LS = 14;
-  const bool structured = !VW && a.gps != nullptr;      // (the VW chain rule mixes the velocity columns: rows only)
-  T *mine = st + lane * (structured ? 20 : LS);
-  if (structured) sr[lane] = valid ? f : -1;            // structured records are indexed by factor, not by row
+  T *mine = st + lane * LS;
   const T *U = a.U.u;
   T p1[12], p2[12], v1[6], v2[6];
   T dt = T(1);
@@ -256,12 +347,7 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       mine[rho] = wt;
       mine[6 + rho] = wb;
     }
-    if (structured) {
-      mine[12] = -(sa * dt + sb); mine[13] = sb; mine[14] = sc; mine[15] = T(0);
-      wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, kGpsE, a.gps);
-    } else {
-      wave_store_scalars<T, 12>(st, sr, lane, a.rowE);
-    }
+    wave_store_scalars<T, 12>(st, sr, lane, a.rowE);
   }
   const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90) -- computed once, used twice
   {   // right state: H3 = [Jinv; FD Jinv] (:88-93), H4 = [0; Jinv] (:95)
@@ -271,12 +357,6 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       T x[6], y[6];
       utri_times_bl6_row(U, Jinv, rho, x);
       utri_times_bl6_row(U, P3, rho, y);
-      if (structured) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = x[c]; mine[12 + c] = sc * y[c]; }
-        wave_store_part<T, kGpsLen, 18, 20>(st, sr, lane, 0, rho * 18, a.gps);
-        continue;
-      }
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sb * x[c]; }
       if (VW) vw_row_transform(p2, v2, mine);
@@ -296,12 +376,6 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
       T x[6], y[6];
       utri_times_bl6_row(U, J, rho, x);
       utri_times_bl6_row(U, P1, rho, y);
-      if (structured) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = sc * y[c]; }
-        wave_store_part<T, kGpsLen, 12, 20>(st, sr, lane, 0, kGpsL + rho * 12, a.gps);
-        continue;
-      }
 #pragma unroll
       for (int c = 0; c < 6; c++) { mine[c] = sa * x[c] + sb * y[c]; mine[6 + c] = (c >= rho) ? k2 * U[rho * 6 + c] : T(0); }
       if (VW) vw_row_transform(p1, v1, mine);
@@ -317,8 +391,11 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
 // One 128-thread block of GP-prior factors; bid = block index among the GP blocks.  stage / srow: the block's LDS staging
 // area (2 * 64 * (2b + 2) elements of T and 128 ints when MODE == 0), owned by the calling kernel so that k_lin can share
 // one area between its factor types.
-template <typename T, int MF, int MODE, bool VW>
+// REC (Pose3 body-velocity chains, fp64, MODE 0): structured records for k_fused_level0 (a.gps) instead of rows -- a template
+// parameter, not a run-time branch: the two bodies in one kernel cost both their register budget (256 VGPRs + 368 B of scratch)
+template <typename T, int MF, int MODE, bool VW, bool REC = false>
 __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *stage, int *srow) {
+  static_assert(!REC || (MF == POSE3 && MODE == 0 && !VW && IsF64<T>::v), "structured GP records: fp64 SE(3) body-velocity chains");
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   constexpr bool JAC = (MODE != 1);
   constexpr int LS = 2 * b + 2;                       // staging stride (16-byte aligned, conflict-free for b128)
@@ -328,7 +405,8 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
   T err = T(0);
   if constexpr (MF == POSE3 && MODE == 0) {
     srow[threadIdx.x] = valid ? a.row0[f] : -1;
-    gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * 20 /* gp_pose3_rows: half rows (14) or structured pieces (20) per lane */, srow + wv * 64, lane, err);
+    if constexpr (REC) gp_pose3_record<T>(a, valid, f, stage + wv * 64 * 20 /* 16 staged doubles per lane, stride 20 */, srow + wv * 64, lane, err);
+    else gp_pose3_rows<T, VW>(a, valid, f, stage + wv * 64 * 20 /* half rows: 14 per lane */, srow + wv * 64, lane, err);
     const T tot = block_sum(T(0.5) * err);
     if (threadIdx.x == 0) a.partial[bid] = tot;
     return;
@@ -458,12 +536,12 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
 }
 
 // MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
-template <typename T, int MF, int MODE, bool VW = false>
+template <typename T, int MF, int MODE, bool VW = false, bool REC = false>
 __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
   constexpr int LS = 4 * MTraits<MF>::d + 2;
   __shared__ T stage[MODE == 0 ? 2 * 64 * LS : 1];
   __shared__ int srow[MODE == 0 ? 128 : 1];
-  gp_block<T, MF, MODE, VW>(a, blockIdx.x, stage, srow);
+  gp_block<T, MF, MODE, VW, REC>(a, blockIdx.x, stage, srow);
 }
 
 // ------------------------------------------------------------------ unary / between rows
@@ -578,7 +656,6 @@ template <typename T> struct LinArgs {
   GpArgs<T> gp;
   FacArgs<T> fac[3];      // pose priors, velocity priors, between factors
   int nb_gp, nb[3];       // blocks per type (0: type absent)
-  int interleave;         // 1: GP and between blocks alternate; 0: all GP blocks first
   // deferred reduction (round 3): the per-block |delta|_inf maxima the PREVIOUS iteration's k_retract left behind are
   // reduced here, by one extra workgroup at the end of the grid, instead of by a launch of their own (fixed order:
   // deterministic; nothing is skipped, the value lands in *red_out one launch later).  red_in == null: nothing pending.
@@ -589,7 +666,7 @@ template <typename T> struct LinArgs {
 // VP: the launch contains velocity priors (full-width rows).  Without them a Pose3 launch stages half rows only (the GP
 // prior writes its rows in halves, pose priors / between factors have compact rows): 14 KB of LDS instead of 27 KB, so that
 // every workgroup of a 1e5-state launch is resident at once.
-template <typename T, int MF, bool VW, bool VP>
+template <typename T, int MF, bool VW, bool VP, bool REC = false>
 __global__ void __launch_bounds__(128, GPS_KLIN_WAVES) k_lin(LinArgs<T> a) {
   constexpr int LS = (MF == POSE3 && !VP) ? 20 : 4 * MTraits<MF>::d + 2;
   __shared__ T stage[2 * 64 * LS];
@@ -602,17 +679,11 @@ __global__ void __launch_bounds__(128, GPS_KLIN_WAVES) k_lin(LinArgs<T> a) {
     if (threadIdx.x == 0) *a.red_out = r;
     return;
   }
-  const int pair = a.interleave ? min(a.nb_gp, a.nb[2]) : 0;
-  if (bid < 2 * pair) {                                    // interleaved part: even = GP, odd = between
-    if (bid & 1) simple_block<T, MF, 2, true>(a.fac[2], bid >> 1, stage, srow);
-    else gp_block<T, MF, 0, VW>(a.gp, bid >> 1, stage, srow);
-    return;
-  }
-  bid -= 2 * pair;
-  if (bid < a.nb_gp - pair) { gp_block<T, MF, 0, VW>(a.gp, pair + bid, stage, srow); return; }
-  bid -= a.nb_gp - pair;
-  if (bid < a.nb[2] - pair) { simple_block<T, MF, 2, true>(a.fac[2], pair + bid, stage, srow); return; }
-  bid -= a.nb[2] - pair;
+  // GP blocks first, then the light ones (measured in round 2: 0.539 ms per iteration; GP and between blocks alternating 0.568)
+  if (bid < a.nb_gp) { gp_block<T, MF, 0, VW, REC>(a.gp, bid, stage, srow); return; }
+  bid -= a.nb_gp;
+  if (bid < a.nb[2]) { simple_block<T, MF, 2, true>(a.fac[2], bid, stage, srow); return; }
+  bid -= a.nb[2];
   if (bid < a.nb[0]) { simple_block<T, MF, 0, true>(a.fac[0], bid, stage, srow); return; }
   bid -= a.nb[0];
   if constexpr (VP) simple_block<T, MF, 1, true>(a.fac[1], bid, stage, srow);
@@ -982,7 +1053,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         err += we * we;
         wgt[r] = w;
         if (!JAC && a.rowE32) a.rowE32[row0 + r] = (float)we;
-        if (JAC) {
+        if (JAC && a.rowLR) {      // (rowLR == null: the inspection call, gpslam_hip_linearize_meas, leaves the row tables alone)
           a.rowE[row0 + r] = we;
           if (a.ld > 0) {
             a.rowLm[row0 + r] = lm;
@@ -998,11 +1069,13 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
       T *st = stage + wv * 64 * LS, *mine = st + lane * LS;
       srow[threadIdx.x] = row0v;
+      if (a.rowLR) {
 #pragma unroll
-      for (int r = 0; r < rows; r++) {
+        for (int r = 0; r < rows; r++) {
 #pragma unroll
-        for (int c = 0; c < b; c++) { mine[c] = wgt[r] * JL[r * b + c]; mine[b + c] = wgt[r] * JR[r * b + c]; }
-        wave_store_rows<T, 2 * b>(st, srow + wv * 64, lane, r, a.rowLR);
+          for (int c = 0; c < b; c++) { mine[c] = wgt[r] * JL[r * b + c]; mine[b + c] = wgt[r] * JR[r * b + c]; }
+          wave_store_rows<T, 2 * b>(st, srow + wv * 64, lane, r, a.rowLR);
+        }
       }
     }
   }
@@ -2188,6 +2261,7 @@ template <typename T, typename TR = T> struct FusedArgs {
   const int *crowptr;     // compact rows
   const TR *rowC, *rowCE; // Mc x 12, Mc
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
+  int gp_count;           // number of records; record gp_count is all zeros (states without a GP prior read it)
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
   int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
@@ -2255,25 +2329,99 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
     int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
-    // structured GP prior of the state (u.gps): lanes 0..5 fetch the pose columns of its rows, six rows at a time; lanes
-    // 6..11 form the velocity columns from U (L) and from the record's WJ block (R) -- see kGps* in GpArgs
+    // structured GP prior of the state (u.gps, layout kGps*): lane c < 12 of the chunk's DPP row builds COLUMN c of the whitened
+    // [L | R] from the record's blocks -- pose columns for c < 6, velocity columns for c >= 6 (see the record's description):
+    //   column r6 = c mod 6 of X = Jinv and of J as six-vectors [top; bottom] (the translation columns have a zero top and
+    //   the diagonal block below it), F times both (F's blocks live one entry per lane: element 3 i + j in lane 3 i + j),
+    //   then  L = [U (aL J_c + b F J_c); U (c F J_c - dR J_c)],  R = [U (aR X_c + b F X_c); U (c F X_c + dR X_c)]
+    // with per-lane coefficients fetched from the record (pose lanes: aL = aR = sa, b = sb, c = sc, dR = 0; velocity lanes:
+    // J_c = the unit vector, aL = k2, aR = sb, b = c = 0, dR = sc -- their zeros are the record's zero slot).
     constexpr bool st_on = ST;
-    const bool lo6 = r < Dh;
-    const int r6 = r < Dh ? r : (r < B ? r - Dh : 0);
-    constexpr int GH = ST ? Dh : 1;
-    // Lanes 6..11 fetch through the SAME ring slots what their velocity columns are multiples of: U[q][r - 6] (a 288-byte
-    // table, L1 resident) in the L slot and WJ[q][r - 6] of the record in the R slot -- no registers beyond the ring.
-    double gL[GH], gR[GH], gE[GH], kk2 = 0.0, ksb = 0.0, ksc = 0.0;
+    constexpr int NRAW = ST ? 21 : 1;
+    double Ur[ST ? 3 : 1];
+    if constexpr (ST) {
 #pragma unroll
-    for (int q = 0; q < GH; q++) { gL[q] = 0.0; gR[q] = 0.0; gE[q] = 0.0; }
+      for (int k = 0; k < 3; k++) Ur[k] = u.Ud[min(16 * k + r, 35)];       // U, row-major: entry e in lane e & 15 of Ur[e >> 4]
+    }
+    // where this lane's operands sit in a record (loop-invariant; the stride-3 walks down a column are immediate offsets)
+    int oX1 = 0, oX2 = 0, oJ1 = 0, oJ2 = 0, oF = 0, oE = 0, oaL = 0, oaR = 0, ob = 0, oc = 0, od = 0;
+    if constexpr (ST) {
+      const int r6 = r < Dh ? r : (r < B ? r - Dh : 0);
+      const bool velc = r >= Dh && r < B, hi3 = r6 >= 3;
+      const int j3 = hi3 ? r6 - 3 : r6;
+      oX1 = kGpsXA + j3; oX2 = (hi3 ? kGpsXA : kGpsXC) + j3;      // top three of X's column (masked for the translation columns), bottom three
+      oJ1 = kGpsJA + j3; oJ2 = (hi3 ? kGpsJA : kGpsJC) + j3;
+      oF = min(r, 8); oE = kGpsE + min(r, 11);
+      oaL = velc ? kGpsS + 0 : kGpsS + 3;    // aL: k2 | sa
+      oaR = velc ? kGpsS + 1 : kGpsS + 3;    // aR: sb | sa
+      ob = velc ? kGpsZ : kGpsS + 1;         // b:  0  | sb
+      oc = velc ? kGpsZ : kGpsS + 2;         // c:  0  | sc
+      od = velc ? kGpsS + 2 : kGpsZ;         // dR: sc | 0
+    }
+    double raw[NRAW];
     int gp = -1;
     int gpn = st_on ? u.gpidx[min(s + 1, ptr_max)] : -1, gpnn = st_on ? u.gpidx[min(s + 2, ptr_max)] : -1;
-    auto ldg = [&](int q, int half) {                    // row 6 * half + q of the record
+    // operands of the GP prior whose left state is s + kimg (record g; no such factor: the all-zero record behind the last one)
+    auto ldraw = [&](int kimg, int g) {
       if constexpr (ST) {
-        const double *rec = u.gps + (size_t)max(gp, 0) * kGpsLen;
-        gL[q] = lo6 ? rec[kGpsL + q * 12 + 6 * half + r6] : u.Ud[q * Dh + r6];
-        gR[q] = rec[q * 18 + (lo6 ? 12 * half : 6) + r6];
-        gE[q] = rec[kGpsE + 6 * half + q];
+        const bool live = valid && (s + kimg) < e && g >= 0;
+        const double *rec = u.gps + (size_t)(live ? g : u.gp_count) * kGpsLen;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          raw[k] = rec[oX1 + 3 * k]; raw[3 + k] = rec[oX2 + 3 * k];
+          raw[6 + k] = rec[oJ1 + 3 * k]; raw[9 + k] = rec[oJ2 + 3 * k];
+        }
+        raw[12] = rec[kGpsFA + oF]; raw[13] = rec[kGpsFC + oF]; raw[14] = rec[kGpsFD + oF];
+        raw[15] = rec[oE];
+        raw[16] = rec[oaL]; raw[17] = rec[oaR]; raw[18] = rec[ob]; raw[19] = rec[oc]; raw[20] = rec[od];
+      }
+    };
+    double Lcol[ST ? B : 1], Rcol[ST ? B : 1], newl = 0.0;
+    auto reconstruct = [&]() {
+      if constexpr (ST) {
+        double X6[6], J6[6], P3[6], P1[6];
+        // the lane's role, recomputed per state from an opaque copy of its index: as loop invariants the masks and the unit
+        // vector would occupy two dozen registers for the whole kernel (the wave spilled with them)
+        int rq = r;
+        asm volatile("" : "+v"(rq));
+        const bool tcol = (rq >= 3 && rq < 6) || (rq >= 9), vcol = rq >= 6;   // translation column; velocity column
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          X6[k] = tcol ? 0.0 : raw[k]; X6[3 + k] = raw[3 + k];
+          J6[k] = vcol ? ((rq == 6 + k) ? 1.0 : 0.0) : (tcol ? 0.0 : raw[6 + k]);
+          J6[3 + k] = vcol ? ((rq == 9 + k) ? 1.0 : 0.0) : raw[9 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) { P3[k] = 0.0; P1[k] = 0.0; }
+        const double *fa = &raw[12], *fc = &raw[13], *fd = &raw[14];
+        static_for<0, 3>([&](auto jj) {            // F [top; bottom] = [FA top; FC top + FD bottom]
+          constexpr int j = decltype(jj)::value;
+          fmac_mat<3, j, 3>(P3, fa, X6[j]);
+          fmac_mat<3, j, 3>(P3 + 3, fc, X6[j]);
+          fmac_mat<3, j, 3>(P3 + 3, fd, X6[3 + j]);
+          fmac_mat<3, j, 3>(P1, fa, J6[j]);
+          fmac_mat<3, j, 3>(P1 + 3, fc, J6[j]);
+          fmac_mat<3, j, 3>(P1 + 3, fd, J6[3 + j]);
+        });
+        const double aL = raw[16], aR = raw[17], bb = raw[18], cc = raw[19], dR = raw[20], ndR = -dR;
+        double Z[4][6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+          Z[0][k] = fma(aL, J6[k], bb * P1[k]);      // top rows of L
+          Z[1][k] = fma(cc, P1[k], ndR * J6[k]);     // bottom rows of L
+          Z[2][k] = fma(aR, X6[k], bb * P3[k]);      // top rows of R
+          Z[3][k] = fma(cc, P3[k], dR * X6[k]);      // bottom rows of R
+        }
+#pragma unroll
+        for (int k = 0; k < B; k++) { Lcol[k] = 0.0; Rcol[k] = 0.0; }
+        static_for<0, 6>([&](auto kk) {              // U Z, U upper triangular: out[i] += U[i][k] Z[k], i <= k
+          constexpr int k = decltype(kk)::value;
+          fmac_mat<k + 1, k, 6>(Lcol, Ur, Z[0][k]);
+          fmac_mat<k + 1, k, 6>(Lcol + 6, Ur, Z[1][k]);
+          fmac_mat<k + 1, k, 6>(Rcol, Ur, Z[2][k]);
+          fmac_mat<k + 1, k, 6>(Rcol + 6, Ur, Z[3][k]);
+        });
+        newl = -raw[15];                             // minus the whitened error of row (lane)
       }
     };
     auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
@@ -2301,12 +2449,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       if (gp >= 0) p0 += B;                              // its 12 rows lead the state's range in the row table: not used
       rp = (live && (!ST || ODD)) ? p0 : 0; nf = (live && (!ST || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
-      if constexpr (ST) {
-        const double *rec = u.gps + (size_t)max(gp, 0) * kGpsLen;
-#pragma unroll
-        for (int q = 0; q < Dh; q++) ldg(q, 0);
-        kk2 = rec[kGpsS]; ksb = rec[kGpsS + 1]; ksc = rec[kGpsS + 2];
-      }
       if constexpr (!ST) {
 #pragma unroll
         for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
@@ -2325,27 +2467,21 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
       for (int k = 0; k < B; k++) { Dacc[k] = carry[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
       gacc = carry_g;
-      if constexpr (ST) {                                // the structured GP prior: its 12 rows, top half then bottom half
-        const bool okg = gp >= 0;
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-          const double kL = half ? -ksc : kk2, kR = half ? ksc : ksb;
-#pragma unroll
-          for (int q = 0; q < Dh; q++) {
-            const double Lv = okg ? (lo6 ? gL[q] : kL * gL[q]) : 0.0;
-            const double Rv = okg ? (lo6 ? gR[q] : kR * gR[q]) : 0.0;
-            const double ev = okg ? gE[q] : 0.0;
+      if constexpr (ST) {                                // the structured GP prior: its 12 rows from the columns built above
+        reconstruct();
+        static_for<0, B>([&](auto qq) {
+          constexpr int q = decltype(qq)::value;
+          // the next state's record is requested once most of this state's columns are consumed (their registers take it)
+          if constexpr (q == 8) ldraw(kimg + 1, gpn);
+          const double Lv = Lcol[q], Rv = Rcol[q];
 #ifndef GPS_ABLATE_ASM
-            fmac_gather<B>(Dacc, Lv, Lv);
-            fmac_gather<B>(Oacc, Lv, Rv);
-            fmac_gather<B>(RRacc, Rv, Rv);
+          fmac_gather<B>(Dacc, Lv, Lv);
+          fmac_gather<B>(Oacc, Lv, Rv);
+          fmac_gather<B>(RRacc, Rv, Rv);
 #endif
-            gacc = fma(-Lv, ev, gacc);
-            grr = fma(-Rv, ev, grr);
-            if (half == 0) ldg(q, 1);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+          fmac_bcast2<q>(gacc, grr, newl, Lv, Rv);       // g -= e[q] L[q][r],  carry_g -= e[q] R[q][r]
+          __builtin_amdgcn_sched_barrier(0);
+        });
       }
       if constexpr (ODD) {
         // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
@@ -2429,7 +2565,11 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
         }
       }
     };
-    open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, st_on ? u.gpidx[min(s, ptr_max)] : -1);
+    {
+      const int g0 = st_on ? u.gpidx[min(s, ptr_max)] : -1;
+      ldraw(0, g0);
+      open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, g0);
+    }
     assemble(0); write_img(0, 0);
     assemble(1); write_img(1, 1);
     lds_barrier();                       // P: images 0 and 1 are there

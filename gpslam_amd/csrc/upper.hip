@@ -189,20 +189,29 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_backward(UpBwdArgs
 template <typename K> hipError_t allow_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
+// The attribute belongs to the CURRENT DEVICE's function object, not to the process: a process that drives a second GPU
+// (ChainSolver(device=1) after device 0) must set it there as well.  One flag per device ordinal.
+constexpr int kMaxDevices = 64;
+inline bool *ready_slot(bool (&tab)[kMaxDevices]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;   // unknown ordinal: set it every time
+  return &tab[dev];
+}
 
 template <int B, int G> int fwd_b(bool top, const UpFwdArgs &a0, hipStream_t st) {
   typedef UpDims<B, G> DM;
-  static bool ready = false;                  // (the attribute is per kernel and process-wide: set once, to the one size)
+  static bool ready_tab[kMaxDevices] = {};   // (the attribute is per kernel and per device: set once each, to the one size)
+  bool *ready = ready_slot(ready_tab);
   hipError_t e;
   UpFwdArgs a = a0;
   static long long *dprobe = nullptr;
   static const bool want_probe = getenv("GPSLAM_UPPER_PROBE") && atoi(getenv("GPSLAM_UPPER_PROBE")) != 0;
   if (want_probe && !dprobe) (void)hipMalloc((void **)&dprobe, 64 * sizeof(long long));
   a.probe = want_probe ? dprobe : nullptr;
-  if (!ready) {
+  if (!ready || !*ready) {
     if ((e = allow_lds(&k_multi_forward<B, G, true>, DM::lds_fwd(true))) != hipSuccess) return (int)e;
     if ((e = allow_lds(&k_multi_forward<B, G, false>, DM::lds_fwd(false))) != hipSuccess) return (int)e;
-    ready = true;
+    if (ready) *ready = true;
   }
   const int groups = (a.n + G - 1) / G;
   if (top) k_multi_forward<B, G, true><<<dim3(1), dim3(DM::NT), DM::lds_fwd(true), st>>>(a);
@@ -219,11 +228,12 @@ template <int B, int G> int fwd_b(bool top, const UpFwdArgs &a0, hipStream_t st)
 }
 template <int B, int G> int bwd_b(const UpBwdArgs &a, hipStream_t st) {
   typedef UpDims<B, G> DM;
-  static bool ready = false;
+  static bool ready_tab[kMaxDevices] = {};
+  bool *ready = ready_slot(ready_tab);
   hipError_t e;
-  if (!ready) {
+  if (!ready || !*ready) {
     if ((e = allow_lds(&k_multi_backward<B, G>, DM::lds_bwd())) != hipSuccess) return (int)e;
-    ready = true;
+    if (ready) *ready = true;
   }
   const int groups = (a.n + G - 1) / G;
   k_multi_backward<B, G><<<dim3(groups), dim3(DM::NT), DM::lds_bwd(), st>>>(a);

@@ -1,0 +1,85 @@
+"""numpy model of the structured GP-prior record of round 4 (gpslam_amd/csrc/kernels.hpp, kGps*) and of what the assembly wave
+of k_fused_level0 does with it, lane by lane: record -> the 24 columns of the whitened 12 x 24 Jacobian [L | R] of one
+GaussianProcessPriorPose3 (gpslam/gp/GaussianProcessPriorPose3.h:60-98).  The index expressions mirror the kernel's
+(`oX1`, `oJ2`, ..., `fmac_mat<N, M0, S>`), so that a slip in either shows up in tests/test_gp_record_model.py on the CPU."""
+import numpy as np
+
+LEN, XA, XC, JA, JC, FA, FC, FD, Z, E, S = 80, 0, 9, 18, 27, 36, 45, 54, 63, 64, 76
+
+
+def make_record(X, J, F, ew, dt):
+    """What K1 (gp_pose3_record) stores: X = Jinv, J = -Jinv Ad(h^-1), F = the finite-difference block, ew = whitened error."""
+    sq = np.sqrt(dt)
+    sa, sb, sc = np.sqrt(12.0) / (dt * sq), -np.sqrt(3.0) / sq, 1.0 / sq
+    rec = np.zeros(LEN)
+    rec[XA:XA + 9] = X[:3, :3].ravel(); rec[XC:XC + 9] = X[3:, :3].ravel()
+    rec[JA:JA + 9] = J[:3, :3].ravel(); rec[JC:JC + 9] = J[3:, :3].ravel()
+    rec[FA:FA + 9] = F[:3, :3].ravel(); rec[FC:FC + 9] = F[3:, :3].ravel(); rec[FD:FD + 9] = F[3:, 3:].ravel()
+    rec[E:E + 12] = ew
+    rec[S:S + 4] = [-(sa * dt + sb), sb, sc, sa]
+    return rec
+
+
+def fmac_mat(d, d0, Mr, n, m0, stride, m):
+    """dpp.hpp fmac_mat<N, M0, S>: d[d0 + i] += M(m0 + i * stride) * m, matrix element e in lane (e & 15) of register Mr[e >> 4]"""
+    for i in range(n):
+        e = m0 + i * stride
+        d[d0 + i] += Mr[e >> 4][e & 15] * m
+
+
+def lane_columns(rec, U):
+    """(L, R): 12 x 12 each; column c as lane c of the DPP row computes it."""
+    Ud = np.zeros(48); Ud[:36] = U.ravel()
+    # one register per lane: lane l of Ur[k] holds Ud[min(16 k + l, 35)]
+    Ur = [[Ud[min(16 * k + l, 35)] for l in range(16)] for k in range(3)]
+    fa = [[rec[FA + min(l, 8)] for l in range(16)]]
+    fc = [[rec[FC + min(l, 8)] for l in range(16)]]
+    fd = [[rec[FD + min(l, 8)] for l in range(16)]]
+    L = np.zeros((12, 12)); R = np.zeros((12, 12)); new = np.zeros(12)
+    for r in range(12):
+        r6 = r if r < 6 else r - 6
+        velc, hi3 = r >= 6, r6 >= 3
+        j3 = r6 - 3 if hi3 else r6
+        oX1, oX2 = XA + j3, (XA if hi3 else XC) + j3
+        oJ1, oJ2 = JA + j3, (JA if hi3 else JC) + j3
+        oaL, oaR = (S + 0 if velc else S + 3), (S + 1 if velc else S + 3)
+        ob, oc, od = (Z if velc else S + 1), (Z if velc else S + 2), (S + 2 if velc else Z)
+        raw = np.zeros(21)
+        for k in range(3):
+            raw[k] = rec[oX1 + 3 * k]; raw[3 + k] = rec[oX2 + 3 * k]; raw[6 + k] = rec[oJ1 + 3 * k]; raw[9 + k] = rec[oJ2 + 3 * k]
+        raw[15] = rec[E + min(r, 11)]
+        raw[16], raw[17], raw[18], raw[19], raw[20] = rec[oaL], rec[oaR], rec[ob], rec[oc], rec[od]
+        tcol, vcol = (3 <= r < 6) or r >= 9, r >= 6
+        X6 = np.zeros(6); J6 = np.zeros(6)
+        for k in range(3):
+            X6[k] = 0.0 if tcol else raw[k]; X6[3 + k] = raw[3 + k]
+            J6[k] = (1.0 if r == 6 + k else 0.0) if vcol else (0.0 if tcol else raw[6 + k])
+            J6[3 + k] = (1.0 if r == 9 + k else 0.0) if vcol else raw[9 + k]
+        P3 = np.zeros(6); P1 = np.zeros(6)
+        for j in range(3):
+            fmac_mat(P3, 0, fa, 3, j, 3, X6[j]); fmac_mat(P3, 3, fc, 3, j, 3, X6[j]); fmac_mat(P3, 3, fd, 3, j, 3, X6[3 + j])
+            fmac_mat(P1, 0, fa, 3, j, 3, J6[j]); fmac_mat(P1, 3, fc, 3, j, 3, J6[j]); fmac_mat(P1, 3, fd, 3, j, 3, J6[3 + j])
+        aL, aR, bb, cc, dR = raw[16], raw[17], raw[18], raw[19], raw[20]
+        Zs = np.zeros((4, 6))
+        for k in range(6):
+            Zs[0, k] = aL * J6[k] + bb * P1[k]
+            Zs[1, k] = cc * P1[k] - dR * J6[k]
+            Zs[2, k] = aR * X6[k] + bb * P3[k]
+            Zs[3, k] = cc * P3[k] + dR * X6[k]
+        Lc = np.zeros(12); Rc = np.zeros(12)
+        for k in range(6):
+            fmac_mat(Lc, 0, Ur, k + 1, k, 6, Zs[0, k]); fmac_mat(Lc, 6, Ur, k + 1, k, 6, Zs[1, k])
+            fmac_mat(Rc, 0, Ur, k + 1, k, 6, Zs[2, k]); fmac_mat(Rc, 6, Ur, k + 1, k, 6, Zs[3, k])
+        L[:, r] = Lc; R[:, r] = Rc; new[r] = -raw[15]
+    return L, R, new
+
+
+def reference_rows(X, J, F, U, dt):
+    """The whitened Jacobian from its definition: R_w [H1 H2 | H3 H4], R_w = [[sa U, sb U], [0, sc U]]."""
+    I6, O6 = np.eye(6), np.zeros((6, 6))
+    H = np.block([[J, -dt * I6, X, O6], [F @ J, -I6, F @ X, X]])
+    sq = np.sqrt(dt)
+    sa, sb, sc = np.sqrt(12.0) / (dt * sq), -np.sqrt(3.0) / sq, 1.0 / sq
+    Rw = np.block([[sa * U, sb * U], [O6, sc * U]])
+    W = Rw @ H
+    return W[:, :12], W[:, 12:]

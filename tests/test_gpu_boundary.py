@@ -87,6 +87,8 @@ def test_one_per_factor_qc_equals_the_shared_qc_path():
         fix = np.arange(0, N, 40)
         s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), 6), 0.02))
         s.compile()
+        # (a graph whose priors all carry the same Qc_model keeps the structured-record path of the fused kernel)
+        assert s.plan_info()["structured_gp"] == s.plan_info()["fused"]
         for _ in range(5):
             s.iterate_gn()
         out.append(s.get_states())
