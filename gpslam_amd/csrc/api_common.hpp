@@ -113,6 +113,9 @@ struct gpslam_hip_handle {
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
   bool struct_now = false;  // ... and the linearisation / elimination being enqueued do so
+  // block size 6 (SE(2), SO(3), 3-D linear chains): the GP priors as 32-double records (kGp3*) that k_assemble_ghost decodes;
+  // rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows, a consumer that reads the row table)
+  bool struct3_ok = false, rows3 = false;
   DevBuf gps, gpidx, dU, gsave2;
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use

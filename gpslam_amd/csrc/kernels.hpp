@@ -138,6 +138,15 @@ template <typename T> struct GpArgs {
 #ifndef GPS_KLIN_WAVES
 #define GPS_KLIN_WAVES 2   /* two K1 waves per SIMD (<= 256 VGPRs): linearise phase 87.8 vs 93.3 us with structured records */
 #endif
+// The same idea for the d = 3 manifolds (SE(2), SO(3), 3-D linear: block size 6; round 4).  There H1 = [J1; 0], H3 = [J3; 0] and
+// H2 = [h2t I; h2b I], H4 = [0; h4b I] with constants (GaussianProcessPriorPose2.h:76-79, GaussianProcessPriorRot3.h:73-76,
+// GaussianProcessPriorLinear.h:72-81), so of the whitened 6 x 12 Jacobian only two 3 x 3 blocks are data:
+//   [0..8] A1 = U (sa J1)   [9..17] A3 = U (sa J3)   (row-major)        rows 0..2: [A1 | kLt U | A3 | kRt U]
+//   [18..23] whitened error   [24] kLt [25] kRt [26] kLb [27] kRb      rows 3..5: [ 0 | kLb U |  0 | kRb U]
+//   [28..31] 0                                                           (kLt = sa h2t + sb h2b, kRt = sb h4b, kLb = sc h2b, kRb = sc h4b)
+// 32 doubles = two 128-byte lines per factor instead of 6 rows x 13 doubles = 624 bytes written as 96-byte fragments (1.45x write
+// amplification measured: profiles/round4_c4_v0).  Consumers: k_assemble_ghost<6> and k_fused_level0<1, double, 6>.
+constexpr int kGp3Len = 32, kGp3A1 = 0, kGp3A3 = 9, kGp3E = 18, kGp3S = 24;
 constexpr int kGpsLen = 80, kGpsXA = 0, kGpsXC = 9, kGpsJA = 18, kGpsJC = 27, kGpsFA = 36, kGpsFC = 45, kGpsFD = 54, kGpsZ = 63,
               kGpsE = 64, kGpsS = 76;
 
@@ -395,7 +404,8 @@ __device__ __forceinline__ void gp_pose3_rows(const GpArgs<T> &a, bool valid, in
 // parameter, not a run-time branch: the two bodies in one kernel cost both their register budget (256 VGPRs + 368 B of scratch)
 template <typename T, int MF, int MODE, bool VW, bool REC = false>
 __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *stage, int *srow) {
-  static_assert(!REC || (MF == POSE3 && MODE == 0 && !VW && IsF64<T>::v), "structured GP records: fp64 SE(3) body-velocity chains");
+  static_assert(!REC || (MODE == 0 && !VW && IsF64<T>::v && (MF == POSE3 || MF == POSE2 || MF == ROT3 || MF == LINEAR3)),
+                "structured GP records: fp64, SE(3) body-velocity chains and the d = 3 manifolds");
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   constexpr bool JAC = (MODE != 1);
   constexpr int LS = 2 * b + 2;                       // staging stride (16-byte aligned, conflict-free for b128)
@@ -482,6 +492,49 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
     const T sa = T(3.4641016151377545870548926830117) / (dt * sq);  // sqrt(12 / dt^3)
     const T sb = T(-1.7320508075688772935274463415059) / sq;        // (-6 / dt^2) / sa
     const T sc = T(1) / sq;                                          // sqrt(4/dt - sb^2)
+    if constexpr (REC && d == 3) {
+      // the d = 3 record (kGp3*): 16 doubles staged per lane at a time (stride 20), whole 128-byte lines out
+      T *st = stage + wv * 64 * 20, *mine = st + lane * 20;
+      int *sr = srow + wv * 64;
+      sr[lane] = valid ? f : -1;
+      auto put = [&](int idx, T v) {            // (idx: a compile-time constant once the loops are unrolled)
+        mine[idx & 15] = v;
+        if ((idx & 15) == 15) wave_store_part<T, kGp3Len, 16, 20>(st, sr, lane, 0, idx - 15, a.gps);
+      };
+#pragma unroll
+      for (int blk = 0; blk < 2; blk++)         // A1 = U (sa J1 + sb .): columns 0..2 of the top rows; A3: columns 6..8
+#pragma unroll
+        for (int rho = 0; rho < 3; rho++)
+#pragma unroll
+          for (int c = 0; c < 3; c++) {
+            T v = T(0);
+#pragma unroll
+            for (int r = rho; r < 3; r++) v += a.U.u[rho * 3 + r] * (sa * Jt[r * 12 + 6 * blk + c] + sb * Jb[r * 12 + 6 * blk + c]);
+            put((blk ? kGp3A3 : kGp3A1) + rho * 3 + c, v);
+          }
+#pragma unroll
+      for (int rho = 0; rho < 3; rho++) {
+        T wt = T(0), wb = T(0);
+#pragma unroll
+        for (int r = rho; r < 3; r++) {
+          wt += a.U.u[rho * 3 + r] * (sa * e[r] + sb * e[3 + r]);
+          wb += a.U.u[rho * 3 + r] * e[3 + r];
+        }
+        wb *= sc;
+        err += wt * wt + wb * wb;
+        put(kGp3E + rho, wt);
+        put(kGp3E + 3 + rho, wb);               // (positions 21..23 of the record: written out of order, both inside the second line)
+      }
+      put(kGp3S + 0, sa * Jt[3] + sb * Jb[3]);  // kLt: the (0, 0) entry of H2's halves
+      put(kGp3S + 1, sa * Jt[9] + sb * Jb[9]);  // kRt: H4's
+      put(kGp3S + 2, sc * Jb[3]);               // kLb
+      put(kGp3S + 3, sc * Jb[9]);               // kRb
+      put(28, T(0)); put(29, T(0)); put(30, T(0));
+      put(31, T(0));
+      const T tot = block_sum(T(0.5) * err);
+      if (threadIdx.x == 0) a.partial[bid] = tot;
+      return;
+    }
     T *st = stage + (MODE == 0 ? wv * 64 * LS : 0);
     T *mine = st + (MODE == 0 ? lane * LS : 0);
     const int *sr = srow + (MODE == 0 ? wv * 64 : 0);
@@ -538,7 +591,7 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
 // MODE 0: whitened rows + error; MODE 1: error only; MODE 2: unwhitened e + H1..H4 in API layout
 template <typename T, int MF, int MODE, bool VW = false, bool REC = false>
 __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
-  constexpr int LS = 4 * MTraits<MF>::d + 2;
+  constexpr int LS = REC ? 20 : 4 * MTraits<MF>::d + 2;
   __shared__ T stage[MODE == 0 ? 2 * 64 * LS : 1];
   __shared__ int srow[MODE == 0 ? 128 : 1];
   gp_block<T, MF, MODE, VW, REC>(a, blockIdx.x, stage, srow);
@@ -668,7 +721,7 @@ template <typename T> struct LinArgs {
 // every workgroup of a 1e5-state launch is resident at once.
 template <typename T, int MF, bool VW, bool VP, bool REC = false>
 __global__ void __launch_bounds__(128, GPS_KLIN_WAVES) k_lin(LinArgs<T> a) {
-  constexpr int LS = (MF == POSE3 && !VP) ? 20 : 4 * MTraits<MF>::d + 2;
+  constexpr int LS = (MF == POSE3 && !VP) ? 20 : (4 * MTraits<MF>::d + 2 > 20 || !REC ? 4 * MTraits<MF>::d + 2 : 20);
   __shared__ T stage[2 * 64 * LS];
   __shared__ int srow[128];
   int bid = blockIdx.x;
@@ -1327,6 +1380,11 @@ template <typename T, typename TR = T> struct AsmArgs {
   T *blk;                 // N records [D | O | G]
   T *gsave;               // N x B copy of the gradient column (for the LM model-fidelity test) or null
   T *halo_add;            // segment sharding: [RD | Rg] the rows of state N-1 owe to the next rank's first state
+  // block size 6, fp64: the GP priors as structured records (kGp3*; K1 wrote no rows for them) or null
+  const T *gps3;          // gp_count + 1 records, the last one all zeros
+  const int *gpidx;       // record of the GP prior whose left state is s, or -1 (N + 2 entries)
+  int gp_count;
+  const T *Ud;            // chol_upper(Qc^-1), row-major 3 x 3
 };
 
 // Wave-cooperative assembly, every row fetched once.  A wave owns G - 1 = 64 / B - 1 consecutive states plus, in
@@ -1356,6 +1414,12 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T, TR> a) {
   if (owner) {
     rp_s = a.rowptr[s];
     n_own = a.rowptr[s + 1] - rp_s;
+  }
+  // structured GP prior of the state (block size 6): its six rows are formed from the record below, the row loop starts behind them
+  int gq = -1;
+  if constexpr (B == 6 && std::is_same<T, double>::value && std::is_same<TR, double>::value) {
+    if (a.gps3 && owner) gq = a.gpidx[s];
+    if (gq >= 0) { rp_s += B; n_own -= B; }
   }
   int n_max = n_own;
 #pragma unroll
@@ -1388,20 +1452,7 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T, TR> a) {
     Rc = row[B + c];
     e = a.rowE[rho];
   };
-  // PF register sets rotate by full unrolling (no register copies: a copy of a set whose load is still in flight
-  // would wait for it and cut the prefetch distance to one iteration -- measured 1000-2400 cycles of exposed
-  // latency per row before this change)
-  constexpr int PF = 3;
-  T rL[PF], rR[PF], rE[PF];
-  if (n_max > 0) {                                // (an empty row table may be a null pointer)
-#pragma unroll
-    for (int j = 0; j < PF; j++) {
-      ld(j, rL[j], rR[j], rE[j]);
-      __builtin_amdgcn_sched_barrier(0);          // issue order = consumption order (vmcnt counts in order)
-    }
-  }
-  auto step = [&](int i, const T Lraw, const T Rraw, const T eraw) {
-    const bool valid = i < n_own;
+  auto step = [&](int i, const bool valid, const T Lraw, const T Rraw, const T eraw) {
     const T Lc = (valid && g >= 1) ? Lraw : T(0), Rc = valid ? Rraw : T(0), e = valid ? eraw : T(0);
     T *buf = xw + (i & 1) * XS;
     buf[lane] = Lc;
@@ -1424,10 +1475,48 @@ __global__ void __launch_bounds__(64 * WPB) k_assemble_ghost(AsmArgs<T, TR> a) {
     gsum -= Lc * e;
     gsum -= Pc * ep;
   };
+  if constexpr (B == 6 && std::is_same<T, double>::value && std::is_same<TR, double>::value) {
+    if (a.gps3) {
+      // Lane c of the state's group holds column c of the six rows [A1 | kLt U | A3 | kRt U; 0 | kLb U | 0 | kRb U]: a pose lane
+      // (c < 3) its column of A1 / A3 (and nothing in the bottom rows), a velocity lane column c - 3 of U times the record's
+      // four coefficients.  States without a GP prior (and idle groups) read the all-zero record.
+      const bool pc = c < 3;
+      const int c3 = pc ? c : c - 3;
+      const T *rec = a.gps3 + (size_t)(gq >= 0 ? gq : a.gp_count) * kGp3Len;
+      T colL[3], colR[3], ew[6];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const T uk = a.Ud[3 * k + c3];
+        colL[k] = pc ? rec[kGp3A1 + 3 * k + c3] : uk;
+        colR[k] = pc ? rec[kGp3A3 + 3 * k + c3] : uk;
+      }
+      const T mLt = pc ? T(1) : rec[kGp3S + 0], mRt = pc ? T(1) : rec[kGp3S + 1];
+      const T mLb = pc ? T(0) : rec[kGp3S + 2], mRb = pc ? T(0) : rec[kGp3S + 3];
+#pragma unroll
+      for (int i = 0; i < 6; i++) ew[i] = rec[kGp3E + i];
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        step(i, true, (i < 3 ? mLt : mLb) * colL[i % 3], (i < 3 ? mRt : mRb) * colR[i % 3], ew[i]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // PF register sets rotate by full unrolling (no register copies: a copy of a set whose load is still in flight
+  // would wait for it and cut the prefetch distance to one iteration -- measured 1000-2400 cycles of exposed
+  // latency per row before this change)
+  constexpr int PF = 3;
+  T rL[PF], rR[PF], rE[PF];
+  if (n_max > 0) {                                // (an empty row table may be a null pointer)
+#pragma unroll
+    for (int j = 0; j < PF; j++) {
+      ld(j, rL[j], rR[j], rE[j]);
+      __builtin_amdgcn_sched_barrier(0);          // issue order = consumption order (vmcnt counts in order)
+    }
+  }
   for (int i0 = 0; i0 < n_max; i0 += PF) {
 #pragma unroll
     for (int j = 0; j < PF; j++) {
-      step(i0 + j, rL[j], rR[j], rE[j]);          // steps past n_max exchange zeros
+      step(i0 + j, i0 + j < n_own, rL[j], rR[j], rE[j]);          // steps past n_max exchange zeros
       ld(i0 + j + PF, rL[j], rR[j], rE[j]);
       __builtin_amdgcn_sched_barrier(0);          // keeps the next step's LDS reads from being hoisted (VGPRs)
     }
