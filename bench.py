@@ -310,22 +310,38 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # GPSLAM_BENCH_BACKEND=segment_model (tests/test_bench_world_cpu.py only): the two phases of a rank are played by the
+    # numpy + oracle model of tests/segment_model.py over gloo, so that THIS file's world > 1 control flow -- partitioning,
+    # the one all-gather per iteration, barriers, max over ranks, the JSON line -- runs end to end on a machine without GPUs.
+    # Nothing measured that way is a benchmark result: the line says "data": "model" and carries no roofline.
+    model = os.environ.get("GPSLAM_BENCH_BACKEND", "hip") == "segment_model"
+    if model and world == 1:
+        raise SystemExit("the segment_model backend exists for the world > 1 control flow only")
+    if not model:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
+    dev = "cpu" if model else "cuda"
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if model:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         # one process per GPU over RCCL, exactly as many as asked for
         assert dist.get_world_size() == world == args.gpus, (dist.get_world_size(), world, args.gpus)
     elif args.gpus != 1:
         raise SystemExit("bench.py --gpus %d: launch with python -m torch.distributed.run --nproc-per-node %d (WORLD_SIZE is 1)" % (args.gpus, args.gpus))
 
+    def device_sync():
+        if not model:
+            torch.cuda.synchronize()
+
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     N = args.states
     total_states = N * world
@@ -346,10 +362,16 @@ def main():
     else:
         problem = S.pose3_chain(total_states)           # ONE chain, cut into `world` contiguous segments
         lp = sharded.local_problem(problem, rank, world)
-        solver = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank, rank=rank, nranks=world)
-        solver.set_stream(torch.cuda.current_stream().cuda_stream)   # order kernels against the RCCL collective
-        sharded.apply_local(lp, solver)
-        send, recv = sharded.device_tensors(solver)
+        if model:
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            from segment_model import SegmentModel
+            solver = sharded.apply_local(lp, SegmentModel(S.POSE3, rank, world))
+            send, recv = solver.send, solver.recv
+        else:
+            solver = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=local_rank, rank=rank, nranks=world)
+            solver.set_stream(torch.cuda.current_stream().cuda_stream)   # order kernels against the RCCL collective
+            sharded.apply_local(lp, solver)
+            send, recv = sharded.device_tensors(solver)
         sv = sharded.ShardedSolver(solver, send, recv, rank, world, dist=dist)
 
         def reset():
@@ -384,7 +406,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -397,7 +419,7 @@ def main():
     barrier()
     conv_seconds = time.perf_counter() - tc0
     if dist is not None:
-        t = torch.tensor([conv_seconds], dtype=torch.float64, device="cuda")
+        t = torch.tensor([conv_seconds], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         conv_seconds = float(t.item())
 
@@ -409,18 +431,65 @@ def main():
         for _ in range(5):
             sv.exchange()
         barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            sv.exchange()
-        e1.record()
-        torch.cuda.synchronize()
-        local_ms = e0.elapsed_time(e1) / reps
-        tc = torch.tensor([local_ms], dtype=torch.float64, device="cuda")
+        if model:
+            tm0 = time.perf_counter()
+            for _ in range(reps):
+                sv.exchange()
+            local_ms = (time.perf_counter() - tm0) / reps * 1e3
+        else:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                sv.exchange()
+            e1.record()
+            torch.cuda.synchronize()
+            local_ms = e0.elapsed_time(e1) / reps
+        tc = torch.tensor([local_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)      # (every rank executes exactly the same sequence of collectives)
         collective_ms = float(tc.item())
 
-    if rank == 0:
+    # N > 1: the prediction this run is checked against -- what THIS rank's share of the sharded code path
+    # costs per iteration when the all-gather is replaced by a device copy of its own record into every slot (the figure
+    # `extras.projected_sharded_1e6_pose3` of the one-GPU run, for this run's segment); measured on every rank after the timed
+    # region, reported as the maximum over the ranks
+    projected_ms = None
+    if world > 1 and not model:
+        rv = recv.view(world, -1)
+
+        def one_local():
+            solver.iterate_phase1(0.0)
+            for k in range(world):
+                rv[k].copy_(send)
+            solver.iterate_phase2(False)
+        reset()
+        for _ in range(3):
+            one_local()
+        reset()
+        barrier()
+        tp0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_local()
+        device_sync()
+        tp = torch.tensor([(time.perf_counter() - tp0) / args.steps * 1e3], dtype=torch.float64, device=dev)
+        dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+        projected_ms = float(tp.item())
+
+    if rank == 0 and model:
+        # the control-flow run of the CPU test: the line a real run prints, without what only a GPU can measure
+        print(json.dumps({
+            "metric": "GN state-iterations/sec (states x Gauss-Newton iters/sec), Pose3 GP chain",
+            "value": total_states * args.steps / elapsed, "unit": "state-iterations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "model",
+            "config": {"workload": "control-flow test: %d poses per rank, numpy + oracle model of the two phases over gloo" % N,
+                       "states_per_gpu": N, "total_states": total_states,
+                       "parallelism": "1 chain in %d contiguous segments, 1 all-gather of interface records per iteration" % world},
+            "ranks": world, "rccl_version": None, "iters_to_convergence": conv_iters, "delta_inf_at_convergence": conv_delta,
+            "final_error": final_error, "seconds_to_convergence": conv_seconds,
+            "collective": {"kind": "all_gather of the interface records (gloo)", "bytes_per_rank": int(send.numel() * send.element_size()),
+                           "ms_per_iteration": collective_ms, "share_of_step": collective_ms / (elapsed / args.steps * 1e3)},
+            "roofline": None, "cpu_baseline": None}))
+    if rank == 0 and not model:
         # per-kernel device time (hipEvents on the handle's stream) of the per-GPU workload, for the roofline
         if world == 1:
             probe, pproblem = solver, problem
@@ -517,6 +586,11 @@ def main():
         if collective_ms is not None:
             out["collective"] = {"kind": "ncclAllGather of the interface records (RCCL), one per iteration", "bytes_per_rank": int(send.numel() * send.element_size()),
                                  "ms_per_iteration": collective_ms, "share_of_step": collective_ms / ms_per_step}
+        if projected_ms is not None:
+            out["projected_sharded"] = {"ms_per_rank_and_iteration_without_collective": projected_ms,
+                                        "measured_ms_per_step": ms_per_step, "measured_over_projected": ms_per_step / projected_ms,
+                                        "note": "the same two phases per rank with the all-gather replaced by device copies of the rank's own "
+                                                "record (max over ranks): measured - projected = what the collective and the rank skew cost"}
         out["k1_batched_jacobian"]["note"] = "in-iteration = k_lin: GP priors + priors + between factors in one launch, algorithmic bytes of all of them"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, threads=1)

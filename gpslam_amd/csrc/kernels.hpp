@@ -2467,6 +2467,14 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     };
     double Lcol[ST ? B : 1], Rcol[ST ? B : 1], newl = 0.0;
     auto reconstruct = [&]() {
+#ifdef GPS_ABLATE_REC   /* timing ablation only (wrong results): the record's operands are fetched, the columns are not formed */
+      if constexpr (ST) {
+#pragma unroll
+        for (int k = 0; k < B; k++) { Lcol[k] = raw[k]; Rcol[k] = raw[(k + 9) % NRAW]; }
+        newl = -raw[15];
+        return;
+      }
+#endif
       if constexpr (ST) {
         double X6[6], J6[6], P3[6], P1[6];
         // the lane's role, recomputed per state from an opaque copy of its index: as loop invariants the masks and the unit

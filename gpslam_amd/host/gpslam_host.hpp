@@ -21,6 +21,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <iostream>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -37,6 +39,12 @@ typedef uint64_t Key;
 inline Key Symbol(unsigned char c, uint64_t j) { return (Key(c) << 56) | j; }
 inline unsigned char symbolChr(Key k) { return (unsigned char)(k >> 56); }
 inline uint64_t symbolIndex(Key k) { return k & ((Key(1) << 56) - 1); }
+/// gtsam::KeyFormatter / DefaultKeyFormatter: "x12" for Symbol('x', 12), the plain number for keys without a character
+typedef std::function<std::string(Key)> KeyFormatter;
+inline std::string DefaultKeyFormatter(Key k) {
+  const unsigned char c = symbolChr(k);
+  return (c ? std::string(1, (char)c) : std::string()) + std::to_string(c ? symbolIndex(k) : k);
+}
 
 template <int N> struct VectorN : std::array<double, N> {
   VectorN() { this->fill(0.0); }
@@ -221,6 +229,49 @@ struct Desc {   // what a factor hands to the graph compiler
   double dt = 0, tau = 0;
   Matrix Qc;
 };
+inline bool close(const std::vector<double> &a, const std::vector<double> &b, double tol) {
+  if (a.size() != b.size()) return false;
+  for (size_t i = 0; i < a.size(); i++) if (!(std::fabs(a[i] - b[i]) < tol) && a[i] != b[i]) return false;
+  return true;
+}
+// NoiseModelFactor::equals of the reference's factors (e.g. GaussianProcessPriorPose3.h:106-109): keys and noise model through
+// Base::equals, then the members the class compares itself -- measurement, sensor pose / calibration, and the GP base
+// (delta_t, tau, Qc) unless the class leaves it out (gp = false: GPInterpolatedRangeFactor2DLinear.h:96-100)
+inline bool desc_equals(const Desc &a, const Desc &b, double tol, bool gp) {
+  if (a.type != b.type || a.manifold != b.manifold || a.vw != b.vw) return false;
+  for (int i = 0; i < 5; i++) if (a.k[i] != b.k[i]) return false;
+  for (int i = 0; i < 2; i++) if (a.kw[i] != b.kw[i]) return false;
+  if (!close(a.meas, b.meas, tol) || !close(a.sig, b.sig, tol) || !close(a.cov, b.cov, tol)) return false;
+  if (!close(a.sensor, b.sensor, tol) || !close(a.aux, b.aux, tol)) return false;
+  if (a.type == F_GP) return std::fabs(a.dt - b.dt) < tol && close(a.Qc.a, b.Qc.a, tol);   // (the prior's noise model IS Q(Qc, delta_t))
+  if (!gp) return true;
+  return std::fabs(a.dt - b.dt) < tol && std::fabs(a.tau - b.tau) < tol && close(a.Qc.a, b.Qc.a, tol);
+}
+inline void desc_print(const Desc &d, const std::string &s, const char *name, int nkeys, const KeyFormatter &kf) {
+  std::cout << s << name << std::endl;
+  std::cout << "  keys = {";
+  static const int order[7] = {0, 1, 2, 3, 4, 5, 6};
+  int shown = 0;
+  for (int i = 0; i < 5 && shown < nkeys; i++) {
+    if (d.k[i] == 0 && !(i == 0)) continue;
+    std::cout << " " << kf(d.k[i]); shown++;
+  }
+  for (int i = 0; i < 2 && shown < nkeys; i++) if (d.kw[i]) { std::cout << " " << kf(d.kw[i]); shown++; }
+  (void)order;
+  std::cout << " }" << std::endl;
+  auto vec = [](const char *label, const std::vector<double> &v) {
+    if (v.empty()) return;
+    std::cout << "  " << label << " = [";
+    for (size_t i = 0; i < v.size(); i++) std::cout << (i ? ", " : "") << v[i];
+    std::cout << "]" << std::endl;
+  };
+  vec("measured", d.meas);
+  if (d.cov.empty()) vec("noise model: diagonal sigmas", d.sig); else vec("noise model: Gaussian covariance", d.cov);
+  vec("body_P_sensor", d.sensor);
+  vec("calibration", d.aux);
+  if (d.dt != 0) std::cout << "  delta_t = " << d.dt << (d.type == F_GP ? "" : ", tau = " + std::to_string(d.tau)) << std::endl;
+  if (!d.Qc.a.empty()) vec("Qc", d.Qc.a);
+}
 }  // namespace detail
 
 class NonlinearFactor {
@@ -230,6 +281,10 @@ class NonlinearFactor {
   virtual detail::Desc describe() const = 0;
   virtual size_t size() const = 0;
   virtual shared_ptr clone() const = 0;
+  /// gtsam::NonlinearFactor::equals / print (every factor class overrides both, as in the reference: e.g.
+  /// gpslam/gp/GaussianProcessPriorPose3.h:104-115)
+  virtual bool equals(const NonlinearFactor &expected, double tol = 1e-9) const = 0;
+  virtual void print(const std::string &s = "", const KeyFormatter &keyFormatter = DefaultKeyFormatter) const = 0;
 };
 
 inline std::vector<double> sigmas_of(const SharedNoiseModel &m) {
@@ -246,13 +301,22 @@ inline void noise_of(const SharedNoiseModel &m, detail::Desc &d) {
   for (int i = 0; i < m->dim_; i++) d.sig[i] = std::sqrt(m->cov_(i, i));
 }
 
-#define GPSLAM_FACTOR_BOILERPLATE(CLS, NKEYS)                                                           \
+// NAME: the first line print() writes (the reference's own strings); EQ_GP: equals() compares the GP base (delta_t, tau, Qc)
+#define GPSLAM_FACTOR_BOILERPLATE_NAMED(CLS, NKEYS, NAME, EQ_GP)                                        \
   size_t size() const override { return NKEYS; }                                                        \
   gtsam::NonlinearFactor::shared_ptr clone() const override { return std::make_shared<CLS>(*this); }    \
   gtsam::detail::Desc describe() const override { return d_; }                                          \
+  bool equals(const gtsam::NonlinearFactor &expected, double tol = 1e-9) const override {               \
+    const CLS *e = dynamic_cast<const CLS *>(&expected);                                                \
+    return e != nullptr && gtsam::detail::desc_equals(d_, e->d_, tol, EQ_GP);                           \
+  }                                                                                                     \
+  void print(const std::string &s = "", const gtsam::KeyFormatter &keyFormatter = gtsam::DefaultKeyFormatter) const override { \
+    gtsam::detail::desc_print(d_, s, NAME, NKEYS, keyFormatter);                                        \
+  }                                                                                                     \
  protected:                                                                                             \
   gtsam::detail::Desc d_;                                                                               \
  public:
+#define GPSLAM_FACTOR_BOILERPLATE(CLS, NKEYS) GPSLAM_FACTOR_BOILERPLATE_NAMED(CLS, NKEYS, #CLS, true)
 
 template <typename T> class PriorFactor : public NonlinearFactor {
  public:
@@ -602,6 +666,8 @@ class NonlinearOptimizer {
       r.push_back(detail::VT<POSE>::un(std::vector<double>(out.begin() + q * s_.pd, out.begin() + (q + 1) * s_.pd)));
     return r;
   }
+  /// the C-ABI handle behind this optimizer (no GTSAM counterpart: for gpslam_hip_plan_info and the other introspection calls)
+  gpslam_hip_handle *handle() const { return s_.h; }
  protected:
   NonlinearOptimizer(const NonlinearFactorGraph &g, const Values &v, const NonlinearOptimizerParams &p) : params_(p) {
     s_.build(g, v);
@@ -883,7 +949,7 @@ inline POSE interpolate_one(int manifold, const gtsam::Matrix &Qc, double delta_
 }
 }  // namespace detail_g
 
-#define GPSLAM_GP_PRIOR(CLS, MANIFOLD, POSE, VEL)                                                                          \
+#define GPSLAM_GP_PRIOR(CLS, MANIFOLD, POSE, VEL, NAME)                                                                          \
   class CLS : public gtsam::NonlinearFactor {                                                                   \
    public:                                                                                                      \
     CLS(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,      \
@@ -894,14 +960,14 @@ inline POSE interpolate_one(int manifold, const gtsam::Matrix &Qc, double delta_
       return detail_g::gp_evaluate(d_, gtsam::detail::VT<POSE>::pack(pose1), gtsam::detail::VT<VEL>::pack(vel1),      \
                                    gtsam::detail::VT<POSE>::pack(pose2), gtsam::detail::VT<VEL>::pack(vel2), H1, H2, H3, H4); \
     }                                                                                                           \
-    GPSLAM_FACTOR_BOILERPLATE(CLS, 4)                                                                           \
+    GPSLAM_FACTOR_BOILERPLATE_NAMED(CLS, 4, NAME, true)                                                         \
   };
 /// gpslam/gp/GaussianProcessPriorPose3.h:43-49
-GPSLAM_GP_PRIOR(GaussianProcessPriorPose3, GPSLAM_POSE3, gtsam::Pose3, gtsam::Vector6)
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose3, GPSLAM_POSE3, gtsam::Pose3, gtsam::Vector6, "4-way Gaussian Process Factor Pose3")
 /// gpslam/gp/GaussianProcessPriorPose2.h:41-47
-GPSLAM_GP_PRIOR(GaussianProcessPriorPose2, GPSLAM_POSE2, gtsam::Pose2, gtsam::Vector3)
+GPSLAM_GP_PRIOR(GaussianProcessPriorPose2, GPSLAM_POSE2, gtsam::Pose2, gtsam::Vector3, "4-way Gaussian Process Factor Pose2")
 /// gpslam/gp/GaussianProcessPriorRot3.h:41-47
-GPSLAM_GP_PRIOR(GaussianProcessPriorRot3, GPSLAM_ROT3, gtsam::Rot3, gtsam::Vector3)
+GPSLAM_GP_PRIOR(GaussianProcessPriorRot3, GPSLAM_ROT3, gtsam::Rot3, gtsam::Vector3, "4-way Gaussian Process Factor Rot3")
 
 /// gpslam/gp/GaussianProcessPriorLinear.h:47-53 (Dim = 2 or 3, gpslam.h:177-181)
 template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFactor {
@@ -918,7 +984,7 @@ template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFac
     typedef gtsam::detail::VT<gtsam::VectorN<Dim>> P;
     return detail_g::gp_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), H1, H2, H3, H4);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GaussianProcessPriorLinear<Dim>, 4)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GaussianProcessPriorLinear<Dim>, 4, (Dim == 2 ? "4-way Gaussian Process Factor Linear<2>" : "4-way Gaussian Process Factor Linear<3>"), true)
 };
 
 /// gpslam/slam/GPInterpolatedRangeFactorPose2.h:46-54
@@ -939,7 +1005,7 @@ class GPInterpolatedRangeFactorPose2 : public gtsam::NonlinearFactor {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose2>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Pose2>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector3>::pack(vel2), &lm, H1, H2, H3, H4, H5);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose2, 5)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedRangeFactorPose2, 5, "RangeFactor (GP interpolated, Pose2)", true)
 };
 
 /// gpslam/slam/GPInterpolatedRangeFactorPose3.h:46-54
@@ -960,7 +1026,7 @@ class GPInterpolatedRangeFactorPose3 : public gtsam::NonlinearFactor {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector6>::pack(vel2), &lm, H1, H2, H3, H4, H5);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactorPose3, 5)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedRangeFactorPose3, 5, "RangeFactor (GP interpolated, Pose3)", true)
 };
 
 /// gpslam/slam/GPInterpolatedRangeFactor2DLinear.h:42-50 -- NOTE: keys come before the noise models here
@@ -980,7 +1046,7 @@ class GPInterpolatedRangeFactor2DLinear : public gtsam::NonlinearFactor {
     const std::vector<double> lm = {point.x, point.y};
     return detail_g::meas_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), &lm, H1, H2, H3, H4, H5);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedRangeFactor2DLinear, 5)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedRangeFactor2DLinear, 5, "RangeFactor (GP interpolated, 2D linear)", false)
 };
 
 /// gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:44-51
@@ -1000,7 +1066,7 @@ class GPInterpolatedAttitudeFactorRot3 : public gtsam::NonlinearFactor {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Rot3>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Rot3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector3>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedAttitudeFactorRot3, 4)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedAttitudeFactorRot3, 4, "GP Interpolated AttitudeFactor", true)
 };
 
 /// gpslam/slam/GPInterpolatedGPSFactorPose3.h:46-54
@@ -1021,7 +1087,7 @@ class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector6>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3, 4)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedGPSFactorPose3, 4, "GPSFactor (GP interpolated)", true)
 };
 
 /// gpslam/gp/GaussianProcessPriorPose3VW.h:43-51 -- world-frame translational (v) and rotational (w) velocity keys
@@ -1032,7 +1098,7 @@ class GaussianProcessPriorPose3VW : public gtsam::NonlinearFactor {
     d_ = detail_g::gp(GPSLAM_POSE3, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model);
     d_.kw[0] = omegaKey1; d_.kw[1] = omegaKey2; d_.vw = true;
   }
-  GPSLAM_FACTOR_BOILERPLATE(GaussianProcessPriorPose3VW, 6)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GaussianProcessPriorPose3VW, 6, "4-way Gaussian Process Factor Pose3 VW", true)
 };
 
 /// gpslam/slam/GPInterpolatedGPSFactorPose3VW.h:50-60
@@ -1048,7 +1114,7 @@ class GPInterpolatedGPSFactorPose3VW : public gtsam::NonlinearFactor {
     d_.dt = delta_t; d_.tau = tau;
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedGPSFactorPose3VW, 6)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedGPSFactorPose3VW, 6, "GPSFactor (GP interpolated, VW)", true)
 };
 
 /// gpslam/slam/GPInterpolatedProjectionFactorPose3.h:64-76 (CALIBRATION = gtsam::Cal3_S2).  throwCheirality /
@@ -1066,7 +1132,7 @@ class GPInterpolatedProjectionFactorPose3 : public gtsam::NonlinearFactor {
     d_.dt = delta_t; d_.tau = tau; d_.aux = {K->fx(), K->fy(), K->skew(), K->px(), K->py()};
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
-  GPSLAM_FACTOR_BOILERPLATE(GPInterpolatedProjectionFactorPose3<CALIBRATION>, 5)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedProjectionFactorPose3<CALIBRATION>, 5, "GPInterpolatedProjectionFactor", true)
 };
 
 /// gpslam/slam/RangeFactor2DLinear.h:30-37
@@ -1076,7 +1142,7 @@ class RangeFactor2DLinear : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
     d_.meas = {measured}; gtsam::noise_of(model, d_);
   }
-  GPSLAM_FACTOR_BOILERPLATE(RangeFactor2DLinear, 2)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(RangeFactor2DLinear, 2, "RangeFactor (2D linear)", true)
 };
 /// gpslam/slam/RangeFactorPose2.h:15 (typedef gtsam::RangeFactor<Pose2, Point2>)
 class RangeFactorPose2 : public gtsam::NonlinearFactor {
@@ -1094,7 +1160,7 @@ class RangeBearingFactor2DLinear : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_BEARING_RANGE; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = poseKey; d_.k[4] = pointKey;
     d_.meas = {bearing, range}; gtsam::noise_of(model, d_);
   }
-  GPSLAM_FACTOR_BOILERPLATE(RangeBearingFactor2DLinear, 2)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(RangeBearingFactor2DLinear, 2, "RangeBearingFactor", true)
 };
 /// gpslam/slam/OdometryFactor2DLinear.h:38-40
 class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
@@ -1103,7 +1169,7 @@ class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_ODOM2D; d_.manifold = GPSLAM_LINEAR3; d_.k[0] = pose1Key; d_.k[2] = pose2Key;
     d_.meas = {betweenMeasured[0], betweenMeasured[1], betweenMeasured[2]}; gtsam::noise_of(model, d_);
   }
-  GPSLAM_FACTOR_BOILERPLATE(OdometryFactor2DLinear, 2)
+  GPSLAM_FACTOR_BOILERPLATE_NAMED(OdometryFactor2DLinear, 2, "2-way projected odometry factor", true)
 };
 
 // ---- GaussianProcessInterpolator{Linear, Pose2, Pose3, Rot3}: the public query use of the interpolators (gpslam.h:57-86):

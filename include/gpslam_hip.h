@@ -275,7 +275,8 @@ int gpslam_hip_body_centric_velocity(gpslam_hip_handle *h, int32_t which, int32_
                                      const double *pose2, const double *dt, double *out);
 /* What compile() chose for the chain solver (introspection for tests and tuning; no reference counterpart):
  * out8 = {levels of the hierarchy, level-0 chunk length, upper chunk length, assembly fused into the level-0 elimination
- * (k_fused_level0) 0/1, GP priors handed to it as structured records instead of Jacobian rows 0/1, rows in the
+ * (k_fused_level0) 0/1, GP priors handed to the assembly as structured records instead of Jacobian rows 0/1 (SE(3): inside the fused
+ * kernel; SE(2) / SO(3) / 3-D linear: where k_assemble_ghost runs), rows in the
  * full-width table, rows in the compact table, right-hand-side columns R}. */
 int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]);
 /* the plan of the segmented landmark elimination chosen by compile(): out = {active (0 / 1), segment length C, fat

@@ -594,7 +594,84 @@ static void test_round3_boundary_additions() {
   }
 }
 
-int main() {
+// Round 4: equals() / print() of the factor classes (gpslam/gp/GaussianProcessPriorPose3.h:104-115 and its siblings): same
+// class + keys + noise model + the members the class compares; the 2D-linear interpolated range factor leaves its GP base
+// out (GPInterpolatedRangeFactor2DLinear.h:96-100).  No device call anywhere here: runs on the CPU as well (--host-only).
+static void test_equals_print_clone() {
+  auto Qc = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+  auto Qc2 = noiseModel::Gaussian::Covariance(0.02 * Matrix::Identity(6));
+  GaussianProcessPriorPose3 a(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc);
+  GaussianProcessPriorPose3 same(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc);
+  GaussianProcessPriorPose3 other_dt(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.2, Qc);
+  GaussianProcessPriorPose3 other_key(Symbol('x', 1), Symbol('v', 1), Symbol('x', 3), Symbol('v', 3), 0.1, Qc);
+  GaussianProcessPriorPose3 other_qc(Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), 0.1, Qc2);
+  GaussianProcessPriorPose3VW vw(Symbol('x', 1), Symbol('v', 1), Symbol('w', 1), Symbol('x', 2), Symbol('v', 2), Symbol('w', 2), 0.1, Qc);
+  EXPECT(a.equals(same) && a.equals(same, 1e-12));
+  EXPECT(!a.equals(other_dt) && !a.equals(other_key) && !a.equals(other_qc));
+  EXPECT(!a.equals(vw) && !vw.equals(a));                     // another class: the dynamic_cast fails
+  EXPECT(a.equals(other_dt, 0.5));                            // |delta_t - delta_t'| < tol, as the reference compares it
+  NonlinearFactor::shared_ptr c = a.clone();
+  EXPECT(c->equals(a) && a.equals(*c) && c->size() == 4);
+  auto Qc3 = noiseModel::Gaussian::Covariance(0.001 * Matrix::Identity(3));
+  auto Qc3b = noiseModel::Gaussian::Covariance(0.002 * Matrix::Identity(3));
+  auto rm = noiseModel::Isotropic::Sigma(1, 0.1);
+  Pose2 sensor(0.1, 0.2, 0.3);
+  GPInterpolatedRangeFactorPose2 r1(2.5, rm, Qc3, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), 0.1, 0.04);
+  GPInterpolatedRangeFactorPose2 r2(2.5, rm, Qc3, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), 0.1, 0.04);
+  GPInterpolatedRangeFactorPose2 r_meas(2.6, rm, Qc3, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), 0.1, 0.04);
+  GPInterpolatedRangeFactorPose2 r_tau(2.5, rm, Qc3, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), 0.1, 0.05);
+  GPInterpolatedRangeFactorPose2 r_sens(2.5, rm, Qc3, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), 0.1, 0.04, &sensor);
+  EXPECT(r1.equals(r2) && !r1.equals(r_meas) && !r1.equals(r_tau) && !r1.equals(r_sens) && r_sens.equals(r_sens));
+  // the 2D-linear variant compares keys, noise model and the measurement only (measurement, then the keys, then the models: its own constructor order)
+  GPInterpolatedRangeFactor2DLinear l1(2.5, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), rm, Qc3, 0.1, 0.04);
+  GPInterpolatedRangeFactor2DLinear l_tau(2.5, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), rm, Qc3b, 0.2, 0.07);
+  GPInterpolatedRangeFactor2DLinear l_meas(2.7, Symbol('x', 1), Symbol('v', 1), Symbol('x', 2), Symbol('v', 2), Symbol('l', 1), rm, Qc3, 0.1, 0.04);
+  EXPECT(l1.equals(l_tau) && !l1.equals(l_meas));
+  PriorFactor<Pose2> p1(Symbol('x', 1), Pose2(1, 2, 0.3), noiseModel::Isotropic::Sigma(3, 0.1));
+  PriorFactor<Pose2> p2(Symbol('x', 1), Pose2(1, 2, 0.3), noiseModel::Isotropic::Sigma(3, 0.1));
+  PriorFactor<Pose2> p3(Symbol('x', 1), Pose2(1, 2, 0.3), noiseModel::Isotropic::Sigma(3, 0.2));
+  EXPECT(p1.equals(p2) && !p1.equals(p3) && !p1.equals(a));
+  RangeBearingFactor2DLinear rb(Symbol('x', 1), Symbol('l', 1), 0.5, 3.0, noiseModel::Isotropic::Sigma(2, 0.1));
+  EXPECT(rb.equals(*rb.clone()));
+  // print(): the reference's first line, then keys through the formatter
+  std::printf("--- print() samples\n");
+  a.print("factor 1: ");
+  r_sens.print("", [](Key k) { return std::string("<") + DefaultKeyFormatter(k) + ">"; });
+  EXPECT(DefaultKeyFormatter(Symbol('x', 12)) == "x12");
+}
+
+// a graph built through the host classes (every GP prior carries its own Qc_model, all the same matrix) keeps the
+// structured-record path of the fused kernel
+static void test_single_qc_graph_keeps_the_structured_path() {
+  auto Qc = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(6));
+  auto prior = noiseModel::Isotropic::Sigma(6, 0.001);
+  const int N = 600;
+  NonlinearFactorGraph graph;
+  Values init;
+  Vector6 v = {0, 0, 0, 1, 0, 0};
+  graph.add(PriorFactor<Pose3>(Symbol('x', 0), Pose3(), prior));
+  graph.add(PriorFactor<Pose3>(Symbol('x', N - 1), Pose3(Rot3(), Point3(0.1 * (N - 1), 0, 0)), prior));   // (two poses pin the velocity as well)
+  for (int i = 0; i < N; i++) {
+    init.insert(Symbol('x', i), Pose3(Rot3(), Point3(0.1 * i, 0.001 * (i % 7), 0)));
+    init.insert(Symbol('v', i), v);
+    if (i + 1 < N) graph.add(GaussianProcessPriorPose3(Symbol('x', i), Symbol('v', i), Symbol('x', i + 1), Symbol('v', i + 1), 0.1, Qc));
+  }
+  GaussNewtonOptimizer opt(graph, init);
+  int32_t info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  EXPECT(gpslam_hip_plan_info(opt.handle(), info) == 0);
+  EXPECT(info[3] == 1 && info[4] == 1);     // fused level 0, structured GP records
+  opt.optimize();
+  EXPECT(graph.error(opt.values()) < 1e-6);
+}
+
+int main(int argc, char **argv) {
+  if (argc > 1 && std::strcmp(argv[1], "--host-only") == 0) {   // what needs no GPU (the CPU test run)
+    test_equals_print_clone();
+    if (failures == 0) std::printf("host_api_tests: all host-only tests passed\n");
+    return failures == 0 ? 0 : 1;
+  }
+  test_equals_print_clone();
+  test_single_qc_graph_keeps_the_structured_path();
   test_gp_prior_pose3_optimization();
   test_gp_prior_pose2_rot3_linear_optimization();
   test_interp_range_pose2_optimization();

@@ -25,6 +25,16 @@ def test_host_header_compiles_and_links_against_the_c_abi():
     assert os.path.exists(exe)
 
 
+def test_equals_print_clone_of_the_host_factor_classes():
+    """equals(expected, tol) / print(s, keyFormatter) / clone() as the reference's factors define them
+    (gpslam/gp/GaussianProcessPriorPose3.h:104-115): no device call, runs on the CPU."""
+    exe = build_exe()
+    out = subprocess.run([exe, "--host-only"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all host-only tests passed" in out.stdout
+    assert "factor 1: 4-way Gaussian Process Factor Pose3" in out.stdout and "<x1>" in out.stdout
+
+
 @pytest.mark.gpu
 def test_reference_style_cpp_tests_pass_on_gpu():
     exe = build_exe()
