@@ -13,6 +13,11 @@ from . import build as _build
 LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
 FP64, FP32 = 0, 1
+# gpslam_hip_config.reserved[6]: kernel families compile() is told to use instead of its default choice (include/gpslam_hip.h)
+PLAN_UNFUSED_LEVEL0, PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS = 1, 2, 4, 8, 16
+# Test harness hook of this PYTHON mirror (the library itself reads no environment): plan bits OR-ed into every ChainSolver a
+# process creates, so that tests/test_gpu_switches.py can re-run whole parity suites on the fallback kernel families.
+_DEFAULT_PLAN = int(os.environ.get("GPSLAM_PY_DEFAULT_PLAN", "0"))
 POSE_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 12, ROT3: 9, ROT3_BIAS: 12}
 TANGENT_DIM = {LINEAR2: 2, LINEAR3: 3, POSE2: 3, POSE3: 6, ROT3: 3, ROT3_BIAS: 6}
 
@@ -93,7 +98,7 @@ def _p(a):
 class ChainSolver:
     def __init__(self, kind, chart=CHART_EXPMAP, landmark_dim=0, device=0, chunk=0, rank=0, nranks=1,
                  force_sharded=False, upper_chunk=0, top_blocks=0, velocity_world=False, segment_length=0,
-                 force_segmented=False, precision=0):
+                 force_segmented=False, precision=0, plan=0):
         self.lib = load_library()
         self.kind, self.chart, self.ld = kind, chart, landmark_dim
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
@@ -107,6 +112,7 @@ class ChainSolver:
         cfg.reserved[3] = 1 if velocity_world else 0   # GPSLAM_VELOCITY_WORLD_VW: the *Pose3VW factor family
         cfg.reserved[4] = segment_length               # segmented landmark elimination: segment length (0 = automatic)
         cfg.reserved[5] = 1 if force_segmented else 0  # ... for any landmark count (default: only beyond the dense border)
+        cfg.reserved[6] = plan | _DEFAULT_PLAN         # GPSLAM_PLAN_* bits
         self._h = C.c_void_p()
         rc = self.lib.gpslam_hip_create(C.byref(cfg), C.byref(self._h))
         if rc != 0:

@@ -391,11 +391,11 @@ inline void launch_rows_k(int b, const FwdArgs<double> &a, int grid, hipStream_t
 }
 inline void launch_rows_k(int, const FwdArgs<float> &, int, hipStream_t) {}
 // segment interiors of the segmented landmark elimination: planar fp64 chains take the cooperative row-layout kernel (four
-// segments per wave); GPSLAM_FS_FACTOR_ROWS=0 keeps the wave-per-segment kernel, for A/B measurements
+// segments per wave), everything else the wave-per-segment kernel
 template <int BB, typename T, typename TR> inline void fs_launch_factor(const FsArgs<T, TR> &a, int nseg, hipStream_t st) {
   if constexpr (BB == 6 && std::is_same<T, double>::value && std::is_same<TR, double>::value) {
-    static const bool off = getenv("GPSLAM_FS_FACTOR_ROWS") && atoi(getenv("GPSLAM_FS_FACTOR_ROWS")) == 0;
-    if (!off) { k_fs_factor_rows6<0><<<dim3((nseg + 3) / 4), dim3(64), 0, st>>>(a); return; }
+    k_fs_factor_rows6<0><<<dim3((nseg + 3) / 4), dim3(64), 0, st>>>(a);
+    return;
   }
   k_fs_factor<T, BB, TR><<<dim3(nseg), dim3(64), 0, st>>>(a);
 }

@@ -82,8 +82,20 @@ typedef struct {
   int32_t reserved[8];   /* [0] force the sharded code path, [1] upper-level chunk length, [2] sequential top size,
                           * [3] GPSLAM_VELOCITY_* (POSE3 only), [4] segment length of the segmented landmark elimination
                           * (0 = smallest that fits), [5] 1 = use the segmented landmark elimination for any landmark
-                          * count (default: only when the landmarks do not fit the dense border); others must be 0 */
+                          * count (default: only when the landmarks do not fit the dense border), [6] mask of GPSLAM_PLAN_* bits
+                          * (below; 0 = the default plan); [7] must be 0 */
 } gpslam_hip_config;
+/* config.reserved[6]: kernel families compile() may be told to use instead of its default choice.  Every one of them is the
+ * path some graphs take anyway (chains with landmark columns, pinned hierarchy shapes, wide landmark borders, graphs whose
+ * full-width rows are not all GP priors); the bits exist so that tests run them on plain chains and so that a maintainer
+ * can A/B them per handle (gpslam_hip_plan_info shows what a handle ended up with).  No reference counterpart. */
+enum {
+  GPSLAM_PLAN_UNFUSED_LEVEL0 = 1,     /* assembly and level-0 elimination as two launches (k_assemble_ghost + k_chunk_forward_rows) */
+  GPSLAM_PLAN_COLUMN_LEVEL0 = 2,      /* column-layout level-0 elimination (k_chunk_forward; implies the two launches) */
+  GPSLAM_PLAN_LEVELS_OF_FOUR = 4,     /* upper hierarchy as one launch per level of chunks of four instead of LDS-resident cyclic reduction */
+  GPSLAM_PLAN_FS_TWO_LAUNCHES = 8,    /* segmented landmark elimination: border sweep and Schur complement as two launches through Y */
+  GPSLAM_PLAN_GP_ROWS = 16            /* GP priors as plain Jacobian rows instead of structured records */
+};
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */
 typedef struct {

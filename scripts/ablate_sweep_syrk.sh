@@ -4,4 +4,4 @@ timeout 900 python -m pytest tests/test_gpu_segmented.py -x -q 2>&1 | tail -2
 for d in 0 1 3 7; do
   echo "dbg=$d"; GPSLAM_FSY_DBG=$d timeout 300 python scripts/bench_c4.py 1000000 2>&1 | tail -1
 done
-GPSLAM_FS_FUSED=0 timeout 300 python scripts/bench_c4.py 1000000 2>&1 | tail -1
+GPSLAM_PY_DEFAULT_PLAN=8 timeout 300 python scripts/bench_c4.py 1000000 2>&1 | tail -1

@@ -169,7 +169,7 @@ sys.path.insert(0, %r)
 import gpslam_amd
 from gpslam_amd import synthetic as S
 p = S.pose2_local_landmarks_chain(%d, L=%d, window=%d)
-s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=%d))
+s = S.apply(p, gpslam_amd.ChainSolver(p["kind"], chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, segment_length=%d, plan=int(sys.argv[2])))
 for _ in range(3):
     s.iterate_gn()
 pose, vel = s.get_states()
@@ -180,7 +180,7 @@ np.savez(sys.argv[1], pose=pose, vel=vel, lmk=s.get_landmarks(), plan=np.array([
 @pytest.mark.parametrize("N,seglen,div", [(20000, 0, 20), (3000, 256, 20), (777, 250, 20), (2400, 0, 80), (2400, 0, 40), (2400, 0, 27), (2400, 0, 16), (2400, 0, 13)])
 def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_bit(N, seglen, div, tmp_path):
     """k_fs_sweep_syrk (sweep and MFMA waves sharing an LDS ring, no Y buffer) against k_fs_sweep + k_fs_syrk through the Y
-    buffer (GPSLAM_FS_FUSED=0, read once per process: two child processes): same expressions in the same order -> the
+    buffer (GPSLAM_PLAN_FS_TWO_LAUNCHES on the second handle; two child processes): same expressions in the same order -> the
     states after three Gauss-Newton iterations are IDENTICAL, including ragged last chunks and short last segments.
     div: landmarks = N / div -- a quarter to 1.6x config 4's density puts the border into every instantiation of the kernel
     (NCP = 32 .. 112 columns)."""
@@ -189,8 +189,8 @@ def test_fused_sweep_and_schur_complement_reproduce_the_two_launch_path_bit_for_
     outs = []
     for fused in ("1", "0"):
         out = str(tmp_path / ("fused%s.npz" % fused))
-        env = dict(os.environ, GPSLAM_FS_FUSED=fused)
-        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, max(N // div, 1), 100 if N < 1000 else 200, seglen), out], check=True, env=env, timeout=600)
+        plan = "0" if fused == "1" else "8"
+        subprocess.run([sys.executable, "-c", _FUSED_AB % (root, N, max(N // div, 1), 100 if N < 1000 else 200, seglen), out, plan], check=True, timeout=600)
         outs.append(np.load(out))
     a, b = outs
     assert a["plan"][1] <= 112, "the fused kernel serves borders up to 112 columns: this case would not exercise it"
