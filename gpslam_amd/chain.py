@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_optimize", "gpslam_hip_normal_equations", "gpslam_hip_get_rows", "gpslam_hip_block_tridiag_solve",
     "gpslam_hip_last_timing", "gpslam_hip_run_gn", "gpslam_hip_time_kernel", "gpslam_hip_interface_send", "gpslam_hip_interface_recv",
     "gpslam_hip_iterate_phase1", "gpslam_hip_iterate_phase2", "gpslam_hip_set_halo_state",
-    "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_iterate_phase2a",
+    "gpslam_hip_interpolate_poses", "gpslam_hip_add_interp_projection", "gpslam_hip_add_interp_projection_ds2", "gpslam_hip_iterate_phase2a",
     "gpslam_hip_iterate_phase2b", "gpslam_hip_landmark_reduce_buffer", "gpslam_hip_lm_begin",
     "gpslam_hip_lm_trial_phase1", "gpslam_hip_lm_trial_phase2", "gpslam_hip_lm_reject", "gpslam_hip_clear_factors", "gpslam_hip_segment_plan", "gpslam_hip_linearize_meas", "gpslam_hip_interpolate_poses_jac",
     "gpslam_hip_add_ahrs", "gpslam_hip_plan_info", "gpslam_hip_fs_set_split", "gpslam_hip_fs_split_info", "gpslam_hip_fs_set_top",
@@ -238,6 +238,10 @@ class ChainSolver:
         left, landmark = _i32(left), _i32(landmark)
         measured, sigmas, dt, tau, K = _f64(measured), _f64(sigmas), _f64(dt), _f64(tau), _f64(K)
         sensor = None if sensor is None else _f64(sensor)
+        if K.size == 9:      # gtsam::Cal3DS2: fx, fy, s, u0, v0, k1, k2, p1, p2
+            return self._chk(self.lib.gpslam_hip_add_interp_projection_ds2(
+                self._h, len(left), _p(left), _p(landmark), _p(measured), _p(sigmas), _p(dt), _p(tau), _p(K),
+                None if sensor is None else _p(sensor)), "add_interp_projection_ds2")
         return self._chk(self.lib.gpslam_hip_add_interp_projection(
             self._h, len(left), _p(left), _p(landmark), _p(measured), _p(sigmas), _p(dt), _p(tau), _p(K),
             None if sensor is None else _p(sensor)), "add_interp_projection")

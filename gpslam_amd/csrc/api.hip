@@ -347,6 +347,13 @@ int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const 
   if (h->vw) return fail(h, GPSLAM_E_UNSUPPORTED, "the reference has no projection factor for the VW velocity family");
   return add_meas(h, FK_INTERP_PROJ, 2, 2, true, true, true, h->mf == POSE3 && h->ld == 3, count, left, landmark, measured, sigmas, dt, tau, sensor, K);
 }
+int gpslam_hip_add_interp_projection_ds2(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                         const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                         const double *K9, const double *sensor) {
+  if (!h || !K9) return GPSLAM_E_INVALID;
+  if (h->vw) return fail(h, GPSLAM_E_UNSUPPORTED, "the reference has no projection factor for the VW velocity family");
+  return add_meas(h, FK_INTERP_PROJ, 2, 2, true, true, true, h->mf == POSE3 && h->ld == 3, count, left, landmark, measured, sigmas, dt, tau, sensor, K9, K9 + 5);
+}
 int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas) {
   if (!h) return GPSLAM_E_INVALID;

@@ -298,7 +298,7 @@ int max_left(const gpslam_hip_handle *h) { return h->N - 2 + (has_right_rank(h) 
 
 int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool haslm, bool interp, bool ok_mf,
              int32_t count, const int32_t *idx, const int32_t *lm, const double *meas, const double *sig,
-             const double *dt, const double *tau, const double *sensor, const double *calib = nullptr) {
+             const double *dt, const double *tau, const double *sensor, const double *calib = nullptr, const double *distortion = nullptr) {
   if (!h || count < 0) return GPSLAM_E_INVALID;
   if (!ok_mf) return fail(h, GPSLAM_E_INVALID, "this factor does not exist for the handle's manifold / landmark dimension");
   if (count > 0 && (!idx || !meas || !sig || (haslm && !lm) || (interp && (!dt || !tau)))) return GPSLAM_E_INVALID;
@@ -323,9 +323,10 @@ int add_meas(gpslam_hip_handle *h, int fk, int rows, int mw, bool two, bool hasl
   }
   if (interp) { s.dt.insert(s.dt.end(), dt, dt + count); s.tau.insert(s.tau.end(), tau, tau + count); }
   {   // this call's body_P_sensor / calibration: find it in (or append it to) the kind's table
-    double ent[kMeasAux] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0};
+    double ent[kMeasAux] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0};
     if (sensor) { std::memcpy(ent, sensor, sizeof(double) * h->pd); ent[17] = 1.0; }
     if (calib) std::memcpy(ent + 12, calib, sizeof(double) * 5);
+    if (distortion) std::memcpy(ent + 18, distortion, sizeof(double) * 4);
     int slot = -1;
     const int nent = (int)(s.aux.size() / kMeasAux);
     for (int q = 0; q < nent && slot < 0; q++)

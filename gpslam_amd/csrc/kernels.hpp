@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(128, GPS_KLIN_WAVES) k_lin(LinArgs<T> a) {
 enum FKind : int { FK_INTERP_RANGE = 0, FK_RANGE = 1, FK_INTERP_ATT = 2, FK_INTERP_GPS = 3, FK_ODOM2D = 4, FK_BEARING_RANGE = 5, FK_INTERP_PROJ = 6, FK_AHRS = 7 };
 constexpr int kNumMeasKinds = 8;
 constexpr int kAhrsWidth = 34;   // per-factor parameters of FK_AHRS: the 25 of ahrs_factor() + sqrt information R (3 x 3, upper triangular)
-constexpr int kMeasAux = 18;
+constexpr int kMeasAux = 22;     // [body_P_sensor (12) | fx, fy, s, u0, v0 | has_sensor | k1, k2, p1, p2 (Cal3DS2; zeros: Cal3_S2)]
 template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
 template <typename T> struct MeasArgs {
@@ -764,7 +764,7 @@ template <typename T> struct MeasArgs {
   float *rowE32;       // error-only pass: fp32 copy of the whitened error (fp32 mode), or null
   T *out_e, *out_J;    // inspection (gpslam_hip_linearize_meas): unwhitened e (count x rows) and per row
                        // [H1 H2 | H3 H4 | H5 (3, zero padded)] exactly as evaluateError returns them, or null
-  const double *aux;       // table of kMeasAux-wide entries [body_P_sensor (12) | Cal3_S2 fx, fy, s, u0, v0 | has_sensor]
+  const double *aux;       // table of kMeasAux-wide entries [body_P_sensor (12) | fx, fy, s, u0, v0 | has_sensor | k1, k2, p1, p2]
   const int *aidx;     // count: entry of each factor (one body_P_sensor / calibration PER FACTOR, as in the reference:
                        // GPInterpolatedRangeFactorPose3.h:46-54), or null: no sensor transform anywhere
   const double *sqi;   // count x rows x rows square-root information R (upper triangular, R^T R = cov^-1) of factors with a
@@ -982,9 +982,10 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
           }
         }
       } else if constexpr (FK == FK_INTERP_PROJ) {
-        // GPInterpolatedProjectionFactorPose3<Cal3_S2>::evaluateError, GPInterpolatedProjectionFactorPose3.h:82-139:
+        // GPInterpolatedProjectionFactorPose3<CALIBRATION>::evaluateError, GPInterpolatedProjectionFactorPose3.h:82-139:
         // PinholeCamera(pose * body_P_sensor, K).project(point); a landmark behind the camera is masked, not thrown
-        // (throwCheirality = false): error = 2 fx, all Jacobians zero (:122-138)
+        // (throwCheirality = false): error = 2 fx, all Jacobians zero (:122-138).  CALIBRATION = Cal3_S2, or Cal3DS2 when the
+        // entry carries distortion coefficients (radial k1, k2, tangential p1, p2: Cal3DS2_Base::uncalibrate)
         Interp6Out<T, JAC> o;
         const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
         const SE3<T> S = as_se3(sens);
@@ -996,13 +997,22 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
           e[0] = T(2) * fx; e[1] = T(2) * fx;
         } else {
           const T dz = T(1) / q.z, u = q.x * dz, v = q.y * dz;
-          e[0] = fx * u + sk * v + cu0 - ms[0];
-          e[1] = fy * v + cv0 - ms[1];
+          const T k1 = ax ? T(ax[18]) : T(0), k2 = ax ? T(ax[19]) : T(0), t1 = ax ? T(ax[20]) : T(0), t2 = ax ? T(ax[21]) : T(0);
+          const T xx = u * u, yy = v * v, xy = u * v, rr = xx + yy;
+          const T g = T(1) + k1 * rr + k2 * rr * rr;
+          const T pdx = g * u + T(2) * t1 * xy + t2 * (rr + T(2) * xx);     // the distorted intrinsic point (= (u, v) for Cal3_S2)
+          const T pdy = g * v + T(2) * t2 * xy + t1 * (rr + T(2) * yy);
+          e[0] = fx * pdx + sk * pdy + cu0 - ms[0];
+          e[1] = fy * pdy + cv0 - ms[1];
           if (JAC) {
-            // PinholeBase::Dpose / Dpoint, then Cal3_S2::uncalibrate's [[fx, s], [0, fy]]
+            // PinholeBase::Dpose / Dpoint, then uncalibrate's [[fx, s], [0, fy]] D(pd)/D(pn)
+            const T dgx = T(2) * k1 * u + T(4) * k2 * rr * u, dgy = T(2) * k1 * v + T(4) * k2 * rr * v;
+            const T d00 = g + u * dgx + T(2) * t1 * v + T(6) * t2 * u, d01 = u * dgy + T(2) * t1 * u + T(2) * t2 * v;
+            const T d10 = v * dgx + T(2) * t2 * v + T(2) * t1 * u, d11 = g + v * dgy + T(2) * t2 * u + T(6) * t1 * v;
+            const T m00 = fx * d00 + sk * d10, m01 = fx * d01 + sk * d11, m10 = fy * d10, m11 = fy * d11;
             const V6<T> r0 = {{u * v, T(-1) - u * u, v}, {-dz, T(0), dz * u}};
             const V6<T> r1 = {{T(1) + v * v, -u * v, -u}, {T(0), -dz, dz * v}};
-            V6<T> h0 = fx * r0 + sk * r1, h1 = fy * r1;
+            V6<T> h0 = m00 * r0 + m01 * r1, h1 = m10 * r0 + m11 * r1;
             if (has_sensor) {
               const BL6<T> AdS = se3_adjoint(se3_inverse(S));
               h0 = rowmul(h0, AdS);
@@ -1011,8 +1021,8 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
             const M3<T> &R = cam.R;
             const V3<T> c0 = {R.m[0], R.m[3], R.m[6]}, c1 = {R.m[1], R.m[4], R.m[7]}, c2 = {R.m[2], R.m[5], R.m[8]};
             const V3<T> d0 = dz * (c0 - u * c2), d1 = dz * (c1 - v * c2);
-            put_v3(fx * d0 + sk * d1, Jm);
-            put_v3(fy * d1, Jm + 3);
+            put_v3(m00 * d0 + m01 * d1, Jm);
+            put_v3(m10 * d0 + m11 * d1, Jm + 3);
             put_v6(rowmul(h0, o.H1), JL); put_v6(rowmul(h0, o.H2), JL + 6); put_v6(rowmul(h0, o.H3), JR); put_v6(rowmul(h0, o.H4), JR + 6);
             put_v6(rowmul(h1, o.H1), JL + b); put_v6(rowmul(h1, o.H2), JL + b + 6); put_v6(rowmul(h1, o.H3), JR + b); put_v6(rowmul(h1, o.H4), JR + b + 6);
           }

@@ -130,6 +130,41 @@ class Cal3_S2 {
   double fx_ = 1, fy_ = 1, s_ = 0, u0_ = 0, v0_ = 0;
 };
 
+/// gtsam::Cal3DS2: Cal3_S2 plus radial (k1, k2) and tangential (p1, p2) distortion -- the second CALIBRATION the projection
+/// factor template is instantiated for here (GPInterpolatedProjectionFactorPose3.h:29; round 4)
+class Cal3DS2 {
+ public:
+  Cal3DS2() {}
+  Cal3DS2(double fx, double fy, double s, double u0, double v0, double k1, double k2, double p1 = 0.0, double p2 = 0.0)
+      : fx_(fx), fy_(fy), s_(s), u0_(u0), v0_(v0), k1_(k1), k2_(k2), p1_(p1), p2_(p2) {}
+  double fx() const { return fx_; }
+  double fy() const { return fy_; }
+  double skew() const { return s_; }
+  double px() const { return u0_; }
+  double py() const { return v0_; }
+  double k1() const { return k1_; }
+  double k2() const { return k2_; }
+  double p1() const { return p1_; }
+  double p2() const { return p2_; }
+ private:
+  double fx_ = 1, fy_ = 1, s_ = 0, u0_ = 0, v0_ = 0, k1_ = 0, k2_ = 0, p1_ = 0, p2_ = 0;
+};
+namespace detail {
+// what a calibration hands to the device: {fx, fy, s, u0, v0} for a linear one, + {k1, k2, p1, p2} for Cal3DS2.  A user-defined
+// CALIBRATION with the Cal3_S2 accessors works through the first overload (the documented hook: anything that is linear in the
+// intrinsic point); anything else needs its uncalibrate() in k_meas.
+template <class CAL> inline std::vector<double> calibration_vector(const CAL &K) { return {K.fx(), K.fy(), K.skew(), K.px(), K.py()}; }
+inline std::vector<double> calibration_vector(const Cal3DS2 &K) { return {K.fx(), K.fy(), K.skew(), K.px(), K.py(), K.k1(), K.k2(), K.p1(), K.p2()}; }
+inline Point2 uncalibrate(const std::vector<double> &K, double x, double y) {
+  if (K.size() == 9) {
+    const double rr = x * x + y * y, g = 1.0 + K[5] * rr + K[6] * rr * rr;
+    const double dx = 2.0 * K[7] * x * y + K[8] * (rr + 2.0 * x * x), dy = 2.0 * K[8] * x * y + K[7] * (rr + 2.0 * y * y);
+    x = g * x + dx; y = g * y + dy;
+  }
+  return Point2(K[0] * x + K[2] * y + K[3], K[1] * y + K[4]);
+}
+}  // namespace detail
+
 /// gtsam::PinholeCamera<CALIBRATION>::project -- host-side helper for building measurements (as the reference's
 /// tests do with cam.project(land), testGPInterpolatedProjectionFactorPose3.cpp:131-134); not part of the device path.
 template <class CALIBRATION> class PinholeCamera {
@@ -140,8 +175,7 @@ template <class CALIBRATION> class PinholeCamera {
     const double *R = pose_.R.R;
     const double qx = R[0] * dx + R[3] * dy + R[6] * dz, qy = R[1] * dx + R[4] * dy + R[7] * dz, qz = R[2] * dx + R[5] * dy + R[8] * dz;
     if (!(qz > 0.0)) throw std::domain_error("CheiralityException: point behind the camera");
-    const double u = qx / qz, v = qy / qz;
-    return Point2(K_.fx() * u + K_.skew() * v + K_.px(), K_.fy() * v + K_.py());
+    return detail::uncalibrate(detail::calibration_vector(K_), qx / qz, qy / qz);
   }
  private:
   Pose3 pose_;
@@ -580,7 +614,7 @@ struct Session {
         case F_BEARING_RANGE: { int32_t s = state_of(f.k[0]), m = lm_of(f.k[4]);
           check(gpslam_hip_add_bearing_range(h, 1, &s, &m, &f.meas[0], &f.meas[1], f.sig.data()), h, "add_bearing_range"); gaussian(GPSLAM_MEAS_BEARING_RANGE); } break;
         case F_INTERP_PROJ: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);
-          check(gpslam_hip_add_interp_projection(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), h,
+          check((f.aux.size() == 9 ? gpslam_hip_add_interp_projection_ds2 : gpslam_hip_add_interp_projection)(h, 1, &l, &m, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), h,
                 "add_interp_projection"); gaussian(GPSLAM_MEAS_INTERP_PROJECTION); } break;
       }
     }
@@ -920,7 +954,7 @@ inline gtsam::Vector meas_evaluate(const gtsam::detail::Desc &f, const std::vect
       break;
     case gtsam::detail::F_INTERP_PROJ:
       kind = GPSLAM_MEAS_INTERP_PROJECTION; rows = 2;
-      gtsam::detail::check(gpslam_hip_add_interp_projection(s.h, 1, &zero, &zero, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), s.h, "add_interp_projection");
+      gtsam::detail::check((f.aux.size() == 9 ? gpslam_hip_add_interp_projection_ds2 : gpslam_hip_add_interp_projection)(s.h, 1, &zero, &zero, f.meas.data(), f.sig.data(), &f.dt, &f.tau, f.aux.data(), sens), s.h, "add_interp_projection");
       break;
     default: throw std::invalid_argument("evaluateError: not a measurement factor");
   }
@@ -1129,7 +1163,7 @@ class GPInterpolatedProjectionFactorPose3 : public gtsam::NonlinearFactor {
     d_.type = gtsam::detail::F_INTERP_PROJ; d_.manifold = GPSLAM_POSE3;
     d_.k[0] = poseKey1; d_.k[1] = velKey1; d_.k[2] = poseKey2; d_.k[3] = velKey2; d_.k[4] = pointKey;
     d_.meas = {measured.x, measured.y}; gtsam::noise_of(cam_model, d_); d_.Qc = Qc_model->covariance();
-    d_.dt = delta_t; d_.tau = tau; d_.aux = {K->fx(), K->fy(), K->skew(), K->px(), K->py()};
+    d_.dt = delta_t; d_.tau = tau; d_.aux = gtsam::detail::calibration_vector(*K);
     if (body_P_sensor) d_.sensor = gtsam::detail::VT<gtsam::Pose3>::pack(*body_P_sensor);
   }
   GPSLAM_FACTOR_BOILERPLATE_NAMED(GPInterpolatedProjectionFactorPose3<CALIBRATION>, 5, "GPInterpolatedProjectionFactor", true)

@@ -202,6 +202,13 @@ int gpslam_hip_add_interp_gps(gpslam_hip_handle *h, int32_t count, const int32_t
 int gpslam_hip_add_interp_projection(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
                                      const double *measured, const double *sigmas, const double *dt, const double *tau,
                                      const double *K, const double *sensor);
+/* The same factor with CALIBRATION = gtsam::Cal3DS2 (the reference class is a template over it,
+ * GPInterpolatedProjectionFactorPose3.h:29): K9 = {fx, fy, s, u0, v0, k1, k2, p1, p2}, radial (k1, k2) and tangential
+ * (p1, p2) distortion of the intrinsic point before the linear calibration (Cal3DS2_Base::uncalibrate).  Zero coefficients
+ * give the Cal3_S2 factor bit for bit; both kinds may share a graph. */
+int gpslam_hip_add_interp_projection_ds2(gpslam_hip_handle *h, int32_t count, const int32_t *left, const int32_t *landmark,
+                                         const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                         const double *K9, const double *sensor);
 /* OdometryFactor2DLinear(x_left, x_left+1, measured) -- gpslam/slam/OdometryFactor2DLinear.h:38-40 */
 int gpslam_hip_add_odometry2d(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                               const double *sigmas);

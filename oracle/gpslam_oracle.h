@@ -122,6 +122,12 @@ void orc_gp_prior_pose3vw_packed(const double *p1, const double *s1, const doubl
 void orc_interp_pose3vw_packed(const double *Lambda, const double *Psi, const double *p1, const double *s1,
                                const double *p2, const double *s2, double *pose, double *H1, double *H2, double *H3,
                                double *H4);
+int orc_pinhole_project_ds2(const double cam[12], const double K[9], const double point[3], double uv[2], double *Dpose,
+                            double *Dpoint);
+int orc_interp_projection_pose3_ds2(const double *Lambda, const double *Psi, const double measured[2], const double K[9],
+                                    const double *sensor, const double *p1, const double *v1, const double *p2,
+                                    const double *v2, const double *point, double *e, double *H1, double *H2, double *H3,
+                                    double *H4, double *H5);
 int orc_pinhole_project(const double cam[12], const double K[5], const double point[3], double uv[2], double *Dpose,
                         double *Dpoint);
 int orc_interp_projection_pose3(const double *Lambda, const double *Psi, const double measured[2], const double K[5],
@@ -254,6 +260,9 @@ int orc_chain_add_odometry2d(orc_chain *c, int count, const int32_t *left, const
 int orc_chain_add_bearing_range(orc_chain *c, int count, const int32_t *idx, const int32_t *landmark,
                                 const double *bearing, const double *range, const double *sigmas);
 /* GPInterpolatedProjectionFactorPose3<Cal3_S2>: measured count x 2 (pixels), sigmas count x 2, K = fx, fy, s, u0, v0 */
+int orc_chain_add_interp_projection_ds2(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
+                                        const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                        const double *K9, const double *sensor);
 int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
                                     const double *measured, const double *sigmas, const double *dt, const double *tau,
                                     const double *K, const double *sensor);

@@ -200,10 +200,15 @@ def interpolate_vw(Lam, Psi, p1, v1, w1, p2, v2, w2, jac=True):
     return out, H
 
 
+def _k9(K):
+    K = np.asarray(K, dtype=np.float64).ravel()
+    return np.concatenate([K, np.zeros(9 - len(K))])       # Cal3_S2 (5) or Cal3DS2 (9: + k1, k2, p1, p2)
+
+
 def pinhole_project(cam, K, point):
-    """PinholeCamera<Cal3_S2>(cam, K).project(point); raises on a cheirality violation."""
+    """PinholeCamera<Cal3_S2 | Cal3DS2>(cam, K).project(point); raises on a cheirality violation."""
     uv = np.zeros(2)
-    if call("orc_pinhole_project", A(cam), A(K), A(point), uv, None, None) != 0:
+    if call("orc_pinhole_project_ds2", A(cam), A(_k9(K)), A(point), uv, None, None) != 0:
         raise ValueError("point behind the camera")
     return uv
 
@@ -212,7 +217,7 @@ def interp_projection(Lam, Psi, meas, K, sensor, p1, v1, p2, v2, land, jac=True)
     """GPInterpolatedProjectionFactorPose3<Cal3_S2>::evaluateError: (e, [H1..H4 (2x6), H5 (2x3)], behind_camera)."""
     e = np.zeros(2)
     H = [np.zeros((2, 6)) for _ in range(4)] + [np.zeros((2, 3))] if jac else [None] * 5
-    behind = call("orc_interp_projection_pose3", A(Lam), A(Psi), A(meas), A(K), None if sensor is None else A(sensor),
+    behind = call("orc_interp_projection_pose3_ds2", A(Lam), A(Psi), A(meas), A(_k9(K)), None if sensor is None else A(sensor),
                   A(p1), A(v1), A(p2), A(v2), A(land), e, *H)
     return e, H, bool(behind)
 
@@ -335,7 +340,8 @@ class Chain:
     def add_interp_projection(self, left, landmark, measured, sigmas, dt, tau, K, sensor=None):
         left, _ = _i(left)
         landmark, _ = _i(landmark)
-        return call("orc_chain_add_interp_projection", self._h, len(left), left, landmark, A(measured), A(sigmas), A(dt),
+        K = _k9(K)
+        return call("orc_chain_add_interp_projection_ds2", self._h, len(left), left, landmark, A(measured), A(sigmas), A(dt),
                     A(tau), A(K), None if sensor is None else A(sensor))
 
     def add_odometry2d(self, left, measured, sigmas):

@@ -34,7 +34,7 @@ typedef struct {
   double meas[12];  /* measurement / prior value */
   double sig[6];    /* diagonal sigmas */
   double dt, tau;
-  double aux[6];    /* attitude: nZ(3), bRef(3) */
+  double aux[9];    /* attitude: nZ(3), bRef(3); projection: fx, fy, s, u0, v0, k1, k2, p1, p2 */
   int has_sensor;
   double sensor[12];
   double ahrs[34];  /* F_AHRS: the 25 parameters of orc_ahrs_factor + square-root information R (3 x 3 upper triangular) */
@@ -287,9 +287,18 @@ int orc_chain_add_bearing_range(orc_chain *c, int count, const int32_t *idx, con
   }
   return 0;
 }
+int orc_chain_add_interp_projection_ds2(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
+                                        const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                        const double *K9, const double *sensor);
 int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
                                     const double *measured, const double *sigmas, const double *dt, const double *tau,
                                     const double *K, const double *sensor) {
+  const double K9[9] = {K[0], K[1], K[2], K[3], K[4], 0.0, 0.0, 0.0, 0.0};
+  return orc_chain_add_interp_projection_ds2(c, count, left, landmark, measured, sigmas, dt, tau, K9, sensor);
+}
+int orc_chain_add_interp_projection_ds2(orc_chain *c, int count, const int32_t *left, const int32_t *landmark,
+                                        const double *measured, const double *sigmas, const double *dt, const double *tau,
+                                        const double *K, const double *sensor) {
   if (c->kind != ORC_POSE3 || c->ld != 3 || c->vw) return -2;
   for (int k = 0; k < count; k++) {
     orc_factor *f = new_factor(c, F_INTERP_PROJ);
@@ -297,7 +306,7 @@ int orc_chain_add_interp_projection(orc_chain *c, int count, const int32_t *left
     f->meas[0] = measured[2 * (size_t)k]; f->meas[1] = measured[2 * (size_t)k + 1];
     f->sig[0] = sigmas[2 * (size_t)k]; f->sig[1] = sigmas[2 * (size_t)k + 1];
     f->dt = dt[k]; f->tau = tau[k];
-    orc_copy(5, K, f->aux);                       /* fx, fy, s, u0, v0 */
+    orc_copy(9, K, f->aux);                       /* fx, fy, s, u0, v0, k1, k2, p1, p2 */
     if (sensor) { f->has_sensor = 1; orc_copy(12, sensor, f->sensor); }
   }
   return 0;
@@ -516,7 +525,7 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
     case F_INTERP_PROJ:
       rows = 2;
       if (orc_calcLambda(d, c->Qc, f->dt, f->tau, Lam) || orc_calcPsi(d, c->Qc, f->dt, f->tau, Psi)) return -1;
-      orc_interp_projection_pose3(Lam, Psi, f->meas, f->aux, f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt, e,
+      orc_interp_projection_pose3_ds2(Lam, Psi, f->meas, f->aux, f->has_sensor ? f->sensor : NULL, p1, v1, p2, v2, pt, e,
                                   H1, H2, H3, H4, H5);
       *uses_right = 1;
       *uses_lm = 1;

@@ -151,21 +151,36 @@ double orc_interp_range_pose3vw(const double *Lambda, const double *Psi, double 
   return hx - measured;
 }
 
-/* PinholeCamera<Cal3_S2>::project(point, Dpose, Dpoint) (GTSAM CalibratedCamera.cpp / Cal3_S2.cpp; call site
- * GPInterpolatedProjectionFactorPose3.h:106-118):  q = R^T (p - t) must have q.z > 0 (else CheiralityException),
- * pn = (q.x, q.y) / q.z, uv = (fx pn.x + s pn.y + u0, fy pn.y + v0), K = [fx, fy, s, u0, v0].
+/* PinholeCamera<CALIBRATION>::project(point, Dpose, Dpoint) (GTSAM CalibratedCamera.cpp, Cal3_S2.cpp, Cal3DS2_Base.cpp; call
+ * site GPInterpolatedProjectionFactorPose3.h:106-118, a template over CALIBRATION, :29):  q = R^T (p - t) must have q.z > 0
+ * (else CheiralityException), pn = (q.x, q.y) / q.z, then CALIBRATION::uncalibrate:
+ *   Cal3_S2   uv = (fx pn.x + s pn.y + u0, fy pn.y + v0),                                  K = [fx, fy, s, u0, v0]
+ *   Cal3DS2   (x, y) = pn, rr = x^2 + y^2, g = 1 + k1 rr + k2 rr^2,                        K9 = [fx, fy, s, u0, v0, k1, k2, p1, p2]
+ *             pd = (g x + 2 p1 x y + p2 (rr + 2 x^2), g y + 2 p2 x y + p1 (rr + 2 y^2)), uv = Cal3_S2(pd)
+ *             (radial-tangential distortion; Cal3DS2_Base::uncalibrate, recalled from GTSAM 4.0 -- no reference test uses it:
+ *              parity unpinned, held here to central differences and to Cal3_S2 at zero distortion)
  * Dpn_pose = [uv', -1-u^2, v, -d, 0, d u; 1+v^2, -uv', -u, 0, -d, d v] with (u, v) = pn, d = 1/q.z (PinholeBase::Dpose),
- * Dpn_point = d [Rt_0 - u Rt_2; Rt_1 - v Rt_2], Rt = R^T (PinholeBase::Dpoint), Duv_pn = [fx, s; 0, fy].
+ * Dpn_point = d [Rt_0 - u Rt_2; Rt_1 - v Rt_2], Rt = R^T (PinholeBase::Dpoint), Duv_pn = [fx, s; 0, fy] D(pd)/D(pn).
  * Returns 0, or 1 on a cheirality violation (outputs untouched). */
-int orc_pinhole_project(const double cam[12], const double K[5], const double point[3], double uv[2], double *Dpose,
-                        double *Dpoint) {
+int orc_pinhole_project_ds2(const double cam[12], const double K[9], const double point[3], double uv[2], double *Dpose,
+                            double *Dpoint) {
   double q[3];
   orc_pose3_transform_to(cam, point, q, NULL, NULL);
   if (q[2] <= 0.0) return 1;
   const double d = 1.0 / q[2], u = q[0] * d, v = q[1] * d;
-  uv[0] = K[0] * u + K[2] * v + K[3];
-  uv[1] = K[1] * v + K[4];
-  const double Dk[4] = {K[0], K[2], 0.0, K[1]};
+  const double k1 = K[5], k2 = K[6], p1 = K[7], p2 = K[8];
+  const double xx = u * u, yy = v * v, xy = u * v, rr = xx + yy;
+  const double g = 1.0 + k1 * rr + k2 * rr * rr;
+  const double pdx = g * u + 2.0 * p1 * xy + p2 * (rr + 2.0 * xx);
+  const double pdy = g * v + 2.0 * p2 * xy + p1 * (rr + 2.0 * yy);
+  uv[0] = K[0] * pdx + K[2] * pdy + K[3];
+  uv[1] = K[1] * pdy + K[4];
+  const double dgx = 2.0 * k1 * u + 4.0 * k2 * rr * u, dgy = 2.0 * k1 * v + 4.0 * k2 * rr * v;
+  const double D2[4] = {g + u * dgx + 2.0 * p1 * v + 6.0 * p2 * u, u * dgy + 2.0 * p1 * u + 2.0 * p2 * v,
+                        v * dgx + 2.0 * p2 * v + 2.0 * p1 * u, g + v * dgy + 2.0 * p2 * u + 6.0 * p1 * v};
+  const double Kk[4] = {K[0], K[2], 0.0, K[1]};
+  double Dk[4];
+  orc_mm(2, 2, 2, Kk, D2, Dk);
   if (Dpose) {
     const double Dp[12] = {u * v, -1.0 - u * u, v, -d, 0.0, d * u,
                            1.0 + v * v, -u * v, -u, 0.0, -d, d * v};
@@ -181,21 +196,38 @@ int orc_pinhole_project(const double cam[12], const double K[5], const double po
   }
   return 0;
 }
+int orc_pinhole_project(const double cam[12], const double K[5], const double point[3], double uv[2], double *Dpose,
+                        double *Dpoint) {
+  const double K9[9] = {K[0], K[1], K[2], K[3], K[4], 0.0, 0.0, 0.0, 0.0};
+  return orc_pinhole_project_ds2(cam, K9, point, uv, Dpose, Dpoint);
+}
 
 /* GPInterpolatedProjectionFactorPose3<Cal3_S2>::evaluateError -- GPInterpolatedProjectionFactorPose3.h:82-139.
  * A landmark behind the camera does not throw (throwCheirality = false, the default): the error is 2 fx in both
  * components and every Jacobian is zero (:122-138).  H1..H4: 2x6, H5: 2x3.  Returns 1 in that case, else 0. */
+int orc_interp_projection_pose3_ds2(const double *Lambda, const double *Psi, const double measured[2], const double K[9],
+                                    const double *sensor, const double *p1, const double *v1, const double *p2,
+                                    const double *v2, const double *point, double *e, double *H1, double *H2, double *H3,
+                                    double *H4, double *H5);
 int orc_interp_projection_pose3(const double *Lambda, const double *Psi, const double measured[2], const double K[5],
                                 const double *sensor, const double *p1, const double *v1, const double *p2,
                                 const double *v2, const double *point, double *e, double *H1, double *H2, double *H3,
                                 double *H4, double *H5) {
+  const double K9[9] = {K[0], K[1], K[2], K[3], K[4], 0.0, 0.0, 0.0, 0.0};
+  return orc_interp_projection_pose3_ds2(Lambda, Psi, measured, K9, sensor, p1, v1, p2, v2, point, e, H1, H2, H3, H4, H5);
+}
+/* the same for GPInterpolatedProjectionFactorPose3<Cal3DS2> (K9 = Cal3_S2's five, then k1, k2, p1, p2) */
+int orc_interp_projection_pose3_ds2(const double *Lambda, const double *Psi, const double measured[2], const double K[9],
+                                    const double *sensor, const double *p1, const double *v1, const double *p2,
+                                    const double *v2, const double *point, double *e, double *H1, double *H2, double *H3,
+                                    double *H4, double *H5) {
   double Hi1[36], Hi2[36], Hi3[36], Hi4[36], pose[12], cam[12], H0[36], Hcam[12], Hpose[12], uv[2];
   int want = H1 || H2 || H3 || H4;
   orc_interp_pose3(Lambda, Psi, p1, v1, p2, v2, pose, want ? Hi1 : NULL, want ? Hi2 : NULL, want ? Hi3 : NULL,
                    want ? Hi4 : NULL);
   if (sensor) orc_pose3_compose(pose, sensor, cam, H0, NULL);
   else orc_copy(12, pose, cam);
-  if (orc_pinhole_project(cam, K, point, uv, Hcam, H5)) {
+  if (orc_pinhole_project_ds2(cam, K, point, uv, Hcam, H5)) {
     e[0] = e[1] = 2.0 * K[0];
     if (H1) orc_zero(12, H1);
     if (H2) orc_zero(12, H2);

@@ -254,9 +254,11 @@ static void test_gp_prior_pose3vw_optimization() {
   EXPECT(near3(pose2.t, values.at<Pose3>(Symbol('x', 2)).t, 1e-6));
 }
 
-static void test_projection_optimization_and_trajectory_query() {
+// the class is a template over CALIBRATION in the reference (GPInterpolatedProjectionFactorPose3.h:29): the same scenario with
+// gtsam::Cal3_S2 (the reference's test) and with a distorting gtsam::Cal3DS2 (round 4)
+template <class CAL> static void projection_scenario(const std::shared_ptr<CAL> &K) {
   // testGPInterpolatedProjectionFactorPose3.cpp:180-262
-  typedef GPInterpolatedProjectionFactorPose3<Cal3_S2> ProjectionFactor;
+  typedef GPInterpolatedProjectionFactorPose3<CAL> ProjectionFactor;
   auto model_prior = noiseModel::Isotropic::Sigma(6, 0.01);
   auto model_cam = noiseModel::Isotropic::Sigma(2, 0.1);
   double delta_t = 0.1, tau1 = 0.02, tau2 = 0.06, tau3 = 0.09;
@@ -267,11 +269,10 @@ static void test_projection_optimization_and_trajectory_query() {
   Pose3 p1i(Rot3::Ypr(0.1, 0.2, 0.4), Point3(0.2, 0.3, -0.2));
   Pose3 p2i(Rot3::Ypr(-0.1, -0.2, -0.4), Point3(1.2, -0.3, 0.2));
   Vector6 v1i = {-0.3, 0, 0, 0.7, 0, 0.2}, v2i = {0, 0, 0.4, 1.2, 0, -0.1};
-  auto K = std::make_shared<Cal3_S2>(50, 50, 0, 40, 30);
   Point3 land(3.4, 1.2, 20), landi(3.3, 1.3, 18);
-  Point2 meas1 = PinholeCamera<Cal3_S2>(pcam1, *K).project(land);
-  Point2 meas2 = PinholeCamera<Cal3_S2>(pcam2, *K).project(land);
-  Point2 meas3 = PinholeCamera<Cal3_S2>(pcam3, *K).project(land);
+  Point2 meas1 = PinholeCamera<CAL>(pcam1, *K).project(land);
+  Point2 meas2 = PinholeCamera<CAL>(pcam2, *K).project(land);
+  Point2 meas3 = PinholeCamera<CAL>(pcam3, *K).project(land);
   NonlinearFactorGraph graph;
   graph.add(PriorFactor<Pose3>(Symbol('x', 1), p1, model_prior));
   graph.add(PriorFactor<Pose3>(Symbol('x', 2), p2, model_prior));
@@ -300,6 +301,18 @@ static void test_projection_optimization_and_trajectory_query() {
   std::vector<Pose3> q = optimizer.interpolatePoses<Pose3>({Symbol('x', 1), Symbol('x', 1), Symbol('x', 1)},
                                                            {delta_t, delta_t, delta_t}, {tau1, tau2, tau3});
   EXPECT(q.size() == 3 && near3(pcam1.t, q[0].t, 1e-6) && near3(pcam2.t, q[1].t, 1e-6) && near3(pcam3.t, q[2].t, 1e-6));
+}
+static void test_projection_optimization_and_trajectory_query() {
+  projection_scenario(std::make_shared<Cal3_S2>(50, 50, 0, 40, 30));
+  // (mild coefficients: the scenario starts 0.4 rad away from the truth, and a strongly non-monotonic radial polynomial gives
+  //  Gauss-Newton local minima to find there)
+  auto Kd = std::make_shared<Cal3DS2>(50, 50, 0, 40, 30, 0.05, -0.01, 0.002, -0.003);
+  projection_scenario(Kd);
+  // the distortion is visible off axis (a dropped term would not be caught by a zero-residual fixed point alone)
+  Pose3 cam(Rot3(), Point3(0.2, 0, 0));
+  Point2 a = PinholeCamera<Cal3_S2>(cam, Cal3_S2(50, 50, 0, 40, 30)).project(Point3(10.0, -6.0, 20));
+  Point2 b = PinholeCamera<Cal3DS2>(cam, *Kd).project(Point3(10.0, -6.0, 20));
+  EXPECT(std::fabs(a.x - b.x) > 1e-2 && std::fabs(a.y - b.y) > 1e-2);
 }
 
 // evaluateError / interpolatePose of single factors, the calls the reference's factor tests make

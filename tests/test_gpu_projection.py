@@ -8,9 +8,10 @@ from test_oracle_golden import build_projection_problem, check_projection_result
 
 pytestmark = pytest.mark.gpu
 K2 = [50.0, 50.0, 0.7, 40.0, 30.0]          # a skewed calibration exercises the s term
+KDS2 = K2 + [0.08, -0.03, 0.004, -0.006]    # gtsam::Cal3DS2: + radial k1, k2 and tangential p1, p2 (round 4)
 
 
-def build_pair(N=24, seed=4, sensor=True, behind=False):
+def build_pair(N=24, seed=4, sensor=True, behind=False, K2=K2):
     c = random_chain(O.POSE3, N, seed, motion=0.2, noise=0.02)
     rng = np.random.default_rng(seed + 9)
     Qc = np.diag(0.01 + 0.02 * rng.random(6))
@@ -80,6 +81,33 @@ def test_projection_normal_equations_and_gauss_newton(sensor):
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
     states_close(O.POSE3, x0, v0, x1, v1, 1e-8)
     assert np.abs(orc.get_landmarks() - dev.get_landmarks()).max() <= 1e-8
+
+
+def test_projection_with_a_distorting_calibration():
+    """GPInterpolatedProjectionFactorPose3<Cal3DS2>: the reference class is a template over CALIBRATION
+    (GPInterpolatedProjectionFactorPose3.h:29); radial + tangential distortion on the HIP path vs the oracle, and zero
+    coefficients through the Cal3DS2 entry point against the Cal3_S2 one, bit for bit."""
+    orc, dev, n = build_pair(sensor=True, K2=KDS2)
+    assert n > 20
+    assert abs(orc.error() - dev.error()) <= 1e-10 * max(1.0, orc.error())
+    D0, O0, g0, B0, _, _ = orc.normal_equations()
+    D1, O1, g1, B1 = dev.normal_equations()
+    for a, b in ((D0, D1), (O0, O1), (g0, g1), (B0, B1)):
+        assert np.abs(a - b).max() <= 1e-8 * max(1.0, np.abs(a).max())
+    for _ in range(5):
+        rc0, st0 = orc.iterate_gn()
+        rc1, st1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(st0.error_after - st1.error_after) <= 1e-6 * max(1.0, st0.error_after)
+    (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+    states_close(O.POSE3, x0, v0, x1, v1, 1e-8)
+    # the distortion matters at image coordinates like these (otherwise the test would not notice a dropped term)
+    cam = O.pose3((0.0, 0.0, 0.0), (0.0, 0.0, 0.0))
+    assert np.abs(O.pinhole_project(cam, K2, [-3.0, 2.5, 8.0]) - O.pinhole_project(cam, KDS2, [-3.0, 2.5, 8.0])).min() > 0.05
+    _, plain, _ = build_pair(sensor=True, K2=K2)
+    _, zero, _ = build_pair(sensor=True, K2=K2 + [0.0, 0.0, 0.0, 0.0])
+    assert zero.error() == plain.error()
+    assert np.array_equal(zero.normal_equations()[0], plain.normal_equations()[0])
 
 
 def test_projection_cheirality_masked_like_the_reference():

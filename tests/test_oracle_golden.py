@@ -596,3 +596,28 @@ def test_jacobian_step_table_is_current():
         h, h_ref = _JAC_LOG[case]
         assert h > h_ref * (1 + 1e-12), "%s now passes at the reference's own step %g: remove it from tests/golden/jac_steps.json" % (case, h_ref)
         assert abs(h - allowed) <= 1e-12 * h, "%s passed at step %g, the table says %g: update it" % (case, h, allowed)
+
+
+def test_cal3ds2_projection_against_central_differences_and_cal3_s2():
+    """GPInterpolatedProjectionFactorPose3<Cal3DS2> in the oracle (no reference test uses a distorting calibration: parity
+    unpinned): H5 and the pose Jacobian of PinholeCamera<Cal3DS2>::project against central differences, Cal3_S2 at zero distortion."""
+    rng = np.random.default_rng(77)
+    cam = O.pose3((0.2, -0.1, 0.3), (0.5, -0.4, 0.2))
+    K9 = [60.0, 55.0, 0.4, 32.0, 24.0, 0.09, -0.04, 0.005, -0.007]
+    for _ in range(5):
+        pt = cam[9:] + cam[:9].reshape(3, 3) @ np.array([rng.uniform(-2, 2), rng.uniform(-2, 2), rng.uniform(4, 9)])
+        uv = np.zeros(2); Dpose = np.zeros((2, 6)); Dpoint = np.zeros((2, 3))
+        assert O.call("orc_pinhole_project_ds2", cam, np.array(K9), pt, uv, Dpose, Dpoint) == 0
+        h = 1e-6
+        num = np.zeros((2, 3))
+        for j in range(3):
+            d = np.zeros(3); d[j] = h
+            num[:, j] = (O.pinhole_project(cam, K9, pt + d) - O.pinhole_project(cam, K9, pt - d)) / (2 * h)
+        assert np.abs(num - Dpoint).max() <= 1e-6 * max(1.0, np.abs(Dpoint).max())
+        nump = np.zeros((2, 6))
+        for j in range(6):
+            d = np.zeros(6); d[j] = h
+            nump[:, j] = (O.pinhole_project(O.retract(O.POSE3, cam, d), K9, pt) - O.pinhole_project(O.retract(O.POSE3, cam, -d), K9, pt)) / (2 * h)
+        assert np.abs(nump - Dpose).max() <= 1e-5 * max(1.0, np.abs(Dpose).max())
+        assert np.array_equal(O.pinhole_project(cam, K9[:5], pt), O.pinhole_project(cam, K9[:5] + [0, 0, 0, 0], pt))
+        assert np.abs(O.pinhole_project(cam, K9[:5], pt) - uv).max() > 1e-3      # the distortion is not a no-op here
