@@ -73,7 +73,9 @@ enum {
 typedef struct {
   int32_t manifold;      /* GPSLAM_LINEAR2 .. GPSLAM_ROT3 */
   int32_t precision;     /* GPSLAM_FP64, or GPSLAM_FP32: fp32 Jacobian rows (evaluated re-centred, with the exact derivative in place of the
-                          * h = 1e-6 difference), fp64 residual, normal equations and solver */
+                          * h = 1e-6 difference), fp64 residual, normal equations and solver.  A TOLERANCE mode
+                          * (north_star's 1e-5-relative sweep, half the row-table footprint), not a throughput mode: the structured
+                          * GP-prior records of the fp64 path are fp64-only, fp32 rows are slower per iteration on every measured mix */
   int32_t device;        /* HIP device ordinal */
   int32_t chart;         /* GPSLAM_CHART_* */
   int32_t landmark_dim;  /* 0 (no landmarks), 2 or 3 */
