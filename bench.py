@@ -569,10 +569,11 @@ def main():
                          "timing": ("hipEvents around the launch INSIDE 6 consecutive Gauss-Newton iterations (gpslam_hip_last_level0_ms); the "
                                     "isolated launches of kernel_ms are faster" if (dom == 2 and l0_in_iter > 0) else "isolated launches (time_kernel)"),
                          # what actually limits the kernel the HBM fraction is quoted for
-                         "note": ("arithmetic and data path of equal length (timing ablations, DESIGN.md section 4): two-wave workgroups "
-                                  "(assembly + elimination), ~2100 fp64 VALU instructions per workgroup block step; measured traffic is below "
-                                  "the SURVEY 8(d) figure because the GP priors arrive as structured records (196 instead of 312 doubles); "
-                                  "round 3: the launch also reduces its four chunk separators (a solver level of its own before)"
+                         "note": ("step-rate bound (timing ablations, DESIGN.md section 4 'Round 4'): two-wave workgroups (assembly + "
+                                  "elimination), ~2700 wave instructions per workgroup block step, 70 % of the launch is there with all "
+                                  "arithmetic removed; measured traffic is below the SURVEY 8(d) figure because the GP priors arrive as "
+                                  "80-double records of Jr^-1, J and the finite-difference block (312 doubles as rows) whose columns the "
+                                  "assembly wave forms; the launch also reduces its four chunk separators"
                                   if fused and dom == 2 else None)},
         }
         # K1 (batched evaluateError + Jacobians of the GP priors) standalone and inside an iteration, where it shares the
