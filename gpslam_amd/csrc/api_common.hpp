@@ -117,6 +117,9 @@ struct gpslam_hip_handle {
   // rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows, a consumer that reads the row table)
   bool struct3_ok = false, rows3 = false;
   DevBuf gps, gpidx, dU, gsave2;
+  // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
+  bool btw_rec_ok = false;
+  DevBuf brec, btwidx;
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;

@@ -147,6 +147,13 @@ template <typename T> struct GpArgs {
 // 32 doubles = two 128-byte lines per factor instead of 6 rows x 13 doubles = 624 bytes written as 96-byte fragments (1.45x write
 // amplification measured: profiles/round4_c4_v0).  Consumers: k_assemble_ghost<6> and k_fused_level0<1, double, 6>.
 constexpr int kGp3Len = 32, kGp3A1 = 0, kGp3A3 = 9, kGp3E = 18, kGp3S = 24;
+// BetweenFactor<Pose3>(x_i, x_i+1) of a chain that runs the structured path (round 4): e = Log(measured^-1 x_i^-1 x_i+1),
+// H2 = Jr^-1(e) = [[RA, 0], [RC, RA]], H1 = -Jr^-1(e) Ad((x_i^-1 x_i+1)^-1) = [[LA, 0], [LC, LA]] (GTSAM BetweenFactor.h through
+// Pose3::between / Logmap; call site matlab/PlazaPose2.m:125), rows weighted by 1 / sigma:
+//   [0..8] RA  [9..17] RC  [18..26] LA  [27..35] LC  (3 x 3, row-major)   [36..41] 1 / sigma   [42..47] whitened error
+// 48 doubles = three whole lines instead of six compact rows of 12 + 1 doubles (624 bytes in 96-byte fragments).  The assembly wave
+// of k_fused_level0 builds column c of [H1 | H2] in lane c < 6 exactly as it builds the columns of the GP prior's J and X.
+constexpr int kBtwLen = 48, kBtwRA = 0, kBtwRC = 9, kBtwLA = 18, kBtwLC = 27, kBtwW = 36, kBtwE = 42;
 constexpr int kGpsLen = 80, kGpsXA = 0, kGpsXC = 9, kGpsJA = 18, kGpsJC = 27, kGpsFA = 36, kGpsFC = 45, kGpsFD = 54, kGpsZ = 63,
               kGpsE = 64, kGpsS = 76;
 
@@ -609,11 +616,71 @@ template <typename T> struct FacArgs {
   float *rowE32;        // error-only pass: fp32 copy of the whitened error (fp32 mode), or null
   T *rowLR, *rowE;
   T *partial;
+  T *rec;               // KIND 2, Pose3, fp64: structured records (kBtw*) instead of compact rows, or null
 };
+
+// BetweenFactor<Pose3> as a structured record (kBtw*): the block-triangular halves of H1 and H2, the weights, the whitened error
+template <typename T>
+__device__ __forceinline__ void between_pose3_record(const FacArgs<T> &a, const int bid, T *stage, int *srow) {
+  const int f = bid * 128 + threadIdx.x;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool valid = f < a.count;
+  T *st = stage + wv * 64 * 20, *mine = st + lane * 20;
+  int *sr = srow + wv * 64;
+  sr[lane] = valid ? f : -1;
+  T x1[12], x2[12], m[12];
+#pragma unroll
+  for (int k = 0; k < 12; k++) { x1[k] = (k == 0 || k == 4 || k == 8) ? T(1) : T(0); x2[k] = x1[k]; m[k] = x1[k]; }   // idle lane: identities
+  if (valid) {
+    const int i = a.idx[f];
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      x1[k] = T(a.pose[(size_t)k * a.stride + i]);
+      x2[k] = T(a.pose[(size_t)k * a.stride + i + 1]);
+      m[k] = T(a.meas[(size_t)f * 12 + k]);
+    }
+  }
+  auto put = [&](int idx, T v) {              // (idx: a compile-time constant once the loops are unrolled)
+    mine[idx & 15] = v;
+    if ((idx & 15) == 15) wave_store_part<T, kBtwLen, 16, 20>(st, sr, lane, 0, idx - 15, a.rec);
+  };
+  const SE3<T> hx = se3_between(as_se3(x1), as_se3(x2));
+  const V6<T> xi = se3_log(se3_between(as_se3(m), hx));          // PoseFactors<T, POSE3>::between
+  const BL6<T> HL = se3_jrinv(xi);
+#pragma unroll
+  for (int k = 0; k < 9; k++) put(kBtwRA + k, HL.A.m[k]);
+#pragma unroll
+  for (int k = 0; k < 9; k++) put(kBtwRC + k, HL.C.m[k]);
+  {
+    const SE3<T> hi = se3_inverse(hx);
+    const M3<T> LA = neg(HL.A * hi.R);
+    const M3<T> LC = neg(HL.C * hi.R + HL.A * (skew(hi.t) * hi.R));
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kBtwLA + k, LA.m[k]);
+#pragma unroll
+    for (int k = 0; k < 9; k++) put(kBtwLC + k, LC.m[k]);
+  }
+  const T e[6] = {xi.w.x, xi.w.y, xi.w.z, xi.v.x, xi.v.y, xi.v.z};
+  T err = T(0), we[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const T w = valid ? T(1) / T(a.sig[(size_t)f * 6 + r]) : T(0);
+    we[r] = e[r] * w;
+    err += we[r] * we[r];
+    put(kBtwW + r, w);
+  }
+#pragma unroll
+  for (int r = 0; r < 6; r++) put(kBtwE + r, we[r]);
+  const T tot = block_sum(T(0.5) * err);
+  if (threadIdx.x == 0) a.partial[bid] = tot;
+}
 
 // KIND 0: PriorFactor<Pose>, 1: PriorFactor<Vector> on the velocity, 2: BetweenFactor<Pose>(x_i, x_i+1)
 template <typename T, int MF, int KIND, bool JAC>
 __device__ __forceinline__ void simple_block(const FacArgs<T> &a, const int bid, T *stage, int *srow) {
+  if constexpr (KIND == 2 && MF == POSE3 && JAC && IsF64<T>::v) {
+    if (a.rec != nullptr) { between_pose3_record<T>(a, bid, stage, srow); return; }
+  }
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
   // PriorFactor<Pose> and BetweenFactor<Pose> have no velocity columns: they go to the compact row table,
   // [d/dpose_left (d) | d/dpose_right (d)] per row, which halves what K3 has to read for them
@@ -2361,6 +2428,9 @@ template <typename T, typename TR = T> struct FusedArgs {
   const TR *rowC, *rowCE; // Mc x 12, Mc
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
   int gp_count;           // number of records; record gp_count is all zeros (states without a GP prior read it)
+  const T *brec;          // BetweenFactor<Pose3> records (kBtw*; K1 wrote no compact rows for them) or null (ST variants only)
+  const int *btwidx;      // n + 2 entries: record of the between factor whose left state is s, or -1
+  int btw_count;          // number of records; record btw_count is all zeros
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
   int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
@@ -2417,7 +2487,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = 6, PC = ST ? 4 : 6, Dh = B / 2;   // (ST: the record ring takes the registers of two compact-ring slots)
+    constexpr int PF = 6, PC = ST ? (SV == 2 ? 4 : 1) : 6, Dh = B / 2;   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     double carry[B], carry_g = 0.0;
@@ -2459,6 +2529,28 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     }
     double raw[NRAW];
     int gp = -1;
+    // BetweenFactor<Pose3> record of the state (u.brec, kBtw*): lane c < 6 builds column c of [H1 | H2] from the block-triangular
+    // halves exactly as above (the same column walk: oX1 / oX2 minus their bases), lanes 6..11 read the all-zero record
+    constexpr int NBR = ST ? 14 : 1;
+    double braw[NBR];
+    // (not in the variant with odd full-width rows: its registers are spoken for -- the host hands it compact rows)
+    const bool btw_on = ST && !ODD && u.brec != nullptr;
+    int bq = -1, bqn = btw_on ? u.btwidx[min(s + 1, ptr_max)] : -1, bqnn = btw_on ? u.btwidx[min(s + 2, ptr_max)] : -1;
+#pragma unroll
+    for (int k = 0; k < NBR; k++) braw[k] = 0.0;
+    auto ldbtw = [&]() {                      // operands of the between factor whose left state the rings point at (bq)
+      if constexpr (ST) {
+        if (!btw_on) return;                  // (no records on this launch: u.brec is null)
+        const double *rec = u.brec + (size_t)((bq >= 0 && r < Dh) ? bq : u.btw_count) * kBtwLen;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          braw[k] = rec[kBtwRA - kGpsXA + oX1 + 3 * k]; braw[3 + k] = rec[kBtwRA - kGpsXA + oX2 + 3 * k];
+          braw[6 + k] = rec[kBtwLA - kGpsXA + oX1 + 3 * k]; braw[9 + k] = rec[kBtwLA - kGpsXA + oX2 + 3 * k];
+        }
+        braw[12] = rec[kBtwW + min(r, Dh - 1)];
+        braw[13] = rec[kBtwE + min(r, Dh - 1)];
+      }
+    };
     int gpn = st_on ? u.gpidx[min(s + 1, ptr_max)] : -1, gpnn = st_on ? u.gpidx[min(s + 2, ptr_max)] : -1;
     // operands of the GP prior whose left state is s + kimg (record g; no such factor: the all-zero record behind the last one)
     auto ldraw = [&](int kimg, int g) {
@@ -2550,10 +2642,12 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #endif
     };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
-    auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g) {
+    auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g, int bqv) {
       const bool live = valid && (s + kimg) < e;
       gp = (live && st_on) ? g : -1;
+      bq = (live && btw_on) ? bqv : -1;
       if (gp >= 0) p0 += B;                              // its 12 rows lead the state's range in the row table: not used
+      if (bq >= 0) q1 -= Dh;                             // ... and its between factor's six rows end its range in the compact table
       rp = (live && (!ST || ODD)) ? p0 : 0; nf = (live && (!ST || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
       if constexpr (!ST) {
@@ -2580,6 +2674,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           constexpr int q = decltype(qq)::value;
           // the next state's record is requested once most of this state's columns are consumed (their registers take it)
           if constexpr (q == 8) ldraw(kimg + 1, gpn);
+          if constexpr (q == 5) ldbtw();                 // this state's between record: wanted right behind these twelve rows
           const double Lv = Lcol[q], Rv = Rcol[q];
 #ifndef GPS_ABLATE_ASM
           fmac_gather<B>(Dacc, Lv, Lv);
@@ -2589,6 +2684,30 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           fmac_bcast2<q>(gacc, grr, newl, Lv, Rv);       // g -= e[q] L[q][r],  carry_g -= e[q] R[q][r]
           __builtin_amdgcn_sched_barrier(0);
         });
+      }
+      if constexpr (ST) {                                // the state's BetweenFactor<Pose3> record: six compact rows from its columns
+        if (btw_on) {
+          int rq = r;
+          asm volatile("" : "+v"(rq));
+          const bool tcol = rq >= 3;                     // translation columns: zero top, the diagonal block below
+          double Lc6[6], Rc6[6];
+#pragma unroll
+          for (int k = 0; k < 3; k++) {
+            Rc6[k] = tcol ? 0.0 : braw[k]; Rc6[3 + k] = braw[3 + k];
+            Lc6[k] = tcol ? 0.0 : braw[6 + k]; Lc6[3 + k] = braw[9 + k];
+          }
+          const double nbe = -braw[13];
+          static_for<0, Dh>([&](auto ii) {
+            constexpr int i = decltype(ii)::value;
+            const double wi = row_bcast<i>(braw[12]);     // 1 / sigma of row i
+            const double Lv = wi * Lc6[i], Rv = wi * Rc6[i];
+            fmac_gather<Dh>(Dacc, Lv, Lv);
+            fmac_gather<Dh>(Oacc, Lv, Rv);
+            fmac_gather<Dh>(RRacc, Rv, Rv);
+            fmac_bcast2<i>(gacc, grr, nbe, Lv, Rv);
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        }
       }
       if constexpr (ODD) {
         // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
@@ -2653,8 +2772,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       for (int k = 0; k < B; k++) carry[k] = RRacc[k];
       carry_g = grr;
       // the next state: its row range is known, open its rings; fetch the pointers of the state after it
-      open_state(kimg + 1, rpn, rpnn, cpn, cpnn, gpn);
-      rpn = rpnn; cpn = cpnn; gpn = gpnn;
+      open_state(kimg + 1, rpn, rpnn, cpn, cpnn, gpn, bqn);
+      rpn = rpnn; cpn = cpnn; gpn = gpnn; bqn = bqnn;
+      if (btw_on) bqnn = u.btwidx[min(s + kimg + 3, ptr_max)];
       rpnn = u.rowptr[min(s + kimg + 3, ptr_max)];
       cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
       if (st_on) gpnn = u.gpidx[min(s + kimg + 3, ptr_max)];
@@ -2675,7 +2795,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     {
       const int g0 = st_on ? u.gpidx[min(s, ptr_max)] : -1;
       ldraw(0, g0);
-      open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, g0);
+      open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, g0, btw_on ? u.btwidx[min(s, ptr_max)] : -1);
     }
     assemble(0); write_img(0, 0);
     assemble(1); write_img(1, 1);

@@ -83,3 +83,37 @@ def reference_rows(X, J, F, U, dt):
     Rw = np.block([[sa * U, sb * U], [O6, sc * U]])
     W = Rw @ H
     return W[:, :12], W[:, 12:]
+
+
+# ---- BetweenFactor<Pose3> record (kBtw*): [RA RC LA LC | 1 / sigma | whitened error]
+BLEN, BRA, BRC, BLA, BLC, BW, BE = 48, 0, 9, 18, 27, 36, 42
+
+
+def make_between_record(H1, H2, w, e):
+    rec = np.zeros(BLEN)
+    rec[BRA:BRA + 9] = H2[:3, :3].ravel(); rec[BRC:BRC + 9] = H2[3:, :3].ravel()
+    rec[BLA:BLA + 9] = H1[:3, :3].ravel(); rec[BLC:BLC + 9] = H1[3:, :3].ravel()
+    rec[BW:BW + 6] = w; rec[BE:BE + 6] = w * e
+    return rec
+
+
+def between_lane_columns(rec):
+    """(L, R): 6 x 6 each, column c as lane c < 6 of the DPP row computes it (k_fused_level0, the record's six compact rows)."""
+    L = np.zeros((6, 6)); R = np.zeros((6, 6))
+    for r in range(6):
+        hi3 = r >= 3
+        j3 = r - 3 if hi3 else r
+        oX1, oX2 = XA + j3, (XA if hi3 else XC) + j3          # the GP record's column walk, rebased
+        braw = np.zeros(14)
+        for k in range(3):
+            braw[k] = rec[BRA - XA + oX1 + 3 * k]; braw[3 + k] = rec[BRA - XA + oX2 + 3 * k]
+            braw[6 + k] = rec[BLA - XA + oX1 + 3 * k]; braw[9 + k] = rec[BLA - XA + oX2 + 3 * k]
+        tcol = r >= 3
+        Rc6 = np.zeros(6); Lc6 = np.zeros(6)
+        for k in range(3):
+            Rc6[k] = 0.0 if tcol else braw[k]; Rc6[3 + k] = braw[3 + k]
+            Lc6[k] = 0.0 if tcol else braw[6 + k]; Lc6[3 + k] = braw[9 + k]
+        for i in range(6):
+            wi = rec[BW + i]                                   # row_bcast<i> of the lanes' weights
+            L[i, r] = wi * Lc6[i]; R[i, r] = wi * Rc6[i]
+    return L, R

@@ -30,3 +30,16 @@ def test_lane_columns_equal_the_whitened_jacobian(seed):
 def test_the_zero_record_contributes_nothing():
     L, R, new = lane_columns(np.zeros(80), np.triu(np.ones((6, 6))))
     assert not L.any() and not R.any() and not new.any()
+
+
+def test_between_record_columns_equal_the_weighted_jacobians():
+    from gp_record_model import between_lane_columns, make_between_record
+    rng = np.random.default_rng(7)
+    for _ in range(3):
+        def bl():
+            A, C = rng.standard_normal((3, 3)), rng.standard_normal((3, 3))
+            return np.block([[A, np.zeros((3, 3))], [C, A]])
+        H1, H2 = bl(), bl()
+        w = 1.0 / (0.01 + rng.random(6))
+        L, R = between_lane_columns(make_between_record(H1, H2, w, rng.standard_normal(6)))
+        assert np.array_equal(L, w[:, None] * H1) and np.array_equal(R, w[:, None] * H2)
