@@ -52,6 +52,11 @@ class ShardedRank {
   }
   /// st == nullptr: no error pass and no host synchronisation (the benchmark loop)
   void phase2b(gpslam_hip_stats *st) { use(); ok(gpslam_hip_iterate_phase2b(h_, st), "iterate_phase2b"); }
+  /// Levenberg-Marquardt across the ranks (include/gpslam_hip.h, gpslam_hip_lm_begin ...): the pieces of a trial
+  void lm_begin() { use(); ok(gpslam_hip_lm_begin(h_), "lm_begin"); }
+  void lm_trial_phase1(double lambda) { use(); ok(gpslam_hip_lm_trial_phase1(h_, lambda), "lm_trial_phase1"); }
+  void lm_trial_phase2(double *out6) { use(); ok(gpslam_hip_lm_trial_phase2(h_, out6), "lm_trial_phase2"); }
+  void lm_reject() { use(); ok(gpslam_hip_lm_reject(h_), "lm_reject"); }
   gpslam_hip_handle *handle() const { return h_; }
   int device() const { return device_; }
   hipStream_t stream() const { return stream_; }
@@ -128,6 +133,64 @@ class ShardedDriver {
       hip_ok(hipSetDevice(devices_[r]), "hipSetDevice");
       hip_ok(hipStreamSynchronize(streams_[r]), "hipStreamSynchronize");
     }
+  }
+  /// LevenbergMarquardtOptimizer::iterate over all ranks (round 4; gpslam_hip_iterate_lm refuses sharded handles because the
+  /// accept / reject decision needs global sums): linearise once, then per trial ONE data-path collective -- the all-gather of
+  /// the interface records -- (+ the landmark all-reduce where the chain has a dense border), and the six scalars of every
+  /// rank {error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag} summed / maximised here on the host, in
+  /// rank order (one process drives all ranks; across processes they travel in one all-gather of 48 bytes per rank:
+  /// gpslam_amd/sharded.py).  Same decisions, same lambda schedule as gpslam_hip_iterate_lm on the unsharded chain.
+  gpslam_hip_stats iterate_lm(double *lambda, const gpslam_hip_params &p) {
+    if ((int)ranks_.size() != nranks()) throw std::invalid_argument("register one handle per rank first");
+    for (ShardedRank &r : ranks_) r.lm_begin();
+    gpslam_hip_stats st;
+    std::fill((char *)&st, (char *)&st + sizeof(st), 0);
+    bool accepted = false;
+    double err0 = 0.0, new_err = 0.0, dinf = 0.0;
+    for (;;) {
+      for (ShardedRank &r : ranks_) r.lm_trial_phase1(*lambda);
+      nccl_ok(ncclGroupStart(), "ncclGroupStart");
+      for (ShardedRank &r : ranks_) r.all_gather();
+      nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      for (ShardedRank &r : ranks_) r.phase2a();
+      if (ranks_[0].has_landmarks() && nranks() > 1) {
+        nccl_ok(ncclGroupStart(), "ncclGroupStart");
+        for (ShardedRank &r : ranks_) r.all_reduce_landmarks();
+        nccl_ok(ncclGroupEnd(), "ncclGroupEnd");
+      }
+      double s[6] = {0, 0, 0, 0, 0, 0};
+      for (ShardedRank &r : ranks_) {
+        double o[6];
+        r.lm_trial_phase2(o);
+        s[0] += o[0]; s[1] += o[1]; s[3] += o[3]; s[4] += o[4];
+        s[2] = std::max(s[2], o[2]); s[5] = std::max(s[5], o[5]);
+      }
+      err0 = s[0];
+      bool ok_step = false;
+      if (s[5] == 0.0) {
+        const double lin_change = 0.5 * s[3] + 0.5 * (*lambda) * s[4];
+        if (lin_change >= 0.0) {
+          const double cost_change = s[0] - s[1];
+          const double fidelity = lin_change > 1e-20 ? cost_change / lin_change : 0.0;
+          if (fidelity > p.min_model_fidelity) { ok_step = true; new_err = s[1]; dinf = s[2]; }
+        }
+      }
+      if (ok_step) {
+        *lambda = std::max(*lambda / p.lambda_factor, p.lambda_lower_bound);
+        accepted = true;
+        break;
+      }
+      for (ShardedRank &r : ranks_) r.lm_reject();
+      if (*lambda >= p.lambda_upper_bound) break;
+      *lambda *= p.lambda_factor;
+    }
+    st.error_before = err0;
+    st.error_after = accepted ? new_err : err0;
+    st.delta_inf_norm = accepted ? dinf : 0.0;
+    st.lambda = *lambda;
+    st.iterations = 1;
+    st.accepted = accepted ? 1 : 0;
+    return st;
   }
 
  private:
