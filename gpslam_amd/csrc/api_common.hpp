@@ -394,6 +394,12 @@ inline void launch_rows_k(int b, const FwdArgs<double> &a, int grid, hipStream_t
   else k_chunk_forward_rows<4><<<dim3(grid), dim3(64), 0, st>>>(a);
 }
 inline void launch_rows_k(int, const FwdArgs<float> &, int, hipStream_t) {}
+inline void launch_bwd_rows_k(int b, const BwdArgs<double> &a, int grid, hipStream_t st) {
+  if (b == 12) k_chunk_backward_rows<12><<<dim3(grid), dim3(64), 0, st>>>(a);
+  else if (b == 6) k_chunk_backward_rows<6><<<dim3(grid), dim3(64), 0, st>>>(a);
+  else k_chunk_backward_rows<4><<<dim3(grid), dim3(64), 0, st>>>(a);
+}
+inline void launch_bwd_rows_k(int, const BwdArgs<float> &, int, hipStream_t) {}
 // segment interiors of the segmented landmark elimination: planar fp64 chains take the cooperative row-layout kernel (four
 // segments per wave), everything else the wave-per-segment kernel
 template <int BB, typename T, typename TR> inline void fs_launch_factor(const FsArgs<T, TR> &a, int nseg, hipStream_t st) {

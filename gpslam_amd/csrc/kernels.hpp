@@ -3126,6 +3126,87 @@ __global__ void __launch_bounds__(64) k_chunk_backward(BwdArgs<T> a) {
   }
 }
 
+// ---------------------------------------------------------------- row-layout back-substitution (single right-hand side)
+//
+// k_chunk_backward_rows (round 4): the back-substitution of chains without landmark columns in the row layout of the forward
+// kernels -- four chunks per wave, one per 16-lane DPP row, lane r < B holds ROW r of U_j and V_j and component r of every
+// solution.  x_j = Y_j - U_j x_(j+1) - V_j x_sep is 2 B multiply-adds per lane with the solution of the state to the right
+// broadcast inside the row (v_fmac_f64_dpp row_newbcast); V_j x_sep does not depend on the recurrence and is formed while the
+// previous state's result is still in flight.  No LDS, no barriers: the record's 2 B + 1 operands per lane come straight from
+// memory (for every q the B lanes of a row read B consecutive doubles of the column-major record [V | U | Y]), PF records ahead.
+// The generic kernel above spends a wave per chunk on 12 active lanes and two LDS round trips per state: 4.2 TB/s at block size
+// 12 and 2.9 TB/s at block size 6 (profiles/round4_v1, round4_c2_1e6_v1) where a streaming read reaches 5 - 6.
+template <int B>
+__global__ void __launch_bounds__(64) k_chunk_backward_rows(BwdArgs<double> a) {
+  constexpr int BS = 2 * B * B + B;                 // R == 1
+  constexpr int PF = (B == 12) ? 3 : 4;             // records in flight per chunk (vmcnt counts to 63: 3 x 25 and 4 x 13 loads, with the consumed slot excluded, stay below)
+  const int lane = threadIdx.x, grp = lane >> 4, r = lane & 15;
+  const int nch = (a.n + a.m - 1) / a.m;
+  const int c = blockIdx.x * 4 + grp;
+  const bool valid = c < nch;
+  const int cc = valid ? c : 0;
+  const int s = cc * a.m;
+  const int e = min(s + a.m, a.n);
+  const bool rowlane = r < B;
+  const int rr = rowlane ? r : 0;
+  const bool has_sep = !a.no_sep;
+  const bool right_exists = has_sep && ((e < a.n) || (a.last_has_right != 0));
+  const double xs = (has_sep && rowlane) ? a.xup[(size_t)cc * B + rr] : 0.0;                 // the chunk's own separator
+  double xn = (right_exists && rowlane) ? a.xup[(size_t)(cc + 1) * B + rr] : 0.0;            // the state right of the chunk
+  if (valid && rowlane) {
+    if (has_sep) a.x[(size_t)s * B + r] = xs;
+    // the right separator of the last chunk lives on the next rank: park its solution in the extra slot x[n]
+    if (right_exists && e == a.n) a.x[(size_t)a.n * B + r] = xn;
+  }
+  const int j0 = has_sep ? s + 1 : s;
+  const int steps = __builtin_amdgcn_readfirstlane(valid ? max(e - j0, 0) : 0);   // lane 0: the wave's first (never shorter) chunk
+  if (steps <= 0) return;
+  const int jlo = min(j0, e - 1);
+  const int dump_off = (a.n + 1) * B + lane;       // 64 values behind the solutions (and the neighbour rank's slot): lanes without a row
+  const double nxs = -xs;
+  double ring[PF][2 * B + 1];
+  // unconditional loads (record index clamped into the chunk): steps past a shorter chunk's first record recompute harmlessly
+  auto arm = [&](int u, int j) {
+    const double *rec = a.blk + (size_t)max(min(j, e - 1), jlo) * BS + rr;
+#pragma unroll
+    for (int q = 0; q < 2 * B; q++) ring[u][q] = rec[q * B];          // V[r][q] (q < B), U[r][q - B]
+    ring[u][2 * B] = rec[2 * B * B];                                   // Y[r]
+  };
+  // (slot by slot, in consumption order: vmcnt counts in issue order, and the wait in front of the loop's first product is placed
+  //  for the worse of its two predecessors -- with the scheduler free to interleave these loads it was vmcnt(0) on every trip)
+#pragma unroll
+  for (int u = 0; u < PF; u++) { arm(u, e - 1 - u); __builtin_amdgcn_sched_barrier(0); }
+  for (int base = 0; base < steps; base += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int j = e - 1 - base - u;
+      // x_j = Y_j + V_j (-x_sep) + U_j (-x_(j+1)): the record's operands are consumed in load order, Y first
+      double av = ring[u][2 * B], au = 0.0;
+      const double nxn = -xn;
+      static_for<0, B>([&](auto qq) {                // V_j x_sep: independent of the recurrence
+        constexpr int q = decltype(qq)::value;
+        fmac_bcast1<q>(av, nxs, ring[u][q]);
+      });
+      static_for<0, B>([&](auto qq) {                // U_j x_(j+1)
+        constexpr int q = decltype(qq)::value;
+        fmac_bcast1<q>(au, nxn, ring[u][B + q]);
+      });
+      double v = av + au;
+      asm volatile("" : "+v"(v));                    // (formed here, not sunk into the loop latch)
+      // the slot's operands are consumed: refill it (issued here, not before the products -- a refill in front of them makes the
+      // compiler rotate the ring by register copies, and a copy of a register whose load is in flight drains vmcnt)
+      arm(u, j - PF);
+      const bool live = j >= j0;                     // (a shorter chunk of the wave is done: keep its last solution, store nothing new)
+      xn = live ? v : xn;
+      // unconditional, branch-free store (a store or an address under a branch breaks the wait-count bookkeeping: vmcnt(0) at the
+      // next operand): finished chunks rewrite their first interior solution with the value it already has, lanes without a
+      // row store to a dump
+      const int off = (valid && rowlane && e > j0) ? max(j, jlo) * B + rr : dump_off;     // (a chunk that is only its separator stores nothing; n B < 2^31)
+      a.x[off] = xn;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ segment sharding: reduced interface system
 
 // Every rank contributes one record [D | C | G | RD | Rg] (BS + AS values): its separator block (first state) after
