@@ -2472,12 +2472,21 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   const int ep = (valid && tail) ? s + a.m : e;
   const bool has_int = valid && j0 < ep;
   const double lambda = a.lambda;
-  __shared__ __attribute__((aligned(16))) double IMG[2 * 4 * BS];    // two rotating record images per chunk
+  // The images [D | O | g] the assembly wave hands over are private to this kernel: their rows are padded to BP = B + 1 doubles.
+  // With a pitch of B the B lanes of a row access (stride 2 B dwords) collide pairwise in the 64 LDS banks (B = 12: lanes r and
+  // r + 8; 32 banks for stores: three ways) -- SQ_LDS_BANK_CONFLICT was 49 % of SQ_LDS_IDX_ACTIVE (round 4); with an odd pitch
+  // row accesses and column accesses are both conflict-free inside a 16-lane row.  OUTR keeps the record's own (unpadded,
+  // column-major) layout: it leaves as contiguous 16-byte pieces.
+  constexpr int BP = B + 1, IS = 2 * B * BP + B + (B & 1);            // image pitch, doubles per image (even)
+  __shared__ __attribute__((aligned(16))) double IMG[2 * 4 * IS > 5 * BS + 4 * AS ? 2 * 4 * IS : 5 * BS + 4 * AS];   // two rotating images per chunk (the tail's group reuses the space)
   __shared__ __attribute__((aligned(16))) double OUTR[4 * BS];       // the factor record on its way out
-  int ro = grp * BS + rr * B;     // row r of an image:    IMG[buf * 4 BS + ro + k]
-  int co = grp * BS + rr;         // column r:             IMG[... + co + k * B]
+  int ro = grp * IS + rr * BP;    // row r of an image:    IMG[buf * 4 IS + ro + k]          (D: + 0, O: + B BP, g: co + 2 B BP)
+  int co = grp * IS + rr;         // column r:             IMG[... + co + k * BP]
   int po = grp * BS + 2 * r;      // 16-byte piece q * 16 + r of OUTR
-  asm volatile("" : "+v"(ro), "+v"(co), "+v"(po));
+  int oc = grp * BS + rr;         // column r of the factor record in OUTR: OUTR[oc + k * B]
+  int tr = grp * BS + rr * BP;    // row r of the (padded) transpose scratch inside OUTR's V | U area
+  int tc = grp * BS + rr;         // ... its column r: OUTR[tc + k * BP]
+  asm volatile("" : "+v"(ro), "+v"(co), "+v"(po), "+v"(oc), "+v"(tr), "+v"(tc));
   const int steps = __builtin_amdgcn_readfirstlane(max(ep - j0, 0));   // lane 0: the wave's first (never shorter) chunk
 
   if (role == 1) {
@@ -2781,10 +2790,10 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     };
     auto write_img = [&](int buf, int kimg) {
       if (rowlane) {
-        double *img = IMG + buf * 4 * BS;
+        double *img = IMG + buf * 4 * IS;
 #pragma unroll
-        for (int k = 0; k < B; k++) { img[ro + k] = Dacc[k]; img[ro + B * B + k] = Oacc[k]; }
-        img[co + 2 * B * B] = gacc;
+        for (int k = 0; k < B; k++) { img[ro + k] = Dacc[k]; img[ro + B * BP + k] = Oacc[k]; }
+        img[co + 2 * B * BP] = gacc;
         if (u.gsave && valid) {          // (LM) the gradient: a state's own record, and what the chunk's last rows owe the next separator
           const int jg = s + kimg;
           if (jg < e) u.gsave[(size_t)jg * B + r] = gacc;
@@ -2819,13 +2828,13 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
   for (int k = 0; k < B; k++) {
     Ar[k] = IMG[ro + k];                           // image 0: the separator
-    Fr[k] = IMG[ro + B * B + k];
-    Gr[k] = IMG[co + B * B + k * B];
-    Dr[k] = IMG[4 * BS + ro + k];                  // image 1: the first interior state (or the virtual end record)
-    Or[k] = IMG[4 * BS + co + B * B + k * B];
+    Fr[k] = IMG[ro + B * BP + k];
+    Gr[k] = IMG[co + B * BP + k * BP];
+    Dr[k] = IMG[4 * IS + ro + k];                  // image 1: the first interior state (or the virtual end record)
+    Or[k] = IMG[4 * IS + co + B * BP + k * BP];
   }
-  as_ = IMG[co + 2 * B * B];
-  gr = IMG[4 * BS + co + 2 * B * B];
+  as_ = IMG[co + 2 * B * BP];
+  gr = IMG[4 * IS + co + 2 * B * BP];
   lds_barrier();                         // Q
   if (valid && !has_int && rowlane) {    // chunk without interior: the separator keeps its coupling, its rows' R^T R is owed
     double *ub = a.up_blk + (size_t)c * BS;
@@ -2845,7 +2854,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   for (int t = 0; t < steps; t++) {
     const int j = j0 + t;
     const bool live = j < e, lastb = (j == e - 1);
-    const double *cur = IMG + ((t + 1) & 1) * 4 * BS, *nxt = IMG + (t & 1) * 4 * BS;   // images t + 1 and t + 2
+    const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
     double invs = 1.0;
     bool bad = false;
 #ifndef GPS_ABLATE_ELIM   /* timing ablation only (wrong results): the elimination wave keeps its LDS traffic, stores and barriers */
@@ -2876,17 +2885,17 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     __builtin_amdgcn_sched_barrier(0);
     double Ol[B];
 #pragma unroll
-    for (int k = 0; k < B; k++) Ol[k] = cur[ro + B * B + k];          // row r of O_j
+    for (int k = 0; k < B; k++) Ol[k] = cur[ro + B * BP + k];         // row r of O_j
 #pragma unroll
     for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
     gr *= invs;
     if (rowlane) {
 #pragma unroll
       for (int k = 0; k < B; k++) {
-        OUTR[co + k * B] = Fr[k];
-        OUTR[co + B * B + k * B] = Or[k];
+        OUTR[oc + k * B] = Fr[k];
+        OUTR[oc + B * B + k * B] = Or[k];
       }
-      OUTR[co + 2 * B * B] = gr;
+      OUTR[oc + 2 * B * B] = gr;
     }
     lds_barrier();                       // step t
 #ifdef GPS_ABLATE_STORE   /* timing ablation only: the factor records stay in LDS */
@@ -2904,7 +2913,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     double Dn[B], Fn[B], gn;
 #pragma unroll
     for (int k = 0; k < B; k++) Dn[k] = nxt[ro + k];
-    gn = nxt[co + 2 * B * B];
+    gn = nxt[co + 2 * B * BP];
     __builtin_amdgcn_sched_barrier(0);
 #ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
@@ -2934,13 +2943,13 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // the recurrence G_{j+1} = -G_j U_j: 24 LDS operations for 144 multiply-adds
     if (rowlane) {
 #pragma unroll
-      for (int k = 0; k < B; k++) OUTR[ro + k] = Fn[k];
+      for (int k = 0; k < B; k++) OUTR[tr + k] = Fn[k];
     }
     wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < B; k++) {
-      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = OUTR[co + k * B];
-      Or[k] = nxt[co + B * B + k * B];
+      Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = OUTR[tc + k * BP];
+      Or[k] = nxt[co + B * BP + k * BP];
     }
     gr = gn;
     wave_lds_sync();
