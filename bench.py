@@ -31,8 +31,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # same kernels on the same workload comes from the committed PMC passes (scripts/collect_profiles.sh ->
 # profiles/<round>_pmc.json; explicit-size L2->fabric request counters TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ{,_64B}).
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
-PMC_KEYS = [("k_gp<double, 3, 0>",), ("k_assemble",), ("k_fused_level0", "k_chunk_forward_rows", "k_chunk_forward<double, 12, true>"),
-            ("k_chunk_backward<double, 12>",), ("k_retract<double, 3>",)]
+PMC_KEYS = [("k_gp<double, 3, 0",), ("k_assemble",), ("k_fused_level0", "k_chunk_forward_rows", "k_chunk_forward<double, 12, true>"),
+            ("k_chunk_backward_rows<12>", "k_chunk_backward<double, 12"), ("k_retract<double, 3>",)]
 
 
 def pmc_traffic(which, n_states):
