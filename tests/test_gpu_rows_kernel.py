@@ -185,3 +185,49 @@ def test_fused_level0_with_measurement_rows_and_ragged_row_counts():
             assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), (chunk, it)
         (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
         T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
+
+
+@pytest.mark.parametrize("variant", ["sparse-between", "double-between", "dense-priors", "gaps-in-gp"])
+def test_structured_path_with_irregular_factor_sets(variant):
+    """Round 4: the structured path of k_fused_level0 takes the GP priors as 80-double records and the between factors as
+    48-double records, one per left state, with an all-zero record for the states that have none.  Irregular graphs:
+    between factors on a third of the states only; two between factors on some states (the records do not apply: compact rows
+    through the one-slot ring); pose priors on every state (the ring busy on every block step); GP priors missing on some
+    intervals that odometry still bridges.  Each against the oracle, 3 Gauss-Newton iterations."""
+    N, kind, d = 700, O.POSE3, 6
+    rng = np.random.default_rng(31)
+    c = T.random_chain(kind, N, 12)
+    Qc = np.diag(0.01 + 0.02 * rng.random(d))
+    ident = O.pose3((0, 0, 0), (0, 0, 0))
+    meas = np.stack([O.retract(kind, ident, O.local(kind, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
+    left_b = np.arange(N - 1)
+    left_gp = np.arange(N - 1)
+    fix = np.arange(0, N, 20)
+    if variant == "sparse-between":
+        left_b = np.sort(rng.choice(N - 1, (N - 1) // 3, replace=False))
+    elif variant == "double-between":
+        left_b = np.concatenate([np.arange(N - 1), np.arange(5, N - 1, 50)])
+    elif variant == "dense-priors":
+        fix = np.arange(N)
+    elif variant == "gaps-in-gp":
+        left_gp = np.array([i for i in range(N - 1) if i % 37 != 5])
+    solvers = []
+    for make in (lambda: O.Chain(kind, O.CHART_EXPMAP), lambda: T.gpu().ChainSolver(kind)):
+        s = make()
+        s.set_qc(Qc)
+        s.set_states(c["pose"], c["vel"])
+        s.add_gp_priors(left_gp, c["dt"][left_gp])
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.01))
+        s.add_between(left_b, meas[left_b], np.full((len(left_b), d), 0.02))
+        s.compile()
+        solvers.append(s)
+    orc, dev = solvers
+    info = dev.plan_info()
+    assert info["fused"] == 1 and info["structured_gp"] == 1
+    for _ in range(3):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), variant
+    (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+    T.states_close(kind, x0, v0, x1, v1, 1e-9)
