@@ -386,7 +386,7 @@ int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]) {
   if (!out8) return GPSLAM_E_INVALID;
   const bool fused = h->fuse_ok && h->lv.size() >= 2;
   const int32_t v[8] = {(int32_t)h->lv.size(), h->lv.empty() ? 0 : h->lv[0].m, h->lv.size() > 1 ? h->lv[1].m : 0, fused ? 1 : 0,
-                        ((fused && h->struct_ok) || (!fused && h->struct3_ok)) ? 1 : 0, h->M, h->Mc, h->R};
+                        ((fused && h->struct_ok) || h->struct3_ok) ? 1 : 0, h->M, h->Mc, h->R};
   for (int i = 0; i < 8; i++) out8[i] = v[i];
   return 0;
 }

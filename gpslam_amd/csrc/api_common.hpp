@@ -113,8 +113,8 @@ struct gpslam_hip_handle {
   bool fuse_now = false;    // ... and the iteration being enqueued uses it (enqueue_gn)
   bool struct_ok = false;   // the GP priors may reach k_fused_level0 as structured records (GpArgs::gps) instead of rows
   bool struct_now = false;  // ... and the linearisation / elimination being enqueued do so
-  // block size 6 (SE(2), SO(3), 3-D linear chains): the GP priors as 32-double records (kGp3*) that k_assemble_ghost decodes;
-  // rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows, a consumer that reads the row table)
+  // block size 6 (SE(2), SO(3), 3-D linear chains): the GP priors as 32-double records (kGp3*) that k_assemble_ghost and
+  // k_fused_level0<1, double, 6> decode; rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows)
   bool struct3_ok = false, rows3 = false;
   DevBuf gps, gpidx, dU, gsave2;
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
@@ -377,7 +377,11 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
 inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, hipStream_t st) {
-  if (b == 6) { k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u); return; }
+  if (b == 6) {
+    if (u.gps) k_fused_level0<1, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);      // d = 3 records (kGp3*)
+    else k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
+    return;
+  }
   if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
   else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);

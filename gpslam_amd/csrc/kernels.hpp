@@ -2449,9 +2449,13 @@ template <int SV, typename TR = double, int B = 12>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
   constexpr bool ST = SV != 0, ODD = SV == 2;
+  // ST12: SE(3) records (kGps*, kBtw*: the assembly wave forms the columns, no full-width row ring);  ST6 (round 4): the d = 3
+  // records (kGp3*) of SE(2) / SO(3) / 3-D linear chains -- six rows per state from 11 operands per lane, next to the row ring
+  // that still serves measurement factors and velocity priors
+  constexpr bool ST12 = ST && B == 12, ST6 = ST && B == 6;
   const FwdArgs<double> &a = u.f;
   static_assert(B == 12 || B == 6, "block sizes with DPP gather blocks");
-  static_assert(SV == 0 || B == 12, "structured GP records are SE(3) records");
+  static_assert(SV == 0 || B == 12 || SV == 1, "the variant with odd rows is an SE(3) variant");
   constexpr int BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
   typedef double V2 __attribute__((ext_vector_type(2)));
@@ -2496,14 +2500,14 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = 6, PC = ST ? (SV == 2 ? 4 : 1) : 6, Dh = B / 2;   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
+    constexpr int PF = ST6 ? 3 : 6, PC = ST12 ? (SV == 2 ? 4 : 1) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     double carry[B], carry_g = 0.0;
 #pragma unroll
     for (int k = 0; k < B; k++) carry[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
-    double fL[ST ? 1 : PF], fR[ST ? 1 : PF], fE[ST ? 1 : PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
+    double fL[ST12 ? 1 : PF], fR[ST12 ? 1 : PF], fE[ST12 ? 1 : PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
     int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
@@ -2515,15 +2519,15 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // with per-lane coefficients fetched from the record (pose lanes: aL = aR = sa, b = sb, c = sc, dR = 0; velocity lanes:
     // J_c = the unit vector, aL = k2, aR = sb, b = c = 0, dR = sc -- their zeros are the record's zero slot).
     constexpr bool st_on = ST;
-    constexpr int NRAW = ST ? 21 : 1;
-    double Ur[ST ? 3 : 1];
-    if constexpr (ST) {
+    constexpr int NRAW = ST12 ? 21 : (ST6 ? 11 : 1);
+    double Ur[ST12 ? 3 : 1];
+    if constexpr (ST12) {
 #pragma unroll
       for (int k = 0; k < 3; k++) Ur[k] = u.Ud[min(16 * k + r, 35)];       // U, row-major: entry e in lane e & 15 of Ur[e >> 4]
     }
     // where this lane's operands sit in a record (loop-invariant; the stride-3 walks down a column are immediate offsets)
     int oX1 = 0, oX2 = 0, oJ1 = 0, oJ2 = 0, oF = 0, oE = 0, oaL = 0, oaR = 0, ob = 0, oc = 0, od = 0;
-    if constexpr (ST) {
+    if constexpr (ST12) {
       const int r6 = r < Dh ? r : (r < B ? r - Dh : 0);
       const bool velc = r >= Dh && r < B, hi3 = r6 >= 3;
       const int j3 = hi3 ? r6 - 3 : r6;
@@ -2540,15 +2544,15 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     int gp = -1;
     // BetweenFactor<Pose3> record of the state (u.brec, kBtw*): lane c < 6 builds column c of [H1 | H2] from the block-triangular
     // halves exactly as above (the same column walk: oX1 / oX2 minus their bases), lanes 6..11 read the all-zero record
-    constexpr int NBR = ST ? 14 : 1;
+    constexpr int NBR = ST12 ? 14 : 1;
     double braw[NBR];
     // (not in the variant with odd full-width rows: its registers are spoken for -- the host hands it compact rows)
-    const bool btw_on = ST && !ODD && u.brec != nullptr;
+    const bool btw_on = ST12 && !ODD && u.brec != nullptr;
     int bq = -1, bqn = btw_on ? u.btwidx[min(s + 1, ptr_max)] : -1, bqnn = btw_on ? u.btwidx[min(s + 2, ptr_max)] : -1;
 #pragma unroll
     for (int k = 0; k < NBR; k++) braw[k] = 0.0;
     auto ldbtw = [&]() {                      // operands of the between factor whose left state the rings point at (bq)
-      if constexpr (ST) {
+      if constexpr (ST12) {
         if (!btw_on) return;                  // (no records on this launch: u.brec is null)
         const double *rec = u.brec + (size_t)((bq >= 0 && r < Dh) ? bq : u.btw_count) * kBtwLen;
 #pragma unroll
@@ -2563,7 +2567,24 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     int gpn = st_on ? u.gpidx[min(s + 1, ptr_max)] : -1, gpnn = st_on ? u.gpidx[min(s + 2, ptr_max)] : -1;
     // operands of the GP prior whose left state is s + kimg (record g; no such factor: the all-zero record behind the last one)
     auto ldraw = [&](int kimg, int g) {
-      if constexpr (ST) {
+      if constexpr (ST6) {
+        // d = 3 record (kGp3*): lane c < 6 holds column c of the six rows [A1 | kLt U | A3 | kRt U; 0 | kLb U | 0 | kRb U] -- a pose
+        // lane (c < 3) its column of A1 / A3, a velocity lane column c - 3 of U and the record's four coefficients; lane q < 6 also
+        // fetches whitened error q (it travels by row_newbcast)
+        const bool live = valid && (s + kimg) < e && g >= 0;
+        const double *rec = u.gps + (size_t)(live ? g : u.gp_count) * kGp3Len;
+        const bool pc = r < 3;
+        const int c3 = pc ? r : (r < 6 ? r - 3 : 0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          raw[k] = pc ? rec[kGp3A1 + 3 * k + c3] : u.Ud[3 * k + c3];
+          raw[3 + k] = pc ? rec[kGp3A3 + 3 * k + c3] : u.Ud[3 * k + c3];
+        }
+        // (the zero record makes the velocity lanes' coefficients zero: a state without a GP prior contributes nothing)
+        raw[6] = rec[kGp3S + 0]; raw[7] = rec[kGp3S + 1]; raw[8] = rec[kGp3S + 2]; raw[9] = rec[kGp3S + 3];
+        raw[10] = rec[kGp3E + min(r, 5)];
+      }
+      if constexpr (ST12) {
         const bool live = valid && (s + kimg) < e && g >= 0;
         const double *rec = u.gps + (size_t)(live ? g : u.gp_count) * kGpsLen;
 #pragma unroll
@@ -2576,17 +2597,17 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
         raw[16] = rec[oaL]; raw[17] = rec[oaR]; raw[18] = rec[ob]; raw[19] = rec[oc]; raw[20] = rec[od];
       }
     };
-    double Lcol[ST ? B : 1], Rcol[ST ? B : 1], newl = 0.0;
+    double Lcol[ST12 ? B : 1], Rcol[ST12 ? B : 1], newl = 0.0;
     auto reconstruct = [&]() {
 #ifdef GPS_ABLATE_REC   /* timing ablation only (wrong results): the record's operands are fetched, the columns are not formed */
-      if constexpr (ST) {
+      if constexpr (ST12) {
 #pragma unroll
         for (int k = 0; k < B; k++) { Lcol[k] = raw[k]; Rcol[k] = raw[(k + 9) % NRAW]; }
         newl = -raw[15];
         return;
       }
 #endif
-      if constexpr (ST) {
+      if constexpr (ST12) {
         double X6[6], J6[6], P3[6], P1[6];
         // the lane's role, recomputed per state from an opaque copy of its index: as loop invariants the masks and the unit
         // vector would occupy two dozen registers for the whole kernel (the wave spilled with them)
@@ -2657,9 +2678,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       bq = (live && btw_on) ? bqv : -1;
       if (gp >= 0) p0 += B;                              // its 12 rows lead the state's range in the row table: not used
       if (bq >= 0) q1 -= Dh;                             // ... and its between factor's six rows end its range in the compact table
-      rp = (live && (!ST || ODD)) ? p0 : 0; nf = (live && (!ST || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
+      rp = (live && (!ST12 || ODD)) ? p0 : 0; nf = (live && (!ST12 || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
-      if constexpr (!ST) {
+      if constexpr (!ST12) {
 #pragma unroll
         for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
       }
@@ -2677,7 +2698,24 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
       for (int k = 0; k < B; k++) { Dacc[k] = carry[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
       gacc = carry_g;
-      if constexpr (ST) {                                // the structured GP prior: its 12 rows from the columns built above
+      if constexpr (ST6) {                               // the d = 3 record: six rows from the lane's column of [A1 | U | A3 | U]
+        const bool pc = r < 3;
+        const double mLt = pc ? 1.0 : raw[6], mRt = pc ? 1.0 : raw[7], mLb = pc ? 0.0 : raw[8], mRb = pc ? 0.0 : raw[9];
+        const double ne3 = -raw[10];
+        static_for<0, 6>([&](auto ii) {
+          constexpr int i = decltype(ii)::value;
+          const double Lv = (i < 3 ? mLt : mLb) * raw[i % 3], Rv = (i < 3 ? mRt : mRb) * raw[3 + i % 3];
+#ifndef GPS_ABLATE_ASM
+          fmac_gather<B>(Dacc, Lv, Lv);
+          fmac_gather<B>(Oacc, Lv, Rv);
+          fmac_gather<B>(RRacc, Rv, Rv);
+#endif
+          fmac_bcast2<i>(gacc, grr, ne3, Lv, Rv);
+          __builtin_amdgcn_sched_barrier(0);
+        });
+        ldraw(kimg + 1, gpn);                            // (the operands are consumed: the next state's record into their registers)
+      }
+      if constexpr (ST12) {                              // the structured GP prior: its 12 rows from the columns built above
         reconstruct();
         static_for<0, B>([&](auto qq) {
           constexpr int q = decltype(qq)::value;
@@ -2694,7 +2732,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           __builtin_amdgcn_sched_barrier(0);
         });
       }
-      if constexpr (ST) {                                // the state's BetweenFactor<Pose3> record: six compact rows from its columns
+      if constexpr (ST12) {                              // the state's BetweenFactor<Pose3> record: six compact rows from its columns
         if (btw_on) {
           int rq = r;
           asm volatile("" : "+v"(rq));
@@ -2735,7 +2773,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           grr = fma(-Rv, ev, grr);
         }
       }
-      if constexpr (!ST)
+      if constexpr (!ST12)
       for (int i0 = 0; i0 < nfm; i0 += PF) {             // full-width rows
 #pragma unroll
         for (int q = 0; q < PF; q++) {
