@@ -21,7 +21,7 @@ HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", 
            "api_decl.inc", os.path.join("..", "..", "include", "gpslam_hip.h")]
 # what each translation unit includes (an edit to upper.hip does not recompile the others)
 DEPS = {"api.hip": HEADERS, "api_impl64.hip": HEADERS + ["api_impl.inc"], "api_impl32.hip": HEADERS + ["api_impl.inc"],
-        "upper.hip": ["dpp.hpp", "cr_step.hpp", "upper.hpp"]}
+        "upper.hip": ["dpp.hpp", "cr_step.hpp", "cr_quad.hpp", "upper.hpp"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -65,6 +65,8 @@ def _src_deps(src):
 
 def up_to_date(extra=()):
     objdir, lib = _paths(list(extra))
+    if not _stale(lib, [d for s in SOURCES for d in _src_deps(s)]):
+        return True            # the objects are intermediates: a library newer than every source needs none of them
     if any(_stale(_obj(s, objdir), _src_deps(s)) for s in SOURCES):
         return False
     return not _stale(lib, [_obj(s, objdir) for s in SOURCES])

@@ -164,7 +164,7 @@ constexpr int kGpsLen = 80, kGpsXA = 0, kGpsXC = 9, kGpsJA = 18, kGpsJC = 27, kG
 // srow[l] = first row of lane l's factor in the row table, or -1.
 // wave_store_part: the lanes staged HW (even) doubles each with stride HW + 2; they land at columns
 // [coloff, coloff + HW) of row (first row of the lane's factor) + roff of a table with W doubles per row.
-template <typename T, int W, int HW, int LS = HW + 2>
+template <typename T, int W, int HW, int LS = HW + 2, bool STREAM = false>
 __device__ __forceinline__ void wave_store_part(const T *st, const int *srow, int lane, int roff, int coloff, T *table) {
   constexpr int P = HW / 2;
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -175,7 +175,13 @@ __device__ __forceinline__ void wave_store_part(const T *st, const int *srow, in
     const int r0 = srow[fl];
     if (r0 >= 0) {
       const V2 v = *reinterpret_cast<const V2 *>(st + fl * LS + piece * 2);
-      *reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + coloff + piece * 2) = v;   // (nontemporal: K1 0.17 instead of 0.09 ms)
+      V2 *dst = reinterpret_cast<V2 *>(table + (size_t)(r0 + roff) * W + coloff + piece * 2);
+      // STREAM (the structured records: written once in whole 128-byte lines, read once by the next launch): 1e6 Pose3 states
+      // K1 0.376 -> 0.337 ms, 1e5: the iteration -5..-12 us.  Not for row tables: their 16-byte fragments of 96-byte half rows
+      // had DOUBLED K1 with this hint (round 2); the factor records of k_fused_level0 and the solutions of the
+      // back-substitution, which the next launch finds in the caches, lose 3 and 20 us of the iteration with it.
+      if constexpr (STREAM) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
     }
   }
 }
@@ -268,12 +274,12 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
       mine[6 + rho] = wb;
     }
     mine[12] = -(sa * dt + sb); mine[13] = sb; mine[14] = sc; mine[15] = sa;
-    wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, kGpsE, a.gps);
+    wave_store_part<T, kGpsLen, 16, 20, true>(st, sr, lane, 0, kGpsE, a.gps);
   }
   // the matrix blocks in record order, 16 doubles (one 128-byte line) staged per lane at a time
   auto put = [&](int idx, T v) {              // (idx is a compile-time constant once the loops below are unrolled)
     mine[idx & 15] = v;
-    if ((idx & 15) == 15) wave_store_part<T, kGpsLen, 16, 20>(st, sr, lane, 0, idx - 15, a.gps);
+    if ((idx & 15) == 15) wave_store_part<T, kGpsLen, 16, 20, true>(st, sr, lane, 0, idx - 15, a.gps);
   };
 #pragma unroll
   for (int k = 0; k < 9; k++) put(kGpsXA + k, Jinv.A.m[k]);
@@ -506,7 +512,7 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
       sr[lane] = valid ? f : -1;
       auto put = [&](int idx, T v) {            // (idx: a compile-time constant once the loops are unrolled)
         mine[idx & 15] = v;
-        if ((idx & 15) == 15) wave_store_part<T, kGp3Len, 16, 20>(st, sr, lane, 0, idx - 15, a.gps);
+        if ((idx & 15) == 15) wave_store_part<T, kGp3Len, 16, 20, true>(st, sr, lane, 0, idx - 15, a.gps);
       };
 #pragma unroll
       for (int blk = 0; blk < 2; blk++)         // A1 = U (sa J1 + sb .): columns 0..2 of the top rows; A3: columns 6..8
@@ -642,7 +648,7 @@ __device__ __forceinline__ void between_pose3_record(const FacArgs<T> &a, const 
   }
   auto put = [&](int idx, T v) {              // (idx: a compile-time constant once the loops are unrolled)
     mine[idx & 15] = v;
-    if ((idx & 15) == 15) wave_store_part<T, kBtwLen, 16, 20>(st, sr, lane, 0, idx - 15, a.rec);
+    if ((idx & 15) == 15) wave_store_part<T, kBtwLen, 16, 20, true>(st, sr, lane, 0, idx - 15, a.rec);
   };
   const SE3<T> hx = se3_between(as_se3(x1), as_se3(x2));
   const V6<T> xi = se3_log(se3_between(as_se3(m), hx));          // PoseFactors<T, POSE3>::between
@@ -2945,7 +2951,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
       for (int q = 0; q < NV; q++) {
         const int idx = q * 16 + r;
-        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);   // (nontemporal: 0.181 vs 0.184 ms, inside the noise)
+        if (idx < NPC) dst[idx] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * q]);   // (nontemporal: the iteration +3 us at 1e5 states)
       }
     }
     double Dn[B], Fn[B], gn;

@@ -5,6 +5,7 @@
 // Back-substitution: x_j = Y_j - U_j x_n - V_j x_s, sub-levels in reverse.
 #include "upper.hpp"
 #include "cr_step.hpp"
+#include "cr_quad.hpp"
 
 #include <cstdio>
 #include <cstdlib>
@@ -18,7 +19,7 @@ template <int B, int G> struct UpDims {
   static constexpr int BS = 2 * B * B + B, AS = B * B + B;
   static constexpr int DP = B * B / 2, GP = B / 2, NPC = BS / 2;     // 16-byte pieces of D (or O), of g, of a record
   static constexpr int Q = (G == 32) ? 5 : 2;                         // sub-levels
-  static constexpr int NT = (G == 32) ? 256 : 64, NW = NT / 64;       // threads, waves: G / 2 pairs on NW * 4 DPP rows
+  static constexpr int NT = (G == 32) ? 512 : 64, NW = NT / 64;       // threads, waves: a pair takes two DPP rows (G / 2 pairs), later four
   static constexpr int UF = (G * NPC + NT - 1) / NT;                  // 16-byte pieces per thread of a group's records
   static constexpr size_t lds_fwd(bool top) { return ((size_t)(G + 1) * BS + (top ? (size_t)(G + 1) * B : 0)) * sizeof(double); }
   static constexpr size_t lds_bwd() { return ((size_t)G * BS + (size_t)(G + 1) * B) * sizeof(double); }
@@ -80,44 +81,46 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
   __syncthreads();
   probe();
 
-  // Sub-levels with at most NW * 2 pairs run WIDE: a pair takes two adjacent DPP rows (CrStepWide, 35 % fewer multiply-adds
-  // per lane, same values).  For G = 32 that is every sub-level but the first (16 pairs on 16 rows), for G = 4 all of them.
-  constexpr int QN = (G >> 1) > NW * 2 ? 1 : 0;   // narrow sub-levels
-#pragma unroll 1
-  for (int q = 0; q < Q; q++) {
+  // A sub-level costs what ONE lane's instruction stream costs (an elimination is VALU-issue bound even for a single wave), so
+  // the panel of a pair is spread over as many DPP rows as the sub-level leaves free: two (CrStepWide: G / 2 pairs on NW * 4
+  // rows) in the first sub-level, four (CrStepQuad, one wave per pair) in all the others.  Same values in every form
+  // (and as CrStep, one row per pair, which the tail of the level-0 kernels runs).
+  static_assert((G >> 1) <= 2 * NW && (G >> 2) <= NW, "two rows per pair in the first sub-level, four from the second on");
+  auto sub_level = [&](int q, auto form) {
+    constexpr bool quad = decltype(form)::value;
     const int h = 1 << q, np = G >> (q + 1);
-    const bool wide = (q >= QN);
     const int half = row & 1;
-    const int p = wide ? (row >> 1) * NW + wave : row * NW + wave;   // the pairs of a sub-level spread over the waves first, then over DPP rows
+    const int p = quad ? wave : (row >> 1) * NW + wave;      // pairs spread over the waves first, then over DPP rows
     const int s = p * 2 * h, j = s + h;
     const bool act = (p < np) && (j < cnt);
     const int n = (j + h < cnt) ? j + h : G;
-    CrStep<B> st;
-    CrStepWide<B> sw;
+    std::conditional_t<quad, CrStepQuad<B>, CrStepWide<B>> st;
     if (__ballot(act) != 0ull) {             // (idle DPP rows of a working wave recompute block 0; they never store)
-      bool bad;
-      if (wide) bad = sw.compute(REC, act ? s : 0, act ? j : 0, r, rr, half);
-      else bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr);
+      const bool bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr, quad ? row : half);
       if (bad && act && r == 0) *a.flag = 1;
     }
     probe();
     lds_barrier();                            // every pair has read its operands
-    if (act && rowlane) { if (wide) sw.store_own(REC, s, j, r, half); else st.store_own(REC, s, j, r); }
+    if (act && rowlane) st.store_own(REC, s, j, r, quad ? row : half);
     lds_barrier();                            // the pairs' own blocks are in place: now the right neighbours' shares
     probe();
-    if (act && rowlane) { if (wide) { if (half == 0) sw.add_right(REC, n, r); } else st.add_right(REC, n, r); }
-    if (!TOP) {   // this sub-level's factor records leave for the back-substitution launch
-      for (int idx = tid; idx < np * NPC; idx += NT) {
-        const int pp = idx / NPC, t = idx - pp * NPC;
-        const int jj = pp * 2 * h + h;
-        if (jj < cnt) reinterpret_cast<V2 *>(a.blk + (size_t)(base + jj) * BS)[t] = reinterpret_cast<const V2 *>(REC + jj * BS)[t];
-      }
+    if (act && rowlane) {
+      if constexpr (quad) { if (row < 2) st.add_right(REC, n, r, row); }
+      else { if (half == 0) st.add_right(REC, n, r); }
     }
     lds_barrier();
     probe();
-  }
+  };
+  if constexpr ((G >> 1) > NW) sub_level(0, std::false_type{});
+  else sub_level(0, std::true_type{});
+#pragma unroll 1
+  for (int q = 1; q < Q; q++) sub_level(q, std::true_type{});
 
   if (!TOP) {
+    // the factor records of every sub-level leave for the back-substitution launch in one pass (blocks 1 .. cnt - 1 were all
+    // eliminated, each at the sub-level of its lowest set bit, and nothing touched their records afterwards)
+    for (int idx = tid; idx < (cnt - 1) * NPC; idx += NT)
+      reinterpret_cast<V2 *>(a.blk + (size_t)(base + 1) * BS)[idx] = reinterpret_cast<const V2 *>(REC + BS)[idx];
     // what is left of the group: its first block (now coupled to the block beyond the group) and what that block is owed
     for (int t = tid; t < NPC; t += NT)
       reinterpret_cast<V2 *>(a.up_blk + (size_t)g * BS)[t] = reinterpret_cast<const V2 *>(REC)[t];

@@ -5,9 +5,10 @@
 // above that is latency, not bandwidth (2 % of the data): one launch per level of chunks of four cost 141 us of a 470 us
 // iteration on the 1e5-state Pose3 chain (profiles/round2_v4).  Here a workgroup takes a GROUP of kUpG = 32 consecutive
 // blocks into LDS and reduces it to its first block by five sub-levels of cyclic reduction (pairs (s, j = s + 2^q): j is
-// eliminated into its left neighbour s and into the block 2^q to its right), one elimination per 16-lane DPP row, the
-// rows of a wave and the waves of the workgroup working independent pairs; sub-levels are separated by LDS-only
-// barriers instead of kernel boundaries.  n blocks -> ceil(n / 32) per launch; the launch that finds <= 32 blocks
+// eliminated into its left neighbour s and into the block 2^q to its right), the panel of a pair spread over two
+// 16-lane DPP rows in the first sub-level and over the four rows of a wave from the second on (cr_step.hpp, cr_quad.hpp),
+// the waves of the workgroup working independent pairs; sub-levels are separated by LDS-only barriers instead of kernel
+// boundaries.  n blocks -> ceil(n / 32) per launch; the launch that finds <= 32 blocks
 // also solves the last one and back-substitutes the whole group in LDS (TOP).
 #pragma once
 
