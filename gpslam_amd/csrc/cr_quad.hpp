@@ -26,20 +26,37 @@ template <int K> __device__ __forceinline__ void fmac_self2(double *d, double m)
       : "+v"(d[0]), "+v"(d[1])
       : "v"(m), "n"(K));
 }
-template <int K> __device__ __forceinline__ void fmac_bcast3(double *d, const double *s, double m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%7 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%7 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
-      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
-      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(m), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast3(double *d, const double *s, double m) {
+  if constexpr (NEG) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %3, -%6 row_newbcast:%7 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %4, -%6 row_newbcast:%7 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %5, -%6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(m), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %3, %6 row_newbcast:%7 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %4, %6 row_newbcast:%7 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %5, %6 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(m), "n"(K));
+  }
 }
-template <int K> __device__ __forceinline__ void fmac_bcast2v(double *d, const double *s, double m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-      : "+v"(d[0]), "+v"(d[1])
-      : "v"(s[0]), "v"(s[1]), "v"(m), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast2v(double *d, const double *s, double m) {
+  if constexpr (NEG) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, -%4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %3, -%4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1])
+        : "v"(s[0]), "v"(s[1]), "v"(m), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1])
+        : "v"(s[0]), "v"(s[1]), "v"(m), "n"(K));
+  }
 }
 // half-width front ends: N = B / 2 in {6, 3, 2}
 template <int K, int N> __device__ __forceinline__ void fmac_self_h(double *d, double m) {
@@ -48,11 +65,11 @@ template <int K, int N> __device__ __forceinline__ void fmac_self_h(double *d, d
   else if constexpr (N == 3) fmac_self3<K>(d, m);
   else fmac_self2<K>(d, m);
 }
-template <int K, int N> __device__ __forceinline__ void fmac_bcast_h(double *d, const double *s, double m) {
+template <int K, int N, bool NEG = false> __device__ __forceinline__ void fmac_bcast_h(double *d, const double *s, double m) {
   static_assert(N == 6 || N == 3 || N == 2, "half panels of the chain solver's block sizes");
-  if constexpr (N == 6) fmac_bcast6<K>(d, s, m);
-  else if constexpr (N == 3) fmac_bcast3<K>(d, s, m);
-  else fmac_bcast2v<K>(d, s, m);
+  if constexpr (N == 6) fmac_bcast6<K, NEG>(d, s, m);
+  else if constexpr (N == 3) fmac_bcast3<K, NEG>(d, s, m);
+  else fmac_bcast2v<K, NEG>(d, s, m);
 }
 
 template <int B> struct CrStepQuad {
@@ -93,12 +110,10 @@ template <int B> struct CrStepQuad {
     gn = 0.0;
     __builtin_amdgcn_sched_barrier(0);
     double invs = 1.0;
-    bool bad = false;
     double piv = row_bcast<0>(Dr[0]);
     double inv = fast_rcp(piv);
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      bad = bad || !(piv > 0.0);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
       const double nmp = isk ? 0.0 : -(Dr[k] * inv);
@@ -132,13 +147,13 @@ template <int B> struct CrStepQuad {
     // zeros to their copy of Ar
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = part ? -Gr[i] : 0.0;
-      fmac_bcast_h<i, H>(P, X, nol);           // part 0: -O_j U_j;  part 1: -O_j V_j (the coupling of s to n)
-      fmac_bcast2<i>(gn, as_, gr, nol, ngg);   // -O_j Y_j (row 0 uses it),  g_s -= F^T Y_j (row 2)
-      fmac_bcast_h<i, H>(Ar, X, ngg);          // part 1: D_s -= F^T V_j
+      const double ol = Ol[i], gg = part ? Gr[i] : 0.0;
+      fmac_bcast_h<i, H, true>(P, X, ol);           // part 0: -O_j U_j;  part 1: -O_j V_j (the coupling of s to n)
+      fmac_bcast2<i, true>(gn, as_, gr, ol, gg);   // -O_j Y_j (row 0 uses it),  g_s -= F^T Y_j (row 2)
+      fmac_bcast_h<i, H, true>(Ar, X, gg);          // part 1: D_s -= F^T V_j
     });
     __builtin_amdgcn_sched_barrier(0);
-    return bad;
+    return !(invs > 0.0);     // a pivot that is not positive (or not a number) leaves such a reciprocal in its own lane
   }
 
   // the pair's own blocks: s in place, j as the factor record [V | U | Y] (row lanes of active pairs only)

@@ -19,8 +19,8 @@ template <int B> struct CrStep {
   double Or[B], Fr[B], Ar[B], Dn[B], Fn[B];
   double gr, as_, gn;
 
-  // rr = r for the row lanes, 0 for the idle lanes of the DPP row (they shadow row 0 and never store).  Returns true when a
-  // pivot was not positive.  Every lane of the wave must call this (DPP): idle DPP rows pass any valid (s, j).
+  // rr = r for the row lanes, 0 for the idle lanes of the DPP row (they shadow row 0 and never store).  Returns true in the lane
+  // of a pivot that was not positive (its reciprocal is not).  Every lane of the wave must call this (DPP): idle DPP rows pass any valid (s, j).
   __device__ __forceinline__ bool compute(const double *REC, int s, int j, int r, int rr) {
     const double *Rj = REC + j * BS, *Rs = REC + s * BS;
     double Dr[B], Gr[B], Ol[B];
@@ -49,12 +49,10 @@ template <int B> struct CrStep {
     // of the NEXT pivot (hardware reciprocal + two Newton steps, a chain of dependent instructions) is formed under the row
     // operations of the current one: its D entry is final as soon as the D part of the current step is done.
     double invs = 1.0;
-    bool bad = false;
     double piv = row_bcast<0>(Dr[0]);
     double inv = fast_rcp(piv);
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      bad = bad || !(piv > 0.0);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
       const double nmp = isk ? 0.0 : -(Dr[k] * inv);
@@ -81,14 +79,14 @@ template <int B> struct CrStep {
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast_n<i, B>(Dn, Or, nol);         // -O_j U_j: row r
-      fmac_bcast2<i>(gn, as_, gr, nol, ngg);   // -O_j Y_j,  g_s -= F^T Y_j
-      fmac_bcast_n<i, B>(Fn, Fr, nol);         // -O_j V_j: the coupling of s to n
-      fmac_bcast_n<i, B>(Ar, Fr, ngg);         // D_s -= F^T V_j
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n<i, B, true>(Dn, Or, ol);         // -O_j U_j: row r
+      fmac_bcast2<i, true>(gn, as_, gr, ol, gg);   // -O_j Y_j,  g_s -= F^T Y_j
+      fmac_bcast_n<i, B, true>(Fn, Fr, ol);         // -O_j V_j: the coupling of s to n
+      fmac_bcast_n<i, B, true>(Ar, Fr, gg);         // D_s -= F^T V_j
     });
     __builtin_amdgcn_sched_barrier(0);
-    return bad;
+    return !(invs > 0.0);     // a pivot that is not positive (or not a number) leaves such a reciprocal in its own lane
   }
 
   // the pair's own blocks: s in place, j as the factor record (row lanes of active pairs only)
@@ -165,12 +163,10 @@ template <int B> struct CrStepWide {
     gn = 0.0;
     __builtin_amdgcn_sched_barrier(0);
     double invs = 1.0;
-    bool bad = false;
     double piv = row_bcast<0>(Dr[0]);
     double inv = fast_rcp(piv);
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
-      bad = bad || !(piv > 0.0);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
       const double nmp = isk ? 0.0 : -(Dr[k] * inv);
@@ -194,13 +190,13 @@ template <int B> struct CrStepWide {
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = half ? -Gr[i] : 0.0;
-      fmac_bcast_n<i, B>(P, X, nol);           // half 0: -O_j U_j;  half 1: -O_j V_j (the coupling of s to n)
-      fmac_bcast2<i>(gn, as_, gr, nol, ngg);   // -O_j Y_j (half 0 uses it),  g_s -= F^T Y_j (half 1)
-      fmac_bcast_n<i, B>(Ar, X, ngg);          // half 1: D_s -= F^T V_j  (half 0: += 0)
+      const double ol = Ol[i], gg = half ? Gr[i] : 0.0;
+      fmac_bcast_n<i, B, true>(P, X, ol);           // half 0: -O_j U_j;  half 1: -O_j V_j (the coupling of s to n)
+      fmac_bcast2<i, true>(gn, as_, gr, ol, gg);   // -O_j Y_j (half 0 uses it),  g_s -= F^T Y_j (half 1)
+      fmac_bcast_n<i, B, true>(Ar, X, gg);          // half 1: D_s -= F^T V_j  (half 0: += 0)
     });
     __builtin_amdgcn_sched_barrier(0);
-    return bad;
+    return !(invs > 0.0);     // a pivot that is not positive (or not a number) leaves such a reciprocal in its own lane
   }
 
   // row lanes of active pairs only

@@ -88,19 +88,34 @@ template <int K> __device__ __forceinline__ void row_bcast12(const double *s, do
 // register that an earlier instruction of the same block wrote.
 #define GPS_FMAC_ROW "row_mask:0xf bank_mask:0xf\n\t"
 // d[q] += bcast_K(s[q]) * m, q = 0..11
-template <int K> __device__ __forceinline__ void fmac_bcast12(double *d, const double *s, double m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %12, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %13, %24 row_newbcast:%25 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %2, %14, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %15, %24 row_newbcast:%25 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %4, %16, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %17, %24 row_newbcast:%25 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %6, %18, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %19, %24 row_newbcast:%25 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %8, %20, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %21, %24 row_newbcast:%25 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %10, %22, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %23, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf"
-      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
-        "+v"(d[10]), "+v"(d[11])
-      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
-        "v"(s[11]), "v"(m), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast12(double *d, const double *s, double m) {
+  if constexpr (NEG) {      // d[q] -= bcast_K(s[q]) * m: the source modifier of the DPP encoding, the same single rounding
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %12, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %13, -%24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %14, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %15, -%24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %4, %16, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %17, -%24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %6, %18, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %19, -%24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %8, %20, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %21, -%24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %10, %22, -%24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %23, -%24 row_newbcast:%25 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
+          "+v"(d[10]), "+v"(d[11])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
+          "v"(s[11]), "v"(m), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %12, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %13, %24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %14, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %15, %24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %4, %16, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %17, %24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %6, %18, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %7, %19, %24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %8, %20, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %9, %21, %24 row_newbcast:%25 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %10, %22, %24 row_newbcast:%25 " GPS_FMAC_ROW "v_fmac_f64_dpp %11, %23, %24 row_newbcast:%25 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]),
+          "+v"(d[10]), "+v"(d[11])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(s[6]), "v"(s[7]), "v"(s[8]), "v"(s[9]), "v"(s[10]),
+          "v"(s[11]), "v"(m), "n"(K));
+  }
 }
 // d[q] += bcast_K(d[q]) * m, q = 0..11 (a Gauss-Jordan row operation: the pivot row is lane K of the same registers)
 template <int K> __device__ __forceinline__ void fmac_self12(double *d, double m) {
@@ -126,12 +141,20 @@ template <int K> __device__ __forceinline__ void fmac_self4(double *d, double m)
       : "v"(m), "n"(K));
 }
 // two scalars: d0 += bcast_K(s) * m0, d1 += bcast_K(s) * m1 (d0 may be s itself only through fmac_self1)
-template <int K> __device__ __forceinline__ void fmac_bcast2(double &d0, double &d1, double s, double m0, double m1) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
-      : "+v"(d0), "+v"(d1)
-      : "v"(s), "v"(m0), "v"(m1), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast2(double &d0, double &d1, double s, double m0, double m1) {
+  if constexpr (NEG) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, -%3 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, -%4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(d0), "+v"(d1)
+        : "v"(s), "v"(m0), "v"(m1), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+        : "+v"(d0), "+v"(d1)
+        : "v"(s), "v"(m0), "v"(m1), "n"(K));
+  }
 }
 template <int K> __device__ __forceinline__ void fmac_bcast1(double &d0, double s, double m0) {
   asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(s), "v"(m0), "n"(K));
@@ -297,22 +320,41 @@ template <int K> __device__ __forceinline__ void fmac_self6(double *d, double m)
       : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
       : "v"(m), "n"(K));
 }
-template <int K> __device__ __forceinline__ void fmac_bcast6(double *d, const double *s, double m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %6, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %7, %12 row_newbcast:%13 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %9, %12 row_newbcast:%13 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %4, %10, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %11, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
-      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
-      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(m), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast6(double *d, const double *s, double m) {
+  if constexpr (NEG) {      // d[q] -= bcast_K(s[q]) * m: the source modifier of the DPP encoding, the same single rounding
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %6, -%12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %7, -%12 row_newbcast:%13 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %8, -%12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %9, -%12 row_newbcast:%13 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %4, %10, -%12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %11, -%12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(m), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %6, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %7, %12 row_newbcast:%13 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %8, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %9, %12 row_newbcast:%13 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %4, %10, %12 row_newbcast:%13 " GPS_FMAC_ROW "v_fmac_f64_dpp %5, %11, %12 row_newbcast:%13 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(s[4]), "v"(s[5]), "v"(m), "n"(K));
+  }
 }
-template <int K> __device__ __forceinline__ void fmac_bcast4(double *d, const double *s, double m) {
-  asm volatile(
-      "s_nop 1\n\t"
-      "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 " GPS_FMAC_ROW
-      "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
-      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
-      : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(m), "n"(K));
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast4(double *d, const double *s, double m) {
+  if constexpr (NEG) {      // d[q] -= bcast_K(s[q]) * m: the source modifier of the DPP encoding, the same single rounding
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, -%8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %5, -%8 row_newbcast:%9 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %6, -%8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %7, -%8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(m), "n"(K));
+  } else {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 " GPS_FMAC_ROW
+        "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 " GPS_FMAC_ROW "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+        : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3])
+        : "v"(s[0]), "v"(s[1]), "v"(s[2]), "v"(s[3]), "v"(m), "n"(K));
+  }
 }
 template <int K, int N> __device__ __forceinline__ void fmac_self_n(double *d, double m) {
   static_assert(N == 4 || N == 6 || N == 12, "block sizes of the chain solver");
@@ -320,11 +362,11 @@ template <int K, int N> __device__ __forceinline__ void fmac_self_n(double *d, d
   else if constexpr (N == 6) fmac_self6<K>(d, m);
   else fmac_self4<K>(d, m);
 }
-template <int K, int N> __device__ __forceinline__ void fmac_bcast_n(double *d, const double *s, double m) {
+template <int K, int N, bool NEG = false> __device__ __forceinline__ void fmac_bcast_n(double *d, const double *s, double m) {
   static_assert(N == 4 || N == 6 || N == 12, "block sizes of the chain solver");
-  if constexpr (N == 12) fmac_bcast12<K>(d, s, m);
-  else if constexpr (N == 6) fmac_bcast6<K>(d, s, m);
-  else fmac_bcast4<K>(d, s, m);
+  if constexpr (N == 12) fmac_bcast12<K, NEG>(d, s, m);
+  else if constexpr (N == 6) fmac_bcast6<K, NEG>(d, s, m);
+  else fmac_bcast4<K, NEG>(d, s, m);
 }
 
 }  // namespace gps

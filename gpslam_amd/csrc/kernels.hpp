@@ -2301,11 +2301,9 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     __builtin_amdgcn_sched_barrier(0);
     // Gauss-Jordan on D~_j by row operations; the pivot row stays unscaled until the end (scaling commutes)
     double invs = 1.0;
-    bool bad = false;
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       const double piv = row_bcast<k>(Dr[k]);
-      bad = bad || !(piv > 0.0);
       const double inv = fast_rcp(piv);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
@@ -2324,7 +2322,9 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
       fmac_self_n<k, B>(Fr, nmp);
       fmac_self1<k>(gr, nmp);
     });
-    if (bad && live && r == 0) *a.flag = 1;
+    // a pivot that is not positive (or not a number) leaves a reciprocal that is not positive in its own lane: one test per
+    // block step instead of one per pivot (lanes without a row keep 1)
+    if (!(invs > 0.0) && live) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
     double Ol[B];
 #pragma unroll
@@ -2362,10 +2362,10 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     // two passes, so that at most seven 12-vectors are live: rows of U_j first (O_j^T is dead afterwards) ...
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast_n<i, B>(Dn, Or, nol);     // D~_{j+1} -= O_j[r][i] * (row i of U_j)
-      fmac_bcast_n<i, B>(Gn, Or, ngg);     // G_{j+1}  -= G_j[r][i] * (row i of U_j)
-      fmac_bcast2<i>(gn, as_, gr, nol, ngg);
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n<i, B, true>(Dn, Or, ol);     // D~_{j+1} -= O_j[r][i] * (row i of U_j)
+      fmac_bcast_n<i, B, true>(Gn, Or, gg);     // G_{j+1}  -= G_j[r][i] * (row i of U_j)
+      fmac_bcast2<i, true>(gn, as_, gr, ol, gg);
     });
     // (pinned here: the compiler otherwise sinks the G_{j+1} sums below the output branch at the end of the step and
     //  spills all 144 broadcast values to feed them there)
@@ -2377,9 +2377,9 @@ __global__ void __launch_bounds__(64, 2) k_chunk_forward_rows(FwdArgs<double> a)
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast_n<i, B>(Fn, Fr, nol);     // F_{j+1} -= O_j[r][i] * (row i of V_j)
-      fmac_bcast_n<i, B>(Ar, Fr, ngg);     // D_sep   -= G_j[r][i] * (row i of V_j)
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n<i, B, true>(Fn, Fr, ol);     // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B, true>(Ar, Fr, gg);     // D_sep   -= G_j[r][i] * (row i of V_j)
     });
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -2900,12 +2900,10 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     const bool live = j < e, lastb = (j == e - 1);
     const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
     double invs = 1.0;
-    bool bad = false;
 #ifndef GPS_ABLATE_ELIM   /* timing ablation only (wrong results): the elimination wave keeps its LDS traffic, stores and barriers */
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       const double piv = row_bcast<k>(Dr[k]);
-      bad = bad || !(piv > 0.0);
       const double inv = fast_rcp(piv);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
@@ -2925,7 +2923,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       fmac_self1<k>(gr, nmp);
     });
 #endif
-    if (bad && live && r == 0) *a.flag = 1;
+    // a pivot that is not positive (or not a number) leaves a reciprocal that is not positive in its own lane: one test per
+    // block step instead of one per pivot (lanes without a row keep 1)
+    if (!(invs > 0.0) && live) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
     double Ol[B];
 #pragma unroll
@@ -2962,9 +2962,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast_n<i, B>(Dn, Or, nol);
-      fmac_bcast2<i>(gn, as_, gr, nol, ngg);
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n<i, B, true>(Dn, Or, ol);
+      fmac_bcast2<i, true>(gn, as_, gr, ol, gg);
     });
 #endif
 #pragma unroll
@@ -2975,9 +2975,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
-      const double nol = -Ol[i], ngg = -Gr[i];
-      fmac_bcast_n<i, B>(Fn, Fr, nol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
-      fmac_bcast_n<i, B>(Ar, Fr, ngg);        // D_sep   -= G_j[r][i] * (row i of V_j)
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n<i, B, true>(Fn, Fr, ol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast_n<i, B, true>(Ar, Fr, gg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -3067,7 +3067,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       const int nq = (jq + h < cnt) ? jq + h : G4;
       if (__ballot(act) != 0ull) {               // (idle DPP rows recompute block 0; they never store)
         const bool bad = st.compute(REC, act ? sq : 0, act ? jq : 0, r, rr);
-        if (bad && act && r == 0) *a.flag = 1;
+        if (bad && act) *a.flag = 1;
       }
       wave_lds_sync();
       if (act && rowlane) st.store_own(REC, sq, jq, r);

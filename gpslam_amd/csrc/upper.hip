@@ -97,7 +97,7 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
     std::conditional_t<quad, CrStepQuad<B>, CrStepWide<B>> st;
     if (__ballot(act) != 0ull) {             // (idle DPP rows of a working wave recompute block 0; they never store)
       const bool bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr, quad ? row : half);
-      if (bad && act && r == 0) *a.flag = 1;
+      if (bad && act) *a.flag = 1;             // (the lane of the failed pivot reports)
     }
     probe();
     lds_barrier();                            // every pair has read its operands
@@ -137,11 +137,9 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
     for (int k = 0; k < B; k++) Dr[k] = REC[rr * B + k];
     double gr = REC[2 * B * B + rr];
     double invs = 1.0;
-    bool bad = false;
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       const double piv = row_bcast<k>(Dr[k]);
-      bad = bad || !(piv > 0.0);
       const double inv = fast_rcp(piv);
       const bool isk = (r == k);
       invs = isk ? inv : invs;
@@ -149,7 +147,7 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
       fmac_self_n<k, B>(Dr, nmp);
       fmac_self1<k>(gr, nmp);
     });
-    if (bad && lane == 0) *a.flag = 1;
+    if (!(invs > 0.0)) *a.flag = 1;
     if (row == 0 && rowlane) XS[r] = gr * invs;
   }
   if (tid < B) XS[G * B + tid] = 0.0;          // nothing beyond the top level
