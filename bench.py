@@ -26,6 +26,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X fp64 vector (= matrix) peak: 256 CUs x 4 SIMD-16 x 2 flop x 2.4 GHz (cdna_hip_programming.md: the SIMD-16 ceiling)
+# k_fused_level0<1, double, 12, true>: (900 + 411) v_fmac_f64_dpp per block step of four states x 64 lanes x 2 flop / 4 states
+FUSED_FMA_FLOPS_PER_STATE = (900 + 411) * 64 * 2 // 4
 
 # rocprofv3 kernel names of the kernels bench.py times itself (time_kernel order); the per-launch HBM traffic of the
 # same kernels on the same workload comes from the committed PMC passes (scripts/collect_profiles.sh ->
@@ -575,10 +578,19 @@ def main():
                          "avg_launch_ms": l0_in_iter if (dom == 2 and l0_in_iter > 0) else kms[dom],
                          "timing": ("hipEvents around the launch INSIDE 6 consecutive Gauss-Newton iterations (gpslam_hip_last_level0_ms); the "
                                     "isolated launches of kernel_ms are faster" if (dom == 2 and l0_in_iter > 0) else "isolated launches (time_kernel)"),
-                         # what actually limits the kernel the HBM fraction is quoted for
-                         "note": ("step-rate bound (timing ablations, DESIGN.md section 4 'Round 4'): two-wave workgroups (assembly + "
-                                  "elimination), ~2700 wave instructions per workgroup block step, 70 % of the launch is there with all "
-                                  "arithmetic removed; measured traffic is below the SURVEY 8(d) figure because the GP priors arrive as "
+                         # what actually limits the kernel the HBM fraction is quoted for: the second roof
+                         "valu_fp64": ({"achieved": FUSED_FMA_FLOPS_PER_STATE * N / ((l0_in_iter if l0_in_iter > 0 else kms[dom]) * 1e-3) / 1e12,
+                                        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": FUSED_FMA_FLOPS_PER_STATE * N / ((l0_in_iter if l0_in_iter > 0 else kms[dom]) * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                                        "flops_per_state_issued": FUSED_FMA_FLOPS_PER_STATE,
+                                        "note": "ISSUED fp64 multiply-adds: v_fmac_f64_dpp wave instructions per block step of four states in the ISA of "
+                                                "the shipped kernel (elimination wave 900, assembly wave 411 with a diagonal Qc) x 64 lanes x 2 / 4; "
+                                                "12 of a DPP row's 16 lanes carry matrix rows, and the two waves issue another ~830 non-FMA "
+                                                "instructions per step through the same port"}
+                                       if fused and dom == 2 else None),
+                         "note": ("VALU-issue bound next to the HBM roof (DESIGN.md section 4 'Round 4'): two-wave workgroups (assembly + "
+                                  "elimination), ~2140 wave instructions per workgroup block step, SIMDs ~88 % busy (SQ_ACTIVE_INST_ANY of two resident "
+                                  "waves); measured traffic is below the SURVEY 8(d) figure because the GP priors arrive as "
                                   "80-double records of Jr^-1, J and the finite-difference block (312 doubles as rows) whose columns the "
                                   "assembly wave forms; the launch also reduces its four chunk separators"
                                   if fused and dom == 2 else None)},

@@ -17,7 +17,7 @@ LIB = os.path.join(LIBDIR, "libgpslam_hip.so")
 # one object each, compiled side by side, linked into the one library: the C ABI, the fp64-row and the fp32-row half of the
 # optimiser (both are api_impl.inc; round 3: they were one 3.5-minute translation unit), the upper solver levels
 SOURCES = ["api.hip", "api_impl64.hip", "api_impl32.hip", "upper.hip"]
-HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "dpp.hpp", "cr_step.hpp", "upper.hpp", "api_common.hpp",
+HEADERS = ["kernels.hpp", "factors.hpp", "lie.hpp", "devbuf.hpp", "fatsep.hpp", "dpp.hpp", "cr_step.hpp", "cr_quad.hpp", "upper.hpp", "api_common.hpp",
            "api_decl.inc", os.path.join("..", "..", "include", "gpslam_hip.h")]
 # what each translation unit includes (an edit to upper.hip does not recompile the others)
 DEPS = {"api.hip": HEADERS, "api_impl64.hip": HEADERS + ["api_impl.inc"], "api_impl32.hip": HEADERS + ["api_impl.inc"],

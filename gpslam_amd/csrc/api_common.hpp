@@ -383,6 +383,7 @@ inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, 
     return;
   }
   if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
+  else if (u.gps && u.u_diag) k_fused_level0<1, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);   // diagonal chol(Qc^-1)
   else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);
 }

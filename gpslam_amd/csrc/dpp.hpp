@@ -196,6 +196,16 @@ template <> __device__ __forceinline__ void fmac_gather<3>(double *d, double s, 
       : "v"(s), "v"(m));
 }
 
+// three lanes from lane K0 on: d[k] += s[lane K0 + k] * m, k = 0..2 (the block-triangular halves of the SE(3) records)
+template <int K0> __device__ __forceinline__ void fmac_gather3_at(double *d, double s, double m) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%5 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %3, %4 row_newbcast:%6 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %2, %3, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf"
+      : "+v"(d[0]), "+v"(d[1]), "+v"(d[2])
+      : "v"(s), "v"(m), "n"(K0), "n"(K0 + 1), "n"(K0 + 2));
+}
+
 template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
 template <> __device__ __forceinline__ void lane_gather<12>(double v, double *d) {
   asm volatile(

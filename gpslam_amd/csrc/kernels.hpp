@@ -26,6 +26,7 @@
 #include "factors.hpp"
 #include "dpp.hpp"
 #include "cr_step.hpp"
+#include "cr_quad.hpp"
 #include <type_traits>
 
 namespace gps {
@@ -2439,6 +2440,7 @@ template <typename T, typename TR = T> struct FusedArgs {
   int btw_count;          // number of records; record btw_count is all zeros
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
   int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
+  int u_diag;             // Ud is diagonal (SE(3) records: k_fused_level0<1, double, 12, true>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
   T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
                           // it that the PREVIOUS chunk's last rows contribute (gsave2; zero elsewhere); null: not wanted
@@ -2451,9 +2453,15 @@ template <typename T, typename TR = T> struct FusedArgs {
 // they are used, without a ring (the pure variant stays free of that loop's registers: with it the kernel spills again).
 // (round 3: the block size is a template parameter -- 12: SE(3), with or without structured GP records; 6: SE(2), SO(3), 3-D linear
 // chains, plain rows only)
-template <int SV, typename TR = double, int B = 12>
+// DG (round 4; SV = 1, B = 12): U = chol_upper(Qc^-1) is DIAGONAL (an isotropic or diagonal Qc, the common case; the host looks at
+// the 36 numbers).  Then row q of the whitened L has, among its six velocity columns, only the one of its own component
+// (L's velocity block is [k2 U; -sc U]): D and O need 7 instead of 12 multiply-adds per Jacobian row, and U Z is six products per
+// six-vector instead of 21 multiply-adds -- 204 of the assembly wave's ~1170 instructions per block step.  What is skipped are
+// products with exact zeros: the same values as the general kernel.
+template <int SV, typename TR = double, int B = 12, bool DG = false>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
+  static_assert(!DG || (SV == 1 && B == 12), "the diagonal-U form belongs to the pure SE(3) record variant");
   constexpr bool ST = SV != 0, ODD = SV == 2;
   // ST12: SE(3) records (kGps*, kBtw*: the assembly wave forms the columns, no full-width row ring);  ST6 (round 4): the d = 3
   // records (kGp3*) of SE(2) / SO(3) / 3-D linear chains -- six rows per state from 11 operands per lane, next to the row ring
@@ -2526,11 +2534,13 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // J_c = the unit vector, aL = k2, aR = sb, b = c = 0, dR = sc -- their zeros are the record's zero slot).
     constexpr bool st_on = ST;
     constexpr int NRAW = ST12 ? 21 : (ST6 ? 11 : 1);
-    double Ur[ST12 ? 3 : 1];
-    if constexpr (ST12) {
+    double Ur[(ST12 && !DG) ? 3 : 1];
+    if constexpr (ST12 && !DG) {
 #pragma unroll
       for (int k = 0; k < 3; k++) Ur[k] = u.Ud[min(16 * k + r, 35)];       // U, row-major: entry e in lane e & 15 of Ur[e >> 4]
     }
+    double udv = 0.0;                                                        // DG: the diagonal, entry k in lane k of every row
+    if constexpr (DG) udv = u.Ud[7 * min(r, 5)];
     // where this lane's operands sit in a record (loop-invariant; the stride-3 walks down a column are immediate offsets)
     int oX1 = 0, oX2 = 0, oJ1 = 0, oJ2 = 0, oF = 0, oE = 0, oaL = 0, oaR = 0, ob = 0, oc = 0, od = 0;
     if constexpr (ST12) {
@@ -2647,15 +2657,26 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           Z[2][k] = fma(aR, X6[k], bb * P3[k]);      // top rows of R
           Z[3][k] = fma(cc, P3[k], dR * X6[k]);      // bottom rows of R
         }
+        if constexpr (DG) {
+          static_for<0, 6>([&](auto kk) {            // U Z, U diagonal
+            constexpr int k = decltype(kk)::value;
+            const double uk = row_bcast<k>(udv);
+            Lcol[k] = uk * Z[0][k]; Lcol[6 + k] = uk * Z[1][k];
+            Rcol[k] = uk * Z[2][k]; Rcol[6 + k] = uk * Z[3][k];
+            // (formed here: sunk into the row loop they would keep Z and the record's operands alive across it -- the wave spilled)
+            asm volatile("" : "+v"(Lcol[k]), "+v"(Lcol[6 + k]), "+v"(Rcol[k]), "+v"(Rcol[6 + k]));
+          });
+        } else {
 #pragma unroll
-        for (int k = 0; k < B; k++) { Lcol[k] = 0.0; Rcol[k] = 0.0; }
-        static_for<0, 6>([&](auto kk) {              // U Z, U upper triangular: out[i] += U[i][k] Z[k], i <= k
-          constexpr int k = decltype(kk)::value;
-          fmac_mat<k + 1, k, 6>(Lcol, Ur, Z[0][k]);
-          fmac_mat<k + 1, k, 6>(Lcol + 6, Ur, Z[1][k]);
-          fmac_mat<k + 1, k, 6>(Rcol, Ur, Z[2][k]);
-          fmac_mat<k + 1, k, 6>(Rcol + 6, Ur, Z[3][k]);
-        });
+          for (int k = 0; k < B; k++) { Lcol[k] = 0.0; Rcol[k] = 0.0; }
+          static_for<0, 6>([&](auto kk) {            // U Z, U upper triangular: out[i] += U[i][k] Z[k], i <= k
+            constexpr int k = decltype(kk)::value;
+            fmac_mat<k + 1, k, 6>(Lcol, Ur, Z[0][k]);
+            fmac_mat<k + 1, k, 6>(Lcol + 6, Ur, Z[1][k]);
+            fmac_mat<k + 1, k, 6>(Rcol, Ur, Z[2][k]);
+            fmac_mat<k + 1, k, 6>(Rcol + 6, Ur, Z[3][k]);
+          });
+        }
         newl = -raw[15];                             // minus the whitened error of row (lane)
       }
     };
@@ -2730,9 +2751,24 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           if constexpr (q == 5) ldbtw();                 // this state's between record: wanted right behind these twelve rows
           const double Lv = Lcol[q], Rv = Rcol[q];
 #ifndef GPS_ABLATE_ASM
-          fmac_gather<B>(Dacc, Lv, Lv);
-          fmac_gather<B>(Oacc, Lv, Rv);
-          fmac_gather<B>(RRacc, Rv, Rv);
+          if constexpr (DG) {
+            // row q of L: the pose columns and velocity column 6 + q mod 6.  X, J and F are block lower triangular ([[A, 0], [C, D]]),
+            // so the rotation rows (q mod 6 < 3) of the whitened [L | R] are zero in every translation column (3..5, and 9..11 of R)
+            constexpr int vq = Dh + q % Dh;
+            if constexpr (q % Dh < 3) {
+              fmac_gather<3>(Dacc, Lv, Lv); fmac_bcast1<vq>(Dacc[vq], Lv, Lv);
+              fmac_gather<3>(Oacc, Lv, Rv); fmac_bcast1<vq>(Oacc[vq], Lv, Rv);
+              fmac_gather<3>(RRacc, Rv, Rv); fmac_gather3_at<Dh>(RRacc + Dh, Rv, Rv);
+            } else {
+              fmac_gather<Dh>(Dacc, Lv, Lv); fmac_bcast1<vq>(Dacc[vq], Lv, Lv);
+              fmac_gather<Dh>(Oacc, Lv, Rv); fmac_bcast1<vq>(Oacc[vq], Lv, Rv);
+              fmac_gather<B>(RRacc, Rv, Rv);
+            }
+          } else {
+            fmac_gather<B>(Dacc, Lv, Lv);
+            fmac_gather<B>(Oacc, Lv, Rv);
+            fmac_gather<B>(RRacc, Rv, Rv);
+          }
 #endif
           fmac_bcast2<q>(gacc, grr, newl, Lv, Rv);       // g -= e[q] L[q][r],  carry_g -= e[q] R[q][r]
           __builtin_amdgcn_sched_barrier(0);
@@ -2754,9 +2790,15 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
             constexpr int i = decltype(ii)::value;
             const double wi = row_bcast<i>(braw[12]);     // 1 / sigma of row i
             const double Lv = wi * Lc6[i], Rv = wi * Rc6[i];
-            fmac_gather<Dh>(Dacc, Lv, Lv);
-            fmac_gather<Dh>(Oacc, Lv, Rv);
-            fmac_gather<Dh>(RRacc, Rv, Rv);
+            if constexpr (i < 3) {                       // rotation rows of [[A, 0], [C, A]]: zero in the translation columns
+              fmac_gather<3>(Dacc, Lv, Lv);
+              fmac_gather<3>(Oacc, Lv, Rv);
+              fmac_gather<3>(RRacc, Rv, Rv);
+            } else {
+              fmac_gather<Dh>(Dacc, Lv, Lv);
+              fmac_gather<Dh>(Oacc, Lv, Rv);
+              fmac_gather<Dh>(RRacc, Rv, Rv);
+            }
             fmac_bcast2<i>(gacc, grr, nbe, Lv, Rv);
             __builtin_amdgcn_sched_barrier(0);
           });
@@ -3058,27 +3100,36 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       rc[2 * B * B + r] = have ? ta[B * B + r] : 0.0;
     }
     wave_lds_sync();
-    CrStep<B> st;
-#pragma unroll 1
-    for (int q = 0; q < 2; q++) {
-      const int h = 1 << q, np = G4 >> (q + 1);
-      const int sq = grp * 2 * h, jq = sq + h;
-      const bool act = (grp < np) && (jq < cnt);
+    // two sub-levels: pairs (0, 1), (2, 3) on two DPP rows each (CrStepWide), then the pair (0, 2) on all four (CrStepQuad) --
+    // the wave is alone in its workgroup by now, every multiply-add it does not issue is time off the launch (round 4: one row
+    // per pair had cost 2 x 834 multiply-adds per lane, this is 612 + 336)
+    auto sub_level = [&](int q, auto form) {
+      constexpr bool quad = decltype(form)::value;
+      const int h = 1 << q;
+      const int pq = quad ? 0 : (grp >> 1), role4 = quad ? grp : (grp & 1);
+      const int sq = pq * 2 * h, jq = sq + h;
+      const bool act = jq < cnt;
       const int nq = (jq + h < cnt) ? jq + h : G4;
+      std::conditional_t<quad, CrStepQuad<B>, CrStepWide<B>> st;
       if (__ballot(act) != 0ull) {               // (idle DPP rows recompute block 0; they never store)
-        const bool bad = st.compute(REC, act ? sq : 0, act ? jq : 0, r, rr);
+        const bool bad = st.compute(REC, act ? sq : 0, act ? jq : 0, r, rr, role4);
         if (bad && act) *a.flag = 1;
       }
       wave_lds_sync();
-      if (act && rowlane) st.store_own(REC, sq, jq, r);
+      if (act && rowlane) st.store_own(REC, sq, jq, r, role4);
       wave_lds_sync();
-      if (act && rowlane) st.add_right(REC, nq, r);
-      if (act) {                                 // the factor record of the eliminated separator: level 1's back-substitution reads it
-        V2 *dst = reinterpret_cast<V2 *>(a.l1_blk + (size_t)(c0 + jq) * BS);
-        const V2 *src = reinterpret_cast<const V2 *>(REC + jq * BS);
-        for (int t = r; t < NPC; t += 16) dst[t] = src[t];
+      if (act && rowlane) {
+        if constexpr (quad) { if (role4 < 2) st.add_right(REC, nq, r, role4); }
+        else { if (role4 == 0) st.add_right(REC, nq, r); }
       }
       wave_lds_sync();
+    };
+    sub_level(0, std::false_type{});
+    sub_level(1, std::true_type{});
+    {   // the factor records of the eliminated separators (blocks 1 .. cnt - 1): level 1's back-substitution reads them
+      V2 *dst = reinterpret_cast<V2 *>(a.l1_blk + (size_t)(c0 + 1) * BS);
+      const V2 *src = reinterpret_cast<const V2 *>(REC + BS);
+      for (int t = lane; t < (cnt - 1) * NPC; t += 64) dst[t] = src[t];
     }
     V2 *ub = reinterpret_cast<V2 *>(a.up_blk + (size_t)blockIdx.x * BS);
     const V2 *s0 = reinterpret_cast<const V2 *>(REC);

@@ -96,7 +96,8 @@ enum {
   GPSLAM_PLAN_COLUMN_LEVEL0 = 2,      /* column-layout level-0 elimination (k_chunk_forward; implies the two launches) */
   GPSLAM_PLAN_LEVELS_OF_FOUR = 4,     /* upper hierarchy as one launch per level of chunks of four instead of LDS-resident cyclic reduction */
   GPSLAM_PLAN_FS_TWO_LAUNCHES = 8,    /* segmented landmark elimination: border sweep and Schur complement as two launches through Y */
-  GPSLAM_PLAN_GP_ROWS = 16            /* GP priors as plain Jacobian rows instead of structured records */
+  GPSLAM_PLAN_GP_ROWS = 16,           /* GP priors as plain Jacobian rows instead of structured records */
+  GPSLAM_PLAN_GENERIC_QC = 32         /* SE(3) records: the general (upper-triangular) chol(Qc^-1) form even when Qc is diagonal */
 };
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */

@@ -77,6 +77,36 @@ def test_structured_records_reproduce_the_row_path():
         assert np.abs(res[0][1] - res[k][1]).max() <= 1e-11 * max(1.0, np.abs(res[k][1]).max())
 
 
+@pytest.mark.parametrize("N", [700, 1500])
+def test_diagonal_qc_takes_the_short_form_of_the_assembly_wave(N):
+    """A diagonal Qc (chol_upper(Qc^-1) diagonal: the host looks at the 36 numbers per launch) selects
+    k_fused_level0<1, double, 12, true>: row q of the whitened L meets only velocity column 6 + q mod 6, U Z is six products.
+    What it skips are products with exact zeros, so it must land on the general form's (GPSLAM_PLAN_GENERIC_QC) numbers exactly,
+    and both on the oracle's; a set_qc to a non-diagonal Qc in mid-run must switch forms (test below keeps that honest too)."""
+    import gpslam_amd
+    rng = np.random.default_rng(5)
+    Qc = np.diag(0.01 + 0.02 * rng.random(6))
+    c = T.random_chain(O.POSE3, N, 31)
+    out = []
+    for make in (lambda: O.Chain(O.POSE3, O.CHART_EXPMAP), lambda: gpslam_amd.ChainSolver(O.POSE3, O.CHART_EXPMAP),
+                 lambda: gpslam_amd.ChainSolver(O.POSE3, O.CHART_EXPMAP, plan=gpslam_amd.PLAN_GENERIC_QC)):
+        s = make()
+        s.set_qc(Qc)
+        s.set_states(c["pose"], c["vel"])
+        s.add_gp_priors(np.arange(N - 1), c["dt"])
+        fix = np.arange(0, N, 20)
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), 6), 0.01))
+        ident = O.pose3((0, 0, 0), (0, 0, 0))
+        meas = np.stack([O.retract(O.POSE3, ident, O.local(O.POSE3, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
+        s.add_between(np.arange(N - 1), meas, np.full((N - 1, 6), 0.02))
+        s.compile()
+        for _ in range(4):
+            s.iterate_gn()
+        out.append(s.get_states())
+    T.states_close(O.POSE3, out[0][0], out[0][1], out[1][0], out[1][1], 1e-9)
+    assert np.array_equal(out[1][0], out[2][0]) and np.array_equal(out[1][1], out[2][1])
+
+
 def test_set_qc_after_compile_reaches_the_structured_path():
     """set_qc after compile(): the row path reads U per launch, the structured records' assembly reads a device copy of U --
     both must see the new Qc (same problem on the oracle)."""
