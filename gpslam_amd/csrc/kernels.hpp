@@ -2473,6 +2473,8 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   constexpr int BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
   typedef double V2 __attribute__((ext_vector_type(2)));
+  // (alternating which wave assembles and which eliminates between workgroups -- by bit 0, 1 or 2 of the workgroup index -- so that a
+  //  SIMD gets one wave of each kind changes nothing: 0.303-0.307 ms per iteration at 1e5 states for all four assignments)
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15;
   const int c = blockIdx.x * 4 + grp;
   const int nch = (a.n + a.m - 1) / a.m;
@@ -3145,6 +3147,12 @@ template <typename T> struct BwdArgs {
   T *x;           // n x R x B solutions of this level (+ one slot for the neighbour rank's separator)
   const T *xup;   // solutions of the next level (separators) or null at the top
   int n, m, R, no_sep, last_has_right;
+  // k_chunk_backward_rows only (round 4): the level above is the level of groups of four that k_fused_level0 reduced in its tail --
+  // a wave's four chunks ARE one such group, so the wave back-substitutes the group itself (l1_blk: that level's factor records,
+  // l1_xup: the solutions of the group's first block and of the next group's, one level further up) instead of a launch of
+  // k_multi_backward<B, 4> writing xup for it.  Null: xup holds the separators' solutions.
+  const T *l1_blk = nullptr, *l1_xup = nullptr;
+  int l1_n = 0;   // blocks of that level (= chunks of this one)
 };
 
 // x_j = Y_j - U_j x_{j+1} - V_j x_sep, right to left through the chunk.  Lane (k, rr) owns component k of the rhs
@@ -3255,8 +3263,44 @@ __global__ void __launch_bounds__(64) k_chunk_backward_rows(BwdArgs<double> a) {
   const int rr = rowlane ? r : 0;
   const bool has_sep = !a.no_sep;
   const bool right_exists = has_sep && ((e < a.n) || (a.last_has_right != 0));
-  const double xs = (has_sep && rowlane) ? a.xup[(size_t)cc * B + rr] : 0.0;                 // the chunk's own separator
-  double xn = (right_exists && rowlane) ? a.xup[(size_t)(cc + 1) * B + rr] : 0.0;            // the state right of the chunk
+  double xs, xn;
+  if (a.l1_blk != nullptr) {
+    // The four separators of the wave are a group of the level above: x_0 and x_4 (the next group's first block, or zero behind
+    // the chain) come from one level further up, x_2 = Y_2 - U_2 x_4 - V_2 x_0, then x_1 = Y_1 - U_1 x_2 - V_1 x_0 and
+    // x_3 = Y_3 - U_3 x_4 - V_3 x_2 (cr_group_backward for G = 4; a block without a right neighbour inside the group takes x_4).
+    // DPP row i holds record i of the group (25 operands per lane); two passes of one instruction stream -- the first is row 2's
+    // x_2, the second rows 1 and 3 with their own operands -- and the results change rows through ds_bpermute.
+    const int g = blockIdx.x, cnt = min(4, a.l1_n - 4 * g);
+    const bool have = 4 * g + cnt < a.l1_n;
+    const double x0 = rowlane ? a.l1_xup[(size_t)g * B + rr] : 0.0;
+    const double x4 = (have && rowlane) ? a.l1_xup[(size_t)(g + 1) * B + rr] : 0.0;
+    double rec[2 * B + 1];
+    {
+      const double *rp = a.l1_blk + (size_t)(4 * g + min(max(grp, 1), max(cnt - 1, 0))) * BS + rr;
+#pragma unroll
+      for (int q = 0; q < 2 * B; q++) rec[q] = rp[q * B];
+      rec[2 * B] = rp[2 * B * B];
+    }
+    auto solve = [&](double xr, double xl) {                 // Y - U xr - V xl, summed in cr_group_backward's order
+      double v = rec[2 * B];
+      const double nl = -xl, nr = -xr;
+      static_for<0, B>([&](auto qq) { constexpr int q = decltype(qq)::value; fmac_bcast1<q>(v, nr, rec[B + q]); });
+      static_for<0, B>([&](auto qq) { constexpr int q = decltype(qq)::value; fmac_bcast1<q>(v, nl, rec[q]); });
+      return v;
+    };
+    const double va = solve(x4, x0);                         // row 2: x_2
+    const double x2 = __shfl(va, 32 + r, 64);
+    const double vb = solve(grp == 1 ? ((2 < cnt) ? x2 : x4) : x4, grp == 3 ? x2 : x0);   // row 1: x_1, row 3: x_3
+    const double x1 = __shfl(vb, 16 + r, 64), x3 = __shfl(vb, 48 + r, 64);
+    // chunk grp of the group: its separator is block grp, the state right of it block grp + 1 (x_4 behind the group's last)
+    xs = grp == 0 ? x0 : (grp == 1 ? x1 : (grp == 2 ? x2 : x3));
+    xn = (grp + 1 < cnt) ? (grp == 0 ? x1 : (grp == 1 ? x2 : x3)) : x4;
+    xs = (has_sep && rowlane) ? xs : 0.0;
+    xn = (right_exists && rowlane) ? xn : 0.0;
+  } else {
+    xs = (has_sep && rowlane) ? a.xup[(size_t)cc * B + rr] : 0.0;                 // the chunk's own separator
+    xn = (right_exists && rowlane) ? a.xup[(size_t)(cc + 1) * B + rr] : 0.0;      // the state right of the chunk
+  }
   if (valid && rowlane) {
     if (has_sep) a.x[(size_t)s * B + r] = xs;
     // the right separator of the last chunk lives on the next rank: park its solution in the extra slot x[n]
