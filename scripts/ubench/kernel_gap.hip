@@ -1,6 +1,6 @@
 // kernel_gap.hip -- what sits between two dependent launches on one stream: the idle time before a tiny kernel as a function of
 // what the kernel in front of it did (bytes written / read, store policy, grid size).  The Gauss-Newton iteration at 1e5 states
-// shows 6-10 us before k_fused_level0, k_multi_forward and k_retract and none between the small launches (profiles/round4_v3).
+// shows 6-10 us before k_fused_level0, k_multi_forward and k_retract and none between the small launches (profiles/round4_v5).
 //   hipcc --offload-arch=gfx950 -O3 scripts/ubench/kernel_gap.hip -o scripts/ubench/kernel_gap
 //   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/gap -o g -- scripts/ubench/kernel_gap ; python scripts/ubench/kernel_gap.py gpurun_out/gap
 #include <hip/hip_runtime.h>
