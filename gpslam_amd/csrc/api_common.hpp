@@ -116,6 +116,7 @@ struct gpslam_hip_handle {
   // block size 6 (SE(2), SO(3), 3-D linear chains): the GP priors as 32-double records (kGp3*) that k_assemble_ghost and
   // k_fused_level0<1, double, 6> decode; rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows)
   bool struct3_ok = false, rows3 = false;
+  bool odd_many = false;    // SE(3) records: more other full-width rows than k_fused_level0<2> fetches without a ring (-> <3>)
   DevBuf gps, gpidx, dU, gsave2;
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
   bool btw_rec_ok = false;
@@ -382,7 +383,10 @@ inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, 
     else k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
     return;
   }
-  if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
+  if (u.gps && u.odd_rows == 2) {            // records + a ring of full-width rows (measurement factors)
+    if (u.u_diag) k_fused_level0<3, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);
+    else k_fused_level0<3><<<dim3(grid), dim3(128), 0, st>>>(u);
+  } else if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
   else if (u.gps && u.u_diag) k_fused_level0<1, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);   // diagonal chol(Qc^-1)
   else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);

@@ -2439,7 +2439,7 @@ template <typename T, typename TR = T> struct FusedArgs {
   const int *btwidx;      // n + 2 entries: record of the between factor whose left state is s, or -1
   int btw_count;          // number of records; record btw_count is all zeros
   const int *gpidx;       // n + 2 entries: record of the GP prior whose left state is s, or -1
-  int odd_rows;           // the structured chain has other full-width rows as well (k_fused_level0<2>)
+  int odd_rows;           // the structured chain has other full-width rows as well: 1 = a few (k_fused_level0<2>), 2 = many (<3>: a ring)
   int u_diag;             // Ud is diagonal (SE(3) records: k_fused_level0<1, double, 12, true>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
   T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
@@ -2461,15 +2461,17 @@ template <typename T, typename TR = T> struct FusedArgs {
 template <int SV, typename TR = double, int B = 12, bool DG = false>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
-  static_assert(!DG || (SV == 1 && B == 12), "the diagonal-U form belongs to the pure SE(3) record variant");
-  constexpr bool ST = SV != 0, ODD = SV == 2;
+  static_assert(!DG || ((SV == 1 || SV == 3) && B == 12), "the diagonal-U form belongs to the SE(3) record variants");
+  // SV = 3 (round 4): records AND a ring of full-width rows -- SE(3) chains with interpolated measurement factors (GPS, range,
+  // projection: a dozen full-width rows per state), which had lost the records to the plain-row kernel
+  constexpr bool ST = SV != 0, ODD = SV >= 2, ORING = SV == 3;
   // ST12: SE(3) records (kGps*, kBtw*: the assembly wave forms the columns, no full-width row ring);  ST6 (round 4): the d = 3
   // records (kGp3*) of SE(2) / SO(3) / 3-D linear chains -- six rows per state from 11 operands per lane, next to the row ring
   // that still serves measurement factors and velocity priors
   constexpr bool ST12 = ST && B == 12, ST6 = ST && B == 6;
   const FwdArgs<double> &a = u.f;
   static_assert(B == 12 || B == 6, "block sizes with DPP gather blocks");
-  static_assert(SV == 0 || B == 12 || SV == 1, "the variant with odd rows is an SE(3) variant");
+  static_assert(SV == 0 || B == 12 || SV == 1, "the variants with odd rows are SE(3) variants");
   constexpr int BS = 2 * B * B + B, AS = B * B + B;   // R == 1
   constexpr int NPC = BS / 2, NV = (NPC + 15) / 16;
   typedef double V2 __attribute__((ext_vector_type(2)));
@@ -2516,14 +2518,15 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = ST6 ? 3 : 6, PC = ST12 ? (SV == 2 ? 4 : 1) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
+    constexpr int PF = ST6 ? 3 : (ORING ? 4 : 6), PC = ST12 ? (SV == 2 ? 4 : (ORING ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     double carry[B], carry_g = 0.0;
 #pragma unroll
     for (int k = 0; k < B; k++) carry[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
-    double fL[ST12 ? 1 : PF], fR[ST12 ? 1 : PF], fE[ST12 ? 1 : PF], cL[PC], cR[PC], cE[PC];   // the two operand rings
+    constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep + 2 compact rows is what 256 VGPRs hold next to the records)
+    double fL[FRING ? PF : 1], fR[FRING ? PF : 1], fE[FRING ? PF : 1], cL[PC], cR[PC], cE[PC];   // the two operand rings
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
     int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
@@ -2709,7 +2712,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       if (bq >= 0) q1 -= Dh;                             // ... and its between factor's six rows end its range in the compact table
       rp = (live && (!ST12 || ODD)) ? p0 : 0; nf = (live && (!ST12 || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
-      if constexpr (!ST12) {
+      if constexpr (FRING) {
 #pragma unroll
         for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
       }
@@ -2806,7 +2809,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           });
         }
       }
-      if constexpr (ODD) {
+      if constexpr (ODD && !ORING) {
         // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
         // only the block step of a state that has one waits for it
         for (int i = 0; i < nfm; i++) {
@@ -2823,7 +2826,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           grr = fma(-Rv, ev, grr);
         }
       }
-      if constexpr (!ST12)
+      if constexpr (FRING)
       for (int i0 = 0; i0 < nfm; i0 += PF) {             // full-width rows
 #pragma unroll
         for (int q = 0; q < PF; q++) {

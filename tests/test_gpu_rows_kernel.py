@@ -45,17 +45,26 @@ def test_pose3_structured_gp_records(chunk):
 
 
 def test_structured_records_reproduce_the_row_path():
-    """The same chain three ways: structured records alone; with ONE zero-weight velocity prior (a full-width row the
-    structured kernel fetches without a ring); with nine of them (too many: the row path).  An infinite sigma makes a prior
-    contribute exactly nothing: all three must agree to rounding (round 4: the record holds Jr^-1, J and the
+    """The same chain four ways: structured records alone; with ONE zero-weight velocity prior (a full-width row the
+    structured kernel fetches without a ring: k_fused_level0<2>); with nine of them (more than that variant takes: the records
+    next to a ring of full-width rows, <3> -- what chains with interpolated measurement factors run); and with the GP priors as
+    plain Jacobian rows (GPSLAM_PLAN_GP_ROWS).  An infinite sigma makes a prior
+    contribute exactly nothing: all four must agree to rounding (round 4: the record holds Jr^-1, J and the
     finite-difference block, the assembly wave forms the whitened columns -- U (sa J + sb F J) where K1's rows are
     sa U J + sb U (F J); the pure variant also takes the between factors as records and adds their rows before the pose
     priors', the variant with odd rows keeps them as compact rows behind the pose priors': same numbers, different order)."""
     N = 900
     res = []
-    for extra in (0, 1, 9):
+    import gpslam_amd
+    for extra in (0, 1, 9, -1):
         orc, dev, c = T.build_pair(O.POSE3, N, seed=77, vel_priors=False)
         if extra:
+            if extra < 0:      # the row path: a handle of its own with the plan bit, same factors as the first one
+                Qc = np.diag(0.01 + 0.02 * np.random.default_rng(77 + 77).random(6))
+                Qc[0, 1] = Qc[1, 0] = 0.003
+                dev = gpslam_amd.ChainSolver(O.POSE3, O.CHART_EXPMAP, plan=gpslam_amd.PLAN_GP_ROWS)
+                dev.set_qc(Qc)
+                dev.set_states(c["pose"], c["vel"])
             dev.clear_factors()
             d = 6
             dev.add_gp_priors(np.arange(N - 1), c["dt"])
@@ -64,15 +73,16 @@ def test_structured_records_reproduce_the_row_path():
             ident = O.pose3((0, 0, 0), (0, 0, 0))
             meas = np.stack([O.retract(O.POSE3, ident, O.local(O.POSE3, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
             dev.add_between(np.arange(N - 1), meas, np.full((N - 1, d), 0.02))
-            where = np.arange(5, 5 + 37 * extra, 37)
-            dev.add_vel_priors(where, np.zeros((extra, d)), np.full((extra, d), np.inf))
+            if extra > 0:
+                where = np.arange(5, 5 + 37 * extra, 37)
+                dev.add_vel_priors(where, np.zeros((extra, d)), np.full((extra, d), np.inf))
             dev.compile()
         info = dev.plan_info()
-        assert info["structured_gp"] == (0 if extra == 9 else 1) and info["rows_full"] == 12 * (N - 1) + 6 * extra
+        assert info["structured_gp"] == (0 if extra < 0 else 1) and info["rows_full"] == 12 * (N - 1) + 6 * max(extra, 0)
         for _ in range(3):
             dev.iterate_gn()
         res.append(dev.get_states())
-    for k in (1, 2):
+    for k in (1, 2, 3):
         assert np.abs(res[0][0] - res[k][0]).max() <= 1e-11 * max(1.0, np.abs(res[k][0]).max())
         assert np.abs(res[0][1] - res[k][1]).max() <= 1e-11 * max(1.0, np.abs(res[k][1]).max())
 
