@@ -1885,7 +1885,9 @@ struct FatSepPlan {
               std::vector<int> &fat_of, std::vector<int> &slot_of, std::vector<int> &counts) {
     N = N_; B = B_; ld = ld_; L = L_;
     if (N < 2) { err = "the segmented landmark elimination needs at least two states"; return false; }
-    for (int Ctry = (c_forced > 0 ? c_forced : 32);; Ctry *= 2) {
+    // one segmentation: cuts every Ctry states, every landmark on one admissible cut, balanced.  Returns whether every landmark
+    // found a cut; nb_out = the fat block size it needs (B + ld * the fullest cut's landmarks)
+    auto attempt = [&](int Ctry, int &nb_out) -> bool {
       cuts = make_cuts(N, Ctry, split);
       K = (int)cuts.size();
       counts.assign(K, 0);
@@ -1967,20 +1969,51 @@ struct FatSepPlan {
       }
       int mx = 0;
       for (int k = 0; k < K; k++) mx = std::max(mx, counts[k]);
-      const int nb = B + ld * mx;
-      if (ok && nb <= kFatMax) { C = Ctry; NB = (nb + 3) & ~3; if (NB > kFatMax) NB = kFatMax; break; }
-      if (c_forced > 0 || K <= 2) {
-        err = ok ? "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)"
-                 : (split ? "no segmentation of this piece keeps its private landmarks off the shared end blocks and the shared ones inside the "
-                            "end segments: the piece is too short for the landmarks' windows of visibility (use fewer, longer pieces)"
-                          : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists");
-        return false;
+      nb_out = B + ld * mx;
+      return ok;
+    };
+    const char *too_many = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)";
+    auto no_fit = [&]() {
+      return split ? "no segmentation of this piece keeps its private landmarks off the shared end blocks and the shared ones inside the "
+                     "end segments: the piece is too short for the landmarks' windows of visibility (use fewer, longer pieces)"
+                   : "a landmark is seen from more than two segments of the chain: no local-visibility segmentation exists";
+    };
+    // What a segmentation costs per state: the Schur complement of a segment is (NCP / 16)(NCP / 16 + 1) / 2 MFMA tiles per four
+    // rows, the border sweep NC columns (measured on the config-4 graph: 0.064 ms per tile and 0.025 ms per column and 1e6
+    // states) -- both set by the FULLEST cut, so a shorter segment with one landmark less on it can drop a whole tile row.
+    auto score = [&](int nb) {
+      const int nbr = std::min((nb + 3) & ~3, kFatMax), nc = 2 * nbr + 1, t = ((nc + 15) & ~15) / 16;
+      return 0.064 * (t * (t + 1) / 2) + 0.025 * nc;
+    };
+    int nb = 0;
+    if (c_forced > 0) {
+      const bool ok = attempt(c_forced, nb);
+      if (!ok || nb > kFatMax) { err = ok ? too_many : no_fit(); return false; }
+      C = c_forced;
+    } else {
+      // doubling finds the first segment length that fits; the lengths between it and half of it (in sixteenths of it, at least 16
+      // states) are then tried as well -- round 4: the config-4 graph fits at 256 (NB 36, 15 tiles) and at 208 (NB 28, 10 tiles:
+      // the solve phase 3.32 -> 2.58 ms).  Among equal costs the longest segments win (fewer fat blocks).
+      int Chi = 0;
+      for (int Ctry = 32;; Ctry *= 2) {
+        const bool ok = attempt(Ctry, nb);
+        if (ok && nb <= kFatMax) { Chi = Ctry; break; }
+        if (K <= 2) { err = ok ? too_many : no_fit(); return false; }
+        if (ok && nb > kFatMax) { err = too_many; return false; }   // longer segments only add landmarks per cut
       }
-      if (ok && nb > kFatMax) {   // longer segments only add landmarks per cut
-        err = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)";
-        return false;
+      int best = Chi;
+      double best_score = score(nb);
+      const int step = std::max(16, Chi / 16);
+      for (int Ctry = Chi - step; Ctry > Chi / 2; Ctry -= step) {
+        const bool ok = attempt(Ctry, nb);
+        if (!ok || nb > kFatMax) continue;
+        if (score(nb) < best_score - 1e-12) { best = Ctry; best_score = score(nb); }
       }
+      (void)attempt(best, nb);
+      C = best;
     }
+    NB = (nb + 3) & ~3;
+    if (NB > kFatMax) NB = kFatMax;
     NC = 2 * NB + 1;
     NCP = (NC + 15) & ~15;
     return true;

@@ -19,5 +19,9 @@ s.set_states(p["pose"], p["vel"])
 s.set_landmarks(p["landmarks"])
 st, ph = s.run_gn(3, timed=True)
 ph = ph / 3
+try:
+    print("plan:", s.segment_plan())
+except Exception as ex:
+    print("plan: n/a", ex)
 print("C4 N=%d L=%d ranges=%d window=%d  ms/iter: lin %.3f asm %.3f solve %.3f retract+err %.3f total %.3f -> %.3g state-iter/s (gen %.1fs, setup %.1fs)"
       % (N, len(p["landmarks"]), len(p["range_left"]), window, ph[0], ph[1], ph[2], ph[3], ph[4], N / (ph[4] * 1e-3), t1 - t0, t2 - t1))
