@@ -645,9 +645,12 @@ constexpr int fs_tri_row(int p) { int t = 0; while ((t + 1) * (t + 2) / 2 <= p) 
 #define GPS_FS_SWEEP_TILES 7
 #endif
 constexpr int kFsSweepTiles = GPS_FS_SWEEP_TILES;
+// (round 4: a border of at most 64 columns -- T16 <= 4, what the segment-length search now finds for config 4 -- is ONE sweep
+//  wave's worth of columns: wave 1 then only multiplies, instead of walking the sweep's instruction stream with no column to own)
+constexpr int fs_sweep_waves(int T16) { return T16 > 4 ? 2 : 1; }
 constexpr int fs_tile_owner(int T16, int p) {
   const int NT = T16 * (T16 + 1) / 2;
-  int load[4] = {kFsSweepTiles, kFsSweepTiles, 0, 0};
+  int load[4] = {kFsSweepTiles, fs_sweep_waves(T16) == 2 ? kFsSweepTiles : 0, 0, 0};
   int owner = 3;
   for (int q = 0; q <= p && q < NT; q++) {
     owner = 3;
@@ -942,7 +945,8 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
 #undef FSY_STAMP
 }
 
-// NCP == 16 * T16 exactly (the caller picks the instantiation); 2 NB + 1 <= 128 columns; 256 threads: waves 0, 1 sweep, 2, 3 multiply
+// NCP == 16 * T16 exactly (the caller picks the instantiation); 2 NB + 1 <= 128 columns; 256 threads: waves 0, 1 sweep (wave 1 only
+// when there are more than 64 columns), 2, 3 multiply
 template <int B, int T16, typename TR = double> __global__ void __launch_bounds__(256, 3) k_fs_sweep_syrk(FsArgs<double, TR> a) {
   constexpr int KC = 24, SPC = KC / B;                      // rows / states per chunk
   constexpr int NCP = 16 * T16;
@@ -958,7 +962,10 @@ template <int B, int T16, typename TR = double> __global__ void __launch_bounds_
   double *out = a.Aseg + (size_t)seg * NCP * NCP;
   switch (wv) {
     case 0: fs_sweep_role<B, T16, 0, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out); break;
-    case 1: fs_sweep_role<B, T16, 1, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out); break;
+    case 1:
+      if constexpr (fs_sweep_waves(T16) == 2) fs_sweep_role<B, T16, 1, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out);
+      else fs_mfma_role<T16, 1, LSP>(ring, nchunks, lane, out, NCP, a.dbg);
+      break;
     case 2: fs_mfma_role<T16, 2, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
     default: fs_mfma_role<T16, 3, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
   }
