@@ -754,20 +754,37 @@ GD M3<T> interp_rot3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T
 // ---- SE(3): Hint1..4 are block lower-triangular
 template <typename T, bool JAC> struct Interp6Out { BL6<T> H1, H2, H3, H4; };
 
+// gp (round 4): the structured record of the GaussianProcessPriorPose3 on the SAME interval, or null.  What the interpolator
+// shares with that prior -- Jinv = Jr^-1(r), Jinv Ad(h^-1) and the finite-difference block d(Jinv v2)/dr -- is three quarters of
+// its arithmetic (the difference quotient alone is twelve Jr^-1 evaluations) and is a function of the two states only, not of tau:
+// K1 has just written all three (kGps*: X, J = -Jinv Ad(h^-1), F), so the four or so measurement factors of an interval read them
+// instead of forming them again.  Same device functions on the same inputs: the same numbers.
 template <typename T, bool JAC>
-GD SE3<T> interp_pose3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, Interp6Out<T, JAC> &o) {
+GD SE3<T> interp_pose3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, Interp6Out<T, JAC> &o, const T *gp = nullptr) {
   const SE3<T> a = as_se3(p1), b = as_se3(p2);
   const SE3<T> h = se3_between(a, b);
   const V6<T> r = se3_log(h);                                          // :68
-  const JrK<T> k0 = jr_coefs(r.w);                                     // trig coefficients shared by Jinv and the FD block
-  const BL6<T> Jinv = se3_jrinv_k(k0, r);                              // :72
   const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+  BL6<T> Jinv, FD, tmp1;
+  if (gp != nullptr) {
+    auto m3 = [&](int off) { M3<T> m; for (int q = 0; q < 9; q++) m.m[q] = gp[off + q]; return m; };
+    Jinv.A = m3(0); Jinv.C = m3(9); Jinv.D = Jinv.A;                   // kGpsXA, kGpsXC
+    if (JAC) {
+      tmp1.A = m3(18); tmp1.C = m3(27); tmp1.D = tmp1.A;               // kGpsJA, kGpsJC
+      FD.A = m3(36); FD.C = m3(45); FD.D = m3(54);                     // kGpsFA, kGpsFC, kGpsFD
+    }
+  } else {
+    const JrK<T> k0 = jr_coefs(r.w);                                   // trig coefficients shared by Jinv and the FD block
+    Jinv = se3_jrinv_k(k0, r);                                         // :72
+    if (JAC) {
+      FD = se3_jrinv_times_x_fd_k(k0, r, u2);                          // (:84, :93) computed once
+      tmp1 = neg(Jinv * se3_adjoint(se3_inverse(h)));                  // Hlogmap Hcomp11 Hinv
+    }
+  }
   const V6<T> xi = k.l12 * u1 + k.p11 * r + k.p12 * (Jinv * u2);       // Lambda_1 r1 + Psi_1 r2, r1 = [0; v1], r2 = [r; Jinv v2]
   const SE3<T> ex = se3_exp(xi);
   if (JAC) {
     const BL6<T> He = se3_jr(xi);                                      // Hcomp22 * Hexp (:80)
-    const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);               // (:84, :93) computed once
-    const BL6<T> tmp1 = neg(Jinv * se3_adjoint(se3_inverse(h)));       // Hlogmap Hcomp11 Hinv
     const BL6<T> s1 = k.p11 * tmp1 + k.p12 * (FD * tmp1);              // Psi_1 * dr2_dT1
     o.H1 = se3_adjoint(se3_inverse(ex)) + He * s1;                     // Hcomp21 + ... (:87)
     o.H2 = k.l12 * He;                                                 // (:89)

@@ -844,6 +844,11 @@ template <typename T> struct MeasArgs {
   const double *sqi;   // count x rows x rows square-root information R (upper triangular, R^T R = cov^-1) of factors with a
                        // noiseModel::Gaussian instead of diagonal sigmas (multi-row kinds; `sig` is then ignored), or null
   int vw;              // Pose3 only: velocities are world-frame [v; w]
+  // Pose3, Jacobian pass (round 4): the structured records K1 has just written (kGps*) and the record index per left state (n + 2
+  // entries, -1: no GP prior on that interval) -- interp_pose3 takes Jinv, Jinv Ad(h^-1) and the finite-difference block of the
+  // interval from there instead of forming them again for every measurement factor on it.  Null: it forms them.
+  const T *gps = nullptr;
+  const int *gpidx = nullptr;
   const int *row0;
   T *rowLR, *rowE, *rowM;
   int *rowLm;
@@ -913,6 +918,13 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         lm = a.lm[f];
         for (int q = 0; q < a.ld; q++) pt[q] = T(a.lmk[(size_t)lm * a.ld + q] - org[q]);
       }
+      const T *gprec = nullptr;      // the interval's GaussianProcessPriorPose3 record, when K1 left one (see MeasArgs::gps)
+      if constexpr (MF == POSE3 && JAC && std::is_same<T, double>::value) {
+        if (a.gps != nullptr && two) {
+          const int g = a.gpidx[i];
+          if (g >= 0) gprec = a.gps + (size_t)g * kGpsLen;
+        }
+      }
       ICoef<T> kc = {T(0), T(0), T(0), T(0)};
       if (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_INTERP_PROJ)
         kc = {T(a.coef[4 * (size_t)f]), T(a.coef[4 * (size_t)f + 1]), T(a.coef[4 * (size_t)f + 2]), T(a.coef[4 * (size_t)f + 3])};
@@ -937,7 +949,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       if constexpr ((FK == FK_INTERP_RANGE || FK == FK_RANGE) && MF == POSE3) {
         // GPInterpolatedRangeFactorPose3::evaluateError, gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
         Interp6Out<T, JAC> o;
-        SE3<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o) : as_se3(p1);
+        SE3<T> pose = (FK == FK_INTERP_RANGE) ? interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o, gprec) : as_se3(p1);
         const SE3<T> S = as_se3(sens);
         const SE3<T> sp = has_sensor ? se3_compose(pose, S) : pose;
         const V3<T> pw = {pt[0], pt[1], pt[2]};
@@ -1041,7 +1053,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       } else if constexpr (FK == FK_INTERP_GPS) {
         // GPInterpolatedGPSFactorPose3::evaluateError, gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
         Interp6Out<T, JAC> o;
-        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
+        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o, gprec);
         const SE3<T> S = as_se3(sens);
         const SE3<T> sp = has_sensor ? se3_compose(pose, S) : pose;
         e[0] = sp.t.x - ms[0]; e[1] = sp.t.y - ms[1]; e[2] = sp.t.z - ms[2];
@@ -1061,7 +1073,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         // (throwCheirality = false): error = 2 fx, all Jacobians zero (:122-138).  CALIBRATION = Cal3_S2, or Cal3DS2 when the
         // entry carries distortion coefficients (radial k1, k2, tangential p1, p2: Cal3DS2_Base::uncalibrate)
         Interp6Out<T, JAC> o;
-        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o);
+        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o, gprec);
         const SE3<T> S = as_se3(sens);
         const SE3<T> cam = has_sensor ? se3_compose(pose, S) : pose;
         const V3<T> pw = {pt[0], pt[1], pt[2]};
