@@ -215,9 +215,20 @@ def test_fused_level0_with_measurement_rows_and_ragged_row_counts():
     p.update(prior_idx=fix, prior_pose=p["pose"][fix].copy(), prior_sig=np.full((len(fix), 6), 0.05))
     vfix = np.sort(rng.choice(N, 17, replace=False)).astype(np.int32)
     p.update(vprior_idx=vfix, vprior=p["vel"][vfix].copy(), vprior_sig=np.full((len(vfix), 6), 0.1))
-    for chunk in (0, 7):
-        orc = S.apply(p, O.Chain(O.POSE3))
-        dev = S.apply(p, gp.ChainSolver(O.POSE3, chunk=chunk))
+    for chunk in (0, 7, -7):
+        q = dict(p)
+        if chunk < 0:
+            # (round 4) some intervals lose their GP prior but keep their GPS factors: the measurement kernel reads the prior's
+            # record where there is one and forms Jr^-1, Jr^-1 Ad and the finite-difference block itself where there is none
+            # (odometry on every interval keeps those states determined)
+            full = S.pose3_gps_chain(N, per_interval=3, seed=4, keep_odometry=True)
+            q.update({k: full[k] for k in ("between_left", "between_meas", "between_sig")})
+            gone = (np.arange(len(q["gp_left"])) % 7) == 3      # isolated gaps: every state keeps a GP prior on one side
+            q["gp_left"], q["gp_dt"] = q["gp_left"][~gone], q["gp_dt"][~gone]
+        orc = S.apply(q, O.Chain(O.POSE3))
+        dev = S.apply(q, gp.ChainSolver(O.POSE3, chunk=abs(chunk)))
+        if chunk < 0:
+            assert dev.plan_info()["structured_gp"] == 1
         for it in range(4):
             rc0, s0 = orc.iterate_gn()
             rc1, s1 = dev.iterate_gn()
