@@ -2533,9 +2533,12 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     constexpr int PF = ST6 ? 3 : (ORING ? 4 : 6), PC = ST12 ? (SV == 2 ? 4 : (ORING ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
-    double carry[B], carry_g = 0.0;
+    // R^T R of the state's rows (and its share of the gradient): what opens the NEXT state's D -- kept where it is summed, the next
+    // state takes it over when it starts (round 4: a copy out at the end of a state and a copy in at the start of the next were
+    // 24 moves per state); dgpend: what write_img adds to the diagonal of the image (LM damping, identity of a padding block)
+    double RRacc[B], grr = 0.0, dgpend = 0.0;
 #pragma unroll
-    for (int k = 0; k < B; k++) carry[k] = 0.0;
+    for (int k = 0; k < B; k++) RRacc[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
     constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep + 2 compact rows is what 256 VGPRs hold next to the records)
     double fL[FRING ? PF : 1], fR[FRING ? PF : 1], fE[FRING ? PF : 1], cL[PC], cR[PC], cE[PC];   // the two operand rings
@@ -2738,10 +2741,10 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       for (int o = 32; o > 0; o >>= 1) { nfm = max(nfm, __shfl_xor(nfm, o, 64)); ncm = max(ncm, __shfl_xor(ncm, o, 64)); }
       nfm = __builtin_amdgcn_readfirstlane(nfm);
       ncm = __builtin_amdgcn_readfirstlane(ncm);
-      double RRacc[B], grr = 0.0;
 #pragma unroll
-      for (int k = 0; k < B; k++) { Dacc[k] = carry[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
-      gacc = carry_g;
+      for (int k = 0; k < B; k++) { Dacc[k] = RRacc[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
+      gacc = grr;
+      grr = 0.0;
       if constexpr (ST6) {                               // the d = 3 record: six rows from the lane's column of [A1 | U | A3 | U]
         const bool pc = r < 3;
         const double mLt = pc ? 1.0 : raw[6], mRt = pc ? 1.0 : raw[7], mLb = pc ? 0.0 : raw[8], mRb = pc ? 0.0 : raw[9];
@@ -2873,16 +2876,11 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       }
       {   // Levenberg-Marquardt damping on the diagonal of a real state's D; the padding blocks behind the chain's last state
           // (tail) are identities
+        // (added by write_img to the image's diagonal entry, one LDS read-modify-write of the lane's own row: as a select over the
+        //  twelve column registers it was 24 instructions per state, for a zero in every Gauss-Newton iteration)
         const bool pad = valid && (s + kimg) >= e && (s + kimg) < ep;
-        const double dg = live ? lambda : (pad ? 1.0 : 0.0);
-        if (live || pad) {
-#pragma unroll
-          for (int k = 0; k < B; k++) Dacc[k] += (k == r) ? dg : 0.0;
-        }
+        dgpend = live ? lambda : (pad ? 1.0 : 0.0);
       }
-#pragma unroll
-      for (int k = 0; k < B; k++) carry[k] = RRacc[k];
-      carry_g = grr;
       // the next state: its row range is known, open its rings; fetch the pointers of the state after it
       open_state(kimg + 1, rpn, rpnn, cpn, cpnn, gpn, bqn);
       rpn = rpnn; cpn = cpnn; gpn = gpnn; bqn = bqnn;
@@ -2896,6 +2894,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
         double *img = IMG + buf * 4 * IS;
 #pragma unroll
         for (int k = 0; k < B; k++) { img[ro + k] = Dacc[k]; img[ro + B * BP + k] = Oacc[k]; }
+        if (dgpend != 0.0) { const double t = img[ro + rr]; img[ro + rr] = t + dgpend; }   // D[r][r] += lambda (or the padding block's 1)
         img[co + 2 * B * BP] = gacc;
         if (u.gsave && valid) {          // (LM) the gradient: a state's own record, and what the chunk's last rows owe the next separator
           const int jg = s + kimg;
