@@ -116,6 +116,7 @@ struct gpslam_hip_handle {
   // block size 6 (SE(2), SO(3), 3-D linear chains): the GP priors as 32-double records (kGp3*) that k_assemble_ghost and
   // k_fused_level0<1, double, 6> decode; rows3: the launch being enqueued needs real rows after all (gpslam_hip_get_rows)
   bool struct3_ok = false, rows3 = false;
+  bool pure6 = false;       // block size 6: nothing but d = 3 GP records in the full-width row table (fused level 0 at every size)
   bool odd_many = false;    // SE(3) records: more other full-width rows than k_fused_level0<2> fetches without a ring (-> <3>)
   DevBuf gps, gpidx, dU, gsave2;
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
