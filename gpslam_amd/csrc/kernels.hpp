@@ -2530,7 +2530,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = ST6 ? 3 : (ORING ? 4 : 6), PC = ST12 ? (SV == 2 ? 4 : (ORING ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
+    constexpr int PF = ST6 ? 3 : (ORING ? (DG ? 6 : 4) : 6), PC = ST12 ? (SV == 2 ? 4 : (ORING ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     // R^T R of the state's rows (and its share of the gradient): what opens the NEXT state's D -- kept where it is summed, the next
@@ -2540,7 +2540,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
     for (int k = 0; k < B; k++) RRacc[k] = 0.0;
     double Dacc[B], Oacc[B], gacc;
-    constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep + 2 compact rows is what 256 VGPRs hold next to the records)
+    constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep -- 6 in the diagonal-Qc form -- + 2 compact rows is what 256 VGPRs hold next to the records)
     double fL[FRING ? PF : 1], fR[FRING ? PF : 1], fE[FRING ? PF : 1], cL[PC], cR[PC], cE[PC];   // the two operand rings
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
