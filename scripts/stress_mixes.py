@@ -1,0 +1,40 @@
+"""The synthetic factor mixes of the BASELINE configs at random small sizes against the oracle (3 Gauss-Newton iterations, 1e-9).
+   python scripts/stress_mixes.py [count] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch  # noqa: F401
+from oracle import oracle as O
+import test_gpu_parity as T
+import gpslam_amd
+from gpslam_amd import synthetic as S
+cnt = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+for t in range(cnt):
+    N = int(rng.integers(150, 1400))
+    which = t % 4
+    kw, okw = {}, {}
+    if which == 0:
+        p = S.pose3_gps_chain(N, per_interval=int(rng.integers(1, 5)), seed=t, keep_odometry=True)
+    elif which == 1:
+        p = S.rot3_attitude_chain(N, seed=t)
+    elif which == 2:
+        p = S.pose2_local_landmarks_chain(N, window=100, seed=t)
+        kw = dict(chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2); okw = dict(chart=O.CHART_FIRST_ORDER, landmark_dim=2)
+    else:
+        p = S.pose3_gps_chain(N, per_interval=2, seed=t, keep_odometry=False)
+        fix = np.arange(0, N, 15).astype(np.int32)      # (position fixes alone leave the attitude weakly observable)
+        p.update(prior_idx=fix, prior_pose=p["pose"][fix].copy(), prior_sig=np.full((len(fix), 6), 0.05))
+    orc = S.apply(p, O.Chain(p["kind"], **okw))
+    dev = S.apply(p, gpslam_amd.ChainSolver(p["kind"], **kw))
+    for it in range(3):
+        rc0, s0 = orc.iterate_gn(); rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0, (t, which, N, rc0, rc1)
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), (t, which, N, it, s0.error_after, s1.error_after)
+    T.states_close(p["kind"], *orc.get_states(), *dev.get_states(), 1e-9)
+    if "landmarks" in p:
+        l0, l1 = orc.get_landmarks(), dev.get_landmarks()
+        assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
+    print("ok mix %d N %d plan %s" % (which, N, dev.plan_info()))
+print("all %d mixes agree with the oracle" % cnt)
