@@ -1,4 +1,5 @@
-"""Random chain lengths through the default plan against the oracle (3 Gauss-Newton iterations, 1e-9): the shapes the fixed-size
+"""Random chain lengths through the default plan against the oracle (3 Gauss-Newton iterations, 1e-9, then 3 Levenberg-Marquardt
+iterations in lock step): the shapes the fixed-size
 tests do not name -- ragged last chunks, groups that are not full, chains barely longer than one level.
    python scripts/stress_sizes.py [count] [seed]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -19,7 +20,7 @@ for t in range(cnt):
     Qc = np.diag(0.01 + 0.02 * rng.random(d))
     if t % 3 == 0 and d > 1:
         Qc[0, 1] = Qc[1, 0] = 0.003
-    sol = []
+    sol, solvers = [], []
     for make in (lambda: O.Chain(kind, chart), lambda: gpslam_amd.ChainSolver(kind, chart)):
         s = make()
         s.set_qc(Qc); s.set_states(c["pose"], c["vel"])
@@ -36,6 +37,16 @@ for t in range(cnt):
         for _ in range(3):
             s.iterate_gn()
         sol.append(s.get_states())
+        solvers.append(s)
     T.states_close(kind, sol[0][0], sol[0][1], sol[1][0], sol[1][1], 1e-9)
+    # Levenberg-Marquardt from the initial values, in lock step: the same lambda schedule, the same errors
+    lam = [1e-2, 1e-2]
+    for s_ in solvers:
+        s_.set_states(c["pose"], c["vel"])
+    for it in range(3):
+        out = [s_.iterate_lm(lam[k])[:3] for k, s_ in enumerate(solvers)]
+        lam = [out[0][2], out[1][2]]
+        assert lam[0] == lam[1], (kind, N, it, lam)
+        assert abs(out[0][1].error_after - out[1][1].error_after) <= 1e-9 * max(1.0, abs(out[0][1].error_after)), (kind, N, it)
     print("ok kind %d N %d" % (kind, N))
 print("all %d sizes agree with the oracle" % cnt)

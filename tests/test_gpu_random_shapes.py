@@ -1,5 +1,5 @@
 """Shapes no fixed-size test names: random chain lengths of every manifold, and the BASELINE factor mixes at random small sizes,
-through the default plan against the oracle (scripts/stress_sizes.py, scripts/stress_mixes.py; 3 Gauss-Newton iterations, 1e-9)."""
+through the default plan against the oracle (scripts/stress_sizes.py: 3 Gauss-Newton iterations at 1e-9, then 3 Levenberg-Marquardt iterations in lock step; scripts/stress_mixes.py)."""
 import os
 import subprocess
 import sys
