@@ -44,6 +44,45 @@ def plan(N, L, touch, C):
     return cuts, fat_of, slot_of, counts
 
 
+def border_cost(nb, fat_max=80):
+    """What a segmentation costs per state (FatSepPlan::choose, round 4): the Schur complement of a segment is
+    (NCP / 16)(NCP / 16 + 1) / 2 MFMA tiles per four rows, the border sweep NC columns; 0.064 ms per tile and 0.025 ms per column
+    for 1e6 states on the config-4 graph.  nb = B + ld * (landmarks on the fullest cut)."""
+    nbr = min((nb + 3) & ~3, fat_max)
+    nc = 2 * nbr + 1
+    t = ((nc + 15) & ~15) // 16
+    return 0.064 * (t * (t + 1) // 2) + 0.025 * nc
+
+
+def choose_segment_length(N, L, touch, B, ld, fat_max=80):
+    """The search of FatSepPlan::choose with this model's (simpler, greedy) landmark-to-cut assignment: double from 32 until
+    every landmark's window fits two segments and the fullest cut fits a fat block, then try the lengths between that and half of
+    it in sixteenths of it (at least 16 states), longest first; a shorter length wins only with a strictly lower border cost.
+    Returns (C, nb) or None."""
+    def attempt(C):
+        p = plan(N, L, touch, C)
+        if p is None:
+            return None
+        return B + ld * max(p[3])
+    C = 32
+    while True:
+        nb = attempt(C)
+        if nb is not None and nb <= fat_max:
+            break
+        if len(make_cuts(N, C)) <= 2 or (nb is not None and nb > fat_max):
+            return None
+        C *= 2
+    best, best_nb, best_cost = C, nb, border_cost(nb, fat_max)
+    step = max(16, C // 16)
+    c = C - step
+    while c > C // 2:
+        nb = attempt(c)
+        if nb is not None and nb <= fat_max and border_cost(nb, fat_max) < best_cost - 1e-12:
+            best, best_nb, best_cost = c, nb, border_cost(nb, fat_max)
+        c -= step
+    return best, best_nb
+
+
 def fat_system(D, O, g, B, HLL, gL, ld, cuts, fat_of, slot_of, NB, lam=0.0):
     """Dense elimination of every segment interior -> (Dfat K x NB x NB, Ofat (K-1) x NB x NB [H[k+1, k]], gfat K x NB).
     Unused slots get a unit diagonal."""

@@ -44,6 +44,29 @@ def test_plan_rules():
     assert fat_of[1] == 1 and fat_of[2] == 2 and sum(counts) == 4
 
 
+def test_segment_length_search_finds_the_narrower_border():
+    """Config 4's geometry (one landmark per 20 states, each seen from a window of 200): the doubling stops at 256 states per segment
+    (the first length whose segments hold every window in two); the search behind it must find a length in (128, 256) with fewer
+    landmarks on the fullest cut -- a cheaper border -- and must never return a length that does not fit."""
+    N, every, window, B, ld = 40000, 20, 200, 6, 2
+    L = N // every
+    centre = [min(int((l + 0.5) * every), N - 1) for l in range(L)]
+    touch = [(max(c - window // 2, 0), min(c + window // 2, N - 1)) for c in centre]
+    C, nb = FM.choose_segment_length(N, L, touch, B, ld)
+    nb256 = B + ld * max(FM.plan(N, L, touch, 256)[3])
+    assert 128 < C < 256 and FM.plan(N, L, touch, C) is not None
+    assert FM.plan(N, L, touch, 128) is None                       # (a 200-state window does not fit two segments of 128)
+    assert nb < nb256 and FM.border_cost(nb) < FM.border_cost(nb256)
+    # (this model's greedy assignment leaves 12 landmarks on the fullest cut at 208 states where the library's balanced one leaves
+    #  11: the library's plan drops a whole 16-column panel there -- NB 36 -> 28, 15 -> 10 tiles -- which is what the cost prices)
+    panels = lambda v: (((2 * ((v + 3) & ~3) + 1) + 15) & ~15) // 16
+    assert panels(36) == 5 and panels(28) == 4 and FM.border_cost(28) < 0.8 * FM.border_cost(36)
+    # a graph whose first fit is already the cheapest keeps it: windows of 40 states fit segments of 32 + 32
+    touch2 = [(max(c - 20, 0), min(c + 20, N - 1)) for c in centre]
+    C2, nb2 = FM.choose_segment_length(N, L, touch2, B, ld)
+    assert FM.plan(N, L, touch2, C2) is not None and C2 <= 64
+
+
 def test_fat_elimination_and_cyclic_reduction_equal_dense_solve():
     for seed, (N, L, C, window) in enumerate([(40, 6, 8, 6), (97, 20, 16, 12), (33, 5, 64, 30), (64, 9, 7, 5)]):
         b, ld = 4, 2
