@@ -43,3 +43,43 @@ def test_between_record_columns_equal_the_weighted_jacobians():
         w = 1.0 / (0.01 + rng.random(6))
         L, R = between_lane_columns(make_between_record(H1, H2, w, rng.standard_normal(6)))
         assert np.array_equal(L, w[:, None] * H1) and np.array_equal(R, w[:, None] * H2)
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_diagonal_qc_zero_pattern_the_short_assembly_wave_relies_on(seed):
+    """k_fused_level0<1, double, 12, true> (a diagonal chol(Qc^-1)) skips products it knows to be zero: row q of the whitened L
+    meets, among the six velocity columns, only column 6 + q mod 6, and the ROTATION rows (q mod 6 < 3) of [L | R] are zero in every
+    translation column (3..5 of L; 3..5 and 9..11 of R) because X, J and F are block lower triangular.  The zeros must be EXACT
+    zeros of the lane arithmetic (the kernel's claim is "the same values"), and what it keeps must be the rest."""
+    rng = np.random.default_rng(300 + seed)
+    X, J, F = _blocks(rng)
+    U = np.diag(0.5 + rng.random(6))
+    dt = 0.05 + rng.random()
+    L, R, _ = lane_columns(make_record(X, J, F, rng.standard_normal(12), dt), U)      # L[q][c], R[q][c]: row q, column (lane) c
+    L0, R0 = reference_rows(X, J, F, U, dt)
+    assert np.abs(L - L0).max() <= 1e-12 * np.abs(L0).max() and np.abs(R - R0).max() <= 1e-12 * np.abs(R0).max()
+    keepL = np.zeros((12, 12), bool)
+    keepR = np.zeros((12, 12), bool)
+    for q in range(12):
+        rot = (q % 6) < 3
+        keepL[q, :3 if rot else 6] = True                     # pose columns: the rotation columns, and for a translation row all six
+        keepL[q, 6 + q % 6] = True                            # its own velocity column
+        keepR[q, :] = True
+        if rot:
+            keepR[q, 3:6] = False
+            keepR[q, 9:12] = False
+    assert np.all(L[~keepL] == 0.0) and np.all(R[~keepR] == 0.0)
+    assert np.all(L[keepL] != 0.0) and np.all(R[keepR] != 0.0)
+
+
+def test_between_record_rotation_rows_are_zero_in_the_translation_columns():
+    """[[A, 0], [C, A]] blocks: rows 0..2 of the whitened [H1 | H2] have nothing in columns 3..5 (the assembly wave gathers three
+    lanes for them instead of six)."""
+    from gp_record_model import between_lane_columns, make_between_record
+    rng = np.random.default_rng(9)
+    def bl():
+        A, C = rng.standard_normal((3, 3)), rng.standard_normal((3, 3))
+        return np.block([[A, np.zeros((3, 3))], [C, A]])
+    L, R = between_lane_columns(make_between_record(bl(), bl(), 1.0 / (0.01 + rng.random(6)), rng.standard_normal(6)))
+    assert np.all(L[:3, 3:6] == 0.0) and np.all(R[:3, 3:6] == 0.0)
+    assert np.all(L[:3, :3] != 0.0) and np.all(L[3:, :6] != 0.0)
