@@ -117,3 +117,50 @@ def between_lane_columns(rec):
             wi = rec[BW + i]                                   # row_bcast<i> of the lanes' weights
             L[i, r] = wi * Lc6[i]; R[i, r] = wi * Rc6[i]
     return L, R
+
+
+# ---- d = 3 manifolds (SE(2), SO(3), 3-D linear chains): the 32-double record kGp3* and the six rows its consumers form from it
+def whitening_scalars(dt):
+    """chol_upper(T^-1), T^-1 = [[12 / dt^3, -6 / dt^2], [-6 / dt^2, 4 / dt]] = [[sa, sb], [0, sc]]"""
+    sq = np.sqrt(dt)
+    return 3.4641016151377545870548926830117 / (dt * sq), -1.7320508075688772935274463415059 / sq, 1.0 / sq
+
+
+def make_record3(J1, J3, h2t, h2b, h4b, U, e, dt):
+    """H1 = [J1; 0], H2 = [h2t I; h2b I], H3 = [J3; 0], H4 = [0; h4b I]; e = the factor's 6-vector error (unwhitened)."""
+    sa, sb, sc = whitening_scalars(dt)
+    rec = np.zeros(32)
+    rec[0:9] = (U @ (sa * J1)).ravel()
+    rec[9:18] = (U @ (sa * J3)).ravel()
+    rec[18:21] = U @ (sa * e[:3] + sb * e[3:])
+    rec[21:24] = sc * (U @ e[3:])
+    rec[24:28] = [sa * h2t + sb * h2b, sb * h4b, sc * h2b, sc * h4b]
+    return rec
+
+
+def rows_from_record3(rec, U):
+    """The six whitened rows [L | R] (6 x 6 each) as k_assemble_ghost<6> / k_fused_level0<1, double, 6> form them, lane c < 6 holding
+    column c: a pose lane (c < 3) its column of A1 / A3, a velocity lane column c - 3 of U scaled by the record's coefficients."""
+    A1, A3 = rec[0:9].reshape(3, 3), rec[9:18].reshape(3, 3)
+    kLt, kRt, kLb, kRb = rec[24:28]
+    L, R = np.zeros((6, 6)), np.zeros((6, 6))
+    for c in range(6):
+        pc = c < 3
+        c3 = c if pc else c - 3
+        colL = A1[:, c3] if pc else U[:, c3]
+        colR = A3[:, c3] if pc else U[:, c3]
+        mLt, mRt, mLb, mRb = (1.0, 1.0, 0.0, 0.0) if pc else (kLt, kRt, kLb, kRb)
+        for i in range(6):
+            L[i, c] = (mLt if i < 3 else mLb) * colL[i % 3]
+            R[i, c] = (mRt if i < 3 else mRb) * colR[i % 3]
+    return L, R, rec[18:24].copy()
+
+
+def reference_rows3(J1, J3, h2t, h2b, h4b, U, e, dt):
+    """R_w [H1 H2 | H3 H4] and R_w e with R_w = chol_upper(Q^-1) = [[sa U, sb U], [0, sc U]]"""
+    sa, sb, sc = whitening_scalars(dt)
+    Z, I = np.zeros((3, 3)), np.eye(3)
+    Rw = np.block([[sa * U, sb * U], [Z, sc * U]])
+    Hl = np.block([[J1, h2t * I], [Z, h2b * I]])
+    Hr = np.block([[J3, Z], [Z, h4b * I]])
+    return Rw @ Hl, Rw @ Hr, Rw @ e

@@ -83,3 +83,27 @@ def test_between_record_rotation_rows_are_zero_in_the_translation_columns():
     L, R = between_lane_columns(make_between_record(bl(), bl(), 1.0 / (0.01 + rng.random(6)), rng.standard_normal(6)))
     assert np.all(L[:3, 3:6] == 0.0) and np.all(R[:3, 3:6] == 0.0)
     assert np.all(L[:3, :3] != 0.0) and np.all(L[3:, :6] != 0.0)
+
+
+@pytest.mark.parametrize("diag", [False, True])
+def test_d3_record_rows_equal_the_whitened_jacobian(diag):
+    """SE(2), SO(3) and 3-D linear chains (round 4): the 32-double record holds A1 = U sa J1, A3 = U sa J3, the whitened error and four
+    coefficients; its consumers rebuild the six whitened rows [L | R] lane by lane.  Against R_w [H1 H2 | H3 H4] with the constants of
+    GaussianProcessPriorLinear (h2t = -dt, h2b = -1, h4b = 1) and of the Lie-group priors (J1, J3 dense, the same constants)."""
+    from gp_record_model import make_record3, reference_rows3, rows_from_record3
+    rng = np.random.default_rng(17)
+    for trial in range(4):
+        dt = 0.05 + rng.random()
+        U = np.diag(0.5 + rng.random(3)) if diag else np.triu(rng.standard_normal((3, 3))) + 2 * np.eye(3)
+        if trial % 2:
+            J1, J3 = -np.eye(3), np.eye(3)                              # GaussianProcessPriorLinear.h:72-81
+        else:
+            J1, J3 = rng.standard_normal((3, 3)), rng.standard_normal((3, 3))   # -Jr^-1 Ad, Jr^-1 of the Lie-group priors
+        e = rng.standard_normal(6)
+        rec = make_record3(J1, J3, -dt, -1.0, 1.0, U, e, dt)
+        L, R, ew = rows_from_record3(rec, U)
+        L0, R0, e0 = reference_rows3(J1, J3, -dt, -1.0, 1.0, U, e, dt)
+        assert np.abs(L - L0).max() <= 1e-12 * np.abs(L0).max()
+        assert np.abs(R - R0).max() <= 1e-12 * np.abs(R0).max()
+        assert np.abs(ew - e0).max() <= 1e-12 * np.abs(e0).max()
+        assert np.all(L[3:, :3] == 0.0) and np.all(R[3:, :3] == 0.0)    # rows 3..5 have no pose part
