@@ -52,56 +52,86 @@ def _obj(src, objdir=None):
     return os.path.join(objdir or OBJDIR, os.path.splitext(src)[0] + ".o")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
-        return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
-
-
 def _src_deps(src):
     return [os.path.join(CSRC, src)] + [os.path.join(CSRC, d) for d in DEPS[src]] + [os.path.abspath(__file__)]
 
 
+def _digest(src, extra):
+    """Content hash of everything one object is made from: the source, the headers it includes, this file (the flags live
+    here) and the extra flags.  Round 5: modification times are not evidence -- an edit made WHILE hipcc runs leaves a
+    library newer than every source and built from none of them (it happened), and a `touch` makes a stale one look fresh."""
+    h = hashlib.sha256(" ".join(FLAGS + list(extra)).encode())
+    for d in _src_deps(src):
+        h.update(b"\0" + os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _recorded(path):
+    try:
+        with open(path + ".srchash") as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def _record(path, digest):
+    tmp = path + ".srchash.tmp%d" % os.getpid()
+    with open(tmp, "w") as f:
+        f.write(digest + "\n")
+    os.replace(tmp, path + ".srchash")
+
+
+def _lib_digest(extra):
+    return hashlib.sha256("".join(_digest(s, extra) for s in SOURCES).encode()).hexdigest()
+
+
 def up_to_date(extra=()):
-    objdir, lib = _paths(list(extra))
-    if not _stale(lib, [d for s in SOURCES for d in _src_deps(s)]):
-        return True            # the objects are intermediates: a library newer than every source needs none of them
-    if any(_stale(_obj(s, objdir), _src_deps(s)) for s in SOURCES):
-        return False
-    return not _stale(lib, [_obj(s, objdir) for s in SOURCES])
+    """True when the library on disk was linked from objects compiled from exactly the current sources and flags (the
+    digests are written next to the outputs, taken from the file contents read BEFORE the compiler starts)."""
+    extra = list(extra)
+    _objdir, lib = _paths(extra)
+    return os.path.exists(lib) and _recorded(lib) == _lib_digest(extra)
 
 
 def build(force=False, verbose=False, extra=None):
     """Returns the path of the library.  Several processes may call this at once (pytest children, one rank per GPU): the
     build runs under a file lock, every output is written to a temporary name and renamed into place."""
     if extra is None:
-        extra = os.environ.get("GPSLAM_HIPCC_FLAGS", "").split()   # e.g. -DGPS_ABLATE_ASM for the timing ablations of DESIGN.md
+        extra = os.environ.get("GPSLAM_HIPCC_FLAGS", "").split()   # A/B builds of kernel variants under their own file names
     objdir, lib = _paths(extra)
     if not force and up_to_date(extra):
         return lib
     os.makedirs(objdir, exist_ok=True)
-    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+    with open(os.path.join(LIBDIR, ".build.lock"), "a") as lock:
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and up_to_date(extra):        # another process built it while this one waited
             return lib
+        digests = {src: _digest(src, extra) for src in SOURCES}      # of the contents as they are NOW, before hipcc reads them
         procs = []
         for src in SOURCES:
-            if not force and not _stale(_obj(src, objdir), _src_deps(src)):
+            obj = _obj(src, objdir)
+            if not force and os.path.exists(obj) and _recorded(obj) == digests[src]:
                 continue
-            tmp = _obj(src, objdir) + ".tmp%d" % os.getpid()
+            tmp = obj + ".tmp%d" % os.getpid()
             cmd = [_hipcc()] + FLAGS + list(extra) + ["-c", os.path.join(CSRC, src), "-o", tmp]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, tmp, _obj(src, objdir), subprocess.Popen(cmd, cwd=CSRC)))
+            procs.append((cmd, tmp, obj, src, subprocess.Popen(cmd, cwd=CSRC)))
         failed = None
-        for cmd, tmp, final, p in procs:
+        for cmd, tmp, final, src, p in procs:
             if p.wait() != 0:
                 failed = failed or subprocess.CalledProcessError(p.returncode, cmd)
                 if os.path.exists(tmp):
                     os.remove(tmp)
+            elif _digest(src, extra) != digests[src]:
+                # the source changed under the compiler: the object is of neither version for sure -- drop it, build again
+                os.remove(tmp)
+                failed = failed or RuntimeError("%s (or a header it includes) was edited while it was being compiled; run the build again" % src)
             else:
                 os.replace(tmp, final)
+                _record(final, digests[src])
         if failed:
             raise failed
         tmp = lib + ".tmp%d" % os.getpid()
@@ -110,6 +140,7 @@ def build(force=False, verbose=False, extra=None):
             print(" ".join(link))
         subprocess.check_call(link, cwd=CSRC)
         os.replace(tmp, lib)
+        _record(lib, hashlib.sha256("".join(digests[s] for s in SOURCES).encode()).hexdigest())
     return lib
 
 

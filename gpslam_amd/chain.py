@@ -40,6 +40,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
     "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
+    "gpslam_hip_lm_decide",
 ]
 
 
@@ -56,7 +57,7 @@ class Config(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("error_before", C.c_double), ("error_after", C.c_double), ("delta_inf_norm", C.c_double),
                 ("lambda_", C.c_double), ("iterations", C.c_int32), ("status", C.c_int32),
-                ("accepted", C.c_int32), ("pad", C.c_int32)]
+                ("accepted", C.c_int32), ("trials", C.c_int32), ("last_trial_error", C.c_double)]
 
 
 class Params(C.Structure):
@@ -81,6 +82,23 @@ def load_library():
         _lib.gpslam_hip_last_error.restype = C.c_char_p
         _lib.gpslam_hip_stream.restype = C.c_void_p
     return _lib
+
+
+def lm_decide(s6, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
+              relative_error_tol=1e-5):
+    """gpslam_hip_lm_decide (host arithmetic, no GPU): one tryLambda decision from the reduced scalars of a trial.
+    Returns (accepted, done, new lambda)."""
+    p = Params()
+    load_library().gpslam_hip_default_params(C.byref(p))
+    p.use_lm = 1
+    p.lambda_factor, p.lambda_upper_bound, p.lambda_lower_bound = lambda_factor, lambda_upper_bound, lambda_lower_bound
+    p.min_model_fidelity, p.relative_error_tol = min_model_fidelity, relative_error_tol
+    s = (C.c_double * 6)(*[float(v) for v in s6])
+    lam_c, acc, done = C.c_double(lam), C.c_int32(0), C.c_int32(0)
+    rc = load_library().gpslam_hip_lm_decide(s, C.byref(p), C.byref(lam_c), C.byref(acc), C.byref(done))
+    if rc:
+        raise GpslamHipError("lm_decide: %d" % rc)
+    return bool(acc.value), bool(done.value), lam_c.value
 
 
 def _f64(a):

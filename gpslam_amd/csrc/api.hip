@@ -28,6 +28,35 @@ void gpslam_hip_default_params(gpslam_hip_params *p) {
   p->pad = 0;
 }
 
+// One LevenbergMarquardtOptimizer::tryLambda decision (GTSAM 4.0.x, as recalled: PARITY UNPINNED) from the scalars of a trial.
+// Host arithmetic only; every Levenberg-Marquardt loop of this repository -- gpslam_hip_iterate_lm, the sharded / split loops
+// of the C++ drivers and of the Python mirror -- takes its branch here, so that all of them follow one rule.
+int gpslam_hip_lm_decide(const double *s6, const gpslam_hip_params *p, double *lambda, int32_t *accepted, int32_t *done) {
+  if (!s6 || !p || !lambda || !accepted || !done) return GPSLAM_E_INVALID;
+  bool ok = false, stop_searching = false;
+  if (s6[5] == 0.0) {                                     // the damped system was solved (no indefinite pivot)
+    const double lin_change = 0.5 * s6[3] + 0.5 * (*lambda) * s6[4];   // linErr(0) - linErr(delta), (H + lambda I) delta = g
+    if (lin_change >= 0.0) {                              // "step is valid"
+      const double cost_change = s6[0] - s6[1];
+      if (lin_change > 1e-20) ok = cost_change / lin_change > p->min_model_fidelity;
+      // the small-cost-change stop: a trial that moves the cost by less than relativeErrorTol * error ends the search for a
+      // lambda whether or not it is kept
+      if (std::fabs(cost_change) < p->relative_error_tol * s6[0]) stop_searching = true;
+    }
+  }
+  if (ok) {                                               // decreaseLambda (useFixedLambdaFactor)
+    *lambda /= p->lambda_factor;
+    if (*lambda < p->lambda_lower_bound) *lambda = p->lambda_lower_bound;
+    *accepted = 1; *done = 1;
+    return 0;
+  }
+  *accepted = 0;
+  if (stop_searching) { *done = 1; return 0; }            // lambda and the values stay as they were
+  *lambda *= p->lambda_factor;                            // increaseLambda, then the bound (GTSAM's order)
+  *done = (*lambda >= p->lambda_upper_bound) ? 1 : 0;     // "giving up because cannot decrease error with maximum lambda"
+  return 0;
+}
+
 int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (!cfg || !out) return GPSLAM_E_INVALID;
   if (cfg->manifold < 0 || cfg->manifold > GPSLAM_ROT3_BIAS) return GPSLAM_E_INVALID;

@@ -736,6 +736,7 @@ class LevenbergMarquardtOptimizer : public NonlinearOptimizer {
     gpslam_hip_default_params(&p);
     p.use_lm = 1; p.lambda_factor = lm_.lambdaFactor; p.lambda_upper_bound = lm_.lambdaUpperBound;
     p.lambda_lower_bound = lm_.lambdaLowerBound; p.min_model_fidelity = lm_.minModelFidelity;
+    p.relative_error_tol = lm_.relativeErrorTol;       // tryLambda's small-cost-change stop uses the optimiser's relativeErrorTol
     gpslam_hip_stats st;
     detail::check(gpslam_hip_iterate_lm(s_.h, &lambda_, &p, &st), s_.h, "iterate_lm");
     error_ = st.error_after; iterations_++; dirty_ = true; stop_ = !st.accepted;

@@ -146,7 +146,8 @@ class ShardedDriver {
     gpslam_hip_stats st;
     std::fill((char *)&st, (char *)&st + sizeof(st), 0);
     bool accepted = false;
-    double err0 = 0.0, new_err = 0.0, dinf = 0.0;
+    int trials = 0;
+    double err0 = 0.0, new_err = 0.0, dinf = 0.0, last_trial = 0.0;
     for (;;) {
       for (ShardedRank &r : ranks_) r.lm_trial_phase1(*lambda);
       nccl_ok(ncclGroupStart(), "ncclGroupStart");
@@ -166,23 +167,13 @@ class ShardedDriver {
         s[2] = std::max(s[2], o[2]); s[5] = std::max(s[5], o[5]);
       }
       err0 = s[0];
-      bool ok_step = false;
-      if (s[5] == 0.0) {
-        const double lin_change = 0.5 * s[3] + 0.5 * (*lambda) * s[4];
-        if (lin_change >= 0.0) {
-          const double cost_change = s[0] - s[1];
-          const double fidelity = lin_change > 1e-20 ? cost_change / lin_change : 0.0;
-          if (fidelity > p.min_model_fidelity) { ok_step = true; new_err = s[1]; dinf = s[2]; }
-        }
-      }
-      if (ok_step) {
-        *lambda = std::max(*lambda / p.lambda_factor, p.lambda_lower_bound);
-        accepted = true;
-        break;
-      }
+      last_trial = s[5] == 0.0 ? s[1] : s[0];
+      trials++;
+      int32_t keep = 0, done = 0;
+      if (gpslam_hip_lm_decide(s, &p, lambda, &keep, &done) < 0) throw std::invalid_argument("gpslam_hip_lm_decide");   // the branch gpslam_hip_iterate_lm takes
+      if (keep) { accepted = true; new_err = s[1]; dinf = s[2]; break; }
       for (ShardedRank &r : ranks_) r.lm_reject();
-      if (*lambda >= p.lambda_upper_bound) break;
-      *lambda *= p.lambda_factor;
+      if (done) break;          // small cost change (lambda untouched) or lambda at its upper bound
     }
     st.error_before = err0;
     st.error_after = accepted ? new_err : err0;
@@ -190,6 +181,8 @@ class ShardedDriver {
     st.lambda = *lambda;
     st.iterations = 1;
     st.accepted = accepted ? 1 : 0;
+    st.trials = trials;
+    st.last_trial_error = last_trial;
     return st;
   }
 

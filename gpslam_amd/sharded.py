@@ -249,39 +249,24 @@ class ShardedSolver:
         m = torch.stack(allv).cpu().numpy()
         return np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
 
-    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
+                   relative_error_tol=1e-5):
         """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the ranks: the loop of gpslam_hip_iterate_lm
         with its three global sums made collective.  Every rank takes the same decisions (identical reduced scalars).
         Returns (stats dict, new lambda)."""
         be = self.backend
-        be.lm_begin()
-        accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
-        while True:
-            be.lm_trial_phase1(lam)
+
+        def trial(lam_):
+            be.lm_trial_phase1(lam_)
             self.exchange()
             be.iterate_phase2a()
             if self.landmark_buf is not None and self.dist is not None:
                 self.dist.all_reduce(self.landmark_buf, group=self.group)
-            s = self._reduce_lm_scalars(be.lm_trial_phase2())
-            err0 = float(s[0])
-            ok = False
-            if s[5] == 0.0:
-                lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
-                if lin_change >= 0.0:
-                    cost_change = s[0] - s[1]
-                    fidelity = cost_change / lin_change if lin_change > 1e-20 else 0.0
-                    if fidelity > min_model_fidelity:
-                        ok, new_err, dinf = True, float(s[1]), float(s[2])
-            if ok:
-                lam = max(lam / lambda_factor, lambda_lower_bound)
-                accepted = True
-                break
-            be.lm_reject()
-            if lam >= lambda_upper_bound:
-                break
-            lam *= lambda_factor
-        return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
-                    accepted=accepted), lam
+            return self._reduce_lm_scalars(be.lm_trial_phase2())
+
+        be.lm_begin()
+        return lm_loop(trial, be.lm_reject, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity,
+                       relative_error_tol)
 
     def run(self, iters, lam=0.0):
         """`iters` iterations back to back; statistics only for the last one."""
@@ -438,28 +423,20 @@ class SplitSolver:
         return dict(error_before=float(vals[0]), error_after=float(vals[1]), delta_inf_norm=float(vals[2]))
 
 
-    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+    def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
+                   relative_error_tol=1e-5):
         """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the pieces: ShardedSolver.iterate_lm with the
         split chain's trial steps.  Returns (stats dict, new lambda)."""
         be = self.backend
-        be.lm_begin()
-        accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
-        while True:
-            be.fs_lm_trial_phase1(lam)
+
+        def trial(lam_):
+            be.fs_lm_trial_phase1(lam_)
             self.exchange()
-            s = self._reduce_lm_scalars(be.fs_lm_trial_phase2())
-            ok, err0 = lm_decision(s, lam, min_model_fidelity)
-            if ok:
-                new_err, dinf = float(s[1]), float(s[2])
-                lam = max(lam / lambda_factor, lambda_lower_bound)
-                accepted = True
-                break
-            be.lm_reject()
-            if lam >= lambda_upper_bound:
-                break
-            lam *= lambda_factor
-        return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
-                    accepted=accepted), lam
+            return self._reduce_lm_scalars(be.fs_lm_trial_phase2())
+
+        be.lm_begin()
+        return lm_loop(trial, be.lm_reject, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity,
+                       relative_error_tol)
 
     def _reduce_lm_scalars(self, loc):
         if self.dist is None:
@@ -476,44 +453,54 @@ def reduce_lm_scalars(m):
     return np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
 
 
-def lm_decision(s, lam, min_model_fidelity=1e-3):
-    """(accept?, current error) from the reduced scalars of one trial -- the test of gpslam_hip_iterate_lm"""
-    if s[5] == 0.0:
-        lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
-        if lin_change >= 0.0:
-            fidelity = (s[0] - s[1]) / lin_change if lin_change > 1e-20 else 0.0
-            if fidelity > min_model_fidelity:
-                return True, float(s[0])
-    return False, float(s[0])
+def lm_loop(trial, reject, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
+            relative_error_tol=1e-5):
+    """The lambda search of one LevenbergMarquardtOptimizer::iterate() around `trial(lambda) -> reduced scalars`
+    (error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag) and `reject()` (restore the linearisation
+    point), for callers that own the loop because the scalars are sums over ranks / pieces.  Every branch is taken by
+    gpslam_hip_lm_decide -- the function gpslam_hip_iterate_lm itself uses (include/gpslam_hip.h) -- so all ranks, which hold
+    identical reduced scalars, follow the lambda schedule of the unsharded chain.  Returns (stats dict, new lambda)."""
+    from .chain import lm_decide
+    accepted, err0, new_err, dinf, trials, last = False, 0.0, 0.0, 0.0, 0, 0.0
+    while True:
+        s = trial(lam)
+        trials += 1
+        err0 = float(s[0])
+        last = float(s[1]) if s[5] == 0.0 else err0
+        accepted, done, lam = lm_decide(s, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity,
+                                        relative_error_tol)
+        if accepted:
+            new_err, dinf = float(s[1]), float(s[2])
+            break
+        reject()
+        if done:                       # small cost change (lambda untouched), or lambda at its upper bound
+            break
+    return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
+                accepted=accepted, trials=trials, last_trial_error=last), lam
 
 
-def iterate_pieces_lm(pieces, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3):
+def iterate_pieces_lm(pieces, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
+                      relative_error_tol=1e-5):
     """iterate_lm for P SplitSolvers living in ONE process (tests)."""
     P = len(pieces)
-    for sv in pieces:
-        sv.backend.lm_begin()
-    accepted, err0, new_err, dinf = False, 0.0, 0.0, 0.0
-    while True:
+
+    def trial(lam_):
         for sv in pieces:
-            sv.backend.fs_lm_trial_phase1(lam)
+            sv.backend.fs_lm_trial_phase1(lam_)
         for sv in pieces:
             rv = sv.recv.view(P, -1)
             for k in range(P):
                 rv[k].copy_(pieces[k].send)
-        s = reduce_lm_scalars(np.stack([sv.backend.fs_lm_trial_phase2() for sv in pieces]))
-        ok, err0 = lm_decision(s, lam, min_model_fidelity)
-        if ok:
-            new_err, dinf = float(s[1]), float(s[2])
-            lam = max(lam / lambda_factor, lambda_lower_bound)
-            accepted = True
-            break
+        return reduce_lm_scalars(np.stack([sv.backend.fs_lm_trial_phase2() for sv in pieces]))
+
+    def reject():
         for sv in pieces:
             sv.backend.lm_reject()
-        if lam >= lambda_upper_bound:
-            break
-        lam *= lambda_factor
-    return dict(error_before=err0, error_after=new_err if accepted else err0, delta_inf_norm=dinf if accepted else 0.0,
-                accepted=accepted), lam
+
+    for sv in pieces:
+        sv.backend.lm_begin()
+    return lm_loop(trial, reject, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity,
+                   relative_error_tol)
 
 
 def iterate_pieces(pieces, lam=0.0):

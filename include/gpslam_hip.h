@@ -109,7 +109,10 @@ typedef struct {
   int32_t iterations;
   int32_t status;
   int32_t accepted;
-  int32_t pad;
+  int32_t trials;         /* iterate_lm: lambdas tried by this call (0 elsewhere) */
+  double last_trial_error;/* iterate_lm: error at the last lambda tried, kept or not; lets a caller see how far the cost moved on a
+                           * trial that was not kept (a change at rounding level makes the fidelity test a ratio of two rounding
+                           * errors: tests compare lambda schedules only above it) */
 } gpslam_hip_stats;
 
 /* GaussNewtonParams / LevenbergMarquardtParams (GTSAM names; defaults = GTSAM 4.0 defaults) */
@@ -254,6 +257,18 @@ int gpslam_hip_error(gpslam_hip_handle *h, double *err);
 int gpslam_hip_iterate_gn(gpslam_hip_handle *h, gpslam_hip_stats *st);
 /* one LevenbergMarquardtOptimizer::iterate() */
 int gpslam_hip_iterate_lm(gpslam_hip_handle *h, double *lambda, const gpslam_hip_params *p, gpslam_hip_stats *st);
+/* The decision of ONE lambda trial of LevenbergMarquardtOptimizer::iterate() (GTSAM 4.0.x tryLambda, third party, as recalled --
+ * parity unpinned; the reference's call sites: matlab/PlazaPose2.m:210-226, matlab/GPAHRSexample.m:259-264), host arithmetic
+ * only, no handle.  s6 = {error at the linearisation point, error after the trial step, |delta|_inf, delta . g, |delta|^2,
+ * indefinite flag} (lm_trial_phase2's out6 after the reduction over ranks; iterate_lm's own scalars).
+ *   rho = (s6[0] - s6[1]) / (0.5 delta.g + 0.5 lambda |delta|^2) > minModelFidelity: *accepted = 1, lambda /= lambdaFactor
+ *       (not below lambdaLowerBound), *done = 1;
+ *   otherwise, |s6[0] - s6[1]| < relativeErrorTol * s6[0]:  *accepted = 0, *done = 1, lambda untouched ("relative cost
+ *       reduction is small": the search for a lambda ends, the values stay);
+ *   otherwise lambda *= lambdaFactor, *accepted = 0, *done = (lambda >= lambdaUpperBound).
+ * A caller that owns the loop (sharded / split handles) calls lm_reject whenever *accepted == 0 and tries again while
+ * *done == 0.  gpslam_hip_iterate_lm takes its branches here as well. */
+int gpslam_hip_lm_decide(const double *s6, const gpslam_hip_params *p, double *lambda, int32_t *accepted, int32_t *done);
 /* NonlinearOptimizer::optimize() with GTSAM's stop rules (+ optional |delta|_inf rule) */
 int gpslam_hip_optimize(gpslam_hip_handle *h, const gpslam_hip_params *p, gpslam_hip_stats *st);
 

@@ -209,7 +209,8 @@ typedef struct {
   int32_t iterations;      /* iterations performed by this call */
   int32_t status;          /* 0 ok, <0 failure (e.g. non-SPD block) */
   int32_t accepted;        /* LM: 1 if the step was accepted */
-  int32_t pad;
+  int32_t trials;          /* LM: lambdas tried by this call (0 from GN) */
+  double last_trial_error; /* LM: error at the last lambda tried, kept or not (error_before if no trial was valid) */
 } orc_stats;
 
 typedef struct {

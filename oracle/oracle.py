@@ -50,7 +50,7 @@ def lib():
 class Stats(C.Structure):
     _fields_ = [("error_before", C.c_double), ("error_after", C.c_double), ("delta_inf_norm", C.c_double),
                 ("lambda_", C.c_double), ("iterations", C.c_int32), ("status", C.c_int32),
-                ("accepted", C.c_int32), ("pad", C.c_int32)]
+                ("accepted", C.c_int32), ("trials", C.c_int32), ("last_trial_error", C.c_double)]
 
 
 class Params(C.Structure):

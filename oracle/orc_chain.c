@@ -950,9 +950,17 @@ int orc_chain_iterate_gn(orc_chain *c, orc_stats *st) {
 }
 
 /* LevenbergMarquardtOptimizer::iterate with the 4.0 defaults (diagonalDamping = false,
- * useFixedLambdaFactor = true): linearise once; loop { damp with lambda*I; solve; evaluate
- * rho = (err - newErr) / (linErr(0) - linErr(delta)); accept if rho > minModelFidelity and
- * lambda /= factor, else lambda *= factor until lambdaUpperBound }.  PARITY UNPINNED. */
+ * useFixedLambdaFactor = true): linearise once; then tryLambda until it says stop:
+ *   damp with lambda*I; solve; if solved and linErr(0) - linErr(delta) >= 0: retract, newErr,
+ *     costChange = err - newErr;
+ *     if the linear decrease > 1e-20: rho = costChange / linear decrease, success = rho > minModelFidelity;
+ *     if |costChange| < relativeErrorTol * err: stopSearchingLambda  (the small-cost-change stop, round 5);
+ *   success            -> keep the step, lambda /= factor (not below lambdaLowerBound), done;
+ *   else, not stopping -> lambda *= factor; done (giving up) if lambda >= lambdaUpperBound, else try again;
+ *   else (stopping)    -> done, lambda and the values untouched ("relative cost reduction is small").
+ * As recalled from GTSAM 4.0.x LevenbergMarquardtOptimizer::tryLambda (the reference's call sites:
+ * matlab/PlazaPose2.m:210-226, matlab/GPAHRSexample.m:259-264); GTSAM is not in this image: PARITY UNPINNED.
+ * st->trials counts the lambdas tried by this call. */
 int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_stats *st) {
   orc_neq q;
   memset(st, 0, sizeof(*st));
@@ -969,9 +977,11 @@ int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_
   if (nl > 0) orc_copy(nl, c->lmk, lm0);
   st->error_before = q.err;
   st->error_after = q.err;
+  st->last_trial_error = q.err;
   for (;;) {
     rc = bordered_solve(&q, *lambda, x, xl);
-    int ok = 0;
+    int ok = 0, stop_searching = 0;
+    st->trials++;
     if (rc == 0) {
       /* model decrease: linErr(0) - linErr(delta) = 0.5 delta.g + 0.5 lambda |delta|^2 since (H + lambda I) delta = g */
       double dg = orc_dot(nx, x, q.g) + (nl > 0 ? orc_dot(nl, xl, q.gL) : 0.0);
@@ -982,8 +992,8 @@ int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_
         apply_update(c, x, xl, &dinf);
         orc_chain_error(c, &new_err);
         double cost_change = q.err - new_err;
-        double fidelity = (lin_change > 1e-20) ? cost_change / lin_change : 0.0;
-        if (fidelity > p->min_model_fidelity) {
+        st->last_trial_error = new_err;
+        if (lin_change > 1e-20 && cost_change / lin_change > p->min_model_fidelity) {
           ok = 1;
           st->error_after = new_err;
           st->delta_inf_norm = dinf;
@@ -992,6 +1002,7 @@ int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_
           orc_copy(c->N * c->d, vel0, c->vel);
           if (nl > 0) orc_copy(nl, lm0, c->lmk);
         }
+        if (fabs(cost_change) < p->relative_error_tol * q.err) stop_searching = 1;
       }
     }
     if (ok) {
@@ -1000,8 +1011,9 @@ int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_
       st->accepted = 1;
       break;
     }
-    if (*lambda >= p->lambda_upper_bound) break;
+    if (stop_searching) break;
     *lambda *= p->lambda_factor;
+    if (*lambda >= p->lambda_upper_bound) break;
   }
   st->iterations = 1;
   st->lambda = *lambda;

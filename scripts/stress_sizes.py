@@ -1,5 +1,5 @@
-"""Random chain lengths through the default plan against the oracle (3 Gauss-Newton iterations, 1e-9, then 3 Levenberg-Marquardt
-iterations in lock step): the shapes the fixed-size
+"""Random chain lengths through the default plan against the oracle (3 Gauss-Newton iterations, 1e-9, then 6 Levenberg-Marquardt
+iterations in lock step, the last ones past convergence): the shapes the fixed-size
 tests do not name -- ragged last chunks, groups that are not full, chains barely longer than one level.
    python scripts/stress_sizes.py [count] [seed]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
@@ -7,6 +7,7 @@ import numpy as np
 import torch  # noqa: F401
 from oracle import oracle as O
 import test_gpu_parity as T
+import lm_lockstep as L
 import gpslam_amd
 cnt = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
@@ -40,13 +41,12 @@ for t in range(cnt):
         solvers.append(s)
     T.states_close(kind, sol[0][0], sol[0][1], sol[1][0], sol[1][1], 1e-9)
     # Levenberg-Marquardt from the initial values, in lock step: the same lambda schedule, the same errors
-    lam = [1e-2, 1e-2]
+    # (tests/lm_lockstep.py: exact while the cost moves; past convergence -- the last iterations here, on the linear chains
+    # from the third on -- one trial per call and lambda kept or divided once)
     for s_ in solvers:
         s_.set_states(c["pose"], c["vel"])
-    for it in range(3):
-        out = [s_.iterate_lm(lam[k])[:3] for k, s_ in enumerate(solvers)]
-        lam = [out[0][2], out[1][2]]
-        assert lam[0] == lam[1], (kind, N, it, lam)
-        assert abs(out[0][1].error_after - out[1][1].error_after) <= 1e-9 * max(1.0, abs(out[0][1].error_after)), (kind, N, it)
-    print("ok kind %d N %d" % (kind, N))
+    lam, n_noise = L.run(solvers[0], solvers[1], 1e-2, 6, tag=(kind, N))
+    sol = [s_.get_states() for s_ in solvers]
+    T.states_close(kind, sol[0][0], sol[0][1], sol[1][0], sol[1][1], 1e-9)
+    print("ok kind %d N %d (LM: lambda %.1e, %d of 6 calls decided at rounding level)" % (kind, N, lam, n_noise))
 print("all %d sizes agree with the oracle" % cnt)

@@ -38,12 +38,8 @@ def test_c5_rot3_attitude_levenberg_marquardt():
     orc = S.apply(p, O.Chain(O.ROT3))
     dev = S.apply(p, gpu().ChainSolver(O.ROT3))
     assert abs(orc.error() - dev.error()) <= 1e-10 * orc.error()
-    lam0 = lam1 = 1e-5
-    for it in range(4):
-        rc0, s0, lam0 = orc.iterate_lm(lam0)[:3]
-        rc1, s1, lam1 = dev.iterate_lm(lam1)[:3]
-        assert rc0 == 0 and rc1 == 0 and lam0 == lam1, it
-        assert abs(s0.error_after - s1.error_after) <= 1e-6 * max(1.0, s0.error_after), it
+    import lm_lockstep
+    lm_lockstep.run(orc, dev, 1e-5, 7, err_tol=1e-6)          # three calls more than round 4: into and past convergence
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
     states_close(O.ROT3, x0, v0, x1, v1, 1e-7)
 

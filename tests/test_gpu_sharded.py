@@ -133,11 +133,8 @@ def test_rccl_exchange_plumbing_world_size_one():
         send, recv = sharded.device_tensors(sp)
         svp = sharded.ShardedSolver(sp, send, recv, 0, 1, dist=dist, landmark_buf=sharded.landmark_tensor(sp))
         ref = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
-        lam_s = lam_r = 1e-5
-        for _ in range(7):
-            st_s, lam_s = svp.iterate_lm(lam_s)
-            rc, st_r, lam_r = ref.iterate_lm(lam_r)[:3]
-            assert lam_s == lam_r and abs(st_s["error_after"] - st_r.error_after) <= 1e-6 * st_r.error_after
+        import lm_lockstep
+        lm_lockstep.run(ref, svp, 1e-5, 7, err_tol=1e-6)
         m = plaza.metrics(problem, sp.get_states()[0], sp.get_landmarks())
         assert m["position_m"] < 0.25
     finally:
@@ -196,15 +193,15 @@ def test_sharded_chain_with_landmarks_matches_unsharded():
     single.close()
 
 
-def _lm_iterate_emulated(ranks, lam, factor=10.0, upper=1e5, lower=0.0, fidelity_min=1e-3):
-    """ShardedSolver.iterate_lm with the collectives done by hand across P handles that share one GPU."""
+def _lm_iterate_emulated(ranks, lam):
+    """ShardedSolver.iterate_lm with the collectives done by hand across P handles that share one GPU: the caller-owned loop
+    of include/gpslam_hip.h around gpslam_hip_lm_decide (gpslam_amd/sharded.py: lm_loop)."""
+    from gpslam_amd import sharded
     P = len(ranks)
-    for r in ranks:
-        r[0].lm_begin()
-    accepted, err0, new_err = False, 0.0, 0.0
-    while True:
+
+    def trial(lam_):
         for r in ranks:
-            r[0].lm_trial_phase1(lam)
+            r[0].lm_trial_phase1(lam_)
         for r in ranks:
             rv = r[2].view(P, -1)
             for k in range(P):
@@ -215,26 +212,15 @@ def _lm_iterate_emulated(ranks, lam, factor=10.0, upper=1e5, lower=0.0, fidelity
             total = sum(r[3].clone() for r in ranks)
             for r in ranks:
                 r[3].copy_(total)
-        m = np.stack([r[0].lm_trial_phase2() for r in ranks])
-        s = np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
-        err0 = s[0]
-        ok = False
-        if s[5] == 0.0:
-            lin_change = 0.5 * s[3] + 0.5 * lam * s[4]
-            if lin_change >= 0.0:
-                fid = (s[0] - s[1]) / lin_change if lin_change > 1e-20 else 0.0
-                if fid > fidelity_min:
-                    ok, new_err = True, s[1]
-        if ok:
-            lam = max(lam / factor, lower)
-            accepted = True
-            break
+        return sharded.reduce_lm_scalars(np.stack([r[0].lm_trial_phase2() for r in ranks]))
+
+    def reject():
         for r in ranks:
             r[0].lm_reject()
-        if lam >= upper:
-            break
-        lam *= factor
-    return err0, (new_err if accepted else err0), lam, accepted
+
+    for r in ranks:
+        r[0].lm_begin()
+    return sharded.lm_loop(trial, reject, lam)
 
 
 @pytest.mark.parametrize("P", [2, 3])
@@ -257,15 +243,8 @@ def test_sharded_levenberg_marquardt_matches_unsharded(P):
         sharded.apply_local(sharded.local_problem(problem, r, P), s)
         send, recv = sharded.device_tensors(s)
         ranks.append((s, send, recv, sharded.landmark_tensor(s)))
-    lam_s = lam_r = 1e-5
-    for it in range(6):
-        e0, e1, lam_s, acc = _lm_iterate_emulated(ranks, lam_s)
-        out = ref.iterate_lm(lam_r)
-        rc, st, lam_r = out[0], out[1], out[2]
-        assert rc == 0 and acc == bool(st.accepted)
-        assert lam_s == lam_r, (it, lam_s, lam_r)
-        assert abs(e0 - st.error_before) <= 1e-7 * st.error_before
-        assert abs(e1 - st.error_after) <= 1e-6 * st.error_after, (it, e1, st.error_after)
+    import lm_lockstep
+    lm_lockstep.run(ref, lambda lam_: _lm_iterate_emulated(ranks, lam_), 1e-5, 6, err_tol=1e-6)
     pose = np.vstack([r[0].get_states()[0] for r in ranks])
     assert np.abs(pose - ref.get_states()[0]).max() <= 1e-5
     for r in ranks:

@@ -90,18 +90,12 @@ def test_split_levenberg_marquardt_follows_the_unsplit_lambda_schedule(P):
     problem = S.pose2_local_landmarks_chain(2400, L=120, window=160, anchor=0)
     locals_, pieces = _pieces(problem, P)
     ref = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True))
-    lam_s = lam_r = 1e-5
-    lams = []
-    for it in range(8):
-        got, lam_s = sharded.iterate_pieces_lm(pieces, lam_s)
-        _, st, lam_r = ref.iterate_lm(lam_r)[:3]
-        lams.append(lam_r)
-        assert lam_s == lam_r and got["accepted"] == bool(st.accepted)
-        assert abs(got["error_before"] - st.error_before) <= 1e-8 * max(1.0, st.error_before)
-        assert abs(got["error_after"] - st.error_after) <= 1e-6 * max(1.0, st.error_after)
-        if st.error_before - st.error_after <= 1e-7 * st.error_before:
-            break           # converged: from here on accept / reject is decided by the rounding of err - newErr
-    assert len(lams) >= 4
+    import lm_lockstep
+    lam, lams = 1e-5, []
+    for it in range(10):
+        st, _, lam, _ = lm_lockstep.step(ref, lambda lam_: sharded.iterate_pieces_lm(pieces, lam_), lam, err_tol=1e-6, tag=it)
+        lams.append(lam)
+    assert len(set(lams)) >= 4
     pose, vel, lmk = _merged(problem, locals_, pieces)
     p1, v1 = ref.get_states()
     assert np.abs(pose - p1).max() <= 1e-7 * max(1.0, np.abs(p1).max())

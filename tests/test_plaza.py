@@ -101,11 +101,7 @@ def test_gpu_plaza2_linear_first_iterations_match_oracle(data):
     """useLinearPose2 = true (PlazaPose2.m:28): OdometryFactor2DLinear + GaussianProcessPriorLinear<3> +
     GPInterpolatedRangeFactor2DLinear.  LM crawls here (79 iterations); the first ones are compared in lock step."""
     p, orc, dev = _pair(data, linear=True)
-    lam0 = lam1 = 1e-5
+    import lm_lockstep
     assert abs(orc.error() - dev.error()) <= 1e-9 * orc.error()
-    for _ in range(6):
-        rc0, st0, lam0 = orc.iterate_lm(lam0)[:3]
-        rc1, st1, lam1 = dev.iterate_lm(lam1)[:3]
-        assert rc0 == 0 and rc1 == 0 and lam0 == lam1
-        assert abs(st0.error_after - st1.error_after) <= 1e-7 * st0.error_after
+    lm_lockstep.run(orc, dev, 1e-5, 6, err_tol=1e-7)
     assert np.abs(orc.get_states()[0] - dev.get_states()[0]).max() <= 1e-6
