@@ -47,11 +47,16 @@ def step(ref, dev, lam, err_tol=1e-9, lambda_factor=10.0, tag=None, ref_kwargs=N
 
 
 def run(ref, dev, lam, iters, **kw):
-    """`iters` calls in lock step; returns (final lambda, number of calls whose decision was rounding noise)."""
-    n_noise = 0
+    """`iters` calls in lock step; returns (final lambda, number of calls whose decision was rounding noise, slack).
+    slack = the sum of |delta|_inf over the steps either side KEPT on a noise decision: where one side keeps such a step and the
+    other does not, their values part by exactly that much (a Newton step at the optimum, i.e. the solver's own rounding floor),
+    so a state comparison after the run is  |a - b| <= tolerance * scale + slack."""
+    n_noise, slack = 0, 0.0
     for it in range(iters):
         kw_it = dict(kw)
         kw_it["tag"] = (kw.get("tag"), it)
-        _, _, lam, noise = step(ref, dev, lam, **kw_it)
-        n_noise += int(noise)
-    return lam, n_noise
+        s0, s1, lam, noise = step(ref, dev, lam, **kw_it)
+        if noise:
+            n_noise += 1
+            slack += sum(s["delta_inf_norm"] for s in (s0, s1) if s["accepted"])
+    return lam, n_noise, slack

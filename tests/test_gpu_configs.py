@@ -39,9 +39,9 @@ def test_c5_rot3_attitude_levenberg_marquardt():
     dev = S.apply(p, gpu().ChainSolver(O.ROT3))
     assert abs(orc.error() - dev.error()) <= 1e-10 * orc.error()
     import lm_lockstep
-    lm_lockstep.run(orc, dev, 1e-5, 7, err_tol=1e-6)          # three calls more than round 4: into and past convergence
+    _, _, slack = lm_lockstep.run(orc, dev, 1e-5, 7, err_tol=1e-6)          # three calls more than round 4: into and past convergence
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
-    states_close(O.ROT3, x0, v0, x1, v1, 1e-7)
+    states_close(O.ROT3, x0, v0, x1, v1, 1e-7 + 2 * slack)
 
 
 # ---- BASELINE config 5 AT ITS SIZE (1e6 states).  The oracle does not go there; what can be checked at full size are the

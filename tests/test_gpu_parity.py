@@ -213,6 +213,22 @@ def test_gauss_newton_iterations_match_oracle(kind):
     states_close(kind, p0, v0, p1, v1, 1e-9)
 
 
+@pytest.mark.parametrize("kind", KINDS, ids=[NAMES[k] for k in KINDS])
+def test_levenberg_marquardt_past_convergence_matches_oracle(kind):
+    """LevenbergMarquardtOptimizer::iterate() in lock step INTO and PAST convergence on every manifold (round 4's red case was a
+    linear chain on its third call): the lambda schedule, accept flags and trial counts are identical while the cost moves; once
+    a call moves it by rounding only, GTSAM's small-cost-change stop ends the call after one trial on both sides and lambda
+    stays or is divided once (tests/lm_lockstep.py).  Nine calls: the linear chains converge in two."""
+    import lm_lockstep
+    orc, dev, _ = build_pair(kind, 300, seed=61 + kind)
+    lam, n_noise, slack = lm_lockstep.run(orc, dev, 1e-2, 9, tag=NAMES[kind])
+    assert n_noise >= 2, (NAMES[kind], n_noise)        # the run really went past convergence
+    assert lam <= 1e-2 and slack <= 1e-6               # lambda never climbed on noise (it did before the stop rule: 1e-5 -> 1e4)
+    p0, v0 = orc.get_states()
+    p1, v1 = dev.get_states()
+    states_close(kind, p0, v0, p1, v1, 1e-9 + 2 * slack)
+
+
 @pytest.mark.parametrize("chart", [O.CHART_EXPMAP, O.CHART_FIRST_ORDER])
 def test_pose2_chart_option_matches_oracle(chart):
     """Pose2 with both charts (Expmap = GTSAM's SLOW_BUT_CORRECT_EXPMAP, first-order = GTSAM's default)."""

@@ -137,9 +137,9 @@ def test_set_qc_after_compile_reaches_the_structured_path():
 def test_pose3_levenberg_marquardt_through_rows_kernel():
     orc, dev, c = T.build_pair(O.POSE3, 300, seed=9, chunk=13)
     import lm_lockstep
-    lm_lockstep.run(orc, dev, 1e-3, 7)               # the lambda schedule is decided by the same comparisons; two calls past convergence
+    _, _, slack = lm_lockstep.run(orc, dev, 1e-3, 7)   # the lambda schedule is decided by the same comparisons; two calls past convergence
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
-    T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9)
+    T.states_close(O.POSE3, x0, v0, x1, v1, 1e-9 + 2 * slack)
 
 
 def test_rows_kernel_matches_block_tridiag_solve_api():

@@ -64,3 +64,52 @@ def test_algorithmic_byte_figures_match_the_survey():
     ab = S.algorithmic_bytes_per_state(S.POSE3)
     assert ab["linearize"] == 2552            # 144 + 8 + 96 + 2304
     assert S.algorithmic_bytes_per_state(S.POSE2)["linearize"] == 680
+
+
+def test_lm_decide_follows_trylambda():
+    """gpslam_hip_lm_decide (host arithmetic of the C ABI, no GPU): the three exits of GTSAM 4.0's tryLambda -- keep the step,
+    stop on a small cost change with lambda untouched, or raise lambda up to the bound -- in GTSAM's order (increase, THEN test the
+    bound).  s6 = (error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag)."""
+    from gpslam_amd.chain import lm_decide
+    # a good step: rho = (100 - 60) / (0.5 * 90 + 0.5 * 1e-3 * 4) > 1e-3
+    assert lm_decide([100.0, 60.0, 0.5, 90.0, 4.0, 0.0], 1e-3) == (True, True, 1e-4)
+    # cost went UP by a lot: not kept, not done, lambda * 10
+    acc, done, lam = lm_decide([100.0, 160.0, 0.5, 90.0, 4.0, 0.0], 1e-3)
+    assert (acc, done) == (False, False) and abs(lam - 1e-2) < 1e-18
+    # ... and gives up when the RAISED lambda reaches the upper bound (the lambda that was just tried is below it)
+    acc, done, lam = lm_decide([100.0, 160.0, 0.5, 90.0, 4.0, 0.0], 1e4)
+    assert (acc, done) == (False, True) and lam == 1e5
+    # converged: the cost moves by rounding only (|change| < 1e-5 * error).  Negative fidelity: not kept, lambda UNTOUCHED, done
+    assert lm_decide([100.0, 100.0 + 1e-11, 1e-9, 1e-13, 1e-18, 0.0], 1e-3) == (False, True, 1e-3)
+    # ... positive fidelity on the same noise: kept (GTSAM keeps a successful step whatever its size), lambda / 10
+    assert lm_decide([100.0, 100.0 - 1e-11, 1e-9, 1e-13, 1e-18, 0.0], 1e-3) == (True, True, 1e-4)
+    # the linear model did not decrease (<= 1e-20): never successful; small change -> stop
+    assert lm_decide([100.0, 100.0, 0.0, 0.0, 0.0, 0.0], 1e-3) == (False, True, 1e-3)
+    # an indefinite damped system: no step to judge, lambda goes up
+    acc, done, lam = lm_decide([100.0, 0.0, 0.0, 0.0, 0.0, 1.0], 1e-3)
+    assert (acc, done) == (False, False) and abs(lam - 1e-2) < 1e-18
+    # lambdaLowerBound holds
+    assert lm_decide([100.0, 60.0, 0.5, 90.0, 4.0, 0.0], 1e-3, lambda_lower_bound=5e-4) == (True, True, 5e-4)
+
+
+def test_oracle_lm_stops_searching_on_a_small_cost_change():
+    """The oracle's LevenbergMarquardtOptimizer::iterate past convergence (round 4: without tryLambda's small-cost-change stop it
+    climbed 1e-5 -> 1e4 on rounding noise): one trial per call, lambda kept or divided once, the values where they were."""
+    from gpslam_amd import synthetic as S
+    from oracle import oracle as O
+    ch = S.apply(S.linear_chain(400), O.Chain(O.LINEAR3))
+    lam, seen = 1e-5, []
+    for it in range(7):
+        rc, st, new = ch.iterate_lm(lam)[:3]
+        assert rc == 0
+        moved = abs(st.error_before - st.last_trial_error)
+        if moved <= 1e-10 * max(1.0, st.error_before):
+            assert st.trials == 1 and new == (lam / 10.0 if st.accepted else lam), (it, st.trials, lam, new)
+            seen.append(it)
+        lam = new
+    assert len(seen) >= 3 and lam <= 1e-5
+    # far from the optimum nothing changes: rejected steps still raise lambda (trial counts above one)
+    p = S.pose3_chain(60)
+    ch = S.apply(p, O.Chain(O.POSE3))
+    rc, st, lam2 = ch.iterate_lm(1e-9)[:3]
+    assert rc == 0 and st.accepted == 1 and st.trials >= 1 and st.last_trial_error == st.error_after
