@@ -35,7 +35,14 @@ FUSED_FMA_FLOPS_PER_STATE = (900 + 411) * 64 * 2 // 4
 # profiles/<round>_pmc.json; explicit-size L2->fabric request counters TCC_EA0_RDREQ_{32B,64B,128B}, WRREQ{,_64B}).
 PMC_FILE = os.path.join(ROOT, "profiles", "latest_pmc.json")
 PMC_KEYS = [("k_gp<double, 3, 0",), ("k_assemble",), ("k_fused_level0", "k_chunk_forward_rows", "k_chunk_forward<double, 12, true>"),
-            ("k_chunk_backward_rows<12>", "k_chunk_backward<double, 12"), ("k_retract<double, 3>",)]
+            ("k_chunk_backward_rows<12>", "k_chunk_backward<double, 12"), ("k_retract<double, 3>",), ("k_lin<double, 3",)]
+PMC_KLIN = 5
+# K1 as it runs now (round 4: records, not rows) -- its own algorithmic bytes per state, stated in DESIGN.md section 6:
+#   read  144 (state, each counted once) + 8 (dt) + 96 (BetweenFactor<Pose3> measured) + 48 (its sigmas)          = 296 B
+#   write 640 (the 80-double GP record: Jr^-1, J, the finite-difference block, whitened error, coefficients)
+#         + 384 (the 48-double between record)                                                                       = 1024 B
+K1_RECORD_BYTES_PER_STATE = 296 + 1024
+K1_GP_RECORD_BYTES_PER_STATE = 152 + 640           # the GP prior alone (gpslam_hip_time_kernel(0): k_gp)
 
 
 def pmc_traffic(which, n_states):
@@ -52,6 +59,11 @@ def pmc_traffic(which, n_states):
             if best is None or grid > best[0]:
                 best = (grid, float(c["ea_read_bytes"] + c["ea_write_bytes"]))
     return best[1] if best else None
+
+
+def frac_or_none(bytes_, ms):
+    """bytes / time as a fraction of the HBM peak, or None without a byte count"""
+    return (bytes_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (bytes_ and ms > 0) else None
 
 
 def cpu_baseline(problem, iters=3, threads=1):
@@ -158,6 +170,10 @@ def extras(gpslam_amd, S, device):
              "seconds_to_convergence_device": (it6 * ms * 1e-3) if it6 else None,
              "states_converged_per_sec": (1000000 / (it6 * ms * 1e-3)) if it6 else None,
              "hbm_roofline_frac_whole_iteration": 7.8e3 * 1000000 / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             # north_star's "batched-Jacobian kernel >= 50 % of HBM roofline" at THIS size, on the record-form bytes K1 moves
+             # (296 B read + 1024 B written per state)
+             "k1_frac_of_hbm_record_form": K1_RECORD_BYTES_PER_STATE * 1000000 / (float(ph[0]) / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+             "level0_frac_of_hbm_sec8d": 4800 * 1000000 / (s.last_level0_ms() / 5 * 1e-3) / 1e9 / HBM_PEAK_GBS,
              "note": "target: >= 1e6 Pose3 GP states converged in < 1 s (BASELINE north_star names 8 GPUs; this is one)"}
         s.close()
         return r
@@ -514,7 +530,8 @@ def main():
         fused = (kms[1] == 0.0)                    # the assembly runs inside the level-0 elimination (k_fused_level0)
         if fused:
             names[2] = "k_fused_level0 (K3 + K4 level 0: assembly + elimination)"
-        alg = [ab["linearize"] * (N - 1),          # K1: read state + dt, write e + H1..H4 (whitened rows)
+        sec8d_k1 = ab["linearize"] * (N - 1)       # read state + dt, write the materialised e + H1..H4 (2552 B per factor)
+        alg = [K1_GP_RECORD_BYTES_PER_STATE * (N - 1),   # K1 as it is: read state + dt, write the 80-double record (the Jacobian rows are never written)
                (blocks + blocks) * N,              # K3: read rows, write blocks
                # K4 forward: SURVEY 8(d) single-pass solve figure (conservative); fused: read the rows, write the factors
                (blocks + blocks if fused else ab["solve"]) * N,
@@ -566,12 +583,17 @@ def main():
             "kernel_ms": {names[i]: float(kms[i]) for i in live},
             # every hot kernel against the same roof: algorithmic GB/s (SURVEY 8(d) bytes per unit) and, where the
             # committed counter passes cover it, the HBM bytes it really moved per launch
-            "kernel_roofline": {n: {"algorithmic_GBps": alg[i] / (kms[i] * 1e-3) / 1e9,
+            "kernel_roofline": {n: {"algorithmic_bytes_per_launch": alg[i],
+                                    "algorithmic_GBps": alg[i] / (kms[i] * 1e-3) / 1e9,
                                     "frac_of_peak": alg[i] / (kms[i] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    "moved_GBps": (pmc_traffic(i, N) / (kms[i] * 1e-3) / 1e9) if pmc_traffic(i, N) else None}
+                                    "moved_bytes_per_launch": pmc_traffic(i, N),
+                                    "moved_GBps": (pmc_traffic(i, N) / (kms[i] * 1e-3) / 1e9) if pmc_traffic(i, N) else None,
+                                    "frac_moved": frac_or_none(pmc_traffic(i, N), kms[i])}
                                 for i, n in enumerate(names) if i in live},
             "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom, N),
+                         # the same launch on the bytes the counters saw it move (below the SURVEY 8(d) figure: records instead of rows)
+                         "frac_moved": frac_or_none(pmc_traffic(dom, N), l0_in_iter if (dom == 2 and l0_in_iter > 0) else kms[dom]),
                          "traffic_source": "rocprofv3 --pmc TCC_EA0_RDREQ_{32B,64B,128B}_sum / TCC_EA0_WRREQ{,_64B}_sum, "
                                            "profiles/latest_pmc.json (bytes per launch, same workload)",
                          "algorithmic_bytes_per_launch": alg[dom],
@@ -597,11 +619,22 @@ def main():
         }
         # K1 (batched evaluateError + Jacobians of the GP priors) standalone and inside an iteration, where it shares the
         # launch (k_lin) with the prior and between factors
-        k1_bytes = alg[0] + (2 * 96 + 6 * 104) * (N - 1)           # + BetweenFactor<Pose3> rows (k_simple, compact table)
+        lin_ms = float(phase[0]) / 3
+        k1_bytes = K1_RECORD_BYTES_PER_STATE * (N - 1)
+        k1_moved = pmc_traffic(PMC_KLIN, N)
         out["k1_batched_jacobian"] = {
-            "standalone_ms": float(kms[0]), "standalone_frac_of_hbm": alg[0] / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "in_iteration_linearize_phase_ms": float(phase[0]) / 3,
-            "in_iteration_frac_of_hbm": k1_bytes / (float(phase[0]) / 3 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "standalone_ms": float(kms[0]),
+            "standalone_frac_of_hbm": alg[0] / (kms[0] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "in_iteration_linearize_phase_ms": lin_ms,
+            "record_form_bytes_per_state": K1_RECORD_BYTES_PER_STATE,
+            "in_iteration_frac_of_hbm": k1_bytes / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "in_iteration_moved_bytes": k1_moved,
+            "in_iteration_frac_moved": frac_or_none(k1_moved, lin_ms),
+            "north_star_k1_at_least_half_of_hbm": bool(k1_bytes / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS >= 0.5),
+            "sec8d_materialised_jacobian_bytes_not_written": sec8d_k1 + (2 * 96 + 6 * 104) * (N - 1),
+            "sec8d_note": "SURVEY 8(d) prices K1 at 2552 B per GP prior (+ 816 B per between factor) for the API-faithful materialised e + H1..H4; "
+                          "since round 4 K1 writes 80- and 48-double records and the assembly wave of the next launch forms the columns, so those "
+                          "bytes are moved by NO kernel and no fraction is quoted on them",
             "note": ""}
         if collective_ms is not None:
             out["collective"] = {"kind": "ncclAllGather of the interface records (RCCL), one per iteration", "bytes_per_rank": int(send.numel() * send.element_size()),
@@ -611,7 +644,9 @@ def main():
                                         "measured_ms_per_step": ms_per_step, "measured_over_projected": ms_per_step / projected_ms,
                                         "note": "the same two phases per rank with the all-gather replaced by device copies of the rank's own "
                                                 "record (max over ranks): measured - projected = what the collective and the rank skew cost"}
-        out["k1_batched_jacobian"]["note"] = "in-iteration = k_lin: GP priors + priors + between factors in one launch, algorithmic bytes of all of them"
+        out["k1_batched_jacobian"]["note"] = ("in-iteration = k_lin: GP priors + priors + between factors in one launch; fractions are on the RECORD-form "
+                                              "bytes (read 296 B, write 1024 B per state: DESIGN.md section 6) and on the counter traffic of "
+                                              "profiles/latest_pmc.json; standalone = the GP priors alone (k_gp, 152 + 640 B)")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(problem, threads=1)
             out["cpu_baseline_all_cores"] = cpu_baseline(problem, threads=0)

@@ -121,6 +121,7 @@ struct gpslam_hip_handle {
   DevBuf gps, gpidx, dU, gsave2;
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
   bool btw_rec_ok = false;
+  bool gp_rows_lead = true, btw_rows_trail = true;   // compile(): the row placement the record decoders rely on holds
   DevBuf brec, btwidx;
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use

@@ -57,8 +57,6 @@ template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jaco
   // fa: the landmark's own cut, fb: the next cut, fc: the previous one.  Null: walk the landmark's whole row list (fs_state_lm)
   const int *fa_ptr, *fa_it, *fb_ptr, *fb_it, *fc_ptr, *fc_it;
   T *lmMM;                           // L x ld x ld: sum over a landmark's rows of m m^T (+ its priors' weights on the diagonal), k_fs_lm_terms
-  long long *probe;                  // (builds with -DGPS_FSY_DBG, GPSLAM_FSY_PROBE=1) cycle totals per phase of sweep wave 0 of segment 0
-  int dbg;                           // timing ablations of k_fs_sweep_syrk (builds with -DGPS_FSY_DBG only; GPSLAM_FSY_DBG bits: 1 no MFMA, 2 no steps, 4 no requests after the first chunk)
   const double *pri_meas, *pri_sig;   // inputs are fp64 whatever T is (kernels.hpp, GpArgs)
   const double *lmk;
   const int *rowptr, *rowLm;
@@ -723,17 +721,13 @@ template <int T16, int WV, int LSP> struct FsTiles {
 };
 
 template <int T16, int WV, int LSP>
-__device__ __forceinline__ void fs_mfma_role(const double *ring, int nchunks, int lane, double *out, int NCP, int dbg = 0) {
+__device__ __forceinline__ void fs_mfma_role(const double *ring, int nchunks, int lane, double *out, int NCP) {
   constexpr int KC = 24;
   FsTiles<T16, WV, LSP> tl;
   tl.init();
 #pragma unroll 1
   for (int i = 0; i <= nchunks; i++) {
-#ifdef GPS_FSY_DBG
-    if (i >= 1 && !(dbg & 1)) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
-#else
     if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
-#endif
     lds_barrier();
   }
   tl.store(out, NCP, lane);
@@ -816,14 +810,6 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
     ent_desc(e0n1, e1n1, pk_n1, src_n1);
     ent_vals(src0);
   }
-#ifdef GPS_FSY_DBG
-  long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tp = 0;
-  const bool prb = a.probe != nullptr && seg == 0 && SWV == 0;
-#define FSY_STAMP(k) if (prb) { const long long tn = (long long)__builtin_readcyclecounter(); ph[k] += tn - tp; tp = tn; }
-  if (prb) tp = (long long)__builtin_readcyclecounter();
-#else
-#define FSY_STAMP(k)
-#endif
 #pragma unroll 1
   for (int i = 0; i <= nchunks; i++) {
     if (i < nchunks) {
@@ -876,23 +862,14 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
           for (int r = 0; r < B; r++) slot[(row + r) * LSP + col] = gp[r];
         }
       }
-      FSY_STAMP(0)
       fs_wave_sync();
-      FSY_STAMP(1)
       // ---- requests of the chunks ahead (in flight under this chunk's steps)
-#ifdef GPS_FSY_DBG
-      if (!(a.dbg & 4)) {
-#endif
       stage(i + 1);
       pk_cur = pk_n1; e0c = e0n1; e1c = e1n1;
       ent_vals(src_n1);
       e0n1 = e0n2; e1n1 = e1n2;
       ent_desc(e0n1, e1n1, pk_n1, src_n1);
       ent_range(i + 3, e0n2, e1n2);
-#ifdef GPS_FSY_DBG
-      }
-#endif
-      FSY_STAMP(2)
       // ---- the steps.  The matrices are the same for every column: lane j of each 16-lane row holds elements j, 16 + j, ...
       // of [W_s | -E_{s-1}] (MQ registers) and every multiply-add takes its matrix element by DPP row broadcast
       // (v_fmac_f64_dpp, dpp.hpp fmac_mat).  The first version read them from LDS as broadcast operands, two per ds_read_b128
@@ -900,11 +877,7 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
 #pragma unroll
       for (int t = 0; t < SPC; t++) {
         const int jj = i * SPC + t;
-#ifdef GPS_FSY_DBG
-        if (jj < n && !(a.dbg & 2)) {
-#else
         if (jj < n) {
-#endif
           double Mr[MQ];
 #pragma unroll
           for (int q = 0; q < MQ; q++) Mr[q] = Fs[t * MP + q * 16 + (lane & 15)];
@@ -928,21 +901,10 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
         }
       }
     }
-    FSY_STAMP(3)
-#ifdef GPS_FSY_DBG
-    if (i >= 1 && !(a.dbg & 1)) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
-#else
     if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
-#endif
-    FSY_STAMP(4)
     lds_barrier();
-    FSY_STAMP(5)
   }
   tl.store(out, NCP, lane);
-#ifdef GPS_FSY_DBG
-  if (prb && lane == 0) { for (int k = 0; k < 6; k++) a.probe[k] = ph[k]; a.probe[6] = nchunks; }
-#endif
-#undef FSY_STAMP
 }
 
 // NCP == 16 * T16 exactly (the caller picks the instantiation); 2 NB + 1 <= 128 columns; 256 threads: waves 0, 1 sweep (wave 1 only
@@ -964,10 +926,10 @@ template <int B, int T16, typename TR = double> __global__ void __launch_bounds_
     case 0: fs_sweep_role<B, T16, 0, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out); break;
     case 1:
       if constexpr (fs_sweep_waves(T16) == 2) fs_sweep_role<B, T16, 1, TR>(a, ring, FsAll, seg, lane, cutL, j0, n, nchunks, out);
-      else fs_mfma_role<T16, 1, LSP>(ring, nchunks, lane, out, NCP, a.dbg);
+      else fs_mfma_role<T16, 1, LSP>(ring, nchunks, lane, out, NCP);
       break;
-    case 2: fs_mfma_role<T16, 2, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
-    default: fs_mfma_role<T16, 3, LSP>(ring, nchunks, lane, out, NCP, a.dbg); break;
+    case 2: fs_mfma_role<T16, 2, LSP>(ring, nchunks, lane, out, NCP); break;
+    default: fs_mfma_role<T16, 3, LSP>(ring, nchunks, lane, out, NCP); break;
   }
 }
 
@@ -1265,13 +1227,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
   for (int i = tid; i < NB; i += nt) X[i * XS + 2 * NB] = a.gfat[(size_t)m * NB + i];
   __syncthreads();
-#ifdef GPS_FSY_DBG
-  if (!(a.dbg & 8))
-#endif
   fat_factor_panel4(Lm, X, Ld, NB, LS, XS, XS, a.flag);
-#ifdef GPS_FSY_DBG
-  if (a.dbg & 16) return;
-#endif
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
     a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);

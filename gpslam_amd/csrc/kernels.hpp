@@ -2635,14 +2635,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     };
     double Lcol[ST12 ? B : 1], Rcol[ST12 ? B : 1], newl = 0.0;
     auto reconstruct = [&]() {
-#ifdef GPS_ABLATE_REC   /* timing ablation only (wrong results): the record's operands are fetched, the columns are not formed */
-      if constexpr (ST12) {
-#pragma unroll
-        for (int k = 0; k < B; k++) { Lcol[k] = raw[k]; Rcol[k] = raw[(k + 9) % NRAW]; }
-        newl = -raw[15];
-        return;
-      }
-#endif
       if constexpr (ST12) {
         double X6[6], J6[6], P3[6], P1[6];
         // the lane's role, recomputed per state from an opaque copy of its index: as loop invariants the masks and the unit
@@ -2703,20 +2695,12 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     auto ldf = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = rp + min(i, max(nf - 1, 0));
       const TR *row = u.rowLR + (size_t)rho * 2 * B;
-#ifdef GPS_ABLATE_LOAD   /* timing ablation only: no row traffic */
-      Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
-#else
       Lv = (double)row[rr]; Rv = (double)row[B + rr]; ev = (double)u.rowE[rho];
-#endif
     };
     auto ldc = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = cp + min(i, max(nc - 1, 0));
       const TR *row = u.rowC + (size_t)rho * B;
-#ifdef GPS_ABLATE_LOAD
-      Lv = (double)rho; Rv = Lv; ev = Lv; (void)row;
-#else
       Lv = (double)row[rc]; Rv = (double)row[Dh + rc]; ev = (double)u.rowCE[rho];
-#endif
     };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
     auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g, int bqv) {
@@ -2752,11 +2736,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
         static_for<0, 6>([&](auto ii) {
           constexpr int i = decltype(ii)::value;
           const double Lv = (i < 3 ? mLt : mLb) * raw[i % 3], Rv = (i < 3 ? mRt : mRb) * raw[3 + i % 3];
-#ifndef GPS_ABLATE_ASM
           fmac_gather<B>(Dacc, Lv, Lv);
           fmac_gather<B>(Oacc, Lv, Rv);
           fmac_gather<B>(RRacc, Rv, Rv);
-#endif
           fmac_bcast2<i>(gacc, grr, ne3, Lv, Rv);
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -2770,7 +2752,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           if constexpr (q == 8) ldraw(kimg + 1, gpn);
           if constexpr (q == 5) ldbtw();                 // this state's between record: wanted right behind these twelve rows
           const double Lv = Lcol[q], Rv = Rcol[q];
-#ifndef GPS_ABLATE_ASM
           if constexpr (DG) {
             // row q of L: the pose columns and velocity column 6 + q mod 6.  X, J and F are block lower triangular ([[A, 0], [C, D]]),
             // so the rotation rows (q mod 6 < 3) of the whitened [L | R] are zero in every translation column (3..5, and 9..11 of R)
@@ -2789,7 +2770,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
             fmac_gather<B>(Oacc, Lv, Rv);
             fmac_gather<B>(RRacc, Rv, Rv);
           }
-#endif
           fmac_bcast2<q>(gacc, grr, newl, Lv, Rv);       // g -= e[q] L[q][r],  carry_g -= e[q] R[q][r]
           __builtin_amdgcn_sched_barrier(0);
         });
@@ -2832,11 +2812,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           ldf(i, Lv, Rv, ev);
           const bool ok = i < nf;
           Lv = ok ? Lv : 0.0; Rv = ok ? Rv : 0.0; ev = ok ? ev : 0.0;
-#ifndef GPS_ABLATE_ASM
           fmac_gather<B>(Dacc, Lv, Lv);
           fmac_gather<B>(Oacc, Lv, Rv);
           fmac_gather<B>(RRacc, Rv, Rv);
-#endif
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
         }
@@ -2848,11 +2826,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           const int i = i0 + q;
           const bool ok = i < nf;
           const double Lv = ok ? fL[q] : 0.0, Rv = ok ? fR[q] : 0.0, ev = ok ? fE[q] : 0.0;
-#ifndef GPS_ABLATE_ASM   /* timing ablation only (wrong results): the assembly wave keeps its loads and barriers, skips the sums */
           fmac_gather<B>(Dacc, Lv, Lv);     // D[r][k] += L[k] L[r]: the row's element of lane k fused into the multiply-add
           fmac_gather<B>(Oacc, Lv, Rv);     // O[r][k] += L[k] R[r]
           fmac_gather<B>(RRacc, Rv, Rv);    // carry[r][k] += R[k] R[r]
-#endif
           gacc = fma(-Lv, ev, gacc);
           grr = fma(-Rv, ev, grr);
           ldf(i + PF, fL[q], fR[q], fE[q]);
@@ -2958,7 +2934,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     const bool live = j < e, lastb = (j == e - 1);
     const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
     double invs = 1.0;
-#ifndef GPS_ABLATE_ELIM   /* timing ablation only (wrong results): the elimination wave keeps its LDS traffic, stores and barriers */
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
       const double piv = row_bcast<k>(Dr[k]);
@@ -2980,7 +2955,6 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       fmac_self_n<k, B>(Fr, nmp);
       fmac_self1<k>(gr, nmp);
     });
-#endif
     // a pivot that is not positive (or not a number) leaves a reciprocal that is not positive in its own lane: one test per
     // block step instead of one per pivot (lanes without a row keep 1)
     if (!(invs > 0.0) && live) *a.flag = 1;
@@ -3000,11 +2974,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       OUTR[oc + 2 * B * B] = gr;
     }
     lds_barrier();                       // step t
-#ifdef GPS_ABLATE_STORE   /* timing ablation only: the factor records stay in LDS */
-    if (live && j < 0) {
-#else
     if (live) {
-#endif
       V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
 #pragma unroll
       for (int q = 0; q < NV; q++) {
@@ -3017,27 +2987,23 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     for (int k = 0; k < B; k++) Dn[k] = nxt[ro + k];
     gn = nxt[co + 2 * B * BP];
     __builtin_amdgcn_sched_barrier(0);
-#ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
       fmac_bcast_n<i, B, true>(Dn, Or, ol);
       fmac_bcast2<i, true>(gn, as_, gr, ol, gg);
     });
-#endif
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Dn[k]));
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) Fn[k] = 0.0;
-#ifndef GPS_ABLATE_ELIM
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
       const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
       fmac_bcast_n<i, B, true>(Fn, Fr, ol);        // F_{j+1} -= O_j[r][i] * (row i of V_j)
       fmac_bcast_n<i, B, true>(Ar, Fr, gg);        // D_sep   -= G_j[r][i] * (row i of V_j)
     });
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));

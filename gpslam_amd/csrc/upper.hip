@@ -37,12 +37,6 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
   const int cnt = min(G, a.n - base);
   const bool rowlane = r < B;
   const int rr = rowlane ? r : 0;            // idle lanes shadow row 0 (they never store)
-  int pi = 0;
-  auto probe = [&]() {                        // GPSLAM_UPPER_PROBE=1: shader-clock stamps of workgroup 0 (diagnostics)
-    if (a.probe != nullptr && blockIdx.x == 0 && tid == 0) { a.probe[pi] = (long long)__builtin_readcyclecounter(); a.probe[pi == 0 ? 62 : 63] = (long long)wall_clock64(); }
-    pi++;
-  };
-  probe();
 
   // ---- the group's records (+ the addends the level below sent them) into LDS, as 16-byte pieces; every load of the
   // thread is issued before the first one is consumed (a load per loop iteration had exposed a memory round trip each:
@@ -79,7 +73,6 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
     }
   }
   __syncthreads();
-  probe();
 
   // A sub-level costs what ONE lane's instruction stream costs (an elimination is VALU-issue bound even for a single wave), so
   // the panel of a pair is spread over as many DPP rows as the sub-level leaves free: two (CrStepWide: G / 2 pairs on NW * 4
@@ -99,17 +92,14 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
       const bool bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr, quad ? row : half);
       if (bad && act) *a.flag = 1;             // (the lane of the failed pivot reports)
     }
-    probe();
     lds_barrier();                            // every pair has read its operands
     if (act && rowlane) st.store_own(REC, s, j, r, quad ? row : half);
     lds_barrier();                            // the pairs' own blocks are in place: now the right neighbours' shares
-    probe();
     if (act && rowlane) {
       if constexpr (quad) { if (row < 2) st.add_right(REC, n, r, row); }
       else { if (half == 0) st.add_right(REC, n, r); }
     }
     lds_barrier();
-    probe();
   };
   if constexpr ((G >> 1) > NW) sub_level(0, std::false_type{});
   else sub_level(0, std::true_type{});
@@ -204,11 +194,7 @@ template <int B, int G> int fwd_b(bool top, const UpFwdArgs &a0, hipStream_t st)
   static bool ready_tab[kMaxDevices] = {};   // (the attribute is per kernel and per device: set once each, to the one size)
   bool *ready = ready_slot(ready_tab);
   hipError_t e;
-  UpFwdArgs a = a0;
-  static long long *dprobe = nullptr;
-  static const bool want_probe = getenv("GPSLAM_UPPER_PROBE") && atoi(getenv("GPSLAM_UPPER_PROBE")) != 0;
-  if (want_probe && !dprobe) (void)hipMalloc((void **)&dprobe, 64 * sizeof(long long));
-  a.probe = want_probe ? dprobe : nullptr;
+  const UpFwdArgs &a = a0;
   if (!ready || !*ready) {
     if ((e = allow_lds(&k_multi_forward<B, G, true>, DM::lds_fwd(true))) != hipSuccess) return (int)e;
     if ((e = allow_lds(&k_multi_forward<B, G, false>, DM::lds_fwd(false))) != hipSuccess) return (int)e;
@@ -217,14 +203,6 @@ template <int B, int G> int fwd_b(bool top, const UpFwdArgs &a0, hipStream_t st)
   const int groups = (a.n + G - 1) / G;
   if (top) k_multi_forward<B, G, true><<<dim3(1), dim3(DM::NT), DM::lds_fwd(true), st>>>(a);
   else k_multi_forward<B, G, false><<<dim3(groups), dim3(DM::NT), DM::lds_fwd(false), st>>>(a);
-  if (a.probe) {   // diagnostics only: synchronous
-    long long hp[64];
-    (void)hipStreamSynchronize(st);
-    (void)hipMemcpy(hp, dprobe, sizeof(hp), hipMemcpyDeviceToHost);
-    fprintf(stderr, "[upper probe] B=%d G=%d top=%d n=%d groups=%d cycles:", B, G, (int)top, a.n, groups);
-    for (int i = 1; i < 2 + 3 * DM::Q; i++) fprintf(stderr, "%s%lld", (i >= 2 && (i - 2) % 3 == 0) ? " | " : " ", hp[i] - hp[i - 1]);
-    fprintf(stderr, " | total %lld cycles, %lld wall ticks (100 MHz)\n", hp[1 + 3 * DM::Q] - hp[0], hp[63] - hp[62]);
-  }
   return (int)hipGetLastError();
 }
 template <int B, int G> int bwd_b(const UpBwdArgs &a, hipStream_t st) {

@@ -29,7 +29,6 @@ struct UpFwdArgs {
   int n;
   int ext;            // a block exists beyond the level's last one (sharded chains: the next rank's separator)
   int *flag;          // set to 1 when a pivot is not positive
-  long long *probe;   // diagnostics (GPSLAM_UPPER_PROBE=1): shader-clock stamps of workgroup 0, or null
 };
 
 struct UpBwdArgs {

@@ -284,14 +284,21 @@ inline bool desc_equals(const Desc &a, const Desc &b, double tol, bool gp) {
 inline void desc_print(const Desc &d, const std::string &s, const char *name, int nkeys, const KeyFormatter &kf) {
   std::cout << s << name << std::endl;
   std::cout << "  keys = {";
-  static const int order[7] = {0, 1, 2, 3, 4, 5, 6};
-  int shown = 0;
-  for (int i = 0; i < 5 && shown < nkeys; i++) {
-    if (d.k[i] == 0 && !(i == 0)) continue;
-    std::cout << " " << kf(d.k[i]); shown++;
+  // which key slots this kind of factor fills, in the order of its constructor's key arguments (slots 0..4 = k[], 5 / 6 = kw[]).
+  // The VALUE of a key says nothing: plain integer keys are legal and 0 is one of them (a zero key used to be dropped).
+  int slots[7], ns = 0;
+  auto put = [&](std::initializer_list<int> l) { for (int v : l) slots[ns++] = v; };
+  const bool lm2 = d.type == F_RANGE || d.type == F_BEARING_RANGE;
+  switch (nkeys) {
+    case 1: put({0}); break;
+    case 2: if (lm2) put({0, 4}); else put({0, 2}); break;
+    case 3: put({0, 2, 4}); break;                                   // AHRSFactor(rot_i, rot_j, bias)
+    case 4: put({0, 1, 2, 3}); break;
+    case 5: put({0, 1, 2, 3, 4}); break;
+    case 6: put({0, 1, 5, 2, 3, 6}); break;                          // *Pose3VW: (pose1, vel1, omega1, pose2, vel2, omega2)
+    default: put({0, 1, 5, 2, 3, 6, 4}); break;                      // ... with a landmark
   }
-  for (int i = 0; i < 2 && shown < nkeys; i++) if (d.kw[i]) { std::cout << " " << kf(d.kw[i]); shown++; }
-  (void)order;
+  for (int i = 0; i < ns && i < nkeys; i++) std::cout << " " << kf(slots[i] < 5 ? d.k[slots[i]] : d.kw[slots[i] - 5]);
   std::cout << " }" << std::endl;
   auto vec = [](const char *label, const std::vector<double> &v) {
     if (v.empty()) return;

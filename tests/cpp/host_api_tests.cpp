@@ -651,6 +651,12 @@ static void test_equals_print_clone() {
   a.print("factor 1: ");
   r_sens.print("", [](Key k) { return std::string("<") + DefaultKeyFormatter(k) + ">"; });
   EXPECT(DefaultKeyFormatter(Symbol('x', 12)) == "x12");
+  // plain integer keys are legal gtsam keys and 0 is one of them (print() used to drop a zero key after the first):
+  // the range factor on (pose key 7, landmark key 0) and the between factor on (3, 0) print both
+  RangeBearingFactor2DLinear rb0(Key(7), Key(0), 0.5, 3.0, noiseModel::Isotropic::Sigma(2, 0.1));
+  rb0.print("zero landmark key: ", [](Key k) { return std::string("[k") + std::to_string((unsigned long long)k) + "]"; });
+  BetweenFactor<Pose2> b0(Key(3), Key(0), Pose2(1, 0, 0), noiseModel::Isotropic::Sigma(3, 0.1));
+  b0.print("zero second key: ", [](Key k) { return std::string("[k") + std::to_string((unsigned long long)k) + "]"; });
 }
 
 // a graph built through the host classes (every GP prior carries its own Qc_model, all the same matrix) keeps the

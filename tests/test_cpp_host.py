@@ -33,6 +33,10 @@ def test_equals_print_clone_of_the_host_factor_classes():
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all host-only tests passed" in out.stdout
     assert "factor 1: 4-way Gaussian Process Factor Pose3" in out.stdout and "<x1>" in out.stdout
+    lines = out.stdout.splitlines()
+    for tag, keys in (("zero landmark key: ", "[k7] [k0]"), ("zero second key: ", "[k3] [k0]")):      # a key VALUE of 0 is printed
+        at = [i for i, l in enumerate(lines) if l.startswith(tag)]
+        assert at and keys in lines[at[0] + 1], (tag, lines[at[0]:at[0] + 3] if at else None)
 
 
 @pytest.mark.gpu
