@@ -40,7 +40,7 @@ ABI_SYMBOLS = [
     "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
     "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
-    "gpslam_hip_lm_decide",
+    "gpslam_hip_lm_decide", "gpslam_hip_set_collectives",
 ]
 
 
@@ -58,6 +58,10 @@ class Stats(C.Structure):
     _fields_ = [("error_before", C.c_double), ("error_after", C.c_double), ("delta_inf_norm", C.c_double),
                 ("lambda_", C.c_double), ("iterations", C.c_int32), ("status", C.c_int32),
                 ("accepted", C.c_int32), ("trials", C.c_int32), ("last_trial_error", C.c_double)]
+
+
+ALL_GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALL_REDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 
 class Params(C.Structure):
@@ -434,6 +438,25 @@ class ChainSolver:
 
     def set_stream(self, hip_stream):
         return self._chk(self.lib.gpslam_hip_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")
+
+    def set_collectives(self, all_gather, all_reduce_sum=None):
+        """gpslam_hip_set_collectives: hand the library the host's collectives, after which iterate_gn / run_gn / iterate_lm /
+        optimize / error work on this rank's handle (or split piece) and return the whole chain's statistics.
+            all_gather(send_ptr, recv_ptr, bytes_per_rank, hip_stream)     all_reduce_sum(buf_ptr, n_doubles, hip_stream)
+        are Python callables working on raw device pointers, on the handle's stream; an exception becomes GPSLAM_E_COMM."""
+        def guard(fn):
+            def run(_user, *args):
+                try:
+                    fn(*args)
+                    return 0
+                except Exception:       # noqa: BLE001 -- no exception may cross the C ABI
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return run
+        self._cb_gather = ALL_GATHER_FN(guard(all_gather)) if all_gather else ALL_GATHER_FN()
+        self._cb_reduce = ALL_REDUCE_FN(guard(all_reduce_sum)) if all_reduce_sum else ALL_REDUCE_FN()
+        return self._chk(self.lib.gpslam_hip_set_collectives(self._h, self._cb_gather, self._cb_reduce, None), "set_collectives")
 
     # ---- segment sharding (nranks > 1)
     def set_halo_state(self, pose, vel):

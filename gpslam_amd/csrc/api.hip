@@ -57,6 +57,12 @@ int gpslam_hip_lm_decide(const double *s6, const gpslam_hip_params *p, double *l
   return 0;
 }
 
+int gpslam_hip_set_collectives(gpslam_hip_handle *h, gpslam_hip_all_gather_fn all_gather, gpslam_hip_all_reduce_sum_fn all_reduce_sum, void *user) {
+  if (!h) return GPSLAM_E_INVALID;
+  h->coll_gather = all_gather; h->coll_reduce = all_reduce_sum; h->coll_user = user;
+  return 0;
+}
+
 int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (!cfg || !out) return GPSLAM_E_INVALID;
   if (cfg->manifold < 0 || cfg->manifold > GPSLAM_ROT3_BIAS) return GPSLAM_E_INVALID;

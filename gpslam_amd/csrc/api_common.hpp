@@ -122,6 +122,11 @@ struct gpslam_hip_handle {
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
   bool btw_rec_ok = false;
   bool gp_rows_lead = true, btw_rows_trail = true;   // compile(): the row placement the record decoders rely on holds
+  // the host's collectives (gpslam_hip_set_collectives): with them the optimiser loops run on sharded handles / split pieces
+  gpslam_hip_all_gather_fn coll_gather = nullptr;
+  gpslam_hip_all_reduce_sum_fn coll_reduce = nullptr;
+  void *coll_user = nullptr;
+  DevBuf coll_s, coll_r;     // 8 doubles of this rank's scalars, nranks x 8 gathered
   DevBuf brec, btwidx;
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use

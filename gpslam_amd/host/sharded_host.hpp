@@ -57,11 +57,28 @@ class ShardedRank {
   void lm_trial_phase1(double lambda) { use(); ok(gpslam_hip_lm_trial_phase1(h_, lambda), "lm_trial_phase1"); }
   void lm_trial_phase2(double *out6) { use(); ok(gpslam_hip_lm_trial_phase2(h_, out6), "lm_trial_phase2"); }
   void lm_reject() { use(); ok(gpslam_hip_lm_reject(h_), "lm_reject"); }
+  /// One process PER rank (the deployment shape: a launcher starts one process per GPU): hand this rank's RCCL communicator to
+  /// the library (gpslam_hip_set_collectives).  From then on the optimiser loops of the C ABI -- gpslam_hip_iterate_gn,
+  /// gpslam_hip_iterate_lm, gpslam_hip_optimize, gpslam_hip_error -- run on handle() and return the whole chain's statistics, the
+  /// collectives being ncclAllGather / ncclAllReduce on this rank's stream.  (Not for ShardedDriver, where ONE thread drives
+  /// every rank: a rank's call would wait in the collective for ranks that same thread has not started yet.)  The object must
+  /// outlive the handle's use: the library keeps `this` as the callbacks' user pointer.
+  void register_collectives() {
+    ok(gpslam_hip_set_collectives(h_, &ShardedRank::gather_cb, &ShardedRank::reduce_cb, this), "set_collectives");
+  }
   gpslam_hip_handle *handle() const { return h_; }
   int device() const { return device_; }
   hipStream_t stream() const { return stream_; }
 
  private:
+  static int gather_cb(void *user, const void *send, void *recv, size_t bytes_per_rank, void *stream) {
+    const ShardedRank *self = static_cast<const ShardedRank *>(user);
+    return ncclAllGather(send, recv, bytes_per_rank, ncclChar, self->comm_, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+  }
+  static int reduce_cb(void *user, void *buf, size_t n_doubles, void *stream) {
+    const ShardedRank *self = static_cast<const ShardedRank *>(user);
+    return ncclAllReduce(buf, buf, n_doubles, ncclDouble, ncclSum, self->comm_, (hipStream_t)stream) == ncclSuccess ? 0 : 1;
+  }
   void use() const { hip_ok(hipSetDevice(device_), "hipSetDevice"); }
   void ok(int rc, const char *what) const {
     if (rc < 0) throw std::runtime_error(std::string(what) + " failed on rank " + std::to_string(rank_) + ": " + gpslam_hip_last_error(h_));
@@ -93,6 +110,7 @@ class ShardedDriver {
     }
   }
   int nranks() const { return (int)devices_.size(); }
+  ShardedRank &rank(int r) { return ranks_.at((size_t)r); }
   /// register rank r's compiled handle (created on devices[r] with {rank = r, nranks})
   void add(gpslam_hip_handle *h) {
     const int r = (int)ranks_.size();

@@ -164,6 +164,26 @@ class _DevView:
                                          "version": 3, "strides": None}
 
 
+def torch_collectives(dist, group, world):
+    """(all_gather, all_reduce_sum) for ChainSolver.set_collectives over torch.distributed (backend "nccl" = RCCL): the
+    library's raw device pointers are wrapped as tensors and the collective is enqueued on torch's current stream -- which is
+    the handle's stream once ShardedSolver / SplitSolver has moved the handle onto it."""
+    import torch
+
+    def all_gather(send, recv, nbytes, _stream):
+        s = torch.as_tensor(_DevView(send, nbytes), device="cuda")
+        r = torch.as_tensor(_DevView(recv, nbytes * world), device="cuda")
+        if hasattr(dist, "all_gather_into_tensor"):
+            dist.all_gather_into_tensor(r, s, group=group)
+        else:
+            dist.all_gather(list(r.view(world, -1).unbind(0)), s, group=group)
+
+    def all_reduce_sum(buf, n, _stream):
+        dist.all_reduce(torch.as_tensor(_DevView(buf, n * 8), device="cuda"), group=group)
+
+    return all_gather, all_reduce_sum
+
+
 def device_tensors(solver):
     """(send, recv) torch views of a GPU backend's interface buffers."""
     import torch
@@ -196,9 +216,22 @@ class ShardedSolver:
         # is moved onto torch's current stream here: RCCL collectives launched through torch.distributed are ordered
         # against that stream (they wait for work already enqueued on it, and later work on it waits for them), which
         # makes phase1 -> all_gather -> phase2a -> all_reduce -> phase2b a correctly ordered sequence with no host sync.
+        self.abi = False
         if getattr(send, "is_cuda", False) and hasattr(backend, "set_stream"):
             import torch
             backend.set_stream(torch.cuda.current_stream().cuda_stream)
+            # the host's collectives handed to the library (round 5): the optimiser LOOPS of the C ABI -- gpslam_hip_iterate_lm,
+            # _optimize, _iterate_gn with the whole chain's statistics -- then run on this rank's handle
+            if dist is not None and hasattr(backend, "set_collectives"):
+                backend.set_collectives(*torch_collectives(dist, group, nranks))
+                self.abi = True
+
+    def optimize(self, params=None):
+        """NonlinearOptimizer::optimize() of the whole chain through the C ABI (gpslam_hip_optimize on this rank's handle; every rank
+        makes the same collective calls and gets the same statistics).  GPU backends with a process group."""
+        if not self.abi:
+            raise RuntimeError("optimize() through the C ABI needs a GPU backend and a process group")
+        return self.backend.optimize(params)
 
     def exchange(self):
         if self.dist is None:
@@ -253,8 +286,12 @@ class ShardedSolver:
                    relative_error_tol=1e-5):
         """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the ranks: the loop of gpslam_hip_iterate_lm
         with its three global sums made collective.  Every rank takes the same decisions (identical reduced scalars).
-        Returns (stats dict, new lambda)."""
+        Returns (stats dict, new lambda).  With the collectives registered on the handle (GPU backend + process group) this IS
+        gpslam_hip_iterate_lm: the loop runs inside the library; otherwise (the numpy model over gloo, the single-process tests)
+        the same loop runs here around the library's trial phases -- both take their branches in gpslam_hip_lm_decide."""
         be = self.backend
+        if self.abi:
+            return _lm_through_abi(be, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity, relative_error_tol)
 
         def trial(lam_):
             be.lm_trial_phase1(lam_)
@@ -371,8 +408,12 @@ class SplitSolver:
         import torch
         self.backend, self.rank, self.nranks, self.dist, self.group = backend, rank, nranks, dist, group
         self.device = device                      # "cpu": the numpy model of the two phases (tests/split_model.py) over gloo
+        self.abi = False
         if device == "cuda":
             backend.set_stream(torch.cuda.current_stream().cuda_stream)     # collectives are ordered against this stream
+            if dist is not None and hasattr(backend, "set_collectives"):     # the optimiser loops of the C ABI on this piece
+                backend.set_collectives(*torch_collectives(dist, group, nranks))
+                self.abi = True
         nb = backend.fs_split_info()["fat_block"]
         self.nb_local = nb
         self.send = self.recv = None
@@ -426,8 +467,11 @@ class SplitSolver:
     def iterate_lm(self, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
                    relative_error_tol=1e-5):
         """LevenbergMarquardtOptimizer::iterate (GTSAM 4.0 defaults) across the pieces: ShardedSolver.iterate_lm with the
-        split chain's trial steps.  Returns (stats dict, new lambda)."""
+        split chain's trial steps.  Returns (stats dict, new lambda).  gpslam_hip_iterate_lm itself once the collectives are
+        registered on the handle (GPU backend + process group)."""
         be = self.backend
+        if self.abi:
+            return _lm_through_abi(be, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity, relative_error_tol)
 
         def trial(lam_):
             be.fs_lm_trial_phase1(lam_)
@@ -451,6 +495,16 @@ class SplitSolver:
 def reduce_lm_scalars(m):
     """rows = pieces: sum of (error, trial error, delta.g, |delta|^2), max of (|delta|_inf, indefinite flag)"""
     return np.array([m[:, 0].sum(), m[:, 1].sum(), m[:, 2].max(), m[:, 3].sum(), m[:, 4].sum(), m[:, 5].max()])
+
+
+def _lm_through_abi(be, lam, lambda_factor, lambda_upper_bound, lambda_lower_bound, min_model_fidelity, relative_error_tol):
+    """gpslam_hip_iterate_lm on a handle that holds the host's collectives -> (stats dict of the whole chain, new lambda)"""
+    p = be.default_params(use_lm=1)
+    p.lambda_factor, p.lambda_upper_bound, p.lambda_lower_bound = lambda_factor, lambda_upper_bound, lambda_lower_bound
+    p.min_model_fidelity, p.relative_error_tol = min_model_fidelity, relative_error_tol
+    _rc, st, lam = be.iterate_lm(lam, p)[:3]
+    return dict(error_before=st.error_before, error_after=st.error_after, delta_inf_norm=st.delta_inf_norm,
+                accepted=bool(st.accepted), trials=int(st.trials), last_trial_error=st.last_trial_error), lam
 
 
 def lm_loop(trial, reject, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,

@@ -67,7 +67,8 @@ enum {
   GPSLAM_E_NOT_SPD = -3,      /* a pivot block was not positive definite (indeterminate system) */
   GPSLAM_E_NOT_COMPILED = -4, /* gpslam_hip_compile() has not been called since the last change */
   GPSLAM_E_UNSUPPORTED = -5,
-  GPSLAM_E_NAN = -6
+  GPSLAM_E_NAN = -6,
+  GPSLAM_E_COMM = -7          /* a collective supplied through gpslam_hip_set_collectives reported a failure */
 };
 
 typedef struct {
@@ -395,6 +396,30 @@ int gpslam_hip_fs_phase2(gpslam_hip_handle *h, gpslam_hip_stats *st);
  * |delta|^2 on the piece to its right only, delta . g adds up over the pieces as it is. */
 int gpslam_hip_fs_lm_trial_phase1(gpslam_hip_handle *h, double lambda);
 int gpslam_hip_fs_lm_trial_phase2(gpslam_hip_handle *h, double *out6);
+/* ---- the whole optimiser loop on a sharded handle or a split piece (round 5) ----
+ * The library does not link a communication library: the ONE data-path collective of an iteration is the
+ * host's to perform.  With the two callbacks below registered, gpslam_hip_iterate_gn / _run_gn / _iterate_lm / _optimize /
+ * _error accept handles with nranks > 1 and pieces of a split chain: they run the phases above in order and call
+ *   all_gather(user, send_dev, recv_dev, bytes_per_rank, hip_stream)  -- every rank's `bytes_per_rank` bytes at send_dev into
+ *       recv_dev, rank order, enqueued on hip_stream (the handle's stream): ncclAllGather(send, recv, bytes, ncclChar, comm, stream)
+ *   all_reduce_sum(user, buf_dev, n_doubles, hip_stream)              -- in-place sum of doubles (the landmark Schur complement
+ *       of a chain with a dense landmark border; may be NULL for chains without landmarks and for split pieces)
+ * and return the statistics of the WHOLE chain (errors summed, |delta|_inf maximised over the ranks), identical on every rank.
+ * A callback returns 0, anything else ends the call with GPSLAM_E_COMM.  Collectives per call:
+ *   iterate_gn      1 all-gather of the interface records (+ 1 all-reduce with a landmark border) + 1 all-gather of 64 B of scalars
+ *                   when statistics are asked for;
+ *   iterate_lm      per lambda trial: the record all-gather (+ the all-reduce) and ONE all-gather of 64 B carrying the trial's six
+ *                   scalars {error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag} -- the scalars of a trial
+ *                   exist only after its back-substitution, which needs the gathered records, so they cannot ride the record;
+ *                   every rank then takes the branch of gpslam_hip_lm_decide on identical reduced numbers;
+ *   optimize        GTSAM's loop (NonlinearOptimizer::defaultOptimize) over the two above.
+ * Every rank must make the same calls in the same order (they are collective).  A single-rank handle that was forced onto the
+ * sharded code path (config.reserved[0]) needs no callbacks.  LevenbergMarquardtOptimizer::iterate on the reference's
+ * landmark graph: matlab/PlazaPose2.m:210-226. */
+typedef int (*gpslam_hip_all_gather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
+typedef int (*gpslam_hip_all_reduce_sum_fn)(void *user, void *buf_dev, size_t n_doubles, void *hip_stream);
+int gpslam_hip_set_collectives(gpslam_hip_handle *h, gpslam_hip_all_gather_fn all_gather, gpslam_hip_all_reduce_sum_fn all_reduce_sum,
+                               void *user);
 /* halo: the first state of the right neighbour (pose_dim + d doubles), kept in sync by the library after init */
 int gpslam_hip_set_halo_state(gpslam_hip_handle *h, const double *pose, const double *vel);
 

@@ -158,6 +158,36 @@ int main() {
     std::printf("Levenberg-Marquardt, 4 iterations: lambda %.3e (unsharded %.3e), first iteration identical %d, max |difference| %.3e\n", lam, lam_ref, (int)same_schedule, worst_lm);
     pass = pass && same_schedule && worst_lm <= 1e-9;
   }
+  // ---- (round 5) the optimiser loop of the C ABI on a sharded handle: gpslam_hip_optimize with this rank's RCCL communicator behind
+  // gpslam_hip_set_collectives (ShardedRank::register_collectives).  One rank per PROCESS is the shape that call needs, so it runs
+  // here on a one-rank communicator (a forced-sharded handle: the sharded code path, real ncclAllGather calls of world size 1):
+  // GTSAM's Levenberg-Marquardt loop, the iteration count and the error of the unsharded handle.
+  {
+    gpslam_hip_params prm;
+    gpslam_hip_default_params(&prm);
+    prm.use_lm = 1;
+    const int N1 = 3000;
+    const Problem p1 = make(N1);
+    gpslam_hip_handle *ref3 = build(p1, 0, 0, 1, false, 0, N1);
+    gpslam_hip_handle *one = build(p1, 0, 0, 1, true, 0, N1);
+    gpslam_hip::ShardedDriver d1(std::vector<int>{0});
+    d1.add(one);
+    d1.rank(0).register_collectives();
+    gpslam_hip_stats a, b;
+    ok(gpslam_hip_optimize(ref3, &prm, &a), ref3, "optimize");
+    ok(gpslam_hip_optimize(one, &prm, &b), one, "optimize (sharded handle, collectives registered)");
+    double e3 = 0.0, e1 = 0.0;
+    ok(gpslam_hip_error(ref3, &e3), ref3, "error");
+    ok(gpslam_hip_error(one, &e1), one, "error");
+    const bool same = a.iterations == b.iterations && std::fabs(a.error_after - b.error_after) <= 1e-9 * std::fmax(1.0, a.error_after) &&
+                      std::fabs(e3 - e1) <= 1e-9 * std::fmax(1.0, e3);
+    std::printf("gpslam_hip_optimize through registered collectives: %d iterations (unsharded %d), error %.9e (%.9e)\n", b.iterations, a.iterations,
+                b.error_after, a.error_after);
+    pass = pass && same;
+    d1.synchronize();
+    gpslam_hip_destroy(one);
+    gpslam_hip_destroy(ref3);
+  }
   std::printf(pass ? "sharded_rccl_test: all tests passed\n" : "sharded_rccl_test: FAILED\n");
   return pass ? 0 : 1;
 }

