@@ -100,8 +100,9 @@ def test_split_levenberg_marquardt_follows_the_unsplit_lambda_schedule(P):
     p1, v1 = ref.get_states()
     assert np.abs(pose - p1).max() <= 1e-7 * max(1.0, np.abs(p1).max())
     assert np.abs(lmk - ref.get_landmarks()).max() <= 1e-7 * max(1.0, np.abs(lmk).max())
-    with pytest.raises(gpslam_amd.GpslamHipError):
-        pieces[0].backend.iterate_lm(1e-5)          # the loop is the caller's on a split chain
+    if P > 1:
+        with pytest.raises(gpslam_amd.GpslamHipError, match="collectives"):
+            pieces[0].backend.iterate_lm(1e-5)      # without the host's collectives (gpslam_hip_set_collectives) the loop is the caller's
     for sv in pieces:
         sv.backend.close()
     ref.close()
