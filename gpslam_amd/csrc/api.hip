@@ -70,7 +70,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
   if (cfg->reserved[3] != 0 && (cfg->reserved[3] != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;
-  constexpr int kPlanBits = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_COLUMN_LEVEL0 | GPSLAM_PLAN_LEVELS_OF_FOUR | GPSLAM_PLAN_FS_TWO_LAUNCHES | GPSLAM_PLAN_GP_ROWS | GPSLAM_PLAN_GENERIC_QC;
+  constexpr int kPlanBits = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_COLUMN_LEVEL0 | GPSLAM_PLAN_LEVELS_OF_FOUR | GPSLAM_PLAN_FS_TWO_LAUNCHES | GPSLAM_PLAN_GP_ROWS | GPSLAM_PLAN_GENERIC_QC | GPSLAM_PLAN_MEAS_ROWS;
   if ((cfg->reserved[6] & ~kPlanBits) != 0 || cfg->reserved[7] != 0) return GPSLAM_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPSLAM_E_HIP;  // no GPU: fail loudly
@@ -421,7 +421,7 @@ int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]) {
   if (!out8) return GPSLAM_E_INVALID;
   const bool fused = h->fuse_ok && h->lv.size() >= 2;
   const int32_t v[8] = {(int32_t)h->lv.size(), h->lv.empty() ? 0 : h->lv[0].m, h->lv.size() > 1 ? h->lv[1].m : 0, fused ? 1 : 0,
-                        ((fused && h->struct_ok) || h->struct3_ok) ? 1 : 0, h->M, h->Mc, h->R};
+                        ((fused && h->struct_ok) || h->struct3_ok) ? ((fused && h->struct_ok && h->irow_ok) ? 2 : 1) : 0, h->M, h->Mc, h->R};
   for (int i = 0; i < 8; i++) out8[i] = v[i];
   return 0;
 }

@@ -53,8 +53,9 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
   // factor, diag(1 / sigma) for those that kept their diagonal model; empty: every factor is diagonal
   std::vector<double> sqi;
   DevBuf d_idx, d_lm, d_meas, d_sig, d_coef, d_row0, d_aux, d_aidx, d_sqi;
+  DevBuf d_irow0;                      // first row of each factor in the table of 16-double interpolated rows (handle: irow_ok)
   int count() const { return (int)idx.size(); }
-  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); d_aux.release(); d_aidx.release(); d_sqi.release(); }
+  void release() { d_idx.release(); d_lm.release(); d_meas.release(); d_sig.release(); d_coef.release(); d_row0.release(); d_aux.release(); d_aidx.release(); d_sqi.release(); d_irow0.release(); }
 };
 
 }  // namespace
@@ -122,6 +123,10 @@ struct gpslam_hip_handle {
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
   bool btw_rec_ok = false;
   bool gp_rows_lead = true, btw_rows_trail = true;   // compile(): the row placement the record decoders rely on holds
+  // SE(3) records + interpolated measurement rows as 16-double lines (round 5, k_fused_level0<4>): every full-width row besides the
+  // GP priors' belongs to a GPInterpolatedGPSFactorPose3 on an interval that has a GP prior
+  bool irow_ok = false;
+  DevBuf rowI, irowptr;
   // the host's collectives (gpslam_hip_set_collectives): with them the optimiser loops run on sharded handles / split pieces
   gpslam_hip_all_gather_fn coll_gather = nullptr;
   gpslam_hip_all_reduce_sum_fn coll_reduce = nullptr;
@@ -390,7 +395,10 @@ inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, 
     else k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
     return;
   }
-  if (u.gps && u.odd_rows == 2) {            // records + a ring of full-width rows (measurement factors)
+  if (u.gps && u.rowI) {                     // records + interpolated measurement rows as 16-double lines (round 5)
+    if (u.u_diag) k_fused_level0<4, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);
+    else k_fused_level0<4><<<dim3(grid), dim3(128), 0, st>>>(u);
+  } else if (u.gps && u.odd_rows == 2) {     // records + a ring of full-width rows (measurement factors)
     if (u.u_diag) k_fused_level0<3, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);
     else k_fused_level0<3><<<dim3(grid), dim3(128), 0, st>>>(u);
   } else if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);

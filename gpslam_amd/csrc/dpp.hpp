@@ -206,6 +206,34 @@ template <int K0> __device__ __forceinline__ void fmac_gather3_at(double *d, dou
       : "v"(s), "v"(m), "n"(K0), "n"(K0 + 1), "n"(K0 + 2));
 }
 
+// two dot products against six lanes of ONE register: a0 += sum_k s[lane K0 + k] * m0[k], a1 += sum_k s[lane K0 + k] * m1[k]
+// (the interpolated measurement rows of k_fused_level0<4>: mu lives in lanes 6..11 of the row's register).  The two sums alternate
+// so that consecutive instructions never wait for one another's result.
+template <int K0> __device__ __forceinline__ void fmac_dot6x2_at(double &a0, double &a1, double s, const double *m0, const double *m1) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%15 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %9 row_newbcast:%15 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %0, %2, %4 row_newbcast:%16 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %10 row_newbcast:%16 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %0, %2, %5 row_newbcast:%17 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %11 row_newbcast:%17 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %0, %2, %6 row_newbcast:%18 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %12 row_newbcast:%18 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %0, %2, %7 row_newbcast:%19 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %13 row_newbcast:%19 " GPS_FMAC_ROW
+      "v_fmac_f64_dpp %0, %2, %8 row_newbcast:%20 " GPS_FMAC_ROW "v_fmac_f64_dpp %1, %2, %14 row_newbcast:%20 row_mask:0xf bank_mask:0xf"
+      : "+v"(a0), "+v"(a1)
+      : "v"(s), "v"(m0[0]), "v"(m0[1]), "v"(m0[2]), "v"(m0[3]), "v"(m0[4]), "v"(m0[5]), "v"(m1[0]), "v"(m1[1]), "v"(m1[2]), "v"(m1[3]), "v"(m1[4]),
+        "v"(m1[5]), "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3), "n"(K0 + 4), "n"(K0 + 5));
+}
+// four lanes of one register broadcast to all lanes of the row: d[k] = s[lane K0 + k]
+template <int K0> __device__ __forceinline__ void row_bcast4_at(double s, double *d) {
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_mov_b64_dpp %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %1, %4 row_newbcast:%6 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %2, %4 row_newbcast:%7 row_mask:0xf bank_mask:0xf\n\t"
+      "v_mov_b64_dpp %3, %4 row_newbcast:%8 row_mask:0xf bank_mask:0xf"
+      : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3])
+      : "v"(s), "n"(K0), "n"(K0 + 1), "n"(K0 + 2), "n"(K0 + 3));
+}
+
 template <int N> __device__ __forceinline__ void lane_gather(double v, double *d);
 template <> __device__ __forceinline__ void lane_gather<12>(double v, double *d) {
   asm volatile(

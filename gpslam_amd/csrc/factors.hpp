@@ -795,6 +795,35 @@ GD SE3<T> interp_pose3(const T *p1, const T *v1, const T *p2, const T *v2, ICoef
   return se3_compose(a, ex);
 }
 
+// The same interpolation in the parts the 16-double interpolated rows are made of (kernels.hpp: kIRow*): the pose, He = Hcomp22 Hexp
+// (:80), Hc21 = Ad(Exp(xi)^-1) (:87) and s1 = p11 J + p12 F J, so that H1 = Hc21 + He s1 -- H2, H3, H4 are He times what the consumer
+// holds already (l12 I, p11 X + p12 F X, p12 X).  gp as above (null: the blocks are formed here).
+template <typename T>
+GD SE3<T> interp_pose3_parts(const T *p1, const T *v1, const T *p2, const T *v2, ICoef<T> k, const T *gp, BL6<T> &He, BL6<T> &Hc21, BL6<T> &s1) {
+  const SE3<T> a = as_se3(p1), b = as_se3(p2);
+  const SE3<T> h = se3_between(a, b);
+  const V6<T> r = se3_log(h);
+  const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
+  BL6<T> Jinv, FD, tmp1;
+  if (gp != nullptr) {
+    auto m3 = [&](int off) { M3<T> m; for (int q = 0; q < 9; q++) m.m[q] = gp[off + q]; return m; };
+    Jinv.A = m3(0); Jinv.C = m3(9); Jinv.D = Jinv.A;
+    tmp1.A = m3(18); tmp1.C = m3(27); tmp1.D = tmp1.A;
+    FD.A = m3(36); FD.C = m3(45); FD.D = m3(54);
+  } else {
+    const JrK<T> k0 = jr_coefs(r.w);
+    Jinv = se3_jrinv_k(k0, r);
+    FD = se3_jrinv_times_x_fd_k(k0, r, u2);
+    tmp1 = neg(Jinv * se3_adjoint(se3_inverse(h)));
+  }
+  const V6<T> xi = k.l12 * u1 + k.p11 * r + k.p12 * (Jinv * u2);
+  const SE3<T> ex = se3_exp(xi);
+  He = se3_jr(xi);
+  s1 = k.p11 * tmp1 + k.p12 * (FD * tmp1);
+  Hc21 = se3_adjoint(se3_inverse(ex));
+  return se3_compose(a, ex);
+}
+
 // ---- Unit3 basis (GTSAM Unit3::basis): B = [b1 b2], b1 = n x axis_min, b2 = n x b1
 template <typename T> GD void unit3_basis(V3<T> n, V3<T> &b1, V3<T> &b2) {
   const T mx = fabs(n.x), my = fabs(n.y), mz = fabs(n.z);

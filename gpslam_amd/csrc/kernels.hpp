@@ -155,6 +155,17 @@ constexpr int kGp3Len = 32, kGp3A1 = 0, kGp3A3 = 9, kGp3E = 18, kGp3S = 24;
 // 48 doubles = three whole lines instead of six compact rows of 12 + 1 doubles (624 bytes in 96-byte fragments).  The assembly wave
 // of k_fused_level0 builds column c of [H1 | H2] in lane c < 6 exactly as it builds the columns of the GP prior's J and X.
 constexpr int kBtwLen = 48, kBtwRA = 0, kBtwRC = 9, kBtwLA = 18, kBtwLC = 27, kBtwW = 36, kBtwE = 42;
+// Interpolated measurement rows of an SE(3) chain on the structured path (round 5; GPInterpolatedGPSFactorPose3.h:66-95 over
+// GaussianProcessInterpolatorPose3.h:82-98).  A whitened row of such a factor is  w Hp [H1 H2 | H3 H4]  with
+//   H1 = Ad(Exp(xi)^-1) + He (p11 J + p12 F J),  H2 = l12 He,  H3 = He (p11 X + p12 F X),  H4 = p12 He X
+// where X = Jr^-1(r), J = -X Ad(h^-1) and F = d(X v2)/dr are the interval's GP record (kGps*) and l12, p11, p12 the interpolation
+// coefficients of tau.  With mu = w Hp He (6) the row is
+//   L = [ Lp | l12 mu ],   R = [ mu (p11 X + p12 F X) | p12 mu X ],   Lp = w Hp Ad(Exp(xi)^-1) + mu (p11 J + p12 F J)
+// so k_meas writes ONE 128-byte line per row -- [Lp (6) | mu (6) | whitened error, p11, p12, l12] -- instead of 24 + 1 doubles, and
+// the assembly wave of k_fused_level0<4> forms R from mu and the X / F X columns it holds for the GP prior anyway: lane c < 16 of
+// a chunk's DPP row loads element c of the line (one load per row and lane), mu travels by row_newbcast from lanes 6..11, the four
+// scalars from lanes 12..15.
+constexpr int kIRowLen = 16, kIRowLp = 0, kIRowMu = 6, kIRowE = 12, kIRowP11 = 13, kIRowP12 = 14, kIRowL12 = 15;
 constexpr int kGpsLen = 80, kGpsXA = 0, kGpsXC = 9, kGpsJA = 18, kGpsJC = 27, kGpsFA = 36, kGpsFC = 45, kGpsFD = 54, kGpsZ = 63,
               kGpsE = 64, kGpsS = 76;
 
@@ -849,6 +860,7 @@ template <typename T> struct MeasArgs {
   // interval from there instead of forming them again for every measurement factor on it.  Null: it forms them.
   const T *gps = nullptr;
   const int *gpidx = nullptr;
+  T *rowI = nullptr;   // k_meas<..., IROW = true>: the table of 16-double interpolated rows (kIRow*); row0 then counts rows of THAT table
   const int *row0;
   T *rowLR, *rowE, *rowM;
   int *rowLm;
@@ -869,17 +881,25 @@ template <typename T> __device__ __forceinline__ void put_v6(V6<T> a, T *row) { 
 // GPInterpolatedRangeFactorPose2/Pose3/2DLinear, RangeFactorPose2 / RangeFactor2DLinear,
 // GPInterpolatedAttitudeFactorRot3, GPInterpolatedGPSFactorPose3, OdometryFactor2DLinear, RangeBearingFactor2DLinear
 // (gpslam/slam/*.h, see the per-branch citations).  One thread per factor.
-template <typename T, int MF, int FK, bool JAC>
+// IROW (round 5; SE(3), fp64, GPInterpolatedGPSFactorPose3): the rows leave as 16-double lines [Lp | mu | e, p11, p12, l12] (kIRow*)
+// for k_fused_level0<4>, which forms the right halves from mu and the interval's GP record
+template <typename T, int MF, int FK, bool JAC, bool IROW = false>
 __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
+  static_assert(!IROW || (FK == FK_INTERP_GPS && MF == POSE3 && JAC && std::is_same<T, double>::value), "interpolated rows: SE(3) GPS factors, fp64");
   constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d, rows = FKRows<FK>::rows;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   T err = T(0);
   if constexpr (MeasValid<MF, FK>::v) {
     // whitened Jacobian rows leave through the per-wave staging buffer (wave_store_rows), like the GP prior's
     T JL[JAC ? rows * b : 1], JR[JAC ? rows * b : 1], wgt[rows];
+    T ew_[IROW ? rows : 1];            // IROW: the whitened errors, staged with the rows
     int row0v = -1;
 #pragma unroll
     for (int r = 0; r < rows; r++) wgt[r] = T(0);
+    if constexpr (IROW) {
+#pragma unroll
+      for (int r = 0; r < rows; r++) ew_[r] = T(0);
+    }
     if (f < a.count) {
       const int i = a.idx[f];
       constexpr bool two = (FK == FK_INTERP_RANGE || FK == FK_INTERP_ATT || FK == FK_INTERP_GPS || FK == FK_ODOM2D || FK == FK_INTERP_PROJ || FK == FK_AHRS);
@@ -1053,11 +1073,24 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       } else if constexpr (FK == FK_INTERP_GPS) {
         // GPInterpolatedGPSFactorPose3::evaluateError, gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
         Interp6Out<T, JAC> o;
-        const SE3<T> pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o, gprec);
+        BL6<T> He, Hc21, s1;
+        SE3<T> pose;
+        if constexpr (IROW) pose = interp_pose3_parts<T>(p1, v1, p2, v2, kc, gprec, He, Hc21, s1);
+        else pose = interp_pose3<T, JAC>(p1, v1, p2, v2, kc, o, gprec);
         const SE3<T> S = as_se3(sens);
         const SE3<T> sp = has_sensor ? se3_compose(pose, S) : pose;
         e[0] = sp.t.x - ms[0]; e[1] = sp.t.y - ms[1]; e[2] = sp.t.z - ms[2];
-        if (JAC) {
+        if constexpr (IROW) {
+          // JL row r = [Lp | mu] (the left half of the Jacobian is [Lp | l12 mu]); JR stays zero: the consumer forms it
+          const BL6<T> AdS = se3_adjoint(se3_inverse(S));
+#pragma unroll
+          for (int r = 0; r < 3; r++) {
+            V6<T> Hp = {{T(0), T(0), T(0)}, {sp.R.m[3 * r], sp.R.m[3 * r + 1], sp.R.m[3 * r + 2]}};   // translation(H) = [0, R]
+            if (has_sensor) Hp = rowmul(Hp, AdS);
+            const V6<T> mu = rowmul(Hp, He);
+            put_v6(rowmul(Hp, Hc21) + rowmul(mu, s1), JL + r * b); put_v6(mu, JL + r * b + 6);
+          }
+        } else if (JAC) {
           const BL6<T> AdS = se3_adjoint(se3_inverse(S));
 #pragma unroll
           for (int r = 0; r < 3; r++) {
@@ -1201,6 +1234,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         const T we = e[r] * w;
         err += we * we;
         wgt[r] = w;
+        if constexpr (IROW) ew_[r] = we;
         if (!JAC && a.rowE32) a.rowE32[row0 + r] = (float)we;
         if (JAC && a.rowLR) {      // (rowLR == null: the inspection call, gpslam_hip_linearize_meas, leaves the row tables alone)
           a.rowE[row0 + r] = we;
@@ -1211,7 +1245,22 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
         }
       }
     }
-    if constexpr (JAC) {
+    if constexpr (IROW) {
+      __shared__ T istage[2 * 64 * 20];
+      __shared__ int isrow[128];
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      T *st = istage + wv * 64 * 20, *mine = st + lane * 20;
+      isrow[threadIdx.x] = row0v;
+      const bool live = f < a.count;
+      const T p11 = live ? T(a.coef[4 * (size_t)f + 2]) : T(0), p12 = live ? T(a.coef[4 * (size_t)f + 3]) : T(0), l12 = live ? T(a.coef[4 * (size_t)f + 1]) : T(0);
+#pragma unroll
+      for (int r = 0; r < rows; r++) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) mine[c] = wgt[r] * JL[r * b + c];
+        mine[kIRowE] = ew_[r]; mine[kIRowP11] = p11; mine[kIRowP12] = p12; mine[kIRowL12] = l12;
+        wave_store_part<T, kIRowLen, 16, 20, true>(st, isrow + wv * 64, lane, r, 0, a.rowI);
+      }
+    } else if constexpr (JAC) {
       constexpr int LS = 2 * b + 2;
       __shared__ T stage[2 * 64 * LS];
       __shared__ int srow[128];
@@ -2445,6 +2494,8 @@ template <typename T, typename TR = T> struct FusedArgs {
   const TR *rowLR, *rowE; // M x 24, M
   const int *crowptr;     // compact rows
   const TR *rowC, *rowCE; // Mc x 12, Mc
+  const T *rowI = nullptr;       // k_fused_level0<4>: the interpolated measurement rows as 16-double lines (kIRow*), indexed by irowptr
+  const int *irowptr = nullptr;  // n + 2 entries, like rowptr, counting only those rows (the GP priors have none: they are records)
   const T *gps;           // structured GP-prior records (kGpsLen each, see GpArgs::gps) or null: the GP rows are in rowLR
   int gp_count;           // number of records; record gp_count is all zeros (states without a GP prior read it)
   const T *brec;          // BetweenFactor<Pose3> records (kBtw*; K1 wrote no compact rows for them) or null (ST variants only)
@@ -2473,10 +2524,13 @@ template <typename T, typename TR = T> struct FusedArgs {
 template <int SV, typename TR = double, int B = 12, bool DG = false>
 __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
-  static_assert(!DG || ((SV == 1 || SV == 3) && B == 12), "the diagonal-U form belongs to the SE(3) record variants");
+  static_assert(!DG || ((SV == 1 || SV == 3 || SV == 4) && B == 12), "the diagonal-U form belongs to the SE(3) record variants");
   // SV = 3 (round 4): records AND a ring of full-width rows -- SE(3) chains with interpolated measurement factors (GPS, range,
   // projection: a dozen full-width rows per state), which had lost the records to the plain-row kernel
-  constexpr bool ST = SV != 0, ODD = SV >= 2, ORING = SV == 3;
+  // SV = 4 (round 5): records AND interpolated measurement rows as 16-double lines (kIRow*): one operand per row and lane, a whole
+  // state's dozen rows in flight, the right halves formed here from mu and the record's X / F X columns
+  constexpr bool ST = SV != 0, ODD = SV >= 2, ORING = SV == 3, IROW = SV == 4;
+  static_assert(!IROW || B == 12, "interpolated rows are an SE(3) form");
   // ST12: SE(3) records (kGps*, kBtw*: the assembly wave forms the columns, no full-width row ring);  ST6 (round 4): the d = 3
   // records (kGp3*) of SE(2) / SO(3) / 3-D linear chains -- six rows per state from 11 operands per lane, next to the row ring
   // that still serves measurement factors and velocity priors
@@ -2530,7 +2584,8 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // ring depths (rows in flight per table).  Whole-state rings (12 full-width rows: one GP prior) were measured SLOWER
     // (0.197 vs 0.182 ms): with all arithmetic of both waves ablated the kernel still takes 0.158 ms -- 313 MB of row reads
     // + 248 MB of factor writes at the mixed read / write rate this part sustains -- so deeper prefetch only costs registers.
-    constexpr int PF = ST6 ? 3 : (ORING ? (DG ? 6 : 4) : 6), PC = ST12 ? (SV == 2 ? 4 : (ORING ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
+    constexpr int PF = ST6 ? 3 : (ORING ? (DG ? 6 : 4) : 6), PC = ST12 ? (SV == 2 ? 4 : ((ORING || IROW) ? 2 : 1)) : (ST6 ? 3 : 6), Dh = B / 2;
+    constexpr int PFI = 12;                               // interpolated rows in flight: one register each (four GPS factors of an interval)   // (ST6: three waves per SIMD need <= 168 VGPRs)   // (ST: the records take the registers of the compact ring: pose priors are what is left in it)
     const int rc = r < Dh ? r : 0;
     const int ptr_max = a.n + 1;                         // rowptr / crowptr have n + 2 entries
     // R^T R of the state's rows (and its share of the gradient): what opens the NEXT state's D -- kept where it is summed, the next
@@ -2542,9 +2597,11 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     double Dacc[B], Oacc[B], gacc;
     constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep -- 6 in the diagonal-Qc form -- + 2 compact rows is what 256 VGPRs hold next to the records)
     double fL[FRING ? PF : 1], fR[FRING ? PF : 1], fE[FRING ? PF : 1], cL[PC], cR[PC], cE[PC];   // the two operand rings
+    double fI[IROW ? PFI : 1];                           // ... and the ring of interpolated rows: element (lane & 15) of each line
+    const int *fptr = IROW ? u.irowptr : u.rowptr;       // the full-width table this variant walks
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
-    int rpn = u.rowptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
-    int rpnn = u.rowptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
+    int rpn = fptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
+    int rpnn = fptr[min(s + 2, ptr_max)], cpnn = u.crowptr[min(s + 2, ptr_max)];    // ... and two
     // structured GP prior of the state (u.gps, layout kGps*): lane c < 12 of the chunk's DPP row builds COLUMN c of the whitened
     // [L | R] from the record's blocks -- pose columns for c < 6, velocity columns for c >= 6 (see the record's description):
     //   column r6 = c mod 6 of X = Jinv and of J as six-vectors [top; bottom] (the translation columns have a zero top and
@@ -2697,6 +2754,21 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       const TR *row = u.rowLR + (size_t)rho * 2 * B;
       Lv = (double)row[rr]; Rv = (double)row[B + rr]; ev = (double)u.rowE[rho];
     };
+    auto ldfi = [&](int i, double &v) {      // element (lane & 15) of interpolated row i of the state the rings point at
+      const int rho = rp + min(i, max(nf - 1, 0));
+      v = u.rowI[(size_t)rho * kIRowLen + r];
+    };
+    // point the ring of interpolated rows at state s + kimg and request its first PFI lines.  assemble() does this for the NEXT
+    // state as soon as the current state's lines are consumed (they then travel under the GP prior's, the between factor's and the
+    // pose prior's rows: ~800 instructions); open_state() only for the very first state.
+    bool iopened = false;
+    auto open_irows = [&](int kimg, int p0, int p1) {
+      const bool live = valid && (s + kimg) < e;
+      rp = live ? p0 : 0; nf = live ? p1 - p0 : 0;
+#pragma unroll
+      for (int q = 0; q < PFI; q++) ldfi(q, fI[q]);
+      iopened = true;
+    };
     auto ldc = [&](int i, double &Lv, double &Rv, double &ev) {
       const int rho = cp + min(i, max(nc - 1, 0));
       const TR *row = u.rowC + (size_t)rho * B;
@@ -2707,16 +2779,21 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       const bool live = valid && (s + kimg) < e;
       gp = (live && st_on) ? g : -1;
       bq = (live && btw_on) ? bqv : -1;
-      if (gp >= 0) p0 += B;                              // its 12 rows lead the state's range in the row table: not used
+      if (gp >= 0 && !IROW) p0 += B;                     // its 12 rows lead the state's range in the row table: not used (the table of interpolated rows never held them)
       if (bq >= 0) q1 -= Dh;                             // ... and its between factor's six rows end its range in the compact table
-      rp = (live && (!ST12 || ODD)) ? p0 : 0; nf = (live && (!ST12 || ODD)) ? p1 - p0 : 0;   // (ODD: the few other full-width rows)
+      if constexpr (!IROW) { rp = (live && (!ST12 || ODD)) ? p0 : 0; nf = (live && (!ST12 || ODD)) ? p1 - p0 : 0; }   // (ODD: the few other full-width rows)
       cp = live ? q0 : 0; nc = live ? q1 - q0 : 0;
       if constexpr (FRING) {
 #pragma unroll
         for (int q = 0; q < PF; q++) ldf(q, fL[q], fR[q], fE[q]);
       }
+      if constexpr (IROW) {
+        if (!iopened) open_irows(kimg, p0, p1);          // (the first state only: every other one was opened early, by assemble)
+        iopened = false;
+      } else {       // (IROW: the compact ring of a state is requested behind that state's interpolated rows, whose loop needs the registers)
 #pragma unroll
-      for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);
+        for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);
+      }
     };
     auto assemble = [&](int kimg) {
       const bool live = valid && (s + kimg) < e;
@@ -2729,6 +2806,53 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       for (int k = 0; k < B; k++) { Dacc[k] = RRacc[k]; Oacc[k] = 0.0; RRacc[k] = 0.0; }
       gacc = grr;
       grr = 0.0;
+      if constexpr (IROW) {
+        // The interpolated measurement rows of the state FIRST, while the record's operands are still whole (the columns of the
+        // GP prior are formed after this loop, into the registers it frees).  Row = [Lp | mu | e, p11, p12, l12], one element per
+        // lane:  L = [Lp | l12 mu],  R = [mu (p11 X + p12 F X) | p12 mu X] = cA (mu . Xc) + cB (mu . Pc)  with this lane's column
+        // Xc of X (velocity lanes: column c - 6) and Pc = F Xc, (cA, cB) = (p11, p12) on pose lanes, (p12, 0) on velocity lanes.
+        int rq = r;
+        asm volatile("" : "+v"(rq));
+        const bool tcol = (rq >= 3 && rq < 6) || (rq >= 9), posel = rq < Dh, vell = rq >= Dh && rq < B;
+        double Xc[6], Pc[6];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { Xc[k] = tcol ? 0.0 : raw[k]; Xc[3 + k] = raw[3 + k]; }
+#pragma unroll
+        for (int k = 0; k < 6; k++) Pc[k] = 0.0;
+        static_for<0, 3>([&](auto jj) {                  // F [top; bottom] = [FA top; FC top + FD bottom]
+          constexpr int j = decltype(jj)::value;
+          fmac_mat<3, j, 3>(Pc, &raw[12], Xc[j]);
+          fmac_mat<3, j, 3>(Pc + 3, &raw[13], Xc[j]);
+          fmac_mat<3, j, 3>(Pc + 3, &raw[14], Xc[3 + j]);
+        });
+        for (int i0 = 0; i0 < nfm; i0 += PFI) {
+          if (i0 > 0) {                                  // more than PFI lines on one state (rare): the ring is refilled in place
+#pragma unroll
+            for (int q = 0; q < PFI; q++) ldfi(i0 + q, fI[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < PFI; q++) {
+            const int i = i0 + q;
+            const double V = (i < nf) ? fI[q] : 0.0;
+            double sc[4];
+            row_bcast4_at<kIRowE>(V, sc);                // whitened error, p11, p12, l12
+            const double Lv = posel ? V : (vell ? sc[3] * V : 0.0);
+            double sX = 0.0, sP = 0.0;
+            fmac_dot6x2_at<kIRowMu>(sX, sP, V, Xc, Pc);  // mu . Xc, mu . Pc
+            const double cA = posel ? sc[1] : sc[2], cB = posel ? sc[2] : 0.0;
+            const double Rv = rowlane ? fma(cA, sX, cB * sP) : 0.0;
+            fmac_gather<B>(Dacc, Lv, Lv);
+            fmac_gather<B>(Oacc, Lv, Rv);
+            fmac_gather<B>(RRacc, Rv, Rv);
+            gacc = fma(-Lv, sc[0], gacc);
+            grr = fma(-Rv, sc[0], grr);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        open_irows(kimg + 1, rpn, rpnn);                 // the next state's lines: in flight under the rest of this state
+#pragma unroll
+        for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);   // this state's compact rows: wanted behind the GP prior's twelve
+      }
       if constexpr (ST6) {                               // the d = 3 record: six rows from the lane's column of [A1 | U | A3 | U]
         const bool pc = r < 3;
         const double mLt = pc ? 1.0 : raw[6], mRt = pc ? 1.0 : raw[7], mLb = pc ? 0.0 : raw[8], mRb = pc ? 0.0 : raw[9];
@@ -2804,7 +2928,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           });
         }
       }
-      if constexpr (ODD && !ORING) {
+      if constexpr (SV == 2) {
         // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
         // only the block step of a state that has one waits for it
         for (int i = 0; i < nfm; i++) {
@@ -2861,7 +2985,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       open_state(kimg + 1, rpn, rpnn, cpn, cpnn, gpn, bqn);
       rpn = rpnn; cpn = cpnn; gpn = gpnn; bqn = bqnn;
       if (btw_on) bqnn = u.btwidx[min(s + kimg + 3, ptr_max)];
-      rpnn = u.rowptr[min(s + kimg + 3, ptr_max)];
+      rpnn = fptr[min(s + kimg + 3, ptr_max)];
       cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
       if (st_on) gpnn = u.gpidx[min(s + kimg + 3, ptr_max)];
     };
@@ -2882,7 +3006,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     {
       const int g0 = st_on ? u.gpidx[min(s, ptr_max)] : -1;
       ldraw(0, g0);
-      open_state(0, u.rowptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, g0, btw_on ? u.btwidx[min(s, ptr_max)] : -1);
+      open_state(0, fptr[min(s, ptr_max)], rpn, u.crowptr[min(s, ptr_max)], cpn, g0, btw_on ? u.btwidx[min(s, ptr_max)] : -1);
     }
     assemble(0); write_img(0, 0);
     assemble(1); write_img(1, 1);

@@ -98,7 +98,8 @@ enum {
   GPSLAM_PLAN_LEVELS_OF_FOUR = 4,     /* upper hierarchy as one launch per level of chunks of four instead of LDS-resident cyclic reduction */
   GPSLAM_PLAN_FS_TWO_LAUNCHES = 8,    /* segmented landmark elimination: border sweep and Schur complement as two launches through Y */
   GPSLAM_PLAN_GP_ROWS = 16,           /* GP priors as plain Jacobian rows instead of structured records */
-  GPSLAM_PLAN_GENERIC_QC = 32         /* SE(3) records: the general (upper-triangular) chol(Qc^-1) form even when Qc is diagonal */
+  GPSLAM_PLAN_GENERIC_QC = 32,        /* SE(3) records: the general (upper-triangular) chol(Qc^-1) form even when Qc is diagonal */
+  GPSLAM_PLAN_MEAS_ROWS = 64          /* SE(3) records: interpolated GPS factors as plain 24-column rows (k_fused_level0<3>) instead of 16-double lines (<4>) */
 };
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */
@@ -314,7 +315,8 @@ int gpslam_hip_body_centric_velocity(gpslam_hip_handle *h, int32_t which, int32_
 /* What compile() chose for the chain solver (introspection for tests and tuning; no reference counterpart):
  * out8 = {levels of the hierarchy, level-0 chunk length, upper chunk length, assembly fused into the level-0 elimination
  * (k_fused_level0) 0/1, GP priors handed to the assembly as structured records instead of Jacobian rows 0/1 (SE(3): inside the fused
- * kernel; SE(2) / SO(3) / 3-D linear: where k_assemble_ghost runs), rows in the
+ * kernel; SE(2) / SO(3) / 3-D linear: where k_assemble_ghost runs; 2: SE(3) records AND the interpolated GPS factors' rows as
+ * 16-double lines whose right halves the assembly wave forms from the interval's record -- round 5), rows in the
  * full-width table, rows in the compact table, right-hand-side columns R}. */
 int gpslam_hip_plan_info(gpslam_hip_handle *h, int32_t out8[8]);
 /* the plan of the segmented landmark elimination chosen by compile(): out = {active (0 / 1), segment length C, fat
