@@ -31,6 +31,12 @@
  *           whitening / error() scaling, iteration counts, the LM lambda schedule,
  *           default retract charts, convergence thresholds, anything with N > 2 states,
  *           GPInterpolatedAttitudeFactorRot3 (the reference has no test for it).
+ *           Round 5, recalled from GTSAM 4.0.x LevenbergMarquardtOptimizer::tryLambda (third party; the reference's call sites:
+ *           matlab/PlazaPose2.m:210-226, matlab/GPAHRSexample.m:259-264): a trial whose |err - newErr| is below
+ *           relativeErrorTol * err ends the search for a lambda ("stopping as relative cost reduction is small") -- the step
+ *           is kept if its model fidelity passes, otherwise lambda and the values stay as they were; lambda is multiplied by
+ *           lambdaFactor BEFORE it is tested against lambdaUpperBound.  orc_chain_iterate_lm follows that; without the stop the
+ *           restatement climbed 1e-5 -> 1e4 on rounding noise at a converged point (round 4's red GPU test).
  */
 #ifndef GPSLAM_ORACLE_H
 #define GPSLAM_ORACLE_H
