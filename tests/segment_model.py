@@ -70,7 +70,8 @@ class SegmentModel:
             getattr(ch, name)(*args)
         return ch
 
-    def iterate_phase1(self, lam=0.0):
+    def _linearise(self):
+        """the segment's normal equations at the current values: H0 (undamped), rhs, error"""
         b, N = self.b, self.N
         ch = self._chain()
         self._err_before = ch.error()
@@ -84,11 +85,19 @@ class SegmentModel:
             if i + 1 < len(D):
                 H[(i + 1) * b:(i + 2) * b, i * b:(i + 1) * b] = Ocp[i]
                 H[i * b:(i + 1) * b, (i + 1) * b:(i + 2) * b] = Ocp[i].T
+        self._H0, self._rhs = H, rhs
+
+    def _reduce(self, lam):
+        """eliminate the interior of the (damped) segment -> interface record"""
+        b, N = self.b, self.N
+        n = N * b
+        H = self._H0.copy()
+        rhs = self._rhs
         H[:n, :n] += lam * np.eye(n)
         I = slice(b, n)               # interior
         S = [slice(0, b), slice(n, n + b)]   # separator, halo
         HII = H[I, I]
-        self._HII, self._H, self._rhs, self._I, self._S = HII, H, rhs, I, S
+        self._HII, self._H, self._I, self._S = HII, H, I, S
         if n > b:
             sol = np.linalg.solve(HII, np.column_stack([H[I, S[0]], H[I, S[1]], rhs[I]]))
             W0, W1, y = sol[:, :b], sol[:, b:2 * b], sol[:, 2 * b]
@@ -107,7 +116,36 @@ class SegmentModel:
         rec = np.concatenate([Drec.ravel(), C.ravel(), Grec, RD.ravel(), Rg])
         self.send.copy_(torch.from_numpy(rec))
 
-    def iterate_phase2(self, want_stats=True):
+    def iterate_phase1(self, lam=0.0):
+        self._linearise()
+        self._reduce(lam)
+
+    # ---- Levenberg-Marquardt trial steps (the caller owns the loop: gpslam_amd/sharded.py, ShardedSolver.iterate_lm; the library's
+    # own steps are gpslam_hip_lm_begin / lm_trial_phase1 / iterate_phase2a / lm_trial_phase2 / lm_reject)
+    def lm_begin(self):
+        self._linearise()
+        self._backup = (self.pose.copy(), self.vel.copy(), None if self.halo_pose is None else self.halo_pose.copy(),
+                        None if self.halo_vel is None else self.halo_vel.copy())
+
+    def lm_trial_phase1(self, lam):
+        self._reduce(lam)
+
+    def iterate_phase2a(self):
+        return 0
+
+    def lm_trial_phase2(self):
+        """[error at the linearisation point, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag] of this rank"""
+        x, xh = self._solve_and_retract()
+        n = self.N * self.b
+        dg = float(x.ravel() @ self._rhs[:n]) + (float(xh @ self._rhs[n:]) if self.has_right else 0.0)
+        return np.array([self._err_before, self._chain().error(), float(np.abs(x).max()), dg, float(x.ravel() @ x.ravel()), 0.0])
+
+    def lm_reject(self):
+        self.pose, self.vel = self._backup[0].copy(), self._backup[1].copy()
+        if self._backup[2] is not None:
+            self.halo_pose, self.halo_vel = self._backup[2].copy(), self._backup[3].copy()
+
+    def _solve_and_retract(self):
         b, N, P = self.b, self.N, self.P
         RS = self.BS + self.AS
         rec = self.recv.numpy().reshape(P, RS)
@@ -141,5 +179,9 @@ class SegmentModel:
         if self.has_right:
             self.halo_pose = O.retract(self.kind, self.halo_pose, xh[:self.d], self.chart)
             self.halo_vel = self.halo_vel + xh[self.d:]
+        return x, xh
+
+    def iterate_phase2(self, want_stats=True):
+        x, _xh = self._solve_and_retract()
         err_after = self._chain().error()
         return Stats(self._err_before, err_after, float(np.abs(x).max()))

@@ -22,7 +22,7 @@ def _launch(world, gpus, states=20, steps=2, warmup=1, timeout=600):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])      # 8: the node the driver's scaling run uses
 def test_bench_line_of_a_multi_rank_run(world):
     out = _launch(world, world)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
