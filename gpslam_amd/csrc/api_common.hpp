@@ -133,6 +133,9 @@ struct gpslam_hip_handle {
   void *coll_user = nullptr;
   DevBuf coll_s, coll_r;     // 8 doubles of this rank's scalars, nranks x 8 gathered
   DevBuf brec, btwidx;
+  // Gauss-Newton runs (gpslam_hip_run_gn): the retraction of an iteration folded into the next iteration's K1 (kernels.hpp: PendUpd).
+  // pend_ok: compile() found the graph eligible;  pend_upd: a solve's update sits in the level-0 solution array, not yet applied
+  bool pend_ok = false, pend_upd = false;
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;

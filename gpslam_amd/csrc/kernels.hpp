@@ -103,7 +103,48 @@ template <> struct IsF64<double> { static constexpr bool v = true; };
 // fp32 mode (GPSLAM_FP32) the Jacobian rows, the normal equations and the solver run with T = float, while the residual
 // is evaluated by the T = double error pass of the same kernels, which then also deposits its whitened error as the
 // fp32 right-hand side (rowE32): fp32 linear algebra + fp64 residual = iterative refinement through the Gauss-Newton loop.
+// Pending update (round 5).  Inside a fixed-count Gauss-Newton run the retraction of iteration k is folded into the linearisation
+// of iteration k + 1: K1 reads a state, applies the update the previous solve left in the level-0 solution array, linearises at the
+// updated values, and the thread that OWNS the state (the GP prior whose left state it is; the last state rides with the last
+// factor) writes it into the OTHER state buffer -- the host swaps the two buffers behind the launch.  One launch (k_retract) and one
+// read + write of every state less per iteration; Values::retract and NonlinearFactorGraph::linearize of GaussNewtonOptimizer::iterate
+//  in one pass over the states.  The same arithmetic in the same order as k_retract: bit-identical states.
+struct PendUpd {
+  const double *dx = nullptr;   // N x b updates (level-0 solutions, R = 1), or null: nothing pending
+  double *pose_w = nullptr, *vel_w = nullptr;   // the other state buffer (same SoA stride)
+  const int *flag = nullptr;    // non-SPD flag of the solve that produced dx: set -> the states stay as they are
+  int chart = 0, last = 0;      // retract chart; index of the chain's last state
+};
+// state i as K1 sees it: the stored value, or -- with an update pending -- its retraction; `own`: this thread writes it back
+template <int MF> __device__ __forceinline__ void load_state_upd(const double *pose, const double *vel, int stride, int i, const PendUpd &u,
+                                                                  bool own, double *p, double *v) {
+  constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
+#pragma unroll
+  for (int k = 0; k < pd; k++) p[k] = pose[(size_t)k * stride + i];
+#pragma unroll
+  for (int k = 0; k < d; k++) v[k] = vel[(size_t)k * stride + i];
+  if (u.dx != nullptr) {
+    if (!*u.flag) {
+      double dl[b], q[pd];
+#pragma unroll
+      for (int k = 0; k < b; k++) dl[k] = u.dx[(size_t)i * b + k];
+      PoseFactors<double, MF, false>::retract(p, dl, u.chart, q);
+#pragma unroll
+      for (int k = 0; k < pd; k++) p[k] = q[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) v[k] += dl[d + k];
+    }
+    if (own) {
+#pragma unroll
+      for (int k = 0; k < pd; k++) u.pose_w[(size_t)k * stride + i] = p[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) u.vel_w[(size_t)k * stride + i] = v[k];
+    }
+  }
+}
+
 template <typename T> struct GpArgs {
+  PendUpd pend;                // fp64 SE(3) record launches inside run_gn: the previous iteration's update, applied here
   const double *pose, *vel;    // SoA
   int stride;             // SoA stride (>= N + 1)
   int count;
@@ -254,10 +295,16 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
   if (valid) {
     const int i = a.left[f];
     dt = a.dt[f];
+    if constexpr (std::is_same<T, double>::value) {
+      // (with an update pending this thread owns state i, and the chain's last state if that is its right one)
+      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, true, p1, v1);
+      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i + 1, a.pend, i + 1 == a.pend.last, p2, v2);
+    } else {
 #pragma unroll
-    for (int k = 0; k < 12; k++) { p1[k] = T(a.pose[(size_t)k * a.stride + i]); p2[k] = T(a.pose[(size_t)k * a.stride + i + 1]); }
+      for (int k = 0; k < 12; k++) { p1[k] = T(a.pose[(size_t)k * a.stride + i]); p2[k] = T(a.pose[(size_t)k * a.stride + i + 1]); }
 #pragma unroll
-    for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+      for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+    }
   }
   const SE3<T> h = se3_between(as_se3(p1), as_se3(p2));
   const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
@@ -625,6 +672,7 @@ __global__ void __launch_bounds__(128) k_gp(GpArgs<T> a) {
 // ------------------------------------------------------------------ unary / between rows
 
 template <typename T> struct FacArgs {
+  PendUpd pend;         // see GpArgs: these factors read the updated states too (they own none)
   const double *pose, *vel;
   int stride, count, chart;
   const int *idx;       // state (left state for between)
@@ -651,11 +699,19 @@ __device__ __forceinline__ void between_pose3_record(const FacArgs<T> &a, const 
   for (int k = 0; k < 12; k++) { x1[k] = (k == 0 || k == 4 || k == 8) ? T(1) : T(0); x2[k] = x1[k]; m[k] = x1[k]; }   // idle lane: identities
   if (valid) {
     const int i = a.idx[f];
+    if constexpr (std::is_same<T, double>::value) {
+      double vv[6];
+      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, false, x1, vv);
+      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i + 1, a.pend, false, x2, vv);
 #pragma unroll
-    for (int k = 0; k < 12; k++) {
-      x1[k] = T(a.pose[(size_t)k * a.stride + i]);
-      x2[k] = T(a.pose[(size_t)k * a.stride + i + 1]);
-      m[k] = T(a.meas[(size_t)f * 12 + k]);
+      for (int k = 0; k < 12; k++) m[k] = T(a.meas[(size_t)f * 12 + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        x1[k] = T(a.pose[(size_t)k * a.stride + i]);
+        x2[k] = T(a.pose[(size_t)k * a.stride + i + 1]);
+        m[k] = T(a.meas[(size_t)f * 12 + k]);
+      }
     }
   }
   auto put = [&](int idx, T v) {              // (idx: a compile-time constant once the loops are unrolled)
@@ -718,17 +774,20 @@ __device__ __forceinline__ void simple_block(const FacArgs<T> &a, const int bid,
   if (valid) {
     const int i = a.idx[f];
     if (KIND == 1) {
+      double pp[pd], vv[d];
+      load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, false, pp, vv);
 #pragma unroll
-      for (int k = 0; k < d; k++) e[k] = T(a.vel[(size_t)k * a.stride + i] - a.meas[(size_t)f * d + k]);
+      for (int k = 0; k < d; k++) e[k] = T(vv[k] - a.meas[(size_t)f * d + k]);
     } else {
       T x1[pd], m[pd], x2[pd];
       {
-        double q1[pd], qm[pd], q2[pd];
+        double q1[pd], qm[pd], q2[pd], vv[d];
+        load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, false, q1, vv);
+        if (KIND == 2) load_state_upd<MF>(a.pose, a.vel, a.stride, i + 1, a.pend, false, q2, vv);
 #pragma unroll
         for (int k = 0; k < pd; k++) {
-          q1[k] = a.pose[(size_t)k * a.stride + i];
           qm[k] = a.meas[(size_t)f * pd + k];
-          q2[k] = (KIND == 2) ? a.pose[(size_t)k * a.stride + i + 1] : 0.0;
+          if (KIND != 2) q2[k] = 0.0;
         }
         if (!IsF64<T>::v) {   // re-centre on x1: PriorFactor compares (prior, x1), BetweenFactor (x1, x2) with a relative measurement
 #pragma unroll
