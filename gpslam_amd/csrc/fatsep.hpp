@@ -29,9 +29,19 @@
 
 namespace gps {
 
-constexpr int kFatMax = 80;   // largest fat block (cut state + landmark columns).  Round 3: 64 -> 80, what one workgroup's LDS
-                              // holds of the three NB x NB operands of k_fat_elim (155 KB of 160); config 4's graph needs 36, twice
-                              // its landmark density 62.  Beyond 80 the fat-block elimination would have to be tiled.
+constexpr int kFatMax = 128;  // largest fat block (cut state + landmark columns): what one workgroup's LDS holds of ONE NB x NB operand
+                              // (k_fat_elim_wide, k_fat_top, k_fat_back: 132 KB of 160).  Config 4's graph needs 28-36, twice its
+                              // landmark density 62, three times 96-100.
+// columns of [H | H | g] per pass of k_fat_elim_wide: what is left of 160 KB beside the block (and the 4 x 4 factors in Ld)
+inline int fat_wide_panel(int elem_bytes, int NB) {
+  const long avail = 160L * 1024 - (long)(kFatMax / 4) * 10 * elem_bytes - (long)NB * (NB + 1) * elem_bytes - 512;
+  long pw = avail / ((long)NB * elem_bytes);
+  if (pw > 2 * NB + 1) pw = 2 * NB + 1;
+  return (int)(pw < 4 ? 4 : pw);
+}
+constexpr int kFatLds = 80;   // round 3: 64 -> 80, what the LDS holds of all three NB x NB operands of k_fat_elim (155 KB of 160).
+                              // Round 5: wider blocks keep the factor in LDS and stream [H | H | g] through it in column panels
+                              // (k_fat_elim_wide).
 
 template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jacobian row tables (kernels.hpp, LmArgs)
   int N, B, ld, L, K, NB, NC, NCP;   // K cuts / fat blocks; NC = 2 NB + 1 border columns; NCP = NC rounded up to 16
@@ -340,7 +350,8 @@ template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(
 
 // ---- forward substitution of the border columns.  One thread per (segment, column):
 // G~_j = G_j - E_{j-1}^T Y_{j-1},  Y_j = W_j G~_j.  Columns: [0, NB) left fat block, [NB, 2 NB) right fat block, 2 NB rhs.
-template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(256) k_fs_sweep(FsArgs<T, TR> a) {
+// (round 5: up to 2 * 128 + 1 = 257 border columns, five waves)
+template <typename T, int B, typename TR = T> __global__ void __launch_bounds__(320) k_fs_sweep(FsArgs<T, TR> a) {
   const int seg = blockIdx.x, c = threadIdx.x;
   const int cutL = a.cuts[seg], cutR = a.cuts[seg + 1];
   const int j0 = cutL + 1, n = cutR - cutL - 1;
@@ -534,6 +545,9 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
   const bool rhs_alone = ((2 * a.NB) % 16) == 0;
   const int T16 = rhs_alone ? (2 * a.NB) / 16 : NCP / 16, ntiles = T16 * (T16 + 1) / 2;
   const int NCF = rhs_alone ? 2 * a.NB + 2 : NCP;           // columns fetched per chunk row (even: 16-byte pieces)
+  // waves that also sum the rhs row, 64 columns each (its 2 NB entries left of the diagonal are the ones k_fs_fat_assemble reads).
+  // Round 5: was "waves 0 and 1" whatever NB -- at NB = 72 and NB = 80 exactly the columns from 128 on were never summed
+  const int nrw = (rhs_alone && blockIdx.y == 0) ? min((2 * a.NB + 63) / 64, 4) : 0;
   const int j0 = a.cuts[seg] + 1, n = a.cuts[seg + 1] - a.cuts[seg] - 1;
   const int kdim = n * a.B;
   const double *Yb = a.Y + (size_t)j0 * a.B * NCP;
@@ -544,7 +558,9 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
     acc[q] = fs_d4{0.0, 0.0, 0.0, 0.0};
-    const int pidx = (3 - wv) + 4 * q;                      // (the low waves get one tile fewer: they also sum the rhs row)
+    // (the low waves get one tile fewer: they also sum the rhs row.  Round 5: borders beyond 176 columns deal the tiles over
+    //  gridDim.y = 2 workgroups per segment -- both stage the whole chunk -- so that a wave's accumulators still fit its registers)
+    const int pidx = (3 - wv) + 4 * (q * (int)gridDim.y + (int)blockIdx.y);
     int ti = 0;
     while ((ti + 1) * (ti + 2) / 2 <= pidx) ti++;
     const int tj = pidx - ti * (ti + 1) / 2;
@@ -599,7 +615,7 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
         }
       }
     }
-    if (rhs_alone && wv < 2) {                               // row 2 NB of Y^T Y: column jr against the rhs column
+    if (wv < nrw) {                                          // row 2 NB of Y^T Y: column jr against the rhs column
       const int jr = min(lane + 64 * wv, 2 * a.NB);
 #pragma unroll
       for (int k = 0; k < KC; k++) racc += bb[k * LSP + jr] * bb[k * LSP + 2 * a.NB];
@@ -608,7 +624,7 @@ template <int TPW, int NCM, typename TR = double> __global__ void __launch_bound
     __syncthreads();
   }
   double *out = a.Aseg + (size_t)seg * NCP * NCP;
-  if (rhs_alone && wv < 2 && lane + 64 * wv <= 2 * a.NB) out[(size_t)(2 * a.NB) * NCP + lane + 64 * wv] = racc;
+  if (wv < nrw && lane + 64 * wv <= 2 * a.NB) out[(size_t)(2 * a.NB) * NCP + lane + 64 * wv] = racc;
 #pragma unroll
   for (int q = 0; q < TPW; q++) {
     if (q < nq) {
@@ -1253,6 +1269,141 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
 }
 
+// ---- round 5: fat blocks wider than kFatLds.  The three NB x NB operands no longer fit the LDS together (NB = 128: 395 KB); the
+// block D_m does (132 KB).  It is factored there once (fat_factor_panel4 without a right-hand side), then the columns of
+// [H(m,l) | H(m,r) | g] pass through the rest of the LDS in panels of PW columns: X <- L^-1 X by the same four-pivot steps
+// (fat_solve_panel4: the 4 x 4 diagonal factors come back from Ld), P / Q / z go out to the places k_fat_elim writes them.  The five
+// products are then formed from P and Q where they lie (L2; 4 x 4 register tiles, the k order of k_fat_elim's sums).
+template <typename T> __device__ __forceinline__ void fat_solve_panel4(const T *Lm, const T *Ld, T *X, int NB, int LS, int XS, int NX) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
+  for (int p = 0; p < NB; p += 4) {
+    T L[4][4], W[4][4], inv[4];
+    {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) L[i][j] = Ld[(p >> 2) * 10 + q++];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) inv[j] = T(1) / L[j][j];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int r = c; r < 4; r++) {
+        T sacc = (r == c) ? T(1) : T(0);
+#pragma unroll
+        for (int k = c; k < r; k++) sacc -= L[r][k] * W[k][c];
+        W[r][c] = sacc * inv[r];
+      }
+    for (int t = tid; t < NX; t += nt) {
+      T *cp = X + p * XS + t;
+      const T b0 = cp[0], b1 = cp[XS], b2 = cp[2 * XS], b3 = cp[3 * XS];
+      cp[0] = W[0][0] * b0;
+      cp[XS] = W[1][0] * b0 + W[1][1] * b1;
+      cp[2 * XS] = W[2][0] * b0 + W[2][1] * b1 + W[2][2] * b2;
+      cp[3 * XS] = W[3][0] * b0 + W[3][1] * b1 + W[3][2] * b2 + W[3][3] * b3;
+    }
+    __syncthreads();
+    for (int i = p + 4 + ty; i < NB; i += nty) {
+      const T *li = Lm + i * LS + p;
+      const T l0 = li[0], l1 = li[1], l2 = li[2], l3 = li[3];
+      for (int cc = tx; cc < NX; cc += 64) {
+        const T *xp = X + p * XS + cc;
+        X[i * XS + cc] -= l0 * xp[0] + l1 * xp[XS] + l2 * xp[2 * XS] + l3 * xp[3 * XS];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_elim_wide(FsArgs<T, TR> a, FatLevel lv, int PW) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
+  const int NB = a.NB, LS = NB + 1, XS = PW, NB2 = NB * NB, NXT = 2 * NB + 1;
+  T *Lm = reinterpret_cast<T *>(fat_smem);
+  T *X = Lm + NB * LS;
+  __shared__ T Ld[(kFatMax / 4) * 10];
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int idx = tid; idx < NB2; idx += nt) {
+    const int i = idx / NB, j = idx - i * NB;
+    Lm[i * LS + j] = a.Dfat[(size_t)m * NB2 + idx];
+  }
+  __syncthreads();
+  fat_factor_panel4(Lm, X, Ld, NB, LS, XS, 0, a.flag);
+  for (int idx = tid; idx < NB2; idx += nt) {
+    const int i = idx / NB, j = idx - i * NB;
+    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);
+  }
+  T *Pg = a.link + (size_t)lk_lm * NB2, *Qg = a.Qbuf + (size_t)m * NB2, *zg = a.gfat + (size_t)m * NB;
+  for (int c0 = 0; c0 < NXT; c0 += PW) {
+    const int pw = min(PW, NXT - c0);
+    __syncthreads();
+    for (int idx = tid; idx < NB * pw; idx += nt) {
+      const int i = idx / pw, cc = idx - i * pw, c = c0 + cc;
+      T v;
+      if (c < NB) v = Pg[(size_t)i * NB + c];                                                             // H[m, l]
+      else if (c < 2 * NB) v = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + (size_t)(c - NB) * NB + i] : T(0);  // H[m, r] = H[r, m]^T
+      else v = zg[i];
+      X[i * XS + cc] = v;
+    }
+    __syncthreads();
+    fat_solve_panel4(Lm, Ld, X, NB, LS, XS, pw);
+    for (int idx = tid; idx < NB * pw; idx += nt) {
+      const int i = idx / pw, cc = idx - i * pw, c = c0 + cc;
+      const T v = X[i * XS + cc];
+      if (c < NB) Pg[(size_t)i * NB + c] = v;                  // P
+      else if (c < 2 * NB) Qg[(size_t)i * NB + (c - NB)] = v;  // Q
+      else zg[i] = v;                                          // z
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- S1 = P^T P, S2 = Q^T Q, new link = -(Q^T P), P^T z, Q^T z
+  const int n4 = NB / 4;
+  for (int tix = tid; tix < n4 * n4; tix += nt) {
+    const int i0 = (tix / n4) * 4, j0 = (tix - (tix / n4) * n4) * 4;
+    T s1[4][4], s2[4][4], s3[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) { s1[u][v] = T(0); s2[u][v] = T(0); s3[u][v] = T(0); }
+    for (int k = 0; k < NB; k++) {
+      T pi[4], pj[4], qi[4], qj[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        pi[u] = Pg[(size_t)k * NB + i0 + u]; pj[u] = Pg[(size_t)k * NB + j0 + u];
+        qi[u] = Qg[(size_t)k * NB + i0 + u]; qj[u] = Qg[(size_t)k * NB + j0 + u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+          s1[u][v] += pi[u] * pj[v];
+          s2[u][v] += qi[u] * qj[v];
+          s3[u][v] += qi[u] * pj[v];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+#pragma unroll
+      for (int v = 0; v < 4; v++) {
+        const size_t o = (size_t)(i0 + u) * NB + j0 + v;
+        a.S1[(size_t)m * NB2 + o] = s1[u][v];
+        a.S2[(size_t)m * NB2 + o] = s2[u][v];
+        if (r >= 0) a.link[(size_t)lk_new * NB2 + o] = -s3[u][v];         // H[r, l] = -(Q^T P)
+      }
+  }
+  for (int i = tid; i < NB; i += nt) {
+    T pz = T(0), qz = T(0);
+    for (int k = 0; k < NB; k++) { pz += Pg[(size_t)k * NB + i] * zg[k]; qz += Qg[(size_t)k * NB + i] * zg[k]; }
+    a.sv[(size_t)m * 2 * NB + i] = pz;
+    a.sv[(size_t)m * 2 * NB + NB + i] = qz;
+  }
+}
+
 // ---- round 3: the same elimination with the whole factorisation in REGISTERS (fat blocks up to 48 columns, fp64).
 // k_fat_elim above takes 37-40 us for ONE 36-column block whatever the level's size (ablations: load 6, the blocked
 // factorisation + L^-1 [H | H | g] through LDS 22, the five products 10) and the cyclic reduction has twelve levels of it, nine
@@ -1411,9 +1562,9 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
 
 // x_m = L^-T (z - P x_l - Q x_r)
 template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T, TR> a, FatLevel lv) {
-  __shared__ T Ls[kFatMax * (kFatMax + 1)];
-  __shared__ T xs[2 * kFatMax], ts[kFatMax];
+  extern __shared__ __align__(16) unsigned char fat_smem[];   // (round 5: dynamic -- NB (NB + 1) + 3 NB values, 135 KB at NB = 128)
   const int NB = a.NB, LS = NB + 1, NB2 = NB * NB, lane = threadIdx.x;
+  T *Ls = reinterpret_cast<T *>(fat_smem), *xs = Ls + NB * LS, *ts = xs + 2 * NB;
   const int *e = lv.elim + 6 * blockIdx.x;
   const int m = e[0], l = e[1], r = e[2], lk_lm = e[3];
   for (int idx = lane; idx < NB2; idx += 64) Ls[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)m * NB2 + idx];
@@ -1935,7 +2086,7 @@ struct FatSepPlan {
       nb_out = B + ld * mx;
       return ok;
     };
-    const char *too_many = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 80)";
+    const char *too_many = "too many landmarks per cut for the fat separators (2d + landmark_dim * landmarks must be <= 128)";
     auto no_fit = [&]() {
       return split ? "no segmentation of this piece keeps its private landmarks off the shared end blocks and the shared ones inside the "
                      "end segments: the piece is too short for the landmarks' windows of visibility (use fewer, longer pieces)"

@@ -54,6 +54,51 @@ def test_twice_config4_landmark_density_matches_oracle():
     assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
 
 
+@pytest.mark.parametrize("L,NB", [(180, 72), (195, 80), (225, 96), (295, 116), (340, 128)],
+                         ids=["NB72-rhs-row-beyond-128", "3x-density-NB80", "NB96-wide", "4.5x-density-NB116-wide", "5.2x-density-NB128-the-limit"])
+def test_three_times_config4_landmark_density_and_beyond_matches_oracle(L, NB):
+    """fat separators wider than 80 columns.  Round 5: kFatMax = 128 -- blocks beyond 80 columns keep the factor in
+    LDS and pass [H | H | g] through it in column panels (k_fat_elim_wide), their borders (up to 257 columns) take the five-wave
+    sweep and a Schur-complement launch of two workgroups per segment (k_fs_syrk<20, 272>).  N = 1300 states with L landmarks
+    (config 4's density is N / 20 = 65): 3x gives NB = 80 exactly, 4.5x NB = 116, 5.2x NB = 128 (257 border columns); L = 345 is
+    refused with a message.  NB = 72 and NB = 80 are also the two widths at which the right-hand-side row of the Schur complement
+    (summed beside the matrix cores when 2 NB is a multiple of 16) has columns beyond 128, which only two of the three waves it
+    needs used to sum: the round-4 library's first Gauss-Newton step is 7-11 % off in error_after on these two graphs."""
+    N = 1300
+    p = S.pose2_local_landmarks_chain(N, L=L, window=200)
+    orc, dev = _pair(p, segment_length=256)
+    plan = dev.segment_plan()
+    assert plan["active"] == 1 and plan["NB"] == NB, plan
+    assert abs(orc.error() - dev.error()) <= 1e-10 * orc.error()
+    for it in range(4):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (it, s0.error_after, s1.error_after)
+        assert abs(s0.delta_inf_norm - s1.delta_inf_norm) <= 1e-8 * max(1.0, s0.delta_inf_norm)
+    states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
+    l0, l1 = orc.get_landmarks(), dev.get_landmarks()
+    assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
+
+
+def test_more_landmarks_per_cut_than_128_columns_hold_are_refused_with_a_message():
+    gp = gpu()
+    p = S.pose2_local_landmarks_chain(1300, L=360, window=200)
+    with pytest.raises(gp.GpslamHipError, match="too many landmarks per cut"):
+        S.apply(p, gp.ChainSolver(O.POSE2, chart=gp.CHART_FIRST_ORDER, landmark_dim=2, segment_length=256))
+
+
+def test_wide_fat_blocks_through_levenberg_marquardt():
+    """The damped trials of the wide path (lambda on the fat blocks' diagonals, the gradient kept for the model): five LM
+    iterations in lock step with the oracle from open-loop dead reckoning."""
+    import lm_lockstep
+    p = S.pose2_local_landmarks_chain(1300, L=240, window=200, anchor=0)
+    orc, dev = _pair(p, segment_length=256)
+    assert dev.segment_plan()["NB"] > 80
+    _, _, slack = lm_lockstep.run(orc, dev, 1e-5, 5)
+    states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9 + 2 * slack)
+
+
 def test_segmented_path_equals_dense_border_on_a_small_graph():
     """The same small graph (8 landmarks seen from everywhere would not segment; 6 local ones do) through both landmark
     paths of the library."""
@@ -79,8 +124,25 @@ def test_c4_levenberg_marquardt_matches_oracle():
     states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
 
 
+def test_eighty_landmarks_seen_from_everywhere_fit_three_wide_blocks():
+    """80 landmarks each seen from the whole chain: the longest segmentation (two segments) deals them over its three cuts -- fat
+    blocks of 84 columns, which exist since round 5.  Until round 4 this graph was refused ("too many landmarks per cut")."""
+    p = S.pose2_range_chain(600, L=80)
+    orc, dev = _pair(p)
+    plan = dev.segment_plan()
+    assert plan["active"] == 1 and plan["K"] <= 3 and 80 < plan["NB"] <= 128, plan
+    for it in range(3):
+        rc0, s0 = orc.iterate_gn()
+        rc1, s1 = dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (it, s0.error_after, s1.error_after)
+    states_close(O.POSE2, *orc.get_states(), *dev.get_states(), rel=1e-9)
+    l0, l1 = orc.get_landmarks(), dev.get_landmarks()
+    assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
+
+
 def test_landmark_seen_from_everywhere_is_rejected_with_a_message():
-    p = S.pose2_range_chain(600, L=80)          # 80 landmarks each seen from the whole chain: no cut holds them
+    p = S.pose2_range_chain(600, L=200)         # 200 landmarks each seen from the whole chain: no cut holds them, nor do the two ends
     gp = gpu()
     with pytest.raises(gp.GpslamHipError, match="more than two segments|too many landmarks per cut"):
         S.apply(p, gp.ChainSolver(O.POSE2, chart=gp.CHART_FIRST_ORDER, landmark_dim=2))
