@@ -500,6 +500,17 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
     const int i = a.left[f];
     dt = a.dt[f];
     T p1[pd], p2[pd], v1[d], v2[d];
+    if constexpr (REC && d == 3 && IsF64<T>::v) {
+      // the d = 3 record launches inside run_gn: the states as the pending update leaves them (PendUpd; nothing pending: as stored);
+      // this factor owns its left state, the last factor the chain's last state as well
+      double q1[pd], q2[pd], w1[d], w2[d];
+      load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, true, q1, w1);
+      load_state_upd<MF>(a.pose, a.vel, a.stride, i + 1, a.pend, i + 1 == a.pend.last, q2, w2);
+#pragma unroll
+      for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
+#pragma unroll
+      for (int k = 0; k < d; k++) { v1[k] = T(w1[k]); v2[k] = T(w2[k]); }
+    } else {
     {
       double q1[pd], q2[pd];
 #pragma unroll
@@ -513,6 +524,7 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
     }
 #pragma unroll
     for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
+    }
     if constexpr (MF == POSE3) {
       if (a.vw) {
         T b1[6], b2[6];

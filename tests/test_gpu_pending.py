@@ -48,6 +48,71 @@ def test_run_gn_is_bit_identical_to_single_iterations(N, chart, vprior):
     assert np.abs(xo - x0).max() <= 1e-9 * max(1.0, np.abs(xo).max()) and np.abs(vo - v0).max() <= 1e-9 * max(1.0, np.abs(vo).max())
 
 
+def _d3_problem(kind, N):
+    """Record chains of the d = 3 manifolds without measurement factors: BASELINE config 2 (3-D linear GP chain with position fixes
+    and a velocity prior), an SE(2) chain with odometry, an SO(3) chain with attitude priors on a few states."""
+    from gpslam_amd import synthetic as S
+    if kind == O.LINEAR3:
+        return S.linear_chain(N)
+    if kind == O.POSE2:
+        p = S.pose2_range_chain(N, L=4)
+        return {k: v for k, v in p.items() if not k.startswith("range_") and not k.startswith("lprior") and not k.startswith("landmark")}
+    p = S.rot3_attitude_chain(N)
+    q = {k: v for k, v in p.items() if not k.startswith("att_")}
+    idx = np.arange(0, N, 7, dtype=np.int32)
+    q.update(prior_idx=idx, prior_pose=p["truth"][idx] if "truth" in p else p["pose"][idx], prior_sig=np.full((len(idx), 3), 0.05))
+    return q
+
+
+@pytest.mark.parametrize("kind,N,chart", [(O.LINEAR3, 1000, 0), (O.LINEAR3, 50, 0), (O.POSE2, 700, 0), (O.POSE2, 333, 1), (O.ROT3, 500, 0)],
+                         ids=["config2-1000", "config2-50", "pose2+odometry-700", "pose2-first-order-chart", "rot3+attitude-priors"])
+def test_run_gn_on_the_d3_record_chains_is_bit_identical_to_single_iterations(kind, N, chart):
+    """The d = 3 records (kGp3*) take the pending update as the SE(3) records do: K1's GP path reads both states through
+    load_state_upd and the left state's owner writes it into the other buffer."""
+    gp = gpu()
+    from gpslam_amd import synthetic as S
+    p = _d3_problem(kind, N)
+    K = 4
+    sols = {}
+    for name, plan, single in (("folded", 0, False), ("separate", gp.PLAN_SEPARATE_RETRACT, False), ("single", 0, True)):
+        s = S.apply(p, gp.ChainSolver(kind, chart=chart, plan=plan))
+        if single:
+            for _ in range(K):
+                _, st = s.iterate_gn()
+        else:
+            st, _ = s.run_gn(K)
+        sols[name] = (s.get_states(), st.error_before, st.error_after, st.delta_inf_norm)
+        s.close()
+    (x0, v0), eb0, ea0, d0 = sols["single"]
+    for name in ("folded", "separate"):
+        (x, v), eb, ea, d = sols[name]
+        assert np.array_equal(x, x0) and np.array_equal(v, v0), name
+        assert (eb, ea, d) == (eb0, ea0, d0), (name, eb, ea, d, eb0, ea0, d0)
+    orc = S.apply(p, O.Chain(kind, chart))
+    for _ in range(K):
+        orc.iterate_gn()
+    xo, vo = orc.get_states()
+    assert np.abs(xo - x0).max() <= 1e-9 * max(1.0, np.abs(xo).max()) and np.abs(vo - v0).max() <= 1e-9 * max(1.0, np.abs(vo).max())
+
+
+def test_rows_requested_in_the_middle_of_a_run_do_not_lose_the_update():
+    """gpslam_hip_get_rows on a d = 3 chain switches K1 back to plain rows (rows3): an update left pending by run_gn must have
+    been applied by then -- run_gn never returns with one pending, and the next call linearises at the retracted states."""
+    gp = gpu()
+    from gpslam_amd import synthetic as S
+    p = S.linear_chain(400)
+    a = S.apply(p, gp.ChainSolver(O.LINEAR3))
+    b = S.apply(p, gp.ChainSolver(O.LINEAR3, plan=gp.PLAN_SEPARATE_RETRACT))
+    a.run_gn(2); b.run_gn(2)
+    ra, rb = a.get_rows(), b.get_rows()
+    for u, v in zip(ra, rb):
+        assert (u is None and v is None) or np.array_equal(u, v)
+    a.run_gn(2); b.run_gn(2)
+    (xa, va), (xb, vb) = a.get_states(), b.get_states()
+    assert np.array_equal(xa, xb) and np.array_equal(va, vb)
+    a.close(); b.close()
+
+
 def test_a_chain_with_a_missing_gp_prior_keeps_the_separate_retraction():
     """A state that is nobody's left state has no owner to write it back: compile() leaves the plan alone and the answers stand."""
     gp = gpu()
