@@ -95,6 +95,37 @@ def test_run_gn_on_the_d3_record_chains_is_bit_identical_to_single_iterations(ki
     assert np.abs(xo - x0).max() <= 1e-9 * max(1.0, np.abs(xo).max()) and np.abs(vo - v0).max() <= 1e-9 * max(1.0, np.abs(vo).max())
 
 
+@pytest.mark.parametrize("N,per,plan_bits", [(500, 4, 0), (301, 2, "rows")], ids=["gps-lines", "gps-rows"])
+def test_run_gn_with_interpolated_gps_factors_is_bit_identical_to_single_iterations(N, per, plan_bits):
+    """SE(3) record chain + odometry + GPInterpolatedGPSFactorPose3: k_meas runs behind k_lin on the same stream (it reads the
+    interval's record), i.e. behind the buffer swap -- the folded retraction needs nothing from it."""
+    gp = gpu()
+    from test_gpu_irows import gps_graph
+    feed, p = gps_graph(N, seed=N, per_interval=per)
+    extra = gp.PLAN_MEAS_ROWS if plan_bits == "rows" else 0
+    K = 4
+    sols = {}
+    for name, plan, single in (("folded", 0, False), ("separate", gp.PLAN_SEPARATE_RETRACT, False), ("single", 0, True)):
+        s = feed(gp.ChainSolver(gp.POSE3, plan=plan | extra))
+        if single:
+            for _ in range(K):
+                _, st = s.iterate_gn()
+        else:
+            st, _ = s.run_gn(K)
+        sols[name] = (s.get_states(), st.error_before, st.error_after, st.delta_inf_norm)
+        s.close()
+    (x0, v0), eb0, ea0, d0 = sols["single"]
+    for name in ("folded", "separate"):
+        (x, v), eb, ea, d = sols[name]
+        assert np.array_equal(x, x0) and np.array_equal(v, v0), name
+        assert (eb, ea, d) == (eb0, ea0, d0), (name, eb, ea, d, eb0, ea0, d0)
+    orc = feed(O.Chain(O.POSE3))
+    for _ in range(K):
+        orc.iterate_gn()
+    xo, vo = orc.get_states()
+    assert np.abs(xo - x0).max() <= 1e-9 * max(1.0, np.abs(xo).max()) and np.abs(vo - v0).max() <= 1e-9 * max(1.0, np.abs(vo).max())
+
+
 def test_rows_requested_in_the_middle_of_a_run_do_not_lose_the_update():
     """gpslam_hip_get_rows on a d = 3 chain switches K1 back to plain rows (rows3): an update left pending by run_gn must have
     been applied by then -- run_gn never returns with one pending, and the next call linearises at the retracted states."""
