@@ -907,6 +907,7 @@ constexpr int kMeasAux = 22;     // [body_P_sensor (12) | fx, fy, s, u0, v0 | ha
 template <int FK> struct FKRows { static constexpr int rows = (FK == FK_INTERP_RANGE || FK == FK_RANGE) ? 1 : ((FK == FK_INTERP_ATT || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ) ? 2 : 3); };
 
 template <typename T> struct MeasArgs {
+  PendUpd pend;        // d = 3 chains inside run_gn: the update k_lin is applying beside this launch (pose / vel: the buffer it READS)
   const double *pose, *vel;
   int stride;
   const double *lmk;   // L x ld (AoS)
@@ -977,6 +978,18 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       constexpr bool haslm = (FK == FK_INTERP_RANGE || FK == FK_RANGE || FK == FK_BEARING_RANGE || FK == FK_INTERP_PROJ);
       T p1[pd], v1[d], p2[pd], v2[d];
       double org[3] = {0.0, 0.0, 0.0};      // fp32 arithmetic: translations re-centred on the first pose (see TransPart)
+      // (round 5) the d = 3 chains run this kernel BESIDE k_lin on a second stream: with an update pending (PendUpd) both read the
+      // old state buffer and apply the update themselves; k_lin alone writes the other buffer
+      constexpr bool PEND = JAC && IsF64<T>::v && two && (MF == POSE2 || MF == ROT3 || MF == LINEAR3);
+      if constexpr (PEND) {
+        double q1[pd], q2[pd], w1[d], w2[d];
+        load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, false, q1, w1);
+        load_state_upd<MF>(a.pose, a.vel, a.stride, i + 1, a.pend, false, q2, w2);
+#pragma unroll
+        for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
+#pragma unroll
+        for (int k = 0; k < d; k++) { v1[k] = T(w1[k]); v2[k] = T(w2[k]); }
+      } else {
       {
         double q1[pd], q2[pd];
 #pragma unroll
@@ -994,6 +1007,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       }
 #pragma unroll
       for (int k = 0; k < d; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = two ? a.vel[(size_t)k * a.stride + i + 1] : T(0); }
+      }
       if constexpr (MF == POSE3 && two) {
         if (a.vw) {     // GaussianProcessInterpolatorPose3VW.h:79-80
           T b1[6], b2[6];

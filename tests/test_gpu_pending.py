@@ -52,6 +52,8 @@ def _d3_problem(kind, N):
     """Record chains of the d = 3 manifolds without measurement factors: BASELINE config 2 (3-D linear GP chain with position fixes
     and a velocity prior), an SE(2) chain with odometry, an SO(3) chain with attitude priors on a few states."""
     from gpslam_amd import synthetic as S
+    if kind == "rot3+interp-attitude":       # BASELINE config 5's SO(3) mix: k_meas runs beside k_lin and applies the update itself
+        return S.rot3_attitude_chain(N)
     if kind == O.LINEAR3:
         return S.linear_chain(N)
     if kind == O.POSE2:
@@ -64,14 +66,17 @@ def _d3_problem(kind, N):
     return q
 
 
-@pytest.mark.parametrize("kind,N,chart", [(O.LINEAR3, 1000, 0), (O.LINEAR3, 50, 0), (O.POSE2, 700, 0), (O.POSE2, 333, 1), (O.ROT3, 500, 0)],
-                         ids=["config2-1000", "config2-50", "pose2+odometry-700", "pose2-first-order-chart", "rot3+attitude-priors"])
+@pytest.mark.parametrize("kind,N,chart", [(O.LINEAR3, 1000, 0), (O.LINEAR3, 50, 0), (O.POSE2, 700, 0), (O.POSE2, 333, 1), (O.ROT3, 500, 0),
+                                          ("rot3+interp-attitude", 600, 0), ("rot3+interp-attitude", 77, 0)],
+                         ids=["config2-1000", "config2-50", "pose2+odometry-700", "pose2-first-order-chart", "rot3+attitude-priors",
+                              "config5-rot3+interpolated-attitude-600", "config5-rot3+interpolated-attitude-77"])
 def test_run_gn_on_the_d3_record_chains_is_bit_identical_to_single_iterations(kind, N, chart):
     """The d = 3 records (kGp3*) take the pending update as the SE(3) records do: K1's GP path reads both states through
     load_state_upd and the left state's owner writes it into the other buffer."""
     gp = gpu()
     from gpslam_amd import synthetic as S
     p = _d3_problem(kind, N)
+    kind = p["kind"]
     K = 4
     sols = {}
     for name, plan, single in (("folded", 0, False), ("separate", gp.PLAN_SEPARATE_RETRACT, False), ("single", 0, True)):
