@@ -31,7 +31,9 @@ for t in range(cnt):
     for it in range(3):
         rc0, s0 = orc.iterate_gn(); rc1, s1 = dev.iterate_gn()
         assert rc0 == 0 and rc1 == 0, (t, which, N, rc0, rc1)
-        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)), (t, which, N, it, s0.error_after, s1.error_after)
+        # (+ 1e-11 error_before: a step that takes the cost from 8.6e6 to 2e3 leaves error_after with the rounding of the larger number --
+        #  the oracle alone moves by 1e-9 of error_after there when its input states are perturbed by 1e-15)
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, abs(s0.error_after)) + 1e-11 * abs(s0.error_before), (t, which, N, it, s0.error_after, s1.error_after)
     T.states_close(p["kind"], *orc.get_states(), *dev.get_states(), 1e-9)
     if "landmarks" in p:
         l0, l1 = orc.get_landmarks(), dev.get_landmarks()

@@ -1,8 +1,8 @@
 """Random landmark graphs through the segmented landmark elimination (fatsep.hpp) against the oracle's dense bordered solve: random
 chain length, landmark density (0.4 ... 5 x config 4's), window of visibility and segment length -- the fat block widths NB, border
 widths and level counts the fixed-size tests do not name.  Three Gauss-Newton iterations in lock step: states and landmarks 1e-9
-relative at the end, error_after 1e-8 on the way (the first step from dead reckoning is a long one through an ill-conditioned system:
-two elimination orders part by 1e-9 there and meet again).
+relative at the end, error_after 1e-9 (+ 1e-11 of error_before: the first step from dead reckoning takes the cost down by three to four
+orders of magnitude and leaves error_after with the rounding of the larger number).
    python scripts/stress_segmented.py [count] [seed]"""
 import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import time
@@ -36,7 +36,7 @@ for t in range(cnt):
         rc1, s1 = dev.iterate_gn()
         rel = abs(s0.error_after - s1.error_after) / max(1.0, s0.error_after)
         worst = max(worst, rel)
-        ok = ok and rc0 == 0 and rc1 == 0 and rel <= 1e-8
+        ok = ok and rc0 == 0 and rc1 == 0 and abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after) + 1e-11 * s0.error_before
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
     dx = max(np.abs(x0 - x1).max() / max(1.0, np.abs(x0).max()), np.abs(v0 - v1).max() / max(1.0, np.abs(v0).max()),
              np.abs(orc.get_landmarks() - dev.get_landmarks()).max() / max(1.0, np.abs(orc.get_landmarks()).max()))
