@@ -44,7 +44,7 @@ def plan(N, L, touch, C):
     return cuts, fat_of, slot_of, counts
 
 
-def border_cost(nb, fat_max=80):
+def border_cost(nb, fat_max=128):
     """What a segmentation costs per state (FatSepPlan::choose, round 4): the Schur complement of a segment is
     (NCP / 16)(NCP / 16 + 1) / 2 MFMA tiles per four rows, the border sweep NC columns; 0.064 ms per tile and 0.025 ms per column
     for 1e6 states on the config-4 graph.  nb = B + ld * (landmarks on the fullest cut)."""
@@ -54,7 +54,7 @@ def border_cost(nb, fat_max=80):
     return 0.064 * (t * (t + 1) // 2) + 0.025 * nc
 
 
-def choose_segment_length(N, L, touch, B, ld, fat_max=80):
+def choose_segment_length(N, L, touch, B, ld, fat_max=128):
     """The search of FatSepPlan::choose with this model's (simpler, greedy) landmark-to-cut assignment: double from 32 until
     every landmark's window fits two segments and the fullest cut fits a fat block, then try the lengths between that and half of
     it in sixteenths of it (at least 16 states), longest first; a shorter length wins only with a strictly lower border cost.
@@ -272,3 +272,43 @@ def split_solve(Dfat, Ofat, gfat, bounds, share=0.5):
         for k, v in xl.items():
             x[lo + k] = v
     return x
+
+
+# ---- round 5: fat blocks beyond 80 columns (fatsep.hpp: k_fat_elim_wide, k_fs_syrk's right-hand-side row and its two-workgroup grid)
+def wide_panel_width(NB, elem_bytes=8, fat_max=128):
+    """fat_wide_panel(): columns of [H | H | g] per pass -- what 160 KB of LDS hold beside the NB x (NB + 1) block and the 4 x 4 factors"""
+    avail = 160 * 1024 - (fat_max // 4) * 10 * elem_bytes - NB * (NB + 1) * elem_bytes - 512
+    return max(4, min(avail // (NB * elem_bytes), 2 * NB + 1))
+
+
+def eliminate_block_in_panels(D, Hl, Hr, g, PW):
+    """One block of the fat chain's cyclic reduction the way k_fat_elim_wide walks it: D = L L^T once; X = [Hl | Hr | g] through a panel
+    of PW columns at a time, X <- L^-1 X by steps of four pivots (the 4 x 4 diagonal factor inverted, a rank-4 update of the rows below);
+    then S1 = P^T P, S2 = Q^T Q, link = -(Q^T P), P^T z, Q^T z."""
+    NB = D.shape[0]
+    Lc = np.linalg.cholesky(D)
+    X = np.concatenate([Hl, Hr, g[:, None]], axis=1)
+    out = np.zeros_like(X)
+    for c0 in range(0, X.shape[1], PW):
+        Xp = X[:, c0:c0 + PW].copy()
+        for p in range(0, NB, 4):
+            W = np.linalg.inv(Lc[p:p + 4, p:p + 4])
+            Xp[p:p + 4] = W @ Xp[p:p + 4]
+            Xp[p + 4:] -= Lc[p + 4:, p:p + 4] @ Xp[p:p + 4]
+        out[:, c0:c0 + PW] = Xp
+    P, Q, z = out[:, :NB], out[:, NB:2 * NB], out[:, 2 * NB]
+    return Lc, P, Q, z, P.T @ P, Q.T @ Q, -(Q.T @ P), P.T @ z, Q.T @ z
+
+
+def syrk_rhs_row_columns(NB):
+    """Columns of the right-hand-side row of a segment's Schur complement that k_fs_syrk sums beside the matrix cores (2 NB a multiple
+    of 16): wave wv < nrw takes column lane + 64 wv."""
+    if (2 * NB) % 16:
+        return None
+    nrw = min((2 * NB + 63) // 64, 4)
+    return sorted({lane + 64 * wv for wv in range(nrw) for lane in range(64) if lane + 64 * wv <= 2 * NB})
+
+
+def syrk_tiles_of(wv, y, ny, tpw, ntiles):
+    """lower-triangle tiles of wave wv in workgroup y of ny: p = (3 - wv) + 4 (q ny + y), q < tpw"""
+    return [(3 - wv) + 4 * (q * ny + y) for q in range(tpw) if (3 - wv) + 4 * (q * ny + y) < ntiles]

@@ -114,3 +114,43 @@ def test_split_fat_chain_equals_the_unsplit_solve():
         np.testing.assert_allclose(x, FM.cyclic_reduction(Dfat, Ofat, gfat), rtol=1e-8, atol=1e-9)
         for k, c in enumerate(cuts):
             np.testing.assert_allclose(x[k, :b], xd[c * b:(c + 1) * b], rtol=1e-7, atol=1e-9)
+
+
+def test_panelled_wide_block_elimination_equals_the_one_pass_algebra():
+    """k_fat_elim_wide (round 5): blocks beyond 80 columns keep only D in LDS and pass [H | H | g] through it in panels; whatever the
+    panel width, P, Q, z and the five products are those of the one-pass elimination."""
+    rng = np.random.default_rng(5)
+    for NB in (84, 104, 128):
+        A = rng.normal(size=(NB, NB + 7)); D = A @ A.T + NB * np.eye(NB)
+        Hl, Hr, g = rng.normal(size=(NB, NB)), rng.normal(size=(NB, NB)), rng.normal(size=NB)
+        Lc = np.linalg.cholesky(D)
+        P0, Q0, z0 = np.linalg.solve(Lc, Hl), np.linalg.solve(Lc, Hr), np.linalg.solve(Lc, g)
+        PW = FM.wide_panel_width(NB)
+        assert 4 <= PW <= 2 * NB + 1 and (NB * (NB + 1) + NB * PW) * 8 + 2560 + 512 <= 160 * 1024      # fits beside the block
+        for pw in (PW, 4, 2 * NB + 1):
+            L1, P, Q, z, S1, S2, lk, pz, qz = FM.eliminate_block_in_panels(D, Hl, Hr, g, pw)
+            for a, b in ((P, P0), (Q, Q0), (z, z0), (S1, P0.T @ P0), (S2, Q0.T @ Q0), (lk, -(Q0.T @ P0)), (pz, P0.T @ z0), (qz, Q0.T @ z0)):
+                assert np.abs(a - b).max() <= 1e-10 * max(1.0, np.abs(b).max())
+    assert FM.wide_panel_width(128) == 28 and FM.wide_panel_width(84) >= 128
+
+
+def test_every_column_of_the_rhs_row_has_a_lane():
+    """Rounds 3-4 summed the row with "waves 0 and 1" whatever NB: at NB = 72 and NB = 80 the columns from 128 on were never written
+    (found in round 5 by the NB = 80 graph of test_gpu_segmented.py).  Every NB up to 128 whose 2 NB is a multiple of 16: the 2 NB
+    columns k_fs_fat_assemble reads (row 2 NB, columns < 2 NB) are all covered."""
+    for NB in range(8, 129, 8):
+        cols = FM.syrk_rhs_row_columns(NB)
+        assert cols is not None and set(range(2 * NB)) <= set(cols), NB
+    assert FM.syrk_rhs_row_columns(28) is None            # config 4: the row is inside the last tile row
+    old = lambda NB: {lane + 64 * wv for wv in range(2) for lane in range(64)}
+    assert not set(range(2 * 72)) <= old(72) and not set(range(2 * 80)) <= old(80) and set(range(2 * 64)) <= old(64)
+
+
+def test_two_workgroups_deal_every_tile_of_a_wide_border_once():
+    """k_fs_syrk<20, 272> (borders of 177 ... 272 columns): the 16 x 16 tiles of the lower triangle dealt over 2 workgroups x 4 waves x
+    20 accumulators; the narrower instantiations keep one workgroup."""
+    for tpw, ncm, ny in ((7, 112, 1), (12, 144, 1), (17, 176, 1), (20, 272, 2)):
+        t16 = ncm // 16
+        ntiles = t16 * (t16 + 1) // 2
+        got = sorted(p for y in range(ny) for wv in range(4) for p in FM.syrk_tiles_of(wv, y, ny, tpw, ntiles))
+        assert got == list(range(ntiles)), (tpw, ncm, ny)
