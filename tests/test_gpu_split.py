@@ -81,6 +81,39 @@ def test_split_chain_against_the_oracle():
         sv.backend.close()
 
 
+@pytest.mark.parametrize("P,N,L,C,precision", [(2, 1300, 225, 256, 0), (3, 2000, 340, 256, 0), (2, 1300, 240, 256, 1)],
+                         ids=["2-pieces-NB96", "3-pieces-NB100+", "2-pieces-fp32-rows"])
+def test_split_chain_with_fat_blocks_beyond_80_columns(P, N, L, C, precision):
+    """Round 5 (kFatMax 128): pieces whose fat blocks -- and whose shared top blocks (gpslam_hip_fs_set_top) -- are wider than 80
+    columns run k_fat_elim_wide both in their own cyclic reduction and in the redundant top solve."""
+    import gpslam_amd
+    from gpslam_amd import sharded, synthetic as S
+    problem = S.pose2_local_landmarks_chain(N, L=L, window=200)
+    locals_, pieces = _pieces(problem, P, C, precision=precision)
+    assert max(sv.nb_local for sv in pieces) > 80
+    ref = S.apply(problem, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, force_segmented=True,
+                                                  segment_length=C, precision=precision))
+    assert ref.segment_plan()["NB"] > 80
+    tol = 1e-9 if precision == 0 else 1e-6
+    for it in range(5):
+        got = sharded.iterate_pieces(pieces)
+        _, st = ref.iterate_gn()
+        assert abs(got["error_after"] - st.error_after) <= max(1e-7, tol) * max(1.0, st.error_after)
+    pose, vel, lmk = _merged(problem, locals_, pieces)
+    p1, v1 = ref.get_states()
+    assert np.abs(pose - p1).max() <= tol * max(1.0, np.abs(p1).max())
+    assert np.abs(lmk - ref.get_landmarks()).max() <= 10 * tol * max(1.0, np.abs(lmk).max())
+    if precision == 0:          # ... and the oracle's dense bordered solve
+        orc = S.apply(problem, O.Chain(O.POSE2, chart=O.CHART_FIRST_ORDER, landmark_dim=2))
+        for it in range(5):
+            orc.iterate_gn()
+        po, vo = orc.get_states()
+        assert np.abs(pose - po).max() <= 1e-9 * max(1.0, np.abs(po).max())
+    for sv in pieces:
+        sv.backend.close()
+    ref.close()
+
+
 @pytest.mark.parametrize("P", [1, 3])
 def test_split_levenberg_marquardt_follows_the_unsplit_lambda_schedule(P):
     """LevenbergMarquardtOptimizer::iterate as matlab/PlazaPose2.m:217-229 drives it, from an open-loop dead-reckoned start
