@@ -1,4 +1,5 @@
-"""The synthetic factor mixes of the BASELINE configs at random small sizes against the oracle (3 Gauss-Newton iterations, 1e-9).
+"""The synthetic factor mixes of the BASELINE configs at random small sizes against the oracle (3 Gauss-Newton iterations, 1e-9, then 5
+Levenberg-Marquardt iterations in lock step).
    python scripts/stress_mixes.py [count] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -7,6 +8,7 @@ import numpy as np
 import torch  # noqa: F401
 from oracle import oracle as O
 import test_gpu_parity as T
+import lm_lockstep as LM
 import gpslam_amd
 from gpslam_amd import synthetic as S
 cnt = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -38,5 +40,14 @@ for t in range(cnt):
     if "landmarks" in p:
         l0, l1 = orc.get_landmarks(), dev.get_landmarks()
         assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max())
-    print("ok mix %d N %d plan %s" % (which, N, dev.plan_info()))
+    # Levenberg-Marquardt from the initial values, in lock step (tests/lm_lockstep.py: the lambda schedule exactly while the cost
+    # moves, its rule past convergence)
+    for s_ in (orc, dev):
+        s_.set_states(p["pose"], p["vel"])
+        if "landmarks" in p:
+            s_.set_landmarks(p["landmarks"])
+    lam, n_noise, slack = LM.run(orc, dev, 1e-3, 5, tag=(which, N))
+    assert slack <= 1e-3, (t, which, N, slack)     # (range-only landmarks leave flat directions: a 1e-4 step there moves the cost by 1e-10 of itself)
+    T.states_close(p["kind"], *orc.get_states(), *dev.get_states(), 1e-9 + 2 * slack)
+    print("ok mix %d N %d plan %s (LM: lambda %.1e, %d of 5 calls at rounding level)" % (which, N, dev.plan_info(), lam, n_noise))
 print("all %d mixes agree with the oracle" % cnt)
