@@ -437,6 +437,16 @@ int gpslam_hip_segment_plan(gpslam_hip_handle *h, int32_t out8[8]) {
   return 0;
 }
 
+#ifdef GPS_TRACE_FUSED
+int gpslam_hip_debug_fused_trace(gpslam_hip_handle *h, unsigned long long *out, int32_t max_waves, int32_t *nwaves) {
+  if (!h || !out || !nwaves) return GPSLAM_E_INVALID;
+  *nwaves = h->dbg_trace_waves;
+  const int n = h->dbg_trace_waves < max_waves ? h->dbg_trace_waves : max_waves;
+  if (hipStreamSynchronize(h->stream) != hipSuccess) return GPSLAM_E_HIP;
+  if (n > 0 && hipMemcpy(out, h->dbg_trace.p, (size_t)n * 64 * 8, hipMemcpyDeviceToHost) != hipSuccess) return GPSLAM_E_HIP;
+  return 0;
+}
+#endif
 int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms) {
   if (!h || !ms) return GPSLAM_E_INVALID;
   *ms = h->l0_ms;

@@ -151,6 +151,10 @@ struct gpslam_hip_handle {
   double l0_ms = 0.0;         // ... accumulated over the last timed run: the dominant kernel INSIDE an iteration
   double ph_lambda = 0.0;
   std::string err;
+#ifdef GPS_TRACE_FUSED
+  DevBuf dbg_trace;           // debug builds only: 64 stamps per wave of the last k_fused_level0 launch
+  int dbg_trace_waves = 0;
+#endif
 };
 
 #define HIPCHK(call)                                                                          \

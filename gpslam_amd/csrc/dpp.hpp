@@ -162,6 +162,29 @@ template <int K> __device__ __forceinline__ void fmac_bcast1(double &d0, double 
 template <int K> __device__ __forceinline__ void fmac_self1(double &d0, double m0) {
   asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(m0), "n"(K));
 }
+// ---- the same operations WITHOUT the leading s_nop (round 6).  The hazard the s_nop covers is "a VALU instruction writes VGPR x, one
+// of the next two instructions reads x THROUGH DPP".  In the inner loops of the eliminations the register read through DPP is a panel
+// column that was last written a whole pivot step (dozens of instructions) earlier, and the freshly computed operand -- the multiplier
+// -- is the plain source: the 2 x 157 s_nop 1 per block step of k_fused_level0 guarded nothing.  These forms are single instructions
+// (asm volatile keeps their order), to be used ONLY where the caller can name the last writer of the DPP source; every phase that uses
+// them opens with one guarded instruction or an explicit dpp_guard().
+__device__ __forceinline__ void dpp_guard() { asm volatile("s_nop 1"); }
+template <int K> __device__ __forceinline__ void fmac_self1_nn(double &d0, double m0) {
+  asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(m0), "n"(K));
+}
+template <int K, bool NEG = false> __device__ __forceinline__ void fmac_bcast1_nn(double &d0, double s, double m0) {
+  if constexpr (NEG) asm volatile("v_fmac_f64_dpp %0, %1, -%2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(s), "v"(m0), "n"(K));
+  else asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d0) : "v"(s), "v"(m0), "n"(K));
+}
+// d[q] += bcast_K(d[q]) * m for q in [LO, HI)
+template <int K, int LO, int HI> __device__ __forceinline__ void fmac_self_range_nn(double *d, double m) {
+  static_for<LO, HI>([&](auto qq) { fmac_self1_nn<K>(d[decltype(qq)::value], m); });
+}
+// d[q] (+/-)= bcast_K(s[q]) * m for q in [0, N)
+template <int K, int N, bool NEG = false> __device__ __forceinline__ void fmac_bcast_n_nn(double *d, const double *s, double m) {
+  static_for<0, N>([&](auto qq) { fmac_bcast1_nn<K, NEG>(d[decltype(qq)::value], s[decltype(qq)::value], m); });
+}
+
 // d[k] += s[lane k] * m, k = 0..N-1: the GATHER form (one source register, twelve broadcast lanes) of the assembly wave
 template <int N> __device__ __forceinline__ void fmac_gather(double *d, double s, double m);
 template <> __device__ __forceinline__ void fmac_gather<12>(double *d, double s, double m) {

@@ -2592,7 +2592,15 @@ template <typename T, typename TR = T> struct FusedArgs {
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
   T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
                           // it that the PREVIOUS chunk's last rows contribute (gsave2; zero elsewhere); null: not wanted
+#ifdef GPS_TRACE_FUSED
+  unsigned long long *trace = nullptr;   // debug builds only: 64 stamps per wave (scripts/trace_fused.py)
+#endif
 };
+#ifdef GPS_TRACE_FUSED
+#define GPS_TR(slot) do { if (u.trace && lane == 0) u.trace[((size_t)blockIdx.x * 2 + role) * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define GPS_TR(slot) do { } while (0)
+#endif
 
 
 // ST: every full-width row of the chain belongs to a GP prior and K1 delivers those as structured records (u.gps): the
@@ -2661,6 +2669,13 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   int tc = grp * BS + rr;         // ... its column r: OUTR[tc + k * BP]
   asm volatile("" : "+v"(ro), "+v"(co), "+v"(po), "+v"(oc), "+v"(tr), "+v"(tc));
   const int steps = __builtin_amdgcn_readfirstlane(max(ep - j0, 0));   // lane 0: the wave's first (never shorter) chunk
+  GPS_TR(0);
+#ifdef GPS_TRACE_FUSED
+  if (u.trace && lane == 0) {
+    u.trace[((size_t)blockIdx.x * 2 + role) * 64 + 61] = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID
+    u.trace[((size_t)blockIdx.x * 2 + role) * 64 + 62] = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // XCC_ID
+  }
+#endif
 
   if (role == 1) {
     // ================================================================ ASM: images 0 .. steps + 1
@@ -3095,16 +3110,20 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     }
     assemble(0); write_img(0, 0);
     assemble(1); write_img(1, 1);
+    GPS_TR(1);
     lds_barrier();                       // P: images 0 and 1 are there
     lds_barrier();                       // Q: ELIM has taken what it needs from image 0
+    GPS_TR(2);
     // (round 3: image 2 is assembled AFTER Q, under the elimination of the first block -- ELIM only needs it at the barrier
     //  of step 0.  Before, ELIM sat at Q through this assembly: one block step of every chunk, 3 % of the kernel)
     assemble(2);
     write_img(0, 2);
     for (int t = 0; t < steps; t++) {
+      GPS_TR(3 + min(t, 50));
       lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
       if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1, t + 3); }
     }
+    GPS_TR(60);
     return;
   }
 
@@ -3112,6 +3131,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   double Dr[B], Or[B], Fr[B], Gr[B], Ar[B];
   double gr, as_;
   lds_barrier();                         // P
+  GPS_TR(1);
 #pragma unroll
   for (int k = 0; k < B; k++) {
     Ar[k] = IMG[ro + k];                           // image 0: the separator
@@ -3123,6 +3143,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   as_ = IMG[co + 2 * B * BP];
   gr = IMG[4 * IS + co + 2 * B * BP];
   lds_barrier();                         // Q
+  GPS_TR(2);
   if (valid && !has_int && rowlane) {    // chunk without interior: the separator keeps its coupling, its rows' R^T R is owed
     double *ub = a.up_blk + (size_t)c * BS;
 #pragma unroll
@@ -3142,6 +3163,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     const int j = j0 + t;
     const bool live = j < e, lastb = (j == e - 1);
     const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
+#ifdef GPS_ELIM_R5
     double invs = 1.0;
     static_for<0, B>([&](auto kk) {
       constexpr int k = decltype(kk)::value;
@@ -3182,6 +3204,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       }
       OUTR[oc + 2 * B * B] = gr;
     }
+    GPS_TR(3 + min(t, 50));
     lds_barrier();                       // step t
     if (live) {
       V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
@@ -3231,6 +3254,128 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     gr = gn;
     wave_lds_sync();
     __builtin_amdgcn_sched_barrier(0);
+#else
+    // Round 6: the elimination wave is the wave a block step waits for (scripts/trace_fused.py: the assembly wave sits at the
+    // barrier 0.65-1.0 us of a 4.6-5.6 us step), and alone on a SIMD it issued one instruction per 8 cycles -- it waited for its own
+    // dependent chains.  Same arithmetic, same operands, same order of every sum (bit-identical), rearranged so that no latency is
+    // exposed to this wave:
+    //  * the reciprocal of pivot k + 1 (broadcast, v_rcp_f64, two Newton steps, the multiplier: nine dependent instructions) is
+    //    started as soon as column k + 1 of D~ has taken pivot k's update, and its steps are dealt between the row operations on
+    //    O, F and g that follow;
+    //  * the columns right of the pivot are updated exactly (66 instead of 84 multiply-adds per block: no blocks of four);
+    //  * row r of O_j is requested before the elimination instead of behind it; the diagonal block of the next image and the
+    //    pieces of the outgoing factor record are requested together behind the barrier and consumed behind the 288 products with
+    //    V_j (F_{j+1}, D_sep), the transposed G_{j+1} and the next O^T behind the 144 products with U_j;
+    //  * the multiply-adds carry no s_nop (dpp.hpp: the DPP source of every one of them was written a pivot step earlier).
+    double Ol[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) Ol[k] = cur[ro + B * BP + k];         // row r of O_j (image t + 1: published a step ago)
+    double invs = 1.0;
+    double inv = fast_rcp(row_bcast<0>(Dr[0]));
+    static_for<0, B>([&](auto kk) {
+      constexpr int k = decltype(kk)::value;
+      const bool isk = (r == k);
+      invs = isk ? inv : invs;
+      const double nmp = isk ? 0.0 : -(Dr[k] * inv);
+      // row r -= (D~[r][k] / pivot) * row k, the pivot row fused into the multiply-add
+      double pn = 1.0, rn = 1.0;
+      if constexpr (k + 1 < B) {
+        fmac_self1_nn<k>(Dr[k + 1], nmp);                // the next pivot's column first ...
+        pn = row_bcast<k + 1>(Dr[k + 1]);                // (guarded: Dr[k + 1] was written by the instruction before)
+        rn = __builtin_amdgcn_rcp(pn);                   // ... and its reciprocal under way beneath what follows
+        fmac_self_range_nn<k, (k + 2 < B ? k + 2 : B), B>(Dr, nmp);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      const double e0 = fma(-pn, rn, 1.0);
+      fmac_self_range_nn<k, 0, B / 2>(Or, nmp);
+      __builtin_amdgcn_sched_barrier(0);
+      rn = fma(e0, rn, rn);
+      fmac_self_range_nn<k, B / 2, B>(Or, nmp);
+      __builtin_amdgcn_sched_barrier(0);
+      const double e1 = fma(-pn, rn, 1.0);
+      fmac_self_range_nn<k, 0, B / 2>(Fr, nmp);
+      __builtin_amdgcn_sched_barrier(0);
+      rn = fma(e1, rn, rn);
+      fmac_self_range_nn<k, B / 2, B>(Fr, nmp);
+      fmac_self1_nn<k>(gr, nmp);
+      __builtin_amdgcn_sched_barrier(0);
+      inv = rn;
+    });
+    // a pivot that is not positive (or not a number) leaves a reciprocal that is not positive in its own lane: one test per
+    // block step instead of one per pivot (lanes without a row keep 1)
+    if (!(invs > 0.0) && live) *a.flag = 1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
+    gr *= invs;
+    if (rowlane) {
+#pragma unroll
+      for (int k = 0; k < B; k++) {
+        OUTR[oc + k * B] = Fr[k];
+        OUTR[oc + B * B + k * B] = Or[k];
+      }
+      OUTR[oc + 2 * B * B] = gr;
+    }
+    GPS_TR(3 + min(t, 50));
+    lds_barrier();                       // step t
+    V2 pc[NV];
+#pragma unroll
+    for (int q = 0; q < NV; q++) pc[q] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * (q * 16 + r < NPC ? q : 0)]);
+    double Dn[B], Fn[B], gn;
+#pragma unroll
+    for (int k = 0; k < B; k++) Dn[k] = nxt[ro + k];
+    gn = nxt[co + 2 * B * BP];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) Fn[k] = 0.0;
+    dpp_guard();
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      const double ol = Ol[i], gg = Gr[i];          // subtracted: the negation is the instructions' source modifier
+      fmac_bcast_n_nn<i, B, true>(Fn, Fr, ol);      // F_{j+1} -= O_j[r][i] * (row i of V_j)
+      fmac_bcast_n_nn<i, B, true>(Ar, Fr, gg);      // D_sep   -= G_j[r][i] * (row i of V_j)
+      fmac_bcast1_nn<i, true>(gn, gr, ol);          // g_{j+1} -= O_j[r][i] * Y_j[i]
+      fmac_bcast1_nn<i, true>(as_, gr, gg);         // g_sep   -= G_j[r][i] * Y_j[i]
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
+    asm volatile("" : "+v"(gn), "+v"(as_));
+    __builtin_amdgcn_sched_barrier(0);
+    if (live) {
+      V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
+#pragma unroll
+      for (int q = 0; q < NV; q++) {
+        const int idx = q * 16 + r;
+        if (idx < NPC) dst[idx] = pc[q];             // (nontemporal: the iteration +3 us at 1e5 states)
+      }
+    }
+    // G_{j+1} = F_{j+1}^T by a transpose through LDS (the V area of the factor image: its pieces were read above, and the DS
+    // operations of a wave execute in order) instead of the recurrence G_{j+1} = -G_j U_j: 24 LDS operations for 144 multiply-adds
+    if (rowlane) {
+#pragma unroll
+      for (int k = 0; k < B; k++) OUTR[tr + k] = Fn[k];
+    }
+    wave_lds_sync();
+    double Gn[B], On[B];
+#pragma unroll
+    for (int k = 0; k < B; k++) { Gn[k] = OUTR[tc + k * BP]; On[k] = nxt[co + B * BP + k * BP]; }
+    __builtin_amdgcn_sched_barrier(0);
+    dpp_guard();
+    static_for<0, B>([&](auto ii) {
+      constexpr int i = decltype(ii)::value;
+      fmac_bcast_n_nn<i, B, true>(Dn, Or, Ol[i]);   // D~_{j+1} -= O_j[r][i] * (row i of U_j)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int k = 0; k < B; k++) asm volatile("" : "+v"(Dn[k]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < B; k++) { Dr[k] = Dn[k]; Fr[k] = Fn[k]; Gr[k] = Gn[k]; Or[k] = On[k]; }
+    gr = gn;
+    wave_lds_sync();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     if (!tail && live && lastb && rowlane) {
       double *ub = a.up_blk + (size_t)c * BS;
 #pragma unroll
@@ -3247,6 +3392,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       }
     }
   }
+  GPS_TR(59);
   if (!tail) return;
 
   // ================================================================== the level of groups of four, in place
@@ -3329,6 +3475,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     const V2 *s4 = reinterpret_cast<const V2 *>(REC + G4 * BS);
     for (int t = lane; t < B * B / 2 + B / 2; t += 64) ua[t] = s4[t < B * B / 2 ? t : t + B * B / 2];
   }
+  GPS_TR(60);
 }
 
 template <typename T> struct BwdArgs {
