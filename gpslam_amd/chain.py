@@ -13,7 +13,7 @@ from . import build as _build
 LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
 FP64, FP32 = 0, 1
-# gpslam_hip_config.reserved[6]: kernel families compile() is told to use instead of its default choice (include/gpslam_hip.h)
+# gpslam_hip_config_v2.plan: kernel families compile() is told to use instead of its default choice (include/gpslam_hip.h)
 PLAN_UNFUSED_LEVEL0, PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS, PLAN_GENERIC_QC, PLAN_MEAS_ROWS, PLAN_SEPARATE_RETRACT = 1, 2, 4, 8, 16, 32, 64, 128
 # Test harness hook of this PYTHON mirror (the library itself reads no environment): plan bits OR-ed into every ChainSolver a
 # process creates, so that tests/test_gpu_switches.py can re-run whole parity suites on the fallback kernel families.
@@ -40,8 +40,11 @@ ABI_SYMBOLS = [
     "gpslam_hip_fs_interface", "gpslam_hip_fs_phase1", "gpslam_hip_fs_phase2", "gpslam_hip_fs_lm_trial_phase1",
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
     "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
-    "gpslam_hip_lm_decide", "gpslam_hip_set_collectives",
+    "gpslam_hip_lm_decide", "gpslam_hip_set_collectives", "gpslam_hip_create_v2", "gpslam_hip_abi_version", "gpslam_hip_struct_size",
 ]
+# the version of include/gpslam_hip.h this binding's structs mirror (GPSLAM_HIP_ABI_MAJOR / _MINOR); load_library() checks the library's
+ABI_MAJOR, ABI_MINOR = 2, 0
+STRUCT_CONFIG, STRUCT_CONFIG_V2, STRUCT_STATS, STRUCT_PARAMS = 0, 1, 2, 3
 
 
 class GpslamHipError(RuntimeError):
@@ -49,9 +52,18 @@ class GpslamHipError(RuntimeError):
 
 
 class Config(C.Structure):
+    """gpslam_hip_config (v1: the eight knobs as anonymous words); kept for callers of gpslam_hip_create"""
     _fields_ = [("manifold", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("chart", C.c_int32),
                 ("landmark_dim", C.c_int32), ("chunk", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
                 ("reserved", C.c_int32 * 8)]
+
+
+class ConfigV2(C.Structure):
+    """gpslam_hip_config_v2: struct_size first, every knob by name (include/gpslam_hip.h)"""
+    _fields_ = [("struct_size", C.c_uint32), ("manifold", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32), ("chart", C.c_int32),
+                ("landmark_dim", C.c_int32), ("chunk", C.c_int32), ("rank", C.c_int32), ("nranks", C.c_int32),
+                ("force_sharded", C.c_int32), ("upper_chunk", C.c_int32), ("top_blocks", C.c_int32), ("velocity", C.c_int32),
+                ("segment_length", C.c_int32), ("force_segmented", C.c_int32), ("plan", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -82,10 +94,29 @@ def load_library():
         path = os.environ.get("GPSLAM_LIB") or _build.build()     # GPSLAM_LIB: an alternative build (A/B timing of kernel variants)
         if not os.path.exists(path):
             raise GpslamHipError("libgpslam_hip.so is missing and could not be built; there is no CPU fallback")
-        _lib = C.CDLL(path)
-        _lib.gpslam_hip_last_error.restype = C.c_char_p
-        _lib.gpslam_hip_stream.restype = C.c_void_p
+        lib = C.CDLL(path)
+        lib.gpslam_hip_last_error.restype = C.c_char_p
+        lib.gpslam_hip_stream.restype = C.c_void_p
+        check_abi(lib, path)
+        _lib = lib
     return _lib
+
+
+def check_abi(lib, path="libgpslam_hip.so"):
+    """The structs below are written into by the library: a library built from another major version of the header, or one whose
+    struct sizes differ from this file's, is refused at load time (gpslam_hip_stats grew by 8 bytes in round 5 with
+    nothing to tell an old caller)."""
+    if not hasattr(lib, "gpslam_hip_abi_version"):
+        raise GpslamHipError("%s exports no gpslam_hip_abi_version: built from a header older than ABI 2.0" % path)
+    lib.gpslam_hip_abi_version.restype = C.c_uint32
+    lib.gpslam_hip_struct_size.restype = C.c_size_t
+    v = lib.gpslam_hip_abi_version()
+    if (v >> 16) != ABI_MAJOR or (v & 0xffff) < ABI_MINOR:
+        raise GpslamHipError("%s speaks ABI %d.%d, this binding %d.%d" % (path, v >> 16, v & 0xffff, ABI_MAJOR, ABI_MINOR))
+    for which, ty in ((STRUCT_CONFIG, Config), (STRUCT_CONFIG_V2, ConfigV2), (STRUCT_STATS, Stats), (STRUCT_PARAMS, Params)):
+        n = lib.gpslam_hip_struct_size(which)
+        if n != C.sizeof(ty):
+            raise GpslamHipError("%s: sizeof(%s) is %d in the library, %d in this binding" % (path, ty.__name__, n, C.sizeof(ty)))
 
 
 def lm_decide(s6, lam, lambda_factor=10.0, lambda_upper_bound=1e5, lambda_lower_bound=0.0, min_model_fidelity=1e-3,
@@ -126,20 +157,18 @@ class ChainSolver:
         self.d, self.pd = TANGENT_DIM[kind], POSE_DIM[kind]
         self.b = 2 * self.d
         self.N = self.L = self.n_gp = 0
-        cfg = Config(manifold=kind, precision=precision, device=device, chart=chart, landmark_dim=landmark_dim, chunk=chunk,
-                     rank=rank, nranks=nranks)
-        cfg.reserved[0] = 1 if force_sharded else 0
-        cfg.reserved[1] = upper_chunk
-        cfg.reserved[2] = top_blocks
-        cfg.reserved[3] = 1 if velocity_world else 0   # GPSLAM_VELOCITY_WORLD_VW: the *Pose3VW factor family
-        cfg.reserved[4] = segment_length               # segmented landmark elimination: segment length (0 = automatic)
-        cfg.reserved[5] = 1 if force_segmented else 0  # ... for any landmark count (default: only beyond the dense border)
-        cfg.reserved[6] = plan | _DEFAULT_PLAN         # GPSLAM_PLAN_* bits
+        cfg = ConfigV2(struct_size=C.sizeof(ConfigV2), manifold=kind, precision=precision, device=device, chart=chart,
+                       landmark_dim=landmark_dim, chunk=chunk, rank=rank, nranks=nranks,
+                       force_sharded=1 if force_sharded else 0, upper_chunk=upper_chunk, top_blocks=top_blocks,
+                       velocity=1 if velocity_world else 0,        # GPSLAM_VELOCITY_WORLD_VW: the *Pose3VW factor family
+                       segment_length=segment_length,              # segmented landmark elimination: states per segment (0 = automatic)
+                       force_segmented=1 if force_segmented else 0,   # ... for any landmark count (default: only beyond the dense border)
+                       plan=plan | _DEFAULT_PLAN)                  # GPSLAM_PLAN_* bits
         self._h = C.c_void_p()
-        rc = self.lib.gpslam_hip_create(C.byref(cfg), C.byref(self._h))
+        rc = self.lib.gpslam_hip_create_v2(C.byref(cfg), C.byref(self._h))
         if rc != 0:
             self._h = None
-            raise GpslamHipError("gpslam_hip_create failed (%d): no usable HIP device, and there is no CPU fallback" % rc)
+            raise GpslamHipError("gpslam_hip_create_v2 failed (%d): no usable HIP device, and there is no CPU fallback" % rc)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -63,15 +63,50 @@ int gpslam_hip_set_collectives(gpslam_hip_handle *h, gpslam_hip_all_gather_fn al
   return 0;
 }
 
-int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
-  if (!cfg || !out) return GPSLAM_E_INVALID;
+uint32_t gpslam_hip_abi_version(void) { return GPSLAM_HIP_ABI_VERSION; }
+size_t gpslam_hip_struct_size(int32_t which) {
+  switch (which) {
+    case GPSLAM_STRUCT_CONFIG: return sizeof(gpslam_hip_config);
+    case GPSLAM_STRUCT_CONFIG_V2: return sizeof(gpslam_hip_config_v2);
+    case GPSLAM_STRUCT_STATS: return sizeof(gpslam_hip_stats);
+    case GPSLAM_STRUCT_PARAMS: return sizeof(gpslam_hip_params);
+  }
+  return 0;
+}
+
+// v1: the eight anonymous words are today's named fields, in order ([7] must be 0)
+int gpslam_hip_create(const gpslam_hip_config *c1, gpslam_hip_handle **out) {
+  if (!c1 || !out) return GPSLAM_E_INVALID;
+  if (c1->reserved[7] != 0) return GPSLAM_E_INVALID;
+  gpslam_hip_config_v2 c;
+  std::memset(&c, 0, sizeof(c));
+  c.struct_size = (uint32_t)sizeof(c);
+  c.manifold = c1->manifold; c.precision = c1->precision; c.device = c1->device; c.chart = c1->chart;
+  c.landmark_dim = c1->landmark_dim; c.chunk = c1->chunk; c.rank = c1->rank; c.nranks = c1->nranks;
+  c.force_sharded = c1->reserved[0]; c.upper_chunk = c1->reserved[1]; c.top_blocks = c1->reserved[2]; c.velocity = c1->reserved[3];
+  c.segment_length = c1->reserved[4]; c.force_segmented = c1->reserved[5]; c.plan = c1->reserved[6];
+  return gpslam_hip_create_v2(&c, out);
+}
+
+int gpslam_hip_create_v2(const gpslam_hip_config_v2 *in, gpslam_hip_handle **out) {
+  if (!in || !out) return GPSLAM_E_INVALID;
+  // the caller's struct may be shorter (an older header: the missing fields are 0) or longer (a newer one: accepted only if the
+  // bytes this build does not know are zero -- a knob we cannot honour must not be dropped silently)
+  if (in->struct_size < offsetof(gpslam_hip_config_v2, nranks) + sizeof(int32_t)) return GPSLAM_E_INVALID;
+  gpslam_hip_config_v2 cv;
+  std::memset(&cv, 0, sizeof(cv));
+  std::memcpy(&cv, in, in->struct_size < sizeof(cv) ? in->struct_size : sizeof(cv));
+  for (size_t i = sizeof(cv); i < in->struct_size; i++)
+    if (reinterpret_cast<const unsigned char *>(in)[i] != 0) return GPSLAM_E_UNSUPPORTED;
+  cv.struct_size = (uint32_t)sizeof(cv);
+  const gpslam_hip_config_v2 *cfg = &cv;
   if (cfg->manifold < 0 || cfg->manifold > GPSLAM_ROT3_BIAS) return GPSLAM_E_INVALID;
   if (cfg->precision != GPSLAM_FP64 && cfg->precision != GPSLAM_FP32) return GPSLAM_E_INVALID;
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
-  if (cfg->reserved[3] != 0 && (cfg->reserved[3] != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;
+  if (cfg->velocity != 0 && (cfg->velocity != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;
   constexpr int kPlanBits = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_COLUMN_LEVEL0 | GPSLAM_PLAN_LEVELS_OF_FOUR | GPSLAM_PLAN_FS_TWO_LAUNCHES | GPSLAM_PLAN_GP_ROWS | GPSLAM_PLAN_GENERIC_QC | GPSLAM_PLAN_MEAS_ROWS | GPSLAM_PLAN_SEPARATE_RETRACT;
-  if ((cfg->reserved[6] & ~kPlanBits) != 0 || cfg->reserved[7] != 0) return GPSLAM_E_INVALID;
+  if ((cfg->plan & ~kPlanBits) != 0) return GPSLAM_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPSLAM_E_HIP;  // no GPU: fail loudly
   if (cfg->device < 0 || cfg->device >= ndev) return GPSLAM_E_INVALID;
@@ -85,7 +120,7 @@ int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out) {
   h->pd = pdd[h->mf];
   h->b = 2 * h->d;
   h->ld = cfg->landmark_dim;
-  h->vw = (cfg->reserved[3] == GPSLAM_VELOCITY_WORLD_VW) ? 1 : 0;
+  h->vw = (cfg->velocity == GPSLAM_VELOCITY_WORLD_VW) ? 1 : 0;
   std::memset(h->Qc, 0, sizeof(h->Qc));
   std::memset(h->U, 0, sizeof(h->U));
   for (int i = 0; i < h->d; i++) h->Qc[i * h->d + i] = h->U[i * h->d + i] = 1.0;

@@ -61,9 +61,9 @@ struct MeasSet {  // measurement factors (kernels.hpp FKind)
 }  // namespace
 
 struct gpslam_hip_handle {
-  gpslam_hip_config cfg;
+  gpslam_hip_config_v2 cfg;   // (gpslam_hip_create maps a v1 config onto it)
   int mf = 0, d = 0, pd = 0, b = 0, ld = 0;
-  int vw = 0;                 // Pose3: velocities are world-frame [v; w] (cfg.reserved[3], the *Pose3VW factors)
+  int vw = 0;                 // Pose3: velocities are world-frame [v; w] (cfg.velocity, the *Pose3VW factors)
   int N = 0, L = 0, stride = 0, R = 1, nl = 0;
   bool own_stream = true;
   hipStream_t stream = nullptr;
@@ -136,6 +136,7 @@ struct gpslam_hip_handle {
   // Gauss-Newton runs (gpslam_hip_run_gn): the retraction of an iteration folded into the next iteration's K1 (kernels.hpp: PendUpd).
   // pend_ok: compile() found the graph eligible;  pend_upd: a solve's update sits in the level-0 solution array, not yet applied
   bool pend_ok = false, pend_upd = false;
+  bool keep_flag = false;   // inside gpslam_hip_run_gn on a sharded handle / split piece: phase 1 leaves the non-positive-pivot flag alone
   bool gsave_now = false;   // the fused kernel being enqueued stores the gradient (Levenberg-Marquardt trials)
   int U_version = 0, dU_version = -1;   // set_qc after compile(): the device copy of U is refreshed before its next use
   bool compiled = false;
@@ -269,8 +270,8 @@ template <typename F> void dispatch_fk(int fk, F &&f) {
   }
 }
 
-// reserved[0] = 1 forces the sharded code path on a single segment (self-test of the exchange plumbing)
-bool sharded(const gpslam_hip_handle *h) { return h->cfg.nranks > 1 || h->cfg.reserved[0] == 1; }
+// force_sharded = 1 forces the sharded code path on a single segment (self-test of the exchange plumbing)
+bool sharded(const gpslam_hip_handle *h) { return h->cfg.nranks > 1 || h->cfg.force_sharded == 1; }
 bool has_right_rank(const gpslam_hip_handle *h) { return sharded(h) && h->cfg.rank < h->cfg.nranks - 1; }
 
 int read_scal(gpslam_hip_handle *h, double *out, int n, int *flag) {

@@ -2598,8 +2598,12 @@ template <typename T, typename TR = T> struct FusedArgs {
 };
 #ifdef GPS_TRACE_FUSED
 #define GPS_TR(slot) do { if (u.trace && lane == 0) u.trace[((size_t)blockIdx.x * 2 + role) * 64 + (slot)] = wall_clock64(); } while (0)
+#define GPS_TRA(slot) do { if (kimg == 13) GPS_TR(slot); } while (0)
+#define GPS_TRE(slot) do { if (t == 10) GPS_TR(slot); } while (0)
 #else
 #define GPS_TR(slot) do { } while (0)
+#define GPS_TRA(slot) do { } while (0)
+#define GPS_TRE(slot) do { } while (0)
 #endif
 
 
@@ -2614,8 +2618,11 @@ template <typename T, typename TR = T> struct FusedArgs {
 // (L's velocity block is [k2 U; -sc U]): D and O need 7 instead of 12 multiply-adds per Jacobian row, and U Z is six products per
 // six-vector instead of 21 multiply-adds -- 204 of the assembly wave's ~1170 instructions per block step.  What is skipped are
 // products with exact zeros: the same values as the general kernel.
+#ifndef GPS_FUSED_WAVES
+#define GPS_FUSED_WAVES 2
+#endif
 template <int SV, typename TR = double, int B = 12, bool DG = false>
-__global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u) {
+__global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
   static_assert(!DG || ((SV == 1 || SV == 3 || SV == 4) && B == 12), "the diagonal-U form belongs to the SE(3) record variants");
   // SV = 3 (round 4): records AND a ring of full-width rows -- SE(3) chains with interpolated measurement factors (GPS, range,
@@ -2669,6 +2676,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
   int tc = grp * BS + rr;         // ... its column r: OUTR[tc + k * BP]
   asm volatile("" : "+v"(ro), "+v"(co), "+v"(po), "+v"(oc), "+v"(tr), "+v"(tc));
   const int steps = __builtin_amdgcn_readfirstlane(max(ep - j0, 0));   // lane 0: the wave's first (never shorter) chunk
+#ifdef GPS_PROBE_ONLY_ROLE
+  if (role != GPS_PROBE_ONLY_ROLE) return;      // (register probes: one role's code alone; never a product build)
+#endif
   GPS_TR(0);
 #ifdef GPS_TRACE_FUSED
   if (u.trace && lane == 0) {
@@ -2897,6 +2907,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     };
     auto assemble = [&](int kimg) {
       const bool live = valid && (s + kimg) < e;
+      GPS_TRA(40);
       int nfm = nf, ncm = nc;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { nfm = max(nfm, __shfl_xor(nfm, o, 64)); ncm = max(ncm, __shfl_xor(ncm, o, 64)); }
@@ -2969,7 +2980,9 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
         ldraw(kimg + 1, gpn);                            // (the operands are consumed: the next state's record into their registers)
       }
       if constexpr (ST12) {                              // the structured GP prior: its 12 rows from the columns built above
+        GPS_TRA(41);
         reconstruct();
+        GPS_TRA(42);
         static_for<0, B>([&](auto qq) {
           constexpr int q = decltype(qq)::value;
           // the next state's record is requested once most of this state's columns are consumed (their registers take it)
@@ -2998,6 +3011,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           __builtin_amdgcn_sched_barrier(0);
         });
       }
+      GPS_TRA(43);
       if constexpr (ST12) {                              // the state's BetweenFactor<Pose3> record: six compact rows from its columns
         if (btw_on) {
           int rq = r;
@@ -3028,6 +3042,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           });
         }
       }
+      GPS_TRA(44);
       if constexpr (SV == 2) {
         // the odd full-width row of a structured chain (host-checked to be few): fetched where it is used, no ring --
         // only the block step of a state that has one waits for it
@@ -3074,6 +3089,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      GPS_TRA(45);
       {   // Levenberg-Marquardt damping on the diagonal of a real state's D; the padding blocks behind the chain's last state
           // (tail) are identities
         // (added by write_img to the image's diagonal entry, one LDS read-modify-write of the lane's own row: as a select over the
@@ -3088,6 +3104,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
       rpnn = fptr[min(s + kimg + 3, ptr_max)];
       cpnn = u.crowptr[min(s + kimg + 3, ptr_max)];
       if (st_on) gpnn = u.gpidx[min(s + kimg + 3, ptr_max)];
+      GPS_TRA(46);
     };
     auto write_img = [&](int buf, int kimg) {
       if (rowlane) {
@@ -3267,6 +3284,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     //    pieces of the outgoing factor record are requested together behind the barrier and consumed behind the 288 products with
     //    V_j (F_{j+1}, D_sep), the transposed G_{j+1} and the next O^T behind the 144 products with U_j;
     //  * the multiply-adds carry no s_nop (dpp.hpp: the DPP source of every one of them was written a pivot step earlier).
+    GPS_TRE(48);
     double Ol[B];
 #pragma unroll
     for (int k = 0; k < B; k++) Ol[k] = cur[ro + B * BP + k];         // row r of O_j (image t + 1: published a step ago)
@@ -3305,6 +3323,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     // block step instead of one per pivot (lanes without a row keep 1)
     if (!(invs > 0.0) && live) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
+    GPS_TRE(49);
 #pragma unroll
     for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
     gr *= invs;
@@ -3318,6 +3337,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     }
     GPS_TR(3 + min(t, 50));
     lds_barrier();                       // step t
+    GPS_TRE(50);
     V2 pc[NV];
 #pragma unroll
     for (int q = 0; q < NV; q++) pc[q] = *reinterpret_cast<const V2 *>(&OUTR[po + 32 * (q * 16 + r < NPC ? q : 0)]);
@@ -3342,6 +3362,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     for (int k = 0; k < B; k++) asm volatile("" : "+v"(Fn[k]), "+v"(Ar[k]));
     asm volatile("" : "+v"(gn), "+v"(as_));
     __builtin_amdgcn_sched_barrier(0);
+    GPS_TRE(51);
     if (live) {
       V2 *dst = reinterpret_cast<V2 *>(a.blk + (size_t)j * BS);
 #pragma unroll
@@ -3361,6 +3382,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
 #pragma unroll
     for (int k = 0; k < B; k++) { Gn[k] = OUTR[tc + k * BP]; On[k] = nxt[co + B * BP + k * BP]; }
     __builtin_amdgcn_sched_barrier(0);
+    GPS_TRE(52);
     dpp_guard();
     static_for<0, B>([&](auto ii) {
       constexpr int i = decltype(ii)::value;
@@ -3375,6 +3397,7 @@ __global__ void __launch_bounds__(128, 2) k_fused_level0(FusedArgs<double, TR> u
     gr = gn;
     wave_lds_sync();
     __builtin_amdgcn_sched_barrier(0);
+    GPS_TRE(53);
 #endif
     if (!tail && live && lastb && rowlane) {
       double *ub = a.up_blk + (size_t)c * BS;

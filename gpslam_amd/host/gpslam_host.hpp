@@ -414,6 +414,33 @@ class NonlinearFactorGraph {
 // ---------------------------------------------------------------- graph compile + device session
 namespace detail {
 
+// The structs of include/gpslam_hip.h are written into by the library: before the first handle is created, the library this process
+// loaded must report the header's major version and the header's struct sizes (gpslam_hip_stats grew in round 5 with
+// nothing to tell an old caller).  Throws; checked once.
+inline void check_abi() {
+  static const bool ok = [] {
+    const uint32_t v = gpslam_hip_abi_version();
+    if ((v >> 16) != (uint32_t)GPSLAM_HIP_ABI_MAJOR || (v & 0xffffu) < (uint32_t)GPSLAM_HIP_ABI_MINOR)
+      throw std::runtime_error("libgpslam_hip.so speaks ABI " + std::to_string(v >> 16) + "." + std::to_string(v & 0xffffu) + ", this header " +
+                               std::to_string(GPSLAM_HIP_ABI_MAJOR) + "." + std::to_string(GPSLAM_HIP_ABI_MINOR));
+    if (gpslam_hip_struct_size(GPSLAM_STRUCT_CONFIG_V2) != sizeof(gpslam_hip_config_v2) || gpslam_hip_struct_size(GPSLAM_STRUCT_STATS) != sizeof(gpslam_hip_stats) ||
+        gpslam_hip_struct_size(GPSLAM_STRUCT_PARAMS) != sizeof(gpslam_hip_params) || gpslam_hip_struct_size(GPSLAM_STRUCT_CONFIG) != sizeof(gpslam_hip_config))
+      throw std::runtime_error("libgpslam_hip.so was built from another include/gpslam_hip.h: struct sizes differ");
+    return true;
+  }();
+  (void)ok;
+}
+// a zeroed gpslam_hip_config_v2 with its size filled in (every knob by name; one segment)
+inline gpslam_hip_config_v2 make_config(int manifold, int device = 0) {
+  check_abi();
+  gpslam_hip_config_v2 cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.struct_size = (uint32_t)sizeof(cfg);
+  cfg.manifold = manifold; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.nranks = 1;
+  cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;   // GTSAM's default charts
+  return cfg;
+}
+
 inline void check(int rc, gpslam_hip_handle *h, const char *what) {
   if (rc < 0) {
     std::string msg = std::string(what) + " failed (" + std::to_string(rc) + "): " + (h ? gpslam_hip_last_error(h) : "");
@@ -509,17 +536,14 @@ struct Session {
     }
     i = 0;
     for (auto &kv : lms) { lm_index.push_back(kv.first); std::memcpy(&LM[(size_t)i * ld], kv.second->d.data(), sizeof(double) * ld); i++; }
-    gpslam_hip_config cfg;
-    std::memset(&cfg, 0, sizeof(cfg));
-    cfg.manifold = manifold; cfg.precision = GPSLAM_FP64; cfg.device = device;
-    cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;   // GTSAM's default charts
-    cfg.landmark_dim = ld; cfg.nranks = 1;
+    gpslam_hip_config_v2 cfg = make_config(manifold, device);
+    cfg.landmark_dim = ld;
     if (vw) {
       if (manifold != GPSLAM_POSE3) throw std::invalid_argument("Pose3VW factors need Pose3 states");
-      cfg.reserved[3] = GPSLAM_VELOCITY_WORLD_VW;
+      cfg.velocity = GPSLAM_VELOCITY_WORLD_VW;
     }
-    int rc = gpslam_hip_create(&cfg, &h);
-    if (rc < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+    int rc = gpslam_hip_create_v2(&cfg, &h);
+    if (rc < 0) throw std::runtime_error("gpslam_hip_create_v2 failed: no usable HIP device (there is no CPU fallback)");
     check(gpslam_hip_set_states(h, N, P.data(), V.data()), h, "set_states");
     if (L > 0) check(gpslam_hip_set_landmarks(h, L, LM.data()), h, "set_landmarks");
     // ---- factors
@@ -884,12 +908,9 @@ struct Single {
     d = dd[manifold]; pd = pdd[manifold]; ld = landmark_dim;
     if ((int)p1.size() != pd || (int)p2.size() != pd || (int)v1.size() != d || (int)v2.size() != d)
       throw std::invalid_argument("evaluateError: argument types do not match the factor's manifold");
-    gpslam_hip_config cfg;
-    std::memset(&cfg, 0, sizeof(cfg));
-    cfg.manifold = manifold; cfg.precision = GPSLAM_FP64;
-    cfg.chart = (manifold == GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;
-    cfg.landmark_dim = ld; cfg.nranks = 1;
-    if (gpslam_hip_create(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+    gpslam_hip_config_v2 cfg = gtsam::detail::make_config(manifold);
+    cfg.landmark_dim = ld;
+    if (gpslam_hip_create_v2(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create_v2 failed: no usable HIP device (there is no CPU fallback)");
     std::vector<double> P(p1), V(v1);
     P.insert(P.end(), p2.begin(), p2.end());
     V.insert(V.end(), v2.begin(), v2.end());
@@ -1276,11 +1297,9 @@ inline std::vector<gtsam::Vector6> body_centric(int which, const std::vector<gts
   const size_t n = pose1.size();
   std::vector<gtsam::Vector6> out(n);
   if (n == 0) return out;
-  gpslam_hip_config cfg;
-  std::memset(&cfg, 0, sizeof(cfg));
-  cfg.manifold = GPSLAM_POSE3; cfg.nranks = 1;
+  gpslam_hip_config_v2 cfg = gtsam::detail::make_config(GPSLAM_POSE3);
   gpslam_hip_handle *h = nullptr;
-  if (gpslam_hip_create(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create failed: no usable HIP device (there is no CPU fallback)");
+  if (gpslam_hip_create_v2(&cfg, &h) < 0) throw std::runtime_error("gpslam_hip_create_v2 failed: no usable HIP device (there is no CPU fallback)");
   std::vector<double> p1(n * 12), p2(n * 12), o(n * 6);
   for (size_t i = 0; i < n; i++) {
     const std::vector<double> a = gtsam::detail::VT<gtsam::Pose3>::pack(pose1[i]), b = gtsam::detail::VT<gtsam::Pose3>::pack(pose2[i]);

@@ -171,14 +171,15 @@ template <typename POSE> class HipChainOptimizerT {
       const typename TR::Point p = init.at<typename TR::Point>(gtsam::Symbol('l', kv.first));
       for (int q = 0; q < TR::ld; q++) LM[(size_t)kv.second * TR::ld + q] = p(q);
     }
-    gpslam_hip_config cfg;
+    gpslam_hip_config_v2 cfg;
     std::memset(&cfg, 0, sizeof(cfg));
+    cfg.struct_size = (uint32_t)sizeof(cfg);
     cfg.manifold = TR::manifold; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.nranks = 1;
     cfg.chart = ((int)TR::manifold == (int)GPSLAM_POSE2) ? GPSLAM_CHART_FIRST_ORDER : GPSLAM_CHART_EXPMAP;
     cfg.landmark_dim = L > 0 ? TR::ld : 0;
     {   // (owned from here on: whatever throws below, the handle is destroyed -- ADVICE r2)
       gpslam_hip_handle *raw = nullptr;
-      if (gpslam_hip_create(&cfg, &raw) != 0) throw std::runtime_error("HipChainOptimizer: no usable HIP device");
+      if ((gpslam_hip_abi_version() >> 16) != (uint32_t)GPSLAM_HIP_ABI_MAJOR || gpslam_hip_create_v2(&cfg, &raw) != 0) throw std::runtime_error("HipChainOptimizer: no usable HIP device");
       hh_.reset(raw);
       h_ = raw;
     }

@@ -53,7 +53,7 @@ enum { GPSLAM_LINEAR2 = 0, GPSLAM_LINEAR3 = 1, GPSLAM_POSE2 = 2, GPSLAM_POSE3 = 
  *              POSE3 (R * Cayley(w), t + R v).  All charts agree to first order: the fixed point is the same. */
 enum { GPSLAM_CHART_EXPMAP = 0, GPSLAM_CHART_FIRST_ORDER = 1 };
 enum { GPSLAM_FP64 = 0, GPSLAM_FP32 = 1 };
-/* velocity parameterisation of a POSE3 chain (config.reserved[3]):
+/* velocity parameterisation of a POSE3 chain (config_v2.velocity; v1: config.reserved[3]):
  * BODY      6-vector body-frame velocity (w, v): GaussianProcessPriorPose3 / InterpolatorPose3 (gpslam.h:32-35, :72-77)
  * WORLD_VW  world-frame translational v and rotational w, stored as [v; w]: GaussianProcessPriorPose3VW,
  *           GaussianProcessInterpolatorPose3VW, GPInterpolatedGPSFactorPose3VW (gpslam.h:38-41, :65-70;
@@ -71,6 +71,43 @@ enum {
   GPSLAM_E_COMM = -7          /* a collective supplied through gpslam_hip_set_collectives reported a failure */
 };
 
+/* ---- ABI version (round 6).  Everything a caller's struct layouts depend on is behind one number: the library reports the
+ * version it was built from (gpslam_hip_abi_version) and the sizes of its structs (gpslam_hip_struct_size); a binding checks
+ * both once at load time (gpslam_amd/chain.py: load_library; gpslam_amd/host/gpslam_host.hpp: check_abi) instead of finding out
+ * through a corrupted stack.  History: 1.0 rounds 1-4 (gpslam_hip_stats 48 bytes); 1.1 round 5 (stats 56 bytes: trials,
+ * last_trial_error; GPSLAM_E_COMM; plan bits 64, 128) -- shipped without a version symbol; 2.0 this header: gpslam_hip_config_v2 +
+ * gpslam_hip_create_v2 (named fields, struct_size first), gpslam_hip_abi_version, gpslam_hip_struct_size.  The v1 config and
+ * gpslam_hip_create stay, bit for bit.  A MAJOR bump changes a struct or a signature, a MINOR bump only adds. */
+#define GPSLAM_HIP_ABI_MAJOR 2
+#define GPSLAM_HIP_ABI_MINOR 0
+#define GPSLAM_HIP_ABI_VERSION ((GPSLAM_HIP_ABI_MAJOR << 16) | GPSLAM_HIP_ABI_MINOR)
+uint32_t gpslam_hip_abi_version(void);
+enum { GPSLAM_STRUCT_CONFIG = 0, GPSLAM_STRUCT_CONFIG_V2 = 1, GPSLAM_STRUCT_STATS = 2, GPSLAM_STRUCT_PARAMS = 3 };
+/* sizeof() of the named struct in the library's build (0: unknown struct) */
+size_t gpslam_hip_struct_size(int32_t which);
+
+/* What a binding written against gpslam.h's class list fills in (gpslam_hip_create_v2).  struct_size = sizeof(gpslam_hip_config_v2)
+ * of the CALLER's header: a library that knows a longer struct reads the fields the caller has and takes defaults (0) for the rest;
+ * a library that knows a shorter one accepts the call only if the bytes it does not know are zero (GPSLAM_E_UNSUPPORTED otherwise). */
+typedef struct {
+  uint32_t struct_size;     /* sizeof(gpslam_hip_config_v2) */
+  int32_t manifold;         /* GPSLAM_LINEAR2 .. GPSLAM_ROT3_BIAS */
+  int32_t precision;        /* GPSLAM_FP64 | GPSLAM_FP32 (a tolerance mode, see gpslam_hip_config.precision) */
+  int32_t device;           /* HIP device ordinal */
+  int32_t chart;            /* GPSLAM_CHART_* */
+  int32_t landmark_dim;     /* 0 (no landmarks), 2 or 3 */
+  int32_t chunk;            /* level-0 chunk length of the partitioned solver; 0 = default */
+  int32_t rank, nranks;     /* contiguous-segment sharding: this handle owns segment `rank` of `nranks` */
+  int32_t force_sharded;    /* 1: the sharded code path on a single segment (self-test of the exchange plumbing)      v1 reserved[0] */
+  int32_t upper_chunk;      /* chunk length of the solver levels above level 0; 0 / 1 = default (LDS-resident groups)  v1 reserved[1] */
+  int32_t top_blocks;       /* size of the sequential top level; 0 = default                                          v1 reserved[2] */
+  int32_t velocity;         /* GPSLAM_VELOCITY_* (POSE3 only): body (w, v) or the *Pose3VW family's world [v; w]      v1 reserved[3] */
+  int32_t segment_length;   /* segmented landmark elimination: states per segment; 0 = the smallest that fits         v1 reserved[4] */
+  int32_t force_segmented;  /* 1: the segmented landmark elimination for any landmark count                           v1 reserved[5] */
+  int32_t plan;             /* mask of GPSLAM_PLAN_* bits; 0 = the default plan                                       v1 reserved[6] */
+} gpslam_hip_config_v2;
+
+/* v1 (rounds 1-5): the same eight knobs as anonymous words.  Kept so that callers built against the old header keep working. */
 typedef struct {
   int32_t manifold;      /* GPSLAM_LINEAR2 .. GPSLAM_ROT3 */
   int32_t precision;     /* GPSLAM_FP64, or GPSLAM_FP32: fp32 Jacobian rows (evaluated re-centred, with the exact derivative in place of the
@@ -88,7 +125,7 @@ typedef struct {
                           * count (default: only when the landmarks do not fit the dense border), [6] mask of GPSLAM_PLAN_* bits
                           * (below; 0 = the default plan); [7] must be 0 */
 } gpslam_hip_config;
-/* config.reserved[6]: kernel families compile() may be told to use instead of its default choice.  Every one of them is the
+/* config_v2.plan (v1: config.reserved[6]): kernel families compile() may be told to use instead of its default choice.  Every one of them is the
  * path some graphs take anyway (chains with landmark columns, pinned hierarchy shapes, wide landmark borders, graphs whose
  * full-width rows are not all GP priors); the bits exist so that tests run them on plain chains and so that a maintainer
  * can A/B them per handle (gpslam_hip_plan_info shows what a handle ended up with).  No reference counterpart. */
@@ -136,6 +173,7 @@ typedef struct {
 
 /* ---- life cycle ---- */
 int gpslam_hip_create(const gpslam_hip_config *cfg, gpslam_hip_handle **out);
+int gpslam_hip_create_v2(const gpslam_hip_config_v2 *cfg, gpslam_hip_handle **out);
 int gpslam_hip_destroy(gpslam_hip_handle *h);
 void gpslam_hip_default_params(gpslam_hip_params *p);
 const char *gpslam_hip_last_error(const gpslam_hip_handle *h);
@@ -410,14 +448,23 @@ int gpslam_hip_fs_lm_trial_phase2(gpslam_hip_handle *h, double *out6);
  * and return the statistics of the WHOLE chain (errors summed, |delta|_inf maximised over the ranks), identical on every rank.
  * A callback returns 0, anything else ends the call with GPSLAM_E_COMM.  Collectives per call:
  *   iterate_gn      1 all-gather of the interface records (+ 1 all-reduce with a landmark border) + 1 all-gather of 64 B of scalars
- *                   when statistics are asked for;
+ *                   (with or without statistics: it is also how a rank learns that another one failed);
+ *   run_gn(K)       K x (the record all-gather (+ the all-reduce)) + ONE all-gather of 64 B at the end: the statistics of the last
+ *                   iteration, the non-positive-pivot flag of ANY iteration (sticky through the run) and the first failure of any rank;
  *   iterate_lm      per lambda trial: the record all-gather (+ the all-reduce) and ONE all-gather of 64 B carrying the trial's six
  *                   scalars {error, trial error, |delta|_inf, delta . g, |delta|^2, indefinite flag} -- the scalars of a trial
  *                   exist only after its back-substitution, which needs the gathered records, so they cannot ride the record;
  *                   every rank then takes the branch of gpslam_hip_lm_decide on identical reduced numbers;
  *   optimize        GTSAM's loop (NonlinearOptimizer::defaultOptimize) over the two above.
- * Every rank must make the same calls in the same order (they are collective).  A single-rank handle that was forced onto the
- * sharded code path (config.reserved[0]) needs no callbacks.  LevenbergMarquardtOptimizer::iterate on the reference's
+ * Every rank must make the same calls in the same order (they are collective).
+ * FAILURES ON ONE RANK (round 6).  A rank whose local work fails inside one of these calls -- a HIP error, a phase's status, its own
+ * all_reduce_sum callback -- does NOT leave the collective sequence: it records the code, skips its remaining local work, goes on making
+ * every collective call of the iteration, and the code travels in a spare slot of the 64-byte scalar gather; EVERY rank then returns
+ * that code (a non-positive pivot anywhere: GPSLAM_E_NOT_SPD everywhere, as before).  What can still leave ranks out of step, and is
+ * the caller's to prevent or to time out: a rank that never enters the call (GPSLAM_E_NOT_COMPILED, no callbacks registered, a
+ * split piece without gpslam_hip_fs_set_top: checked before the first collective), an all_gather callback that fails or hangs on
+ * one rank only, and a HIP failure inside the scalar gather's own two 64-byte copies.
+ * A single-rank handle that was forced onto the sharded code path (config_v2.force_sharded) needs no callbacks.  LevenbergMarquardtOptimizer::iterate on the reference's
  * landmark graph: matlab/PlazaPose2.m:210-226. */
 typedef int (*gpslam_hip_all_gather_fn)(void *user, const void *send_dev, void *recv_dev, size_t bytes_per_rank, void *hip_stream);
 typedef int (*gpslam_hip_all_reduce_sum_fn)(void *user, void *buf_dev, size_t n_doubles, void *hip_stream);

@@ -60,5 +60,16 @@ for c in sorted(set(cnt)):
     q("ELIM end, CU holds %d workgroups" % c, us(elim[sel, 60]))
 dur = us(elim[:, 60]).max() - min(us(elim[:, 0]).min(), us(asm[:, 0]).min())
 print("  first start -> last end: %.2f us" % dur)
+# fine stamps of one block step (builds that carry them): assembly wave of image 13, elimination wave of step 10
+if (asm[:, 40] > 0).any():
+    names = ["shuffles + moves", "reconstruct (waits for the GP record)", "12 GP rows", "6 between rows (waits for its record)", "odd / compact rows", "damping", "open next state"]
+    for k, nm in enumerate(names):
+        q("ASM image 13: " + nm, us(asm[:, 41 + k]) - us(asm[:, 40 + k]))
+    q("ASM image 13: total", us(asm[:, 46]) - us(asm[:, 40]))
+if (elim[:, 48] > 0).any():
+    names = ["Gauss-Jordan", "scale + record to LDS + wait at the barrier", "products with V_j", "stores + transpose", "products with U_j"]
+    for k, nm in enumerate(names):
+        q("ELIM step 10: " + nm, us(elim[:, 49 + k]) - us(elim[:, 48 + k]))
+    q("ELIM step 10: total", us(elim[:, 53]) - us(elim[:, 48]))
 if out:
     np.savez_compressed(out, trace=t)

@@ -6,6 +6,7 @@
 // gpslam/slam/tests/testRangeBearingFactor2DLinear.cpp (optimization), gpslam/gp/tests/testGaussianProcessPriorPose3VW.cpp
 // (Optimization) and gpslam/slam/tests/testGPInterpolatedProjectionFactorPose3.cpp (optimization).
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -683,13 +684,80 @@ static void test_single_qc_graph_keeps_the_structured_path() {
   EXPECT(graph.error(opt.values()) < 1e-6);
 }
 
+// ABI 2.0 (round 6): the version symbol, the struct sizes, and what gpslam_hip_create_v2 does with a caller's struct_size
+static void test_abi_version_and_struct_sizes() {      // (host only: no handle is created)
+  EXPECT(gpslam_hip_abi_version() == (uint32_t)GPSLAM_HIP_ABI_VERSION);
+  EXPECT(gpslam_hip_struct_size(GPSLAM_STRUCT_CONFIG) == sizeof(gpslam_hip_config));
+  EXPECT(gpslam_hip_struct_size(GPSLAM_STRUCT_CONFIG_V2) == sizeof(gpslam_hip_config_v2));
+  EXPECT(gpslam_hip_struct_size(GPSLAM_STRUCT_STATS) == sizeof(gpslam_hip_stats));
+  EXPECT(gpslam_hip_struct_size(GPSLAM_STRUCT_PARAMS) == sizeof(gpslam_hip_params));
+  EXPECT(gpslam_hip_struct_size(99) == 0);
+  EXPECT(sizeof(gpslam_hip_config) == 64 && sizeof(gpslam_hip_config_v2) == 64 && sizeof(gpslam_hip_stats) == 56);
+  gtsam::detail::check_abi();                           // what the host classes do before their first handle
+  gpslam_hip_handle *h = nullptr;
+  gpslam_hip_config_v2 c;
+  std::memset(&c, 0, sizeof(c));
+  c.manifold = GPSLAM_POSE3; c.nranks = 1;
+  c.struct_size = 8;                                    // shorter than the fields every version has
+  EXPECT(gpslam_hip_create_v2(&c, &h) == GPSLAM_E_INVALID && h == nullptr);
+  EXPECT(gpslam_hip_create_v2(nullptr, &h) == GPSLAM_E_INVALID);
+  c.struct_size = (uint32_t)sizeof(c); c.plan = 1 << 20;     // an unknown plan bit is refused, by name
+  EXPECT(gpslam_hip_create_v2(&c, &h) == GPSLAM_E_INVALID && h == nullptr);
+  struct { gpslam_hip_config_v2 c; int32_t knob_of_a_newer_header; } big;
+  std::memset(&big, 0, sizeof(big));
+  big.c.struct_size = (uint32_t)sizeof(big); big.c.manifold = GPSLAM_POSE3; big.c.nranks = 1;
+  big.knob_of_a_newer_header = 3;                       // a knob this build cannot honour is not dropped silently
+  EXPECT(gpslam_hip_create_v2(&big.c, &h) == GPSLAM_E_UNSUPPORTED && h == nullptr);
+}
+static void test_config_v1_v2_and_truncated_v2_reach_the_same_handle() {      // (GPU)
+  int32_t i1[8], i2[8], i3[8];
+  gpslam_hip_handle *h1 = nullptr, *h2 = nullptr, *h3 = nullptr;
+  gpslam_hip_config c1;                                 // v1: a caller built against the rounds 1-5 header
+  std::memset(&c1, 0, sizeof(c1));
+  c1.manifold = GPSLAM_POSE3; c1.nranks = 1; c1.reserved[6] = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_GP_ROWS;
+  EXPECT(gpslam_hip_create(&c1, &h1) == 0);
+  gpslam_hip_config_v2 c2 = gtsam::detail::make_config(GPSLAM_POSE3);
+  c2.chart = GPSLAM_CHART_EXPMAP; c2.plan = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_GP_ROWS;
+  EXPECT(gpslam_hip_create_v2(&c2, &h2) == 0);
+  gpslam_hip_config_v2 c3 = gtsam::detail::make_config(GPSLAM_POSE3);     // a v2 caller whose header ended before `plan`
+  c3.struct_size = (uint32_t)offsetof(gpslam_hip_config_v2, plan);
+  c3.plan = 0x7fffffff;                                 // (beyond its struct_size: not read)
+  EXPECT(gpslam_hip_create_v2(&c3, &h3) == 0);
+  c1.reserved[7] = 1;
+  gpslam_hip_handle *h4 = nullptr;
+  EXPECT(gpslam_hip_create(&c1, &h4) == GPSLAM_E_INVALID);
+  const int N = 600;
+  std::vector<double> P((size_t)N * 12, 0.0), V((size_t)N * 6, 0.0);
+  std::vector<int32_t> left(N - 1);
+  std::vector<double> dt(N - 1, 0.1);
+  for (int k = 0; k < N; k++) { P[12 * k] = P[12 * k + 4] = P[12 * k + 8] = 1.0; P[12 * k + 9] = 0.1 * k; V[6 * k + 3] = 1.0; }
+  for (int k = 0; k + 1 < N; k++) left[k] = k;
+  const int32_t i0 = 0; const double sig[6] = {1e-3, 1e-3, 1e-3, 1e-3, 1e-3, 1e-3};
+  for (gpslam_hip_handle *h : {h1, h2, h3}) {
+    EXPECT(gpslam_hip_set_states(h, N, P.data(), V.data()) == 0);
+    EXPECT(gpslam_hip_add_gp_priors(h, N - 1, left.data(), dt.data()) == 0);
+    EXPECT(gpslam_hip_add_pose_priors(h, 1, &i0, P.data(), sig) == 0);
+    EXPECT(gpslam_hip_compile(h) == 0);
+  }
+  EXPECT(gpslam_hip_plan_info(h1, i1) == 0 && gpslam_hip_plan_info(h2, i2) == 0 && gpslam_hip_plan_info(h3, i3) == 0);
+  EXPECT(std::memcmp(i1, i2, sizeof(i1)) == 0);         // the same plan through either struct
+  EXPECT(i1[3] == 0 && i1[4] == 0 && i3[3] == 1 && i3[4] == 1);   // ... the two-launch row path where asked for, the default plan where not
+  gpslam_hip_stats s1, s2;
+  EXPECT(gpslam_hip_iterate_gn(h1, &s1) == 0 && gpslam_hip_iterate_gn(h2, &s2) == 0);
+  EXPECT(s1.error_before == s2.error_before && s1.error_after == s2.error_after);
+  gpslam_hip_destroy(h1); gpslam_hip_destroy(h2); gpslam_hip_destroy(h3);
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "--host-only") == 0) {   // what needs no GPU (the CPU test run)
     test_equals_print_clone();
+    test_abi_version_and_struct_sizes();
     if (failures == 0) std::printf("host_api_tests: all host-only tests passed\n");
     return failures == 0 ? 0 : 1;
   }
   test_equals_print_clone();
+  test_abi_version_and_struct_sizes();
+  test_config_v1_v2_and_truncated_v2_reach_the_same_handle();
   test_single_qc_graph_keeps_the_structured_path();
   test_gp_prior_pose3_optimization();
   test_gp_prior_pose2_rot3_linear_optimization();

@@ -40,12 +40,13 @@ static Problem make(int N) {
 
 // the factors whose LEFT (or only) state lies in [lo, hi) go to this handle, indices relative to lo
 static gpslam_hip_handle *build(const Problem &p, int device, int rank, int nranks, bool force_sharded, int lo, int hi) {
-  gpslam_hip_config cfg;
+  gpslam_hip_config_v2 cfg;
   std::memset(&cfg, 0, sizeof(cfg));
+  cfg.struct_size = (uint32_t)sizeof(cfg);
   cfg.manifold = GPSLAM_LINEAR3; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.rank = rank; cfg.nranks = nranks;
-  cfg.reserved[0] = force_sharded ? 1 : 0;
+  cfg.force_sharded = force_sharded ? 1 : 0;
   gpslam_hip_handle *h = nullptr;
-  if (gpslam_hip_create(&cfg, &h) != 0) { std::printf("FAILED create\n"); std::exit(1); }
+  if (gpslam_hip_create_v2(&cfg, &h) != 0) { std::printf("FAILED create\n"); std::exit(1); }
   const int n = hi - lo;
   ok(gpslam_hip_set_states(h, n, &p.pose[(size_t)lo * 3], &p.vel[(size_t)lo * 3]), h, "set_states");
   if (hi < p.N) ok(gpslam_hip_set_halo_state(h, &p.pose[(size_t)hi * 3], &p.vel[(size_t)hi * 3]), h, "set_halo_state");

@@ -107,12 +107,13 @@ static Piece build(const Problem &p, int device, int rank, int P, const std::vec
     pc.own.push_back(pmax[l] == rank);
     lm.push_back(p.lmk[(size_t)l * 2]); lm.push_back(p.lmk[(size_t)l * 2 + 1]);
   }
-  gpslam_hip_config cfg;
+  gpslam_hip_config_v2 cfg;
   std::memset(&cfg, 0, sizeof(cfg));
+  cfg.struct_size = (uint32_t)sizeof(cfg);
   cfg.manifold = GPSLAM_POSE2; cfg.precision = GPSLAM_FP64; cfg.device = device; cfg.rank = 0; cfg.nranks = 1;
   cfg.chart = GPSLAM_CHART_FIRST_ORDER; cfg.landmark_dim = 2;
-  cfg.reserved[5] = 1;                 // the reference run takes the segmented path as well
-  ok(gpslam_hip_create(&cfg, &pc.h) != 0 ? -1 : 0, nullptr, "create");
+  cfg.force_segmented = 1;             // the reference run takes the segmented path as well
+  ok(gpslam_hip_create_v2(&cfg, &pc.h) != 0 ? -1 : 0, nullptr, "create");
   gpslam_hip_handle *h = pc.h;
   ok(gpslam_hip_set_states(h, n, &p.pose[(size_t)lo * 3], &p.vel[(size_t)lo * 3]), h, "set_states");
   ok(gpslam_hip_set_landmarks(h, (int)pc.lm_global.size(), lm.data()), h, "set_landmarks");

@@ -413,3 +413,95 @@ def test_sharded_handle_without_collectives_still_refuses_the_whole_chain_loops(
         with pytest.raises(gpslam_amd.GpslamHipError, match="collectives"):
             call()
     s.close()
+
+
+def test_indefinite_pivot_inside_a_sharded_run_is_reported_by_every_rank_with_or_without_statistics():
+    """gpslam_hip_run_gn on a sharded handle looped iterate_gn(h, NULL) for every iteration but the last: phase 1 cleared the
+    non-positive-pivot flag, nothing read it, and a run WITHOUT a statistics struct returned 0 on every rank whatever happened.  Round 6:
+    the flag is cleared once and stays up through the run, one 64-byte gather at the end carries it (and the first failure of any
+    rank) to everybody.  A chain with no absolute information at all (GP priors only pin differences: the reduced system is singular,
+    GTSAM's IndeterminantLinearSystemException) through run_gn(3) with statistics, through the raw entry point with st = NULL, and
+    through a single iterate_gn(h, NULL)."""
+    import ctypes as C
+    import gpslam_amd
+    from gpslam_amd import sharded
+    from test_gpu_parity import random_chain
+    from thread_ranks import ThreadRanks
+    P, N, kind = 2, 96, O.LINEAR3
+    c = random_chain(kind, N, 9)
+    problem = dict(kind=kind, N=N, qc=np.eye(3) * 0.01, pose=c["pose"], vel=c["vel"], gp_left=np.arange(N - 1, dtype=np.int32), gp_dt=c["dt"])
+    tr = ThreadRanks(P)
+    hs = []
+    for r in range(P):
+        s = gpslam_amd.ChainSolver(kind, device=0, rank=r, nranks=P)
+        sharded.apply_local(sharded.local_problem(problem, r, P), s)
+        s.set_collectives(*tr.collectives(r))
+        hs.append(s)
+
+    def with_stats(r):
+        try:
+            hs[r].run_gn(3)
+        except gpslam_amd.GpslamHipError as ex:
+            return str(ex)
+        return "no error"
+    for msg in tr.run(with_stats):
+        assert "(-3)" in msg and "non-positive pivot" in msg, msg
+    lib = hs[0].lib
+    assert tr.run(lambda r: lib.gpslam_hip_run_gn(hs[r]._h, 3, None, None)) == [-3] * P          # (round 5: 0 on every rank)
+    assert tr.run(lambda r: lib.gpslam_hip_iterate_gn(hs[r]._h, None)) == [-3] * P
+    for s in hs:
+        s.close()
+
+
+@pytest.mark.parametrize("loop", ["iterate_gn", "run_gn", "iterate_lm", "optimize"])
+def test_a_failure_on_one_rank_ends_the_call_on_every_rank_with_the_same_code(loop):
+    """a rank that failed locally returned at once and left its peers blocked in the next collective.  Round 6: it goes on
+    making every collective call and its code travels with the scalars.  Here rank 1's all_reduce_sum (the landmark Schur complement
+    of the Plaza graph) completes -- so that its peer is not stuck inside THAT collective -- and then reports failure: rank 1 sees
+    GPSLAM_E_COMM from its own callback; the test is that rank 0 returns GPSLAM_E_COMM as well instead of waiting forever in the gather of
+    the scalars (the round-5 library hangs here; ThreadRanks gives up after its join timeout)."""
+    import os
+    import gpslam_amd
+    from gpslam_amd import plaza, sharded
+    from thread_ranks import ThreadRanks
+    data = plaza.load(os.path.join(os.path.dirname(__file__), "golden", "plaza2.npz"))
+    problem = plaza.build_problem(data)
+    kind, chart, P = gpslam_amd.POSE2, gpslam_amd.CHART_FIRST_ORDER, 2
+    tr = ThreadRanks(P)
+    hs = []
+    calls = [0]
+    for r in range(P):
+        s = gpslam_amd.ChainSolver(kind, chart=chart, landmark_dim=2, device=0, rank=r, nranks=P)
+        sharded.apply_local(sharded.local_problem(problem, r, P), s)
+        gather, reduce_ = tr.collectives(r)
+        if r == 1:
+            good = reduce_
+
+            def reduce_(buf, n, stream, good=good):
+                good(buf, n, stream)
+                calls[0] += 1
+                if calls[0] == 2:
+                    raise RuntimeError("injected: rank 1's all_reduce_sum reports failure on its second call")
+        s.set_collectives(gather, reduce_)
+        hs.append(s)
+
+    def body(r):
+        s = hs[r]
+        try:
+            if loop == "iterate_gn":
+                s.iterate_gn(); s.iterate_gn()
+            elif loop == "run_gn":
+                s.run_gn(3)
+            elif loop == "iterate_lm":
+                lam = 1e-5
+                for _ in range(3):
+                    _rc, _st, lam = s.iterate_lm(lam)[:3]
+            else:
+                s.optimize(s.default_params(use_lm=1))
+        except gpslam_amd.GpslamHipError as ex:
+            return str(ex)
+        return "no error"
+    msgs = tr.run(body)
+    assert all("(-7)" in m for m in msgs), msgs
+    for s in hs:
+        s.close()
