@@ -185,6 +185,11 @@ template <int K, int N, bool NEG = false> __device__ __forceinline__ void fmac_b
   static_for<0, N>([&](auto qq) { fmac_bcast1_nn<K, NEG>(d[decltype(qq)::value], s[decltype(qq)::value], m); });
 }
 
+// d[k] += s[lane K0 + k] * m, k = 0..N-1 (the gather form below, unguarded)
+template <int N, int K0 = 0> __device__ __forceinline__ void fmac_gather_nn(double *d, double s, double m) {
+  static_for<0, N>([&](auto kk) { fmac_bcast1_nn<K0 + decltype(kk)::value>(d[decltype(kk)::value], s, m); });
+}
+
 // d[k] += s[lane k] * m, k = 0..N-1: the GATHER form (one source register, twelve broadcast lanes) of the assembly wave
 template <int N> __device__ __forceinline__ void fmac_gather(double *d, double s, double m);
 template <> __device__ __forceinline__ void fmac_gather<12>(double *d, double s, double m) {

@@ -2989,25 +2989,29 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
           if constexpr (q == 8) ldraw(kimg + 1, gpn);
           if constexpr (q == 5) ldbtw();                 // this state's between record: wanted right behind these twelve rows
           const double Lv = Lcol[q], Rv = Rcol[q];
+          // (round 6: unguarded multiply-adds -- what they read through DPP, the row's entries Lcol[q] / Rcol[q] and the whitened
+          //  error, was written by reconstruct() before this loop began; one guard opens the loop)
+          if constexpr (q == 0) dpp_guard();
           if constexpr (DG) {
             // row q of L: the pose columns and velocity column 6 + q mod 6.  X, J and F are block lower triangular ([[A, 0], [C, D]]),
             // so the rotation rows (q mod 6 < 3) of the whitened [L | R] are zero in every translation column (3..5, and 9..11 of R)
             constexpr int vq = Dh + q % Dh;
             if constexpr (q % Dh < 3) {
-              fmac_gather<3>(Dacc, Lv, Lv); fmac_bcast1<vq>(Dacc[vq], Lv, Lv);
-              fmac_gather<3>(Oacc, Lv, Rv); fmac_bcast1<vq>(Oacc[vq], Lv, Rv);
-              fmac_gather<3>(RRacc, Rv, Rv); fmac_gather3_at<Dh>(RRacc + Dh, Rv, Rv);
+              fmac_gather_nn<3>(Dacc, Lv, Lv); fmac_bcast1_nn<vq>(Dacc[vq], Lv, Lv);
+              fmac_gather_nn<3>(Oacc, Lv, Rv); fmac_bcast1_nn<vq>(Oacc[vq], Lv, Rv);
+              fmac_gather_nn<3>(RRacc, Rv, Rv); fmac_gather_nn<3, Dh>(RRacc + Dh, Rv, Rv);
             } else {
-              fmac_gather<Dh>(Dacc, Lv, Lv); fmac_bcast1<vq>(Dacc[vq], Lv, Lv);
-              fmac_gather<Dh>(Oacc, Lv, Rv); fmac_bcast1<vq>(Oacc[vq], Lv, Rv);
-              fmac_gather<B>(RRacc, Rv, Rv);
+              fmac_gather_nn<Dh>(Dacc, Lv, Lv); fmac_bcast1_nn<vq>(Dacc[vq], Lv, Lv);
+              fmac_gather_nn<Dh>(Oacc, Lv, Rv); fmac_bcast1_nn<vq>(Oacc[vq], Lv, Rv);
+              fmac_gather_nn<B>(RRacc, Rv, Rv);
             }
           } else {
-            fmac_gather<B>(Dacc, Lv, Lv);
-            fmac_gather<B>(Oacc, Lv, Rv);
-            fmac_gather<B>(RRacc, Rv, Rv);
+            fmac_gather_nn<B>(Dacc, Lv, Lv);
+            fmac_gather_nn<B>(Oacc, Lv, Rv);
+            fmac_gather_nn<B>(RRacc, Rv, Rv);
           }
-          fmac_bcast2<q>(gacc, grr, newl, Lv, Rv);       // g -= e[q] L[q][r],  carry_g -= e[q] R[q][r]
+          fmac_bcast1_nn<q>(gacc, newl, Lv);             // g -= e[q] L[q][r]
+          fmac_bcast1_nn<q>(grr, newl, Rv);              // carry_g -= e[q] R[q][r]
           __builtin_amdgcn_sched_barrier(0);
         });
       }
@@ -3028,16 +3032,18 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
             constexpr int i = decltype(ii)::value;
             const double wi = row_bcast<i>(braw[12]);     // 1 / sigma of row i
             const double Lv = wi * Lc6[i], Rv = wi * Rc6[i];
+            dpp_guard();                                 // (Lv, Rv are one instruction old; everything else in the row is not)
             if constexpr (i < 3) {                       // rotation rows of [[A, 0], [C, A]]: zero in the translation columns
-              fmac_gather<3>(Dacc, Lv, Lv);
-              fmac_gather<3>(Oacc, Lv, Rv);
-              fmac_gather<3>(RRacc, Rv, Rv);
+              fmac_gather_nn<3>(Dacc, Lv, Lv);
+              fmac_gather_nn<3>(Oacc, Lv, Rv);
+              fmac_gather_nn<3>(RRacc, Rv, Rv);
             } else {
-              fmac_gather<Dh>(Dacc, Lv, Lv);
-              fmac_gather<Dh>(Oacc, Lv, Rv);
-              fmac_gather<Dh>(RRacc, Rv, Rv);
+              fmac_gather_nn<Dh>(Dacc, Lv, Lv);
+              fmac_gather_nn<Dh>(Oacc, Lv, Rv);
+              fmac_gather_nn<Dh>(RRacc, Rv, Rv);
             }
-            fmac_bcast2<i>(gacc, grr, nbe, Lv, Rv);
+            fmac_bcast1_nn<i>(gacc, nbe, Lv);
+            fmac_bcast1_nn<i>(grr, nbe, Rv);
             __builtin_amdgcn_sched_barrier(0);
           });
         }

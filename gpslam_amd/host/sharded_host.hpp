@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <deque>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -208,7 +209,7 @@ class ShardedDriver {
   std::vector<int> devices_;
   std::vector<ncclComm_t> comms_;
   std::vector<hipStream_t> streams_;
-  std::vector<ShardedRank> ranks_;
+  std::deque<ShardedRank> ranks_;     // (a deque: add() never moves a rank -- register_collectives() hands the library a rank's address)
 };
 
 // ---- chains with many locally visible landmarks (BASELINE config 4) across GPUs: pieces joined at shared cut states

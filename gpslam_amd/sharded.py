@@ -166,20 +166,31 @@ class _DevView:
 
 def torch_collectives(dist, group, world):
     """(all_gather, all_reduce_sum) for ChainSolver.set_collectives over torch.distributed (backend "nccl" = RCCL): the
-    library's raw device pointers are wrapped as tensors and the collective is enqueued on torch's current stream -- which is
-    the handle's stream once ShardedSolver / SplitSolver has moved the handle onto it."""
+    library's raw device pointers are wrapped as tensors and the collective is enqueued ON THE STREAM THE LIBRARY NAMES (the handle's
+    stream: torch.cuda.ExternalStream made current around the call -- ADVICE r5: the argument used to be ignored, which was only
+    right while torch's current stream happened to be the handle's)."""
     import torch
+    streams = {}
 
-    def all_gather(send, recv, nbytes, _stream):
-        s = torch.as_tensor(_DevView(send, nbytes), device="cuda")
-        r = torch.as_tensor(_DevView(recv, nbytes * world), device="cuda")
-        if hasattr(dist, "all_gather_into_tensor"):
-            dist.all_gather_into_tensor(r, s, group=group)
-        else:
-            dist.all_gather(list(r.view(world, -1).unbind(0)), s, group=group)
+    def on(hip_stream):
+        if not hip_stream:                       # the null stream: torch's default stream
+            return torch.cuda.stream(torch.cuda.default_stream())
+        if hip_stream not in streams:
+            streams[hip_stream] = torch.cuda.ExternalStream(int(hip_stream))
+        return torch.cuda.stream(streams[hip_stream])
 
-    def all_reduce_sum(buf, n, _stream):
-        dist.all_reduce(torch.as_tensor(_DevView(buf, n * 8), device="cuda"), group=group)
+    def all_gather(send, recv, nbytes, hip_stream):
+        with on(hip_stream):
+            s = torch.as_tensor(_DevView(send, nbytes), device="cuda")
+            r = torch.as_tensor(_DevView(recv, nbytes * world), device="cuda")
+            if hasattr(dist, "all_gather_into_tensor"):
+                dist.all_gather_into_tensor(r, s, group=group)
+            else:
+                dist.all_gather(list(r.view(world, -1).unbind(0)), s, group=group)
+
+    def all_reduce_sum(buf, n, hip_stream):
+        with on(hip_stream):
+            dist.all_reduce(torch.as_tensor(_DevView(buf, n * 8), device="cuda"), group=group)
 
     return all_gather, all_reduce_sum
 

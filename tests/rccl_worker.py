@@ -49,6 +49,15 @@ def main():
         st_s, lam_s = sv.iterate_lm(lam_s)
         _, st_r, lam_r = ref.iterate_lm(lam_r)[:3]
         ok = ok and lam_s == lam_r and st_s["accepted"] == bool(st_r.accepted) and abs(st_s["error_after"] - st_r.error_after) <= 1e-9 * max(1.0, st_r.error_after)
+    # ... and LevenbergMarquardtOptimizer::iterate through the C ABI itself (gpslam_hip_iterate_lm on this rank's handle, the collectives
+    # enqueued by torch_collectives on the stream the library names)
+    restart()
+    lam_s = lam_r = 1e-5
+    for _ in range(3):
+        _, st_c, lam_s = s.iterate_lm(lam_s)[:3]
+        _, st_r, lam_r = ref.iterate_lm(lam_r)[:3]
+        ok = ok and lam_s == lam_r and bool(st_c.accepted) == bool(st_r.accepted) and int(st_c.trials) == int(st_r.trials) \
+            and abs(st_c.error_after - st_r.error_after) <= 1e-9 * max(1.0, st_r.error_after)
     restart()
     _, so = sv.optimize()
     _, so_r = ref.optimize()
