@@ -32,6 +32,35 @@
 
 #include "../../include/gpslam_hip.h"
 
+// boost::optional<Matrix&> -- the type of the reference's Jacobian arguments (gpslam/gp/GaussianProcessPriorPose3.h:60-64:
+// `boost::optional<gtsam::Matrix&> H1 = boost::none`).  Where Boost is installed its header is used; where it is not (this image), the
+// two names a call site of evaluateError / interpolatePose can spell -- boost::none and boost::optional<T&> -- are provided here, so
+// that `f.evaluateError(p1, v1, p2, v2, H1, boost::none, H3)` compiles unchanged (round 6; rounds 2-5 took `Matrix*`, which still works).
+#if defined(__has_include) && __has_include(<boost/optional.hpp>)
+#include <boost/optional.hpp>
+#else
+namespace boost {
+struct none_t { struct init_tag {}; explicit constexpr none_t(init_tag) {} };
+inline constexpr none_t none{none_t::init_tag{}};
+template <class T> class optional;
+template <class T> class optional<T &> {
+ public:
+  optional() : p_(nullptr) {}
+  optional(none_t) : p_(nullptr) {}
+  optional(T &r) : p_(&r) {}
+  explicit operator bool() const { return p_ != nullptr; }
+  bool is_initialized() const { return p_ != nullptr; }
+  T &operator*() const { return *p_; }
+  T *operator->() const { return p_; }
+  T &get() const { return *p_; }
+  T *get_ptr() const { return p_; }
+  void reset() { p_ = nullptr; }
+ private:
+  T *p_;
+};
+}  // namespace boost
+#endif
+
 namespace gtsam {
 
 typedef uint64_t Key;
@@ -66,6 +95,22 @@ struct Matrix {  // dynamic, row-major
   Matrix operator*(double s) const { Matrix m = *this; for (double &v : m.a) v *= s; return m; }
 };
 inline Matrix operator*(double s, const Matrix &m) { return m * s; }
+
+/// What a Jacobian argument of evaluateError / interpolatePose accepts: everything a call site of the reference can pass to a
+/// `boost::optional<gtsam::Matrix&>` parameter -- a Matrix lvalue, boost::none, a boost::optional<Matrix&> -- and, as in rounds 2-5 of
+/// this header, a `Matrix*` (nullptr = not wanted).  Converts to `Matrix*` for the implementation.
+class OptionalMatrix {
+ public:
+  OptionalMatrix() {}
+  OptionalMatrix(boost::none_t) {}
+  OptionalMatrix(std::nullptr_t) {}
+  OptionalMatrix(Matrix &m) : p_(&m) {}
+  OptionalMatrix(Matrix *m) : p_(m) {}
+  OptionalMatrix(const boost::optional<Matrix &> &o) : p_(o ? &*o : nullptr) {}
+  operator Matrix *() const { return p_; }
+ private:
+  Matrix *p_ = nullptr;
+};
 
 struct Point2 { double x = 0, y = 0; Point2() {} Point2(double x_, double y_) : x(x_), y(y_) {} };
 struct Point3 { double x = 0, y = 0, z = 0; Point3() {} Point3(double x_, double y_, double z_) : x(x_), y(y_), z(z_) {} };
@@ -1018,8 +1063,8 @@ inline POSE interpolate_one(int manifold, const gtsam::Matrix &Qc, double delta_
     CLS(gtsam::Key poseKey1, gtsam::Key velKey1, gtsam::Key poseKey2, gtsam::Key velKey2, double delta_t,      \
         const gtsam::SharedNoiseModel &Qc_model) { d_ = detail_g::gp(MANIFOLD, poseKey1, velKey1, poseKey2, velKey2, delta_t, Qc_model); } \
     /** evaluateError(pose1, vel1, pose2, vel2, H1..H4): the reference's signature with pointers for boost::optional */ \
-    gtsam::Vector evaluateError(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::Matrix *H1 = nullptr, \
-                                gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const { \
+    gtsam::Vector evaluateError(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::OptionalMatrix H1 = boost::none, \
+                                gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const { \
       return detail_g::gp_evaluate(d_, gtsam::detail::VT<POSE>::pack(pose1), gtsam::detail::VT<VEL>::pack(vel1),      \
                                    gtsam::detail::VT<POSE>::pack(pose2), gtsam::detail::VT<VEL>::pack(vel2), H1, H2, H3, H4); \
     }                                                                                                           \
@@ -1042,8 +1087,8 @@ template <int Dim> class GaussianProcessPriorLinear : public gtsam::NonlinearFac
   }
   /// gpslam/gp/GaussianProcessPriorLinear.h:63-83
   gtsam::Vector evaluateError(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
-                              const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
-                              gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+                              const gtsam::VectorN<Dim> &vel2, gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none,
+                              gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const {
     typedef gtsam::detail::VT<gtsam::VectorN<Dim>> P;
     return detail_g::gp_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), H1, H2, H3, H4);
   }
@@ -1063,7 +1108,7 @@ class GPInterpolatedRangeFactorPose2 : public gtsam::NonlinearFactor {
   }
   /// gpslam/slam/GPInterpolatedRangeFactorPose2.h:64-98
   gtsam::Vector evaluateError(const gtsam::Pose2 &pose1, const gtsam::Vector3 &vel1, const gtsam::Pose2 &pose2, const gtsam::Vector3 &vel2, const gtsam::Point2 &point,
-                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+                              gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none, gtsam::OptionalMatrix H5 = boost::none) const {
     const std::vector<double> lm = {point.x, point.y};
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose2>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Pose2>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector3>::pack(vel2), &lm, H1, H2, H3, H4, H5);
@@ -1084,7 +1129,7 @@ class GPInterpolatedRangeFactorPose3 : public gtsam::NonlinearFactor {
   }
   /// gpslam/slam/GPInterpolatedRangeFactorPose3.h:64-98
   gtsam::Vector evaluateError(const gtsam::Pose3 &pose1, const gtsam::Vector6 &vel1, const gtsam::Pose3 &pose2, const gtsam::Vector6 &vel2, const gtsam::Point3 &point,
-                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+                              gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none, gtsam::OptionalMatrix H5 = boost::none) const {
     const std::vector<double> lm = {point.x, point.y, point.z};
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector6>::pack(vel2), &lm, H1, H2, H3, H4, H5);
@@ -1104,7 +1149,7 @@ class GPInterpolatedRangeFactor2DLinear : public gtsam::NonlinearFactor {
   }
   /// gpslam/slam/GPInterpolatedRangeFactor2DLinear.h:60-88
   gtsam::Vector evaluateError(const gtsam::Vector3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Vector3 &pose2, const gtsam::Vector3 &vel2, const gtsam::Point2 &point,
-                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr, gtsam::Matrix *H5 = nullptr) const {
+                              gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none, gtsam::OptionalMatrix H5 = boost::none) const {
     typedef gtsam::detail::VT<gtsam::Vector3> P;
     const std::vector<double> lm = {point.x, point.y};
     return detail_g::meas_evaluate(d_, P::pack(pose1), P::pack(vel1), P::pack(pose2), P::pack(vel2), &lm, H1, H2, H3, H4, H5);
@@ -1125,7 +1170,7 @@ class GPInterpolatedAttitudeFactorRot3 : public gtsam::NonlinearFactor {
   }
   /// gpslam/slam/GPInterpolatedAttitudeFactorRot3.h:61-83
   gtsam::Vector evaluateError(const gtsam::Rot3 &pose1, const gtsam::Vector3 &vel1, const gtsam::Rot3 &pose2, const gtsam::Vector3 &vel2,
-                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+                              gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Rot3>::pack(pose1), gtsam::detail::VT<gtsam::Vector3>::pack(vel1), gtsam::detail::VT<gtsam::Rot3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector3>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
   }
@@ -1146,7 +1191,7 @@ class GPInterpolatedGPSFactorPose3 : public gtsam::NonlinearFactor {
   }
   /// gpslam/slam/GPInterpolatedGPSFactorPose3.h:66-95
   gtsam::Vector evaluateError(const gtsam::Pose3 &pose1, const gtsam::Vector6 &vel1, const gtsam::Pose3 &pose2, const gtsam::Vector6 &vel2,
-                              gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+                              gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const {
     return detail_g::meas_evaluate(d_, gtsam::detail::VT<gtsam::Pose3>::pack(pose1), gtsam::detail::VT<gtsam::Vector6>::pack(vel1), gtsam::detail::VT<gtsam::Pose3>::pack(pose2),
                                    gtsam::detail::VT<gtsam::Vector6>::pack(vel2), nullptr, H1, H2, H3, H4, nullptr);
   }
@@ -1242,8 +1287,8 @@ class OdometryFactor2DLinear : public gtsam::NonlinearFactor {
    public:                                                                                                       \
     CLS(const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau)                                     \
         : Qc_(Qc_model->covariance()), delta_t_(delta_t), tau_(tau) {}                                           \
-    POSE interpolatePose(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::Matrix *H1 = nullptr, \
-                         gtsam::Matrix *H2 = nullptr, gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const { \
+    POSE interpolatePose(const POSE &pose1, const VEL &vel1, const POSE &pose2, const VEL &vel2, gtsam::OptionalMatrix H1 = boost::none, \
+                         gtsam::OptionalMatrix H2 = boost::none, gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const { \
       return detail_g::interpolate_one<POSE, VEL>(MANIFOLD, Qc_, delta_t_, tau_, pose1, vel1, pose2, vel2, H1, H2, H3, H4); \
     }                                                                                                            \
    private:                                                                                                      \
@@ -1262,16 +1307,16 @@ template <int Dim> class GaussianProcessInterpolatorLinear {
   GaussianProcessInterpolatorLinear(const gtsam::SharedNoiseModel &Qc_model, double delta_t, double tau)
       : Qc_(Qc_model->covariance()), delta_t_(delta_t), tau_(tau) { static_assert(Dim == 2 || Dim == 3, "DOF = {2, 3}"); }
   gtsam::VectorN<Dim> interpolatePose(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
-                                      const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
-                                      gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+                                      const gtsam::VectorN<Dim> &vel2, gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none,
+                                      gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const {
     return detail_g::interpolate_one<gtsam::VectorN<Dim>, gtsam::VectorN<Dim>>(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, Qc_, delta_t_, tau_,
                                                                                pose1, vel1, pose2, vel2, H1, H2, H3, H4);
   }
   /// interpolate velocity with Jacobians -- gpslam/gp/GaussianProcessInterpolatorLinear.h:106-126 (gpslam.h:193); evaluated on the
   /// device like interpolatePose (gpslam_hip_interpolate_velocities on a two-state session)
   gtsam::VectorN<Dim> interpolateVelocity(const gtsam::VectorN<Dim> &pose1, const gtsam::VectorN<Dim> &vel1, const gtsam::VectorN<Dim> &pose2,
-                                          const gtsam::VectorN<Dim> &vel2, gtsam::Matrix *H1 = nullptr, gtsam::Matrix *H2 = nullptr,
-                                          gtsam::Matrix *H3 = nullptr, gtsam::Matrix *H4 = nullptr) const {
+                                          const gtsam::VectorN<Dim> &vel2, gtsam::OptionalMatrix H1 = boost::none, gtsam::OptionalMatrix H2 = boost::none,
+                                          gtsam::OptionalMatrix H3 = boost::none, gtsam::OptionalMatrix H4 = boost::none) const {
     typedef gtsam::VectorN<Dim> V;
     detail_g::Single s(Dim == 2 ? GPSLAM_LINEAR2 : GPSLAM_LINEAR3, 0, gtsam::detail::VT<V>::pack(pose1), gtsam::detail::VT<V>::pack(vel1),
                        gtsam::detail::VT<V>::pack(pose2), gtsam::detail::VT<V>::pack(vel2), &Qc_, nullptr);

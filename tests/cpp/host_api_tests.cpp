@@ -337,6 +337,18 @@ static void test_evaluate_error_and_interpolators() {
     Pose3 pp(Rot3(), Point3(h, 0, 0)), pm(Rot3(), Point3(-h, 0, 0));
     Vector ep = factor.evaluateError(pp, v, p2, v), em = factor.evaluateError(pm, v, p2, v);
     for (int r = 0; r < 12; r++) EXPECT_NEAR((ep[r] - em[r]) / (2 * h), H1(r, 3), 1e-6);
+    // the reference's own spelling of the same call (testGaussianProcessPriorPose3.cpp:49-60: Matrix lvalues into
+    // boost::optional<Matrix&> parameters, boost::none for what is not wanted): compiles unchanged (round 6)
+    Matrix G1, G2, G3, G4;
+    Vector e2 = factor.evaluateError(p1, v, p2, v, G1, G2, G3, G4);
+    EXPECT(e2 == e && G1.a == H1.a && G2.a == H2.a && G3.a == H3.a && G4.a == H4.a);
+    Matrix K2;
+    Vector e3 = factor.evaluateError(p1, v, p2, v, boost::none, K2);
+    EXPECT(e3 == e && K2.a == H2.a);
+    boost::optional<Matrix &> none_of_them = boost::none, third(G3);
+    G3 = Matrix();
+    Vector e4 = factor.evaluateError(p1, v, p2, v, none_of_them, boost::none, third, boost::none);
+    EXPECT(e4 == e && G3.a == H3.a);
   }
   {   // GaussianProcessPriorLinear<3>: e = [p1 + dt v1 - p2; v1 - v2], H1 = [I; 0], H2 = [dt I; I], H3 = [-I; 0], H4 = [0; -I]
     auto Qc_model = noiseModel::Gaussian::Covariance(0.01 * Matrix::Identity(3));
