@@ -338,6 +338,38 @@ def rot3_bias_ahrs_chain(N, seed=0, dt=0.1, qc_sigma=1.0, gyro_sigma=0.03, acc_s
                 att_dt=np.full(M, dt), att_tau=np.full(M, dt))
 
 
+def add_loop_closures(problem, pairs, seed=0, sigma=None):
+    """Loop closures on a problem: gtsam::BetweenFactor<Pose>(x_first, x_second, measured) between NON-adjacent states (any order of
+    the two), measured = truth_first^-1 truth_second + noise.  pairs: K x 2 state indices.  Adds closure_first / _second / _meas / _sig."""
+    p = dict(problem)
+    kind = p["kind"]
+    rng = np.random.default_rng(SEED_BASE + 77 + seed)
+    pairs = np.asarray(pairs, dtype=np.int32).reshape(-1, 2)
+    a, b = pairs[:, 0], pairs[:, 1]
+    truth = np.asarray(p["truth"], dtype=np.float64) if "truth" in p else np.asarray(p["pose"], dtype=np.float64)
+    if kind in (LINEAR2, LINEAR3):
+        d = truth.shape[1]
+        sig = np.full(d, 0.05) if sigma is None else np.asarray(sigma, dtype=np.float64)
+        meas = truth[b] - truth[a] + sig * rng.standard_normal((len(a), d))
+    elif kind == POSE2:
+        sig = np.array([0.02, 0.02, 0.01]) if sigma is None else np.asarray(sigma, dtype=np.float64)
+        c, s = np.cos(truth[a, 2]), np.sin(truth[a, 2])
+        dx, dy = truth[b, 0] - truth[a, 0], truth[b, 1] - truth[a, 1]
+        rel = np.stack([c * dx + s * dy, -s * dx + c * dy, truth[b, 2] - truth[a, 2]], -1)
+        meas = se2_compose(rel, se2_exp(sig * rng.standard_normal((len(a), 3))))
+    elif kind == POSE3:
+        sig = np.array([0.01, 0.01, 0.01, 0.02, 0.02, 0.02]) if sigma is None else np.asarray(sigma, dtype=np.float64)
+        Ra, Rb = truth[a, :9].reshape(-1, 3, 3), truth[b, :9].reshape(-1, 3, 3)
+        R = np.einsum("nji,njk->nik", Ra, Rb)
+        t = np.einsum("nji,nj->ni", Ra, truth[b, 9:] - truth[a, 9:])
+        nR, nt = se3_exp(sig * rng.standard_normal((len(a), 6)))
+        meas = flat_pose3(np.einsum("nij,njk->nik", R, nR), t + np.einsum("nij,nj->ni", R, nt))
+    else:
+        raise ValueError("loop closures: LINEAR2 / LINEAR3 / POSE2 / POSE3 problems")
+    p.update(closure_first=a.copy(), closure_second=b.copy(), closure_meas=np.ascontiguousarray(meas), closure_sig=np.tile(sig, (len(a), 1)))
+    return p
+
+
 def apply(problem, solver):
     """Feed a problem description to a solver (ChainSolver or oracle.Chain) and compile it."""
     p = problem
@@ -362,6 +394,8 @@ def apply(problem, solver):
         solver.add_ahrs(p["ahrs_left"], p["ahrs_dR"], p["ahrs_dRdb"], p["ahrs_bias_hat"], p["ahrs_dt"], p["ahrs_cov"], None)
     if "att_left" in p:
         solver.add_interp_attitude(p["att_left"], p["att_nz"], p["att_bref"], p["att_sigma"], p["att_dt"], p["att_tau"])
+    if "closure_first" in p:
+        solver.add_between_pairs(p["closure_first"], p["closure_second"], p["closure_meas"], p["closure_sig"])
     solver.compile()
     return solver
 

@@ -252,6 +252,12 @@ int orc_chain_set_meas_covariance(orc_chain *c, int type, int count, int rows, c
 int orc_chain_add_pose_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
 int orc_chain_add_vel_priors(orc_chain *c, int count, const int32_t *idx, const double *prior, const double *sigmas);
 int orc_chain_add_between(orc_chain *c, int count, const int32_t *left, const double *measured, const double *sigmas);
+/* gtsam::BetweenFactor<Pose>(x_first, x_second, measured) between ANY two states (a loop closure); chains that hold one are solved
+ * by an envelope Cholesky of the whole system in chain order instead of the block-tridiagonal elimination */
+int orc_chain_add_between_pairs(orc_chain *c, int count, const int32_t *first, const int32_t *second, const double *measured,
+                                const double *sigmas);
+/* tests: solve every chain with the envelope Cholesky (the solver of graphs with loop closures) */
+void orc_force_envelope_solver(int on);
 int orc_chain_add_landmark_priors(orc_chain *c, int count, const int32_t *idx, const double *prior,
                                   const double *sigmas);
 int orc_chain_add_interp_range(orc_chain *c, int count, const int32_t *left, const int32_t *landmark, const double *z,

@@ -308,6 +308,13 @@ class Chain:
         left, _ = _i(left)
         return call("orc_chain_add_between", self._h, len(left), left, A(measured), A(sigmas))
 
+    def add_between_pairs(self, first, second, measured, sigmas):
+        """gtsam::BetweenFactor<Pose>(x_first, x_second, measured) between any two states (loop closures)"""
+        first, _ = _i(first)
+        second, _ = _i(second)
+        assert len(first) == len(second)
+        return call("orc_chain_add_between_pairs", self._h, len(first), first, second, A(measured), A(sigmas))
+
     def add_landmark_priors(self, idx, prior, sigmas):
         idx, _ = _i(idx)
         return call("orc_chain_add_landmark_priors", self._h, len(idx), idx, A(prior), A(sigmas))
@@ -406,6 +413,11 @@ class Chain:
         p = params or default_params()
         rc = lib().orc_chain_optimize(self._h, C.byref(p), C.byref(st))
         return rc, st
+
+
+def force_envelope_solver(on):
+    """tests: every chain through the envelope Cholesky (the solver of graphs with loop closures)"""
+    lib().orc_force_envelope_solver(1 if on else 0)
 
 
 def block_tridiag_solve(D, O, g):

@@ -24,12 +24,14 @@
 
 enum {
   F_GP = 0, F_POSE_PRIOR, F_VEL_PRIOR, F_BETWEEN, F_LM_PRIOR, F_INTERP_RANGE, F_RANGE, F_INTERP_ATT,
-  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ, F_AHRS
+  F_INTERP_GPS, F_ODOM2D, F_BEARING_RANGE, F_INTERP_PROJ, F_AHRS,
+  F_CLOSURE   /* gtsam::BetweenFactor<Pose> between ANY two states (idx, idx2): a loop closure */
 };
 
 typedef struct {
   int type;
   int idx;          /* state index (left state for binary-in-time factors) */
+  int idx2;         /* F_CLOSURE: the second state (any state but idx) */
   int lm;           /* landmark index or -1 */
   double meas[12];  /* measurement / prior value */
   double sig[6];    /* diagonal sigmas */
@@ -208,6 +210,21 @@ int orc_chain_add_between(orc_chain *c, int count, const int32_t *left, const do
   for (int k = 0; k < count; k++) {
     orc_factor *f = new_factor(c, F_BETWEEN);
     f->idx = left[k];
+    orc_copy(c->pd, measured + (size_t)k * c->pd, f->meas);
+    orc_copy(c->d, sigmas + (size_t)k * c->d, f->sig);
+  }
+  return 0;
+}
+/* gtsam::BetweenFactor<Pose>(x_first, x_second, measured, diagonal model) between any two states -- what a loop closure is in a
+ * GTSAM graph (third party; the reference's factors take arbitrary keys the same way, gpslam/gp/GaussianProcessPriorPose3.h:43-47).
+ * Such a factor breaks the block-tridiagonal pattern: chains that hold one are solved by the envelope Cholesky below. */
+int orc_chain_add_between_pairs(orc_chain *c, int count, const int32_t *first, const int32_t *second, const double *measured,
+                                const double *sigmas) {
+  for (int k = 0; k < count; k++) {
+    if (first[k] == second[k] || first[k] < 0 || second[k] < 0) return -2;
+    orc_factor *f = new_factor(c, F_CLOSURE);
+    f->idx = first[k];
+    f->idx2 = second[k];
     orc_copy(c->pd, measured + (size_t)k * c->pd, f->meas);
     orc_copy(c->d, sigmas + (size_t)k * c->d, f->sig);
   }
@@ -430,6 +447,12 @@ static int factor_eval(const orc_chain *c, const orc_factor *f, int want_jac, do
       rows = d;
       orc_between_factor(c->kind, c->chart, f->meas, p1, p2, e, H1, H2);
       *uses_right = 1;
+      if (want_jac) { PUT(JL, H1, 0, d); PUT(JR, H2, 0, d); }
+      break;
+    case F_CLOSURE:   /* JL: columns of state idx, JR: columns of state idx2 (uses_right = 2: "right" is not idx + 1) */
+      rows = d;
+      orc_between_factor(c->kind, c->chart, f->meas, p1, c->pose + (size_t)f->idx2 * pd, e, H1, H2);
+      *uses_right = 2;
       if (want_jac) { PUT(JL, H1, 0, d); PUT(JR, H2, 0, d); }
       break;
     case F_LM_PRIOR:
@@ -675,9 +698,16 @@ typedef struct {
   int N, b, nl;
   double *D, *O, *g, *B, *HLL, *gL;
   double err;
+  /* loop closures: block k = H[clo_hi[k], clo_lo[k]] (b x b, rows of the later state), clo_lo < clo_hi */
+  int nclo;
+  int *clo_lo, *clo_hi;
+  double *clo_H;
 } orc_neq;
 
-static void neq_free(orc_neq *q) { free(q->D); free(q->O); free(q->g); free(q->B); free(q->HLL); free(q->gL); }
+static void neq_free(orc_neq *q) {
+  free(q->D); free(q->O); free(q->g); free(q->B); free(q->HLL); free(q->gL);
+  free(q->clo_lo); free(q->clo_hi); free(q->clo_H);
+}
 
 static int build_neq(const orc_chain *c, orc_neq *q) {
   const int N = c->N, b = c->b, ld = c->ld, nl = c->L * ld;
@@ -690,6 +720,15 @@ static int build_neq(const orc_chain *c, orc_neq *q) {
     q->B = (double *)calloc((size_t)N * b * nl, sizeof(double));
     q->HLL = (double *)calloc((size_t)nl * nl, sizeof(double));
     q->gL = (double *)calloc((size_t)nl, sizeof(double));
+  }
+  {
+    int nclo = 0;
+    for (int k = 0; k < c->nf; k++) nclo += (c->f[k].type == F_CLOSURE);
+    if (nclo > 0) {
+      q->clo_lo = (int *)calloc((size_t)nclo, sizeof(int));
+      q->clo_hi = (int *)calloc((size_t)nclo, sizeof(int));
+      q->clo_H = (double *)calloc((size_t)nclo * b * b, sizeof(double));
+    }
   }
   double total = 0.0;
   /* pass 1 (parallel): evaluate every factor into its own slot; pass 2 (serial, factor order): accumulate */
@@ -712,7 +751,20 @@ static int build_neq(const orc_chain *c, orc_neq *q) {
       orc_axpy(b * b, 1.0, T, q->D + (size_t)i * b * b);
       orc_mtm(rows, b, 1, JL, we, tv);
       orc_axpy(b, -1.0, tv, q->g + (size_t)i * b);
-      if (ur) {
+      if (ur == 2) {   /* loop closure: diagonal blocks and gradient where they belong, the coupling block in the closure list */
+        const int j = f->idx2;
+        if (j < 0 || j >= N || i < 0 || i >= N) { free(lin); neq_free(q); return -2; }
+        orc_mtm(rows, b, b, JR, JR, T);
+        orc_axpy(b * b, 1.0, T, q->D + (size_t)j * b * b);
+        orc_mtm(rows, b, 1, JR, we, tv);
+        orc_axpy(b, -1.0, tv, q->g + (size_t)j * b);
+        double *Hk = q->clo_H + (size_t)q->nclo * b * b;
+        if (j > i) orc_mtm(rows, b, b, JR, JL, Hk);   /* H[j, i] = JR^T JL */
+        else orc_mtm(rows, b, b, JL, JR, Hk);          /* H[i, j] = JL^T JR */
+        q->clo_lo[q->nclo] = i < j ? i : j;
+        q->clo_hi[q->nclo] = i < j ? j : i;
+        q->nclo++;
+      } else if (ur) {
         orc_mtm(rows, b, b, JR, JR, T);
         orc_axpy(b * b, 1.0, T, q->D + (size_t)(i + 1) * b * b);
         orc_mtm(rows, b, b, JR, JL, T);   /* O[i] = H[i+1, i] */
@@ -900,6 +952,91 @@ done:
   return rc;
 }
 
+/* Envelope (skyline) Cholesky of the whole system in the order [x0, v0, x1, v1, ..., l0, l1, ...] -- the solver of chains that hold
+ * loop closures, whose coupling blocks H[hi, lo] lie outside the block-tridiagonal pattern.  Row r of the lower triangle is stored
+ * from its first non-zero column first[r] to the diagonal; fill stays inside the envelope, so the factorisation is exact and costs
+ * b (span b)^2 / 2 for the b rows of a closure's later state on top of the chain's N b^3.  Deliberately a different elimination
+ * than the product's (which keeps the chain solver and applies the closures as a low-rank correction). */
+static int skyline_solve(const orc_neq *q, double lambda, double *x, double *xl) {
+  const int N = q->N, b = q->b, nl = q->nl, nx = N * b, n = nx + nl;
+  int *first = (int *)malloc(sizeof(int) * (size_t)n);
+  size_t *ptr = (size_t *)malloc(sizeof(size_t) * (size_t)(n + 1));
+  for (int s = 0; s < N; s++)
+    for (int r = 0; r < b; r++) first[s * b + r] = (s > 0 ? s - 1 : 0) * b;
+  for (int k = 0; k < q->nclo; k++)
+    for (int r = 0; r < b; r++) {
+      int *f = &first[q->clo_hi[k] * b + r];
+      if (q->clo_lo[k] * b < *f) *f = q->clo_lo[k] * b;
+    }
+  for (int l = 0; l < nl; l++) {
+    int f = nx;   /* the landmark block itself is dense */
+    for (int rs = 0; rs < nx && f == nx; rs++)
+      if (q->B[(size_t)rs * nl + l] != 0.0) f = rs - rs % b;
+    first[nx + l] = f;
+  }
+  ptr[0] = 0;
+  for (int r = 0; r < n; r++) ptr[r + 1] = ptr[r] + (size_t)(r - first[r] + 1);
+  double *A = (double *)calloc(ptr[n], sizeof(double));
+  double *y = (double *)malloc(sizeof(double) * (size_t)n);
+#define SKY(r, c) A[ptr[r] + (size_t)((c) - first[r])]
+  for (int s = 0; s < N; s++)
+    for (int r = 0; r < b; r++) {
+      const int R = s * b + r;
+      for (int cc = 0; cc <= r; cc++) SKY(R, s * b + cc) = q->D[((size_t)s * b + r) * b + cc];
+      SKY(R, R) += lambda;
+      if (s > 0)
+        for (int cc = 0; cc < b; cc++) SKY(R, (s - 1) * b + cc) = q->O[((size_t)(s - 1) * b + r) * b + cc];   /* O[s-1] = H[s, s-1] */
+      y[R] = q->g[(size_t)s * b + r];
+    }
+  for (int k = 0; k < q->nclo; k++)
+    for (int r = 0; r < b; r++)
+      for (int cc = 0; cc < b; cc++) SKY(q->clo_hi[k] * b + r, q->clo_lo[k] * b + cc) += q->clo_H[((size_t)k * b + r) * b + cc];
+  for (int l = 0; l < nl; l++) {
+    const int R = nx + l;
+    for (int rs = first[R]; rs < nx; rs++) SKY(R, rs) = q->B[(size_t)rs * nl + l];
+    for (int m = 0; m <= l; m++) SKY(R, nx + m) = q->HLL[(size_t)l * nl + m];
+    SKY(R, R) += lambda;
+    y[R] = q->gL[l];
+  }
+  int rc = 0;
+  for (int r = 0; r < n && !rc; r++) {
+    for (int cc = first[r]; cc <= r; cc++) {
+      const int k0 = first[r] > first[cc] ? first[r] : first[cc];
+      double s = SKY(r, cc);
+      const double *Lr = &SKY(r, k0), *Lc = &SKY(cc, k0);
+      for (int k = 0; k < cc - k0; k++) s -= Lr[k] * Lc[k];
+      if (cc < r) SKY(r, cc) = s / SKY(cc, cc);
+      else if (!(s > 0.0)) rc = (r < nx) ? -3 : -4;
+      else SKY(r, r) = sqrt(s);
+    }
+  }
+  if (!rc) {
+    for (int r = 0; r < n; r++) {
+      double s = y[r];
+      for (int cc = first[r]; cc < r; cc++) s -= SKY(r, cc) * y[cc];
+      y[r] = s / SKY(r, r);
+    }
+    for (int r = n - 1; r >= 0; r--) {
+      const double v = y[r] / SKY(r, r);
+      y[r] = v;
+      for (int cc = first[r]; cc < r; cc++) y[cc] -= SKY(r, cc) * v;
+    }
+    orc_copy(nx, y, x);
+    for (int l = 0; l < nl; l++) xl[l] = y[nx + l];
+  }
+#undef SKY
+  free(A); free(y); free(first); free(ptr);
+  return rc;
+}
+
+/* chains: the sequential block Cholesky with the landmark border; chains with loop closures: the envelope Cholesky */
+static int g_force_skyline = 0;
+void orc_force_envelope_solver(int on) { g_force_skyline = on; }   /* tests: the second solver on graphs the first one serves */
+static int solve_neq(const orc_neq *q, double lambda, double *x, double *xl) {
+  if (q->nclo > 0 || g_force_skyline) return skyline_solve(q, lambda, x, xl);
+  return bordered_solve(q, lambda, x, xl);
+}
+
 int orc_block_tridiag_solve(int N, int b, const double *D, const double *O, const double *g, double *x) {
   orc_neq q;
   memset(&q, 0, sizeof(q));
@@ -935,7 +1072,7 @@ int orc_chain_iterate_gn(orc_chain *c, orc_stats *st) {
   if (rc) { st->status = rc; return rc; }
   double *x = (double *)malloc(sizeof(double) * (size_t)c->N * c->b);
   double *xl = (double *)calloc((size_t)(q.nl > 0 ? q.nl : 1), sizeof(double));
-  rc = bordered_solve(&q, 0.0, x, xl);
+  rc = solve_neq(&q, 0.0, x, xl);
   st->error_before = q.err;
   if (rc == 0) {
     apply_update(c, x, xl, &st->delta_inf_norm);
@@ -979,7 +1116,7 @@ int orc_chain_iterate_lm(orc_chain *c, double *lambda, const orc_params *p, orc_
   st->error_after = q.err;
   st->last_trial_error = q.err;
   for (;;) {
-    rc = bordered_solve(&q, *lambda, x, xl);
+    rc = solve_neq(&q, *lambda, x, xl);
     int ok = 0, stop_searching = 0;
     st->trials++;
     if (rc == 0) {
