@@ -41,9 +41,10 @@ ABI_SYMBOLS = [
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
     "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
     "gpslam_hip_lm_decide", "gpslam_hip_set_collectives", "gpslam_hip_create_v2", "gpslam_hip_abi_version", "gpslam_hip_struct_size",
+    "gpslam_hip_add_between_pairs",
 ]
 # the version of include/gpslam_hip.h this binding's structs mirror (GPSLAM_HIP_ABI_MAJOR / _MINOR); load_library() checks the library's
-ABI_MAJOR, ABI_MINOR = 2, 0
+ABI_MAJOR, ABI_MINOR = 2, 1
 STRUCT_CONFIG, STRUCT_CONFIG_V2, STRUCT_STATS, STRUCT_PARAMS = 0, 1, 2, 3
 
 
@@ -243,6 +244,15 @@ class ChainSolver:
         left, measured, sigmas = _i32(left), _f64(measured), _f64(sigmas)
         return self._chk(self.lib.gpslam_hip_add_between(self._h, len(left), _p(left), _p(measured), _p(sigmas)),
                          "add_between")
+
+    def add_between_pairs(self, first, second, measured, sigmas):
+        """gtsam::BetweenFactor<Pose>(x_first, x_second, measured) between any two states: loop closures (consecutive pairs are
+        ordinary chain factors)"""
+        first, second, measured, sigmas = _i32(first), _i32(second), _f64(measured), _f64(sigmas)
+        if len(first) != len(second):
+            raise ValueError("add_between_pairs: first and second differ in length")
+        return self._chk(self.lib.gpslam_hip_add_between_pairs(self._h, len(first), _p(first), _p(second), _p(measured), _p(sigmas)),
+                         "add_between_pairs")
 
     def add_landmark_priors(self, idx, prior, sigmas):
         idx, prior, sigmas = _i32(idx), _f64(prior), _f64(sigmas)

@@ -352,6 +352,32 @@ int gpslam_hip_add_between(gpslam_hip_handle *h, int32_t count, const int32_t *l
                            const double *sigmas) {
   return h ? add_simple(h, h->btw, h->pd, h->d, count, left, measured, sigmas, max_left(h)) : GPSLAM_E_INVALID;
 }
+int gpslam_hip_add_between_pairs(gpslam_hip_handle *h, int32_t count, const int32_t *first, const int32_t *second,
+                                 const double *measured, const double *sigmas) {
+  if (!h || count < 0 || (count > 0 && (!first || !second || !measured || !sigmas))) return GPSLAM_E_INVALID;
+  for (int k = 0; k < count; k++) {
+    if (first[k] < 0 || first[k] >= h->N || second[k] < 0 || second[k] >= h->N) return fail(h, GPSLAM_E_INVALID, "factor index out of range");
+    if (first[k] == second[k]) return fail(h, GPSLAM_E_INVALID, "a BetweenFactor needs two different states");
+  }
+  for (size_t k = 0; k < (size_t)count * h->d; k++)
+    if (!(sigmas[k] > 0.0)) return fail(h, GPSLAM_E_INVALID, "sigmas must be positive");
+  for (int k = 0; k < count; k++) {
+    const double *m = measured + (size_t)k * h->pd, *sg = sigmas + (size_t)k * h->d;
+    if (second[k] == first[k] + 1) {          // the chain's own BetweenFactor(x_i, x_i+1): the ordinary row path
+      int rc = add_simple(h, h->btw, h->pd, h->d, 1, first + k, m, sg, max_left(h));
+      if (rc) return rc;
+      continue;
+    }
+    if (sharded(h)) return fail(h, GPSLAM_E_UNSUPPORTED, "loop closures on a sharded handle (nranks > 1): both states must live on one rank");
+    h->clo.width = h->pd;
+    h->clo.idx.push_back(first[k]);
+    h->clo_second.push_back(second[k]);
+    h->clo.meas.insert(h->clo.meas.end(), m, m + h->pd);
+    h->clo.sig.insert(h->clo.sig.end(), sg, sg + h->d);
+  }
+  h->compiled = false;
+  return 0;
+}
 int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                                    const double *sigmas) {
   if (!h) return GPSLAM_E_INVALID;
@@ -442,7 +468,8 @@ int gpslam_hip_add_bearing_range(gpslam_hip_handle *h, int32_t count, const int3
 int gpslam_hip_clear_factors(gpslam_hip_handle *h) {
   if (!h) return GPSLAM_E_INVALID;
   h->gp_left.clear(); h->gp_dt.clear(); h->gp_q.clear(); h->gp_Utab.clear(); h->gp_perm.clear(); h->gp_groups.clear();
-  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) { s->idx.clear(); s->meas.clear(); s->sig.clear(); }
+  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri, &h->clo}) { s->idx.clear(); s->meas.clear(); s->sig.clear(); }
+  h->clo_second.clear();
   for (MeasSet &s : h->ms) {
     s.idx.clear(); s.lm.clear(); s.meas.clear(); s.sig.clear(); s.dt.clear(); s.tau.clear(); s.aux.clear(); s.aidx.clear(); s.sqi.clear();
     s.any_aux = false;

@@ -88,6 +88,11 @@ struct gpslam_hip_handle {
   int gp_single_q = 0;      // > 0: every GP prior came through add_gp_priors_qc with the SAME Qc (entry gp_single_q - 1 of gp_Utab):
                             // one group, one launch, and the structured-record path of k_fused_level0 stays available
   SimpleSet pri, vpri, btw, lpri;
+  // loop closures (gpslam_hip_add_between_pairs; kernels.hpp "loop closures"): clo.idx = first state, clo_second = second state
+  SimpleSet clo;
+  std::vector<int32_t> clo_second;
+  DevBuf d_clo_second, clo_A, clo_Y;
+  int nclo = 0, nc = 0;       // closures of the compiled graph, their right-hand-side columns (nclo * d)
   MeasSet ms[kNumMeasKinds];
   // row table
   int M = 0;

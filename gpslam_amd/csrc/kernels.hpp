@@ -1596,6 +1596,159 @@ template <typename T> __global__ void __launch_bounds__(256) k_gather_delta(cons
   out[i] = x[(size_t)s * R * B + k];
 }
 
+// ------------------------------------------------------------------ loop closures (round 6)
+// gtsam::BetweenFactor<Pose>(x_i, x_j, measured) between NON-adjacent states: the one factor of a SLAM graph that leaves the chain
+// (the reference's factors take arbitrary keys the same way, gpslam/gp/GaussianProcessPriorPose3.h:43-47).  Its whitened rows
+// U = [.. A_i .. A_j ..] (d x N b, pose columns of two states) make the normal equations H0 + U^T U with H0 the block-tridiagonal
+// (+ landmark border) matrix of everything else.  The chain solver stays what it is: the d columns of U^T ride through it as extra
+// right-hand sides behind the landmark columns (Z = H0^-1 U^T), and
+//   (H0 + U^T U)^-1 [g + U^T r | B] = X + Z Y,   X = H0^-1 [g | B],   Y = (I + U Z)^-1 ([r | 0] - U X),   r = -(whitened error)
+// (Sherman-Morrison-Woodbury; I + U Z is d K x d K, symmetric positive definite) corrects the solution column AND the landmark
+// columns before the landmark Schur complement is formed, so that landmarks and closures mix freely.  K closures cost K d of the
+// kMaxRhs - 1 border columns.  Four small kernels: evaluate, inject the columns into the level-0 records, solve, correct.
+struct CloArgs {
+  const double *pose;     // SoA states
+  int stride, count, chart;
+  const int *first, *second;
+  const double *meas, *sig;   // count x pose_dim, count x d
+  double *A;              // count records [A_i (d x d) | A_j (d x d) | r (d)]: whitened H1, H2 and right-hand side
+  double *partial;        // the closures' 0.5 |R e|^2 (one value)
+  double *blk;            // level-0 block records [D | O | G (B x R)]
+  int BS, B, R, col0;     // record length, block size, right-hand sides, first closure column (1 + nl)
+  double *gsave;          // Levenberg-Marquardt: the gradient copy takes U^T r as well, or null
+  double *x;              // level-0 solutions N x R x B
+  int N, ncols;           // columns 0 .. ncols - 1 (the update and the landmark columns) are corrected
+  double *Y;              // nc x ncols
+  int *flag;
+};
+constexpr int kCloLen(int d) { return 2 * d * d + d; }
+
+template <int MF, bool JAC> __global__ void __launch_bounds__(128) k_clo_eval(CloArgs a) {
+  constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd;
+  double err = 0.0;
+  for (int f = threadIdx.x; f < a.count; f += 128) {
+    const int i = a.first[f], j = a.second[f];
+    double x1[pd], x2[pd], m[pd], e[d], H1[JAC ? d * d : 1], H2[JAC ? d * d : 1];
+#pragma unroll
+    for (int k = 0; k < pd; k++) {
+      x1[k] = a.pose[(size_t)k * a.stride + i];
+      x2[k] = a.pose[(size_t)k * a.stride + j];
+      m[k] = a.meas[(size_t)f * pd + k];
+    }
+    PoseFactors<double, MF, JAC>::between(m, x1, x2, a.chart, e, H1, H2);
+    double *rec = a.A + (size_t)f * kCloLen(d);
+#pragma unroll
+    for (int r = 0; r < d; r++) {
+      const double w = 1.0 / a.sig[(size_t)f * d + r];
+      const double we = w * e[r];
+      err += we * we;
+      if (JAC) {
+#pragma unroll
+        for (int c = 0; c < d; c++) { rec[r * d + c] = w * H1[r * d + c]; rec[d * d + r * d + c] = w * H2[r * d + c]; }
+        rec[2 * d * d + r] = -we;
+      }
+    }
+  }
+  const double tot = block_sum(0.5 * err);
+  if (threadIdx.x == 0) a.partial[0] = tot;
+}
+
+// the columns of U^T into the records of the two states of every closure (k_assemble_ghost left those columns zero); one workgroup
+template <int d> __global__ void __launch_bounds__(256) k_clo_inject(CloArgs a) {
+  const int per = 2 * d * d;
+  for (int t = threadIdx.x; t < a.count * per; t += 256) {
+    const int k = t / per, u = t - k * per;
+    const int side = u / (d * d), v = u - side * d * d;
+    const int q = v / d, c = v - q * d;
+    const int s = side ? a.second[k] : a.first[k];
+    a.blk[(size_t)s * a.BS + 2 * a.B * a.B + (size_t)(a.col0 + k * d + q) * a.B + c] = a.A[(size_t)k * kCloLen(d) + u];
+  }
+  if (a.gsave && threadIdx.x == 0) {     // several closures may meet in one state: one thread, the order they were added in
+    for (int k = 0; k < a.count; k++) {
+      const double *rec = a.A + (size_t)k * kCloLen(d);
+      for (int side = 0; side < 2; side++) {
+        const int s = side ? a.second[k] : a.first[k];
+        for (int c = 0; c < d; c++) {
+          double acc = 0.0;
+          for (int q = 0; q < d; q++) acc += rec[side * d * d + q * d + c] * rec[2 * d * d + q];
+          a.gsave[(size_t)s * a.B + c] += acc;
+        }
+      }
+    }
+  }
+}
+
+// Y = (I + U Z)^-1 ([r | 0] - U X): one wave.  W = U [X | Z] from the solution columns of the closures' states, Cholesky of the
+// symmetrised I + U Z in LDS, one lane per right-hand side for the two substitutions.
+template <int d> __global__ void __launch_bounds__(64) k_clo_solve(CloArgs a) {
+  constexpr int NM = kMaxRhs - 1;
+  __shared__ double W[NM][kMaxRhs + 1];
+  __shared__ double C[NM][NM + 1];
+  const int lane = threadIdx.x, nc = a.count * d, R = a.R;
+  for (int idx = lane; idx < nc * R; idx += 64) {
+    const int p = idx / R, c = idx - p * R;
+    const int k = p / d, q = p - k * d;
+    const double *rec = a.A + (size_t)k * kCloLen(d);
+    const double *xi = a.x + ((size_t)a.first[k] * R + c) * a.B, *xj = a.x + ((size_t)a.second[k] * R + c) * a.B;
+    double acc = 0.0;
+    for (int m = 0; m < d; m++) acc += rec[q * d + m] * xi[m];
+    for (int m = 0; m < d; m++) acc += rec[d * d + q * d + m] * xj[m];
+    W[p][c] = acc;
+  }
+  wave_lds_sync();
+  for (int idx = lane; idx < nc * nc; idx += 64) {
+    const int p = idx / nc, p2 = idx - p * nc;
+    C[p][p2] = (p == p2 ? 1.0 : 0.0) + 0.5 * (W[p][a.col0 + p2] + W[p2][a.col0 + p]);
+  }
+  wave_lds_sync();
+  for (int j = 0; j < nc; j++) {      // right-looking Cholesky, lower triangle
+    double dd = C[j][j];
+    if (!(dd > 0.0)) { if (lane == 0) *a.flag = 1; dd = 1.0; }
+    const double l = sqrt(dd), linv = 1.0 / l;
+    wave_lds_sync();
+    for (int i = j + lane; i < nc; i += 64) C[i][j] = (i == j) ? l : C[i][j] * linv;
+    wave_lds_sync();
+    const int m = nc - j - 1;
+    for (int idx = lane; idx < m * m; idx += 64) {
+      const int i = j + 1 + idx / m, k = j + 1 + idx % m;
+      if (k <= i) C[i][k] -= C[i][j] * C[k][j];
+    }
+    wave_lds_sync();
+  }
+  if (lane < a.ncols) {               // lane c: column c of [r | 0] - U X through L y = b, L^T z = y
+    const int c = lane;
+    double y[NM];
+    for (int p = 0; p < nc; p++) {
+      const int k = p / d, q = p - k * d;
+      double v = (c == 0 ? a.A[(size_t)k * kCloLen(d) + 2 * d * d + q] : 0.0) - W[p][c];
+      for (int m = 0; m < p; m++) v -= C[p][m] * y[m];
+      y[p] = v / C[p][p];
+    }
+    for (int p = nc - 1; p >= 0; p--) {
+      double v = y[p];
+      for (int m = p + 1; m < nc; m++) v -= C[m][p] * y[m];
+      y[p] = v / C[p][p];
+    }
+    for (int p = 0; p < nc; p++) a.Y[(size_t)p * a.ncols + c] = y[p];
+  }
+}
+
+// X <- X + Z Y on the update column and the landmark columns of every state
+template <int d> __global__ void __launch_bounds__(256) k_clo_correct(CloArgs a) {
+  const int nc = a.count * d;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = tid / a.B, k = tid - s * a.B;
+  if (s >= a.N) return;
+  double *xs = a.x + (size_t)s * a.R * a.B;
+  double z[kMaxRhs - 1];
+  for (int q = 0; q < nc; q++) z[q] = xs[(size_t)(a.col0 + q) * a.B + k];
+  for (int c = 0; c < a.ncols; c++) {
+    double v = xs[(size_t)c * a.B + k];
+    for (int q = 0; q < nc; q++) v += z[q] * a.Y[(size_t)q * a.ncols + c];
+    xs[(size_t)c * a.B + k] = v;
+  }
+}
+
 // ------------------------------------------------------------------ K3: assemble normal equations
 
 template <typename T, typename TR = T> struct AsmArgs {

@@ -668,15 +668,15 @@ struct Session {
           if (bias) { m.resize(6, 0.0); sg.resize(6, 1.0); }     // the three pad components of the velocity slot
           check(gpslam_hip_add_vel_priors(h, 1, &s, m.data(), sg.data()), h, "add_vel_priors"); } break;
         case F_LM_PRIOR: { int32_t s = lm_of(f.k[0]); check(gpslam_hip_add_landmark_priors(h, 1, &s, f.meas.data(), f.sig.data()), h, "add_landmark_priors"); } break;
-        case F_BETWEEN: {
-          int32_t l = adjacent(f.k[0], f.k[2]);
+        case F_BETWEEN: {   // any two states: consecutive ones are a chain factor, anything else a loop closure (round 6)
+          int32_t s1 = state_of(f.k[0]), s2 = state_of(f.k[2]);
           if (bias) {   // BetweenFactorRot3 on the rotation half
             std::vector<double> m(12, 0.0), sg(6, INFINITY);
             std::memcpy(m.data(), f.meas.data(), sizeof(double) * 9);
             std::memcpy(sg.data(), f.sig.data(), sizeof(double) * 3);
-            check(gpslam_hip_add_between(h, 1, &l, m.data(), sg.data()), h, "add_between");
+            check(gpslam_hip_add_between_pairs(h, 1, &s1, &s2, m.data(), sg.data()), h, "add_between_pairs");
           } else {
-            check(gpslam_hip_add_between(h, 1, &l, f.meas.data(), f.sig.data()), h, "add_between");
+            check(gpslam_hip_add_between_pairs(h, 1, &s1, &s2, f.meas.data(), f.sig.data()), h, "add_between_pairs");
           }
         } break;
         case F_INTERP_RANGE: { set_qc(f.Qc); int32_t l = adjacent(f.k[0], f.k[2]), m = lm_of(f.k[4]);

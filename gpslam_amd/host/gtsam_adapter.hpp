@@ -223,12 +223,12 @@ template <typename POSE> class HipChainOptimizerT {
         const std::vector<double> sg = detail::sigmas(pl->noiseModel());
         check(gpslam_hip_add_landmark_priors(h_, 1, &idx, mm, sg.data()), "add_landmark_priors");
       } else if (auto bt = boost::dynamic_pointer_cast<gtsam::BetweenFactor<POSE>>(f)) {
-        const int32_t left = state_of(bt->key1());
-        if (state_of(bt->key2()) != left + 1) throw std::invalid_argument("HipChainOptimizer: BetweenFactor must join consecutive states");
+        // consecutive states: a chain factor; any other pair: a loop closure (round 6, gpslam_hip_add_between_pairs)
+        const int32_t first = state_of(bt->key1()), second = state_of(bt->key2());
         double m[12];
         detail::pack(bt->measured(), m);
         const std::vector<double> sg = detail::sigmas(bt->noiseModel());
-        check(gpslam_hip_add_between(h_, 1, &left, m, sg.data()), "add_between");
+        check(gpslam_hip_add_between_pairs(h_, 1, &first, &second, m, sg.data()), "add_between_pairs");
       } else {
         throw std::invalid_argument("HipChainOptimizer: factor type not covered by the chain solver (keep it on stock GTSAM)");
       }

@@ -77,9 +77,10 @@ enum {
  * through a corrupted stack.  History: 1.0 rounds 1-4 (gpslam_hip_stats 48 bytes); 1.1 round 5 (stats 56 bytes: trials,
  * last_trial_error; GPSLAM_E_COMM; plan bits 64, 128) -- shipped without a version symbol; 2.0 this header: gpslam_hip_config_v2 +
  * gpslam_hip_create_v2 (named fields, struct_size first), gpslam_hip_abi_version, gpslam_hip_struct_size.  The v1 config and
- * gpslam_hip_create stay, bit for bit.  A MAJOR bump changes a struct or a signature, a MINOR bump only adds. */
+ * gpslam_hip_create stay, bit for bit; 2.1 gpslam_hip_add_between_pairs (loop closures).  A MAJOR bump changes a struct or a
+ * signature, a MINOR bump only adds. */
 #define GPSLAM_HIP_ABI_MAJOR 2
-#define GPSLAM_HIP_ABI_MINOR 0
+#define GPSLAM_HIP_ABI_MINOR 1
 #define GPSLAM_HIP_ABI_VERSION ((GPSLAM_HIP_ABI_MAJOR << 16) | GPSLAM_HIP_ABI_MINOR)
 uint32_t gpslam_hip_abi_version(void);
 enum { GPSLAM_STRUCT_CONFIG = 0, GPSLAM_STRUCT_CONFIG_V2 = 1, GPSLAM_STRUCT_STATS = 2, GPSLAM_STRUCT_PARAMS = 3 };
@@ -212,6 +213,17 @@ int gpslam_hip_add_vel_priors(gpslam_hip_handle *h, int32_t count, const int32_t
 /* gtsam::BetweenFactor<Pose>(x_left, x_left+1, measured) (matlab/PlazaPose2.m:125) */
 int gpslam_hip_add_between(gpslam_hip_handle *h, int32_t count, const int32_t *left, const double *measured,
                            const double *sigmas);
+/* gtsam::BetweenFactor<Pose>(x_first, x_second, measured) between ANY two states of the chain -- a loop closure (round 6; ABI 2.1).
+ * The reference's factors take arbitrary keys (gpslam/gp/GaussianProcessPriorPose3.h:43-47) and GTSAM eliminates whatever graph
+ * they form; here everything but closures couples state i with i + 1, and a closure is applied to the chain solve as a low-rank
+ * correction: its d whitened rows ride through the block-tridiagonal solver as d extra right-hand sides behind the landmark
+ * columns (Sherman-Morrison-Woodbury; kernels.hpp "loop closures").  Pairs with second == first + 1 are ordinary chain factors
+ * (add_between).  Capacity: 1 + landmarks * landmark_dim + closures * d <= 28 right-hand sides (Pose2 / Rot3 / Linear3: 9 closures
+ * without landmarks, Pose3: 4); compile() answers GPSLAM_E_UNSUPPORTED beyond that, on fp32 handles, on sharded handles and on
+ * the segmented landmark path.  measured: count x pose_dim, sigmas: count x d.  Gauss-Newton, Levenberg-Marquardt, optimize and
+ * error include the closures; gpslam_hip_normal_equations reports the chain part H0 (the closures' blocks are not in D / O / g). */
+int gpslam_hip_add_between_pairs(gpslam_hip_handle *h, int32_t count, const int32_t *first, const int32_t *second,
+                                 const double *measured, const double *sigmas);
 /* gtsam::PriorFactor<Point> on landmark idx (matlab/PlazaPose2.m:63) */
 int gpslam_hip_add_landmark_priors(gpslam_hip_handle *h, int32_t count, const int32_t *idx, const double *prior,
                                    const double *sigmas);

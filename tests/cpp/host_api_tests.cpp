@@ -760,6 +760,51 @@ static void test_config_v1_v2_and_truncated_v2_reach_the_same_handle() {      //
   gpslam_hip_destroy(h1); gpslam_hip_destroy(h2); gpslam_hip_destroy(h3);
 }
 
+// A loop closure the way a GTSAM user writes one (round 6): BetweenFactor<Pose2> between the LAST and the FIRST state of a chain
+// that drives once around a circle -- the reference's factors take arbitrary keys (gpslam/gp/GaussianProcessPriorPose3.h:43-47) and
+// GTSAM's optimisers eliminate whatever graph results; rounds 1-5 of this header threw std::invalid_argument here.
+static void test_loop_closure_between_non_adjacent_keys() {
+  const int N = 48;
+  const double dt = 0.25, w = 2 * M_PI / ((N - 1) * dt), v = 1.0;      // constant twist: one full turn over the N - 1 intervals
+  auto step = [&](double bias) {                                        // Pose2::Expmap(dt * (v, 0, w + bias))
+    const double th = dt * (w + bias);
+    return Pose2(v * dt * std::sin(th) / th, v * dt * (1 - std::cos(th)) / th, th);
+  };
+  auto compose = [](const Pose2 &a, const Pose2 &b) {
+    return Pose2(a.x + std::cos(a.theta) * b.x - std::sin(a.theta) * b.y, a.y + std::sin(a.theta) * b.x + std::cos(a.theta) * b.y, a.theta + b.theta);
+  };
+  std::vector<Pose2> truth(N), dead(N);
+  for (int k = 0; k + 1 < N; k++) { truth[k + 1] = compose(truth[k], step(0.0)); dead[k + 1] = compose(dead[k], step(0.02)); }   // biased gyro: drift
+  auto Qc_model = noiseModel::Gaussian::Covariance(1.0 * Matrix::Identity(3));
+  auto build = [&](bool closure) {
+    NonlinearFactorGraph graph;
+    graph.add(PriorFactor<Pose2>(Symbol('x', 0), truth[0], noiseModel::Isotropic::Sigma(3, 1e-3)));
+    for (int k = 0; k + 1 < N; k++) {
+      graph.add(GaussianProcessPriorPose2(Symbol('x', k), Symbol('v', k), Symbol('x', k + 1), Symbol('v', k + 1), dt, Qc_model));
+      graph.add(BetweenFactor<Pose2>(Symbol('x', k), Symbol('x', k + 1), step(0.02), noiseModel::Isotropic::Sigma(3, 2e-2)));
+    }
+    // the closure: the robot recognises its starting place; x_{N-1}^-1 x_0 = identity after a full turn (keys in "backward" order)
+    if (closure) graph.add(BetweenFactor<Pose2>(Symbol('x', N - 1), Symbol('x', 0), Pose2(0, 0, -2 * M_PI), noiseModel::Isotropic::Sigma(3, 1e-3)));
+    return graph;
+  };
+  Values init;
+  for (int k = 0; k < N; k++) { init.insert(Symbol('x', k), dead[k]); init.insert(Symbol('v', k), Vector3{v, 0, w}); }
+  auto dist = [&](const Values &val, int k) { const Pose2 q = val.at<Pose2>(Symbol('x', k)); return std::hypot(q.x - truth[k].x, q.y - truth[k].y); };
+  NonlinearFactorGraph open_graph = build(false), closed_graph = build(true);
+  Values open_values = LevenbergMarquardtOptimizer(open_graph, init).optimize();
+  LevenbergMarquardtOptimizer opt(closed_graph, init);
+  Values closed_values = opt.optimize();
+  EXPECT(dist(open_values, N - 1) > 0.15);                       // odometry alone: the drift stays (0.02 rad/s of gyro bias over a turn)
+  EXPECT(dist(closed_values, N - 1) < 5e-3);                     // with the closure the last pose is back at the start
+  EXPECT(dist(closed_values, N / 2) < 0.6 * dist(open_values, N / 2));   // ... and the correction is spread along the chain
+  EXPECT(closed_graph.error(closed_values) < closed_graph.error(init) * 1e-2);
+  EXPECT(opt.iterations() >= 2);
+  // evaluateError of the closure factor itself through the ABI at the optimum: small against its sigma-scaled initial value
+  GaussNewtonOptimizer gn(closed_graph, closed_values);           // Gauss-Newton from the LM optimum: a fixed point
+  Values again = gn.optimize();
+  EXPECT_NEAR(closed_graph.error(again), closed_graph.error(closed_values), 1e-6 * closed_graph.error(closed_values));
+}
+
 int main(int argc, char **argv) {
   if (argc > 1 && std::strcmp(argv[1], "--host-only") == 0) {   // what needs no GPU (the CPU test run)
     test_equals_print_clone();
@@ -782,6 +827,7 @@ int main(int argc, char **argv) {
   test_error_conventions();
   test_ahrs_graph_with_bias_states();
   test_round3_boundary_additions();
+  test_loop_closure_between_non_adjacent_keys();
   if (failures == 0) std::printf("host_api_tests: all tests passed\n");
   return failures == 0 ? 0 : 1;
 }
