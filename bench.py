@@ -312,6 +312,10 @@ def extras(gpslam_amd, S, device):
             (x64, v64), (x32, v32) = finals["fp64"], finals["fp32"]
             scale = max(1.0, float(np.abs(x64).max()), float(np.abs(v64).max()))
             res["fp32_vs_fp64_final_state_rel_diff"] = float(max(np.abs(x64 - x32).max(), np.abs(v64 - v32).max()) / scale)
+            # say what the fp32 handle is.  Its row tables are plain fp32 Jacobian rows; the structured records that
+            # make the fp64 path fast are fp64-only, so fp32 is the SLOWER of the two on every mix: a tolerance mode, never a throughput mode
+            res["fp32_is"] = "tolerance mode only (north_star's 1e-5-relative sweep); slower than fp64 per iteration: %.2f x" % (
+                res["fp32"]["ms_per_iteration_device"] / max(res["fp64"]["ms_per_iteration_device"], 1e-12))
             sweep[name] = res
         return sweep
     section("config5_fp32_vs_fp64_tolerance_sweep_1e6", config5)

@@ -2774,6 +2774,40 @@ template <typename T, typename TR = T> struct FusedArgs {
 #ifndef GPS_FUSED_WAVES
 #define GPS_FUSED_WAVES 2
 #endif
+// Wave priority inside k_fused_level0 (round 6).  The two waves a SIMD holds belong to two different workgroups, and the
+// instruction arbiter serves the OLDER wave first: in a launch of one resident set (1e5 states: 1000 workgroups) the workgroups whose
+// waves were placed first run at the speed of a wave that has its SIMD to itself and end at 115 us, those placed second take what is
+// left and end at 145-154 us -- the launch lasts as long as the slowest (scripts/trace_fused.py, HW_ID wave slots).  GPS_PRIO = 1
+// (the default): every block step a wave sets its priority to 3 - (step mod 4), so the wave that is BEHIND on its SIMD is the one
+// that is served first and the workgroups of a CU advance together: the spread of a CU's workgroups falls from ~30 us to 4 us, the
+// launch from 154 to 142-145 us at the same median (132 us: the work is what it was), 1e6 states unchanged (workgroups come and go
+// there).  Measured and not kept: 2 / 3 (one role always first: no gain), 4 (two-step quantum: half the gain), 5 (half-step
+// quantum: no better than 1).  0: no s_setprio (rounds 1-5).  HISTORY.md "Round 6" has the tables.
+#ifndef GPS_PRIO
+#define GPS_PRIO 1
+#endif
+// c: progress in half steps (2 t at the top of block step t, 2 t + 1 in its middle)
+__device__ __forceinline__ void fused_step_prio(int c, int role) {
+#if GPS_PRIO == 5
+  const int t = c;
+#else
+  if (c & 1) return;
+  const int t = c >> 1;
+#endif
+#if GPS_PRIO == 1 || GPS_PRIO == 4 || GPS_PRIO == 5
+  const int q = (GPS_PRIO == 4 ? (t >> 1) : t) & 3;
+  if (q == 0) __builtin_amdgcn_s_setprio(3);
+  else if (q == 1) __builtin_amdgcn_s_setprio(2);
+  else if (q == 2) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+#elif GPS_PRIO == 2
+  if (t == 0) { if (role == 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+#elif GPS_PRIO == 3
+  if (t == 0) { if (role == 0) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3); }
+#else
+  (void)t; (void)role;
+#endif
+}
 template <int SV, typename TR = double, int B = 12, bool DG = false>
 __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs<double, TR> u) {
   static_assert(SV == 0 || std::is_same<TR, double>::value, "structured GP records are fp64");
@@ -3169,6 +3203,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
         });
       }
       GPS_TRA(43);
+      if (kimg >= 3) fused_step_prio(2 * (kimg - 3) + 1, 1);   // (image t + 3 is assembled under block step t: its middle)
       if constexpr (ST12) {                              // the state's BetweenFactor<Pose3> record: six compact rows from its columns
         if (btw_on) {
           int rq = r;
@@ -3295,6 +3330,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     assemble(2);
     write_img(0, 2);
     for (int t = 0; t < steps; t++) {
+      fused_step_prio(2 * t, 1);
       GPS_TR(3 + min(t, 50));
       lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
       if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1, t + 3); }
@@ -3336,6 +3372,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     }
   }
   for (int t = 0; t < steps; t++) {
+    fused_step_prio(2 * t, 0);
     const int j = j0 + t;
     const bool live = j < e, lastb = (j == e - 1);
     const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
@@ -3482,6 +3519,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     // block step instead of one per pivot (lanes without a row keep 1)
     if (!(invs > 0.0) && live) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
+    fused_step_prio(2 * t + 1, 0);
     GPS_TRE(49);
 #pragma unroll
     for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
