@@ -749,6 +749,9 @@ __device__ __forceinline__ void fs_mfma_role(const double *ring, int nchunks, in
   tl.store(out, NCP, lane);
 }
 
+#ifndef GPS_FS_PRIO
+#define GPS_FS_PRIO 3
+#endif
 // the sweep wave SWV (0 / 1: border columns 64 SWV ..) of k_fs_sweep_syrk, including the few tiles fs_tile_owner deals to it
 template <int B, int T16, int SWV, typename TR>
 __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, double *ring, double *FsAll, int seg, int lane, int cutL, int j0, int n,
@@ -828,6 +831,9 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
   }
 #pragma unroll 1
   for (int i = 0; i <= nchunks; i++) {
+#if GPS_FS_PRIO
+    __builtin_amdgcn_s_setprio(GPS_FS_PRIO);   // the sweep is what the workgroup's other waves wait for at the chunk barrier
+#endif
     if (i < nchunks) {
       double *slot = ring + (i & 1) * KC * LSP;
       // ---- the chunk's right-hand sides: zero the column, then the staged values and the entries
@@ -917,6 +923,9 @@ __device__ __forceinline__ void fs_sweep_role(const FsArgs<double, TR> &a, doubl
         }
       }
     }
+#if GPS_FS_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     if (i >= 1) tl.chunk(ring + ((i - 1) & 1) * KC * LSP, lane);
     lds_barrier();
   }
