@@ -425,6 +425,16 @@ inline void launch_fused_k(int b, const FusedArgs<double, float> &u, int grid, h
   if (b == 6) k_fused_level0<0, float, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
   else k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u);
 }
+// GPInterpolatedGPSFactorPose3 as 16-double lines: fp64 only (compile(): irow_ok)
+inline void launch_gps_lines_k(const MeasArgs<double> &a, int nb, hipStream_t st) {
+#if GPS_GPS_LINES_WAVES > 0
+  if (a.aidx != nullptr) k_gps_lines<GPS_GPS_LINES_WAVES, true><<<dim3(nb), dim3(128), 0, st>>>(a);   // (round 6: a kernel written for its register count)
+  else k_gps_lines<GPS_GPS_LINES_WAVES, false><<<dim3(nb), dim3(128), 0, st>>>(a);
+#else
+  k_meas<double, POSE3, FK_INTERP_GPS, true, true><<<dim3(nb), dim3(128), 0, st>>>(a);
+#endif
+}
+inline void launch_gps_lines_k(const MeasArgs<float> &, int, hipStream_t) {}
 inline void launch_rows_k(int b, const FwdArgs<double> &a, int grid, hipStream_t st) {
   if (b == 12) k_chunk_forward_rows<12><<<dim3(grid), dim3(64), 0, st>>>(a);
   else if (b == 6) k_chunk_forward_rows<6><<<dim3(grid), dim3(64), 0, st>>>(a);

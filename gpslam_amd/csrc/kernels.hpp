@@ -1366,6 +1366,210 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
   if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
 }
 
+// GPInterpolatedGPSFactorPose3 on the structured path, as 16-double lines (kIRow*) -- the kernel k_meas<double, POSE3, FK_INTERP_GPS,
+// true, true> is, written for its register count (round 6).  The general kernel keeps every row of the factor (rows x 24 doubles), the
+// interpolator's three 6 x 6 blocks and the interval's record alive at once: 256 VGPRs + AGPR spill space, ONE wave per SIMD, 0.88 ms
+// for 4e6 factors at 0.37 of the HBM roof -- a latency chain nobody covers.  Here the whitening enters through Hp (the rows are
+// linear in it: diag(1 / sigma) or the square-root information R of a Gaussian model), so a row is final the moment it is formed;
+// the interval's Jinv is dead once xi exists, the record's J and F blocks are requested when the lines are half done, and the pose's
+// 12 numbers are the only thing that lives from the first load to the last row.  Same device functions on the same operands as
+// interp_pose3_parts (GaussianProcessInterpolatorPose3.h:57-105, GPInterpolatedGPSFactorPose3.h:66-95): products with the weight
+// commute by one rounding.  The interval must carry a GP prior (compile(): irow_ok), body-frame velocities (struct_ok).
+// materialise values HERE: an empty volatile asm that "modifies" them keeps the compiler from sinking their computation towards the
+// use (and, on a pointer, from hoisting the loads behind it) -- the phases of k_gps_lines below stay phases
+__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void pin(V3<double> &x) { pin(x.x); pin(x.y); pin(x.z); }
+__device__ __forceinline__ void pin(V6<double> &x) { pin(x.w); pin(x.v); }
+__device__ __forceinline__ void pin(M3<double> &x) { for (int q = 0; q < 9; q++) pin(x.m[q]); }
+template <typename P> __device__ __forceinline__ void pin_ptr(P *&p) { asm volatile("" : "+v"(p)); }
+#ifndef GPS_GPS_LINES_WAVES
+#define GPS_GPS_LINES_WAVES 2   /* 0: the general k_meas<..., IROW> kernel (round 5) */
+#endif
+// se3_Q (lie.hpp; Pose3utils.cpp:92-113) term by term: the same products and the same order of every sum, each term folded into
+// the result before the next one's operands exist (the expression as one statement keeps eight 3 x 3 temporaries alive)
+__device__ __forceinline__ M3<double> se3_Q_seq(V3<double> w, V3<double> rho) {
+  typedef double T;
+  const T th = sqrt(dot(w, w));
+  T a, b, c;
+  if (fabs(th) > T(1e-5)) {
+    const T s = sin(th), co = cos(th);
+    const T t2 = th * th, t3 = t2 * th, t4 = t3 * th, t5 = t4 * th;
+    a = (th - s) / t3;
+    b = (T(1) - T(0.5) * t2 - co) / t4;
+    c = T(-0.5) * ((T(1) - T(0.5) * t2 - co) / t4 - T(3) * (th - s - t3 / T(6)) / t5);
+  } else {
+    a = T(1) / T(6);
+    b = T(1) / T(24);
+    c = T(-0.5) * (T(1) / T(24) + T(3) / T(120));
+  }
+  pin(a); pin(b); pin(c);
+  const M3<T> X = skew(w), Y = skew(rho);
+  M3<T> XY = X * Y, YX = Y * X, XYX = X * YX;
+  M3<T> Q = T(-0.5) * Y + a * (XY + YX - XYX);
+  pin(Q);
+  Q = Q + b * (X * XY + YX * X - T(3) * XYX);
+  pin(Q);
+  Q = Q + c * (XYX * X + X * XYX);
+  return Q;
+}
+// SENS: some factor of the launch carries a body_P_sensor (a.aidx != null).  Without one Hp = W [0 | R]: its rotational half is
+// exactly zero and only the lower block rows of He and Ad(Exp(xi)^-1) are touched -- half of Hp's registers and products.
+template <int WAVES, bool SENS>
+__global__ void __launch_bounds__(128, WAVES) k_gps_lines(MeasArgs<double> a) {
+  typedef double T;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = f < a.count;
+  const int ff = live ? f : 0;                   // (idle lanes of the last block recompute factor 0; they store nothing)
+  const int i = a.idx[ff];
+  const T l12 = a.coef[4 * (size_t)ff + 1], p11 = a.coef[4 * (size_t)ff + 2], p12 = a.coef[4 * (size_t)ff + 3];
+  const T *gp = a.gps + (size_t)a.gpidx[i] * kGpsLen;
+  const T *gp2 = gp;
+  auto m3 = [&](int off) { M3<T> m; for (int q = 0; q < 9; q++) m.m[q] = gp[off + q]; return m; };
+  SE3<T> A1;
+  V6<T> xi;
+  {
+    // SoA states through ONE 32-bit byte offset per lane and uniform bases (global_load saddr + voffset): 36 loads with 64-bit
+    // per-lane addresses were 72 address registers, more than everything they fetched
+    const unsigned off = (unsigned)i * 8u;
+    auto ldu = [&](const double *base) { return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + off); };
+    T p1[12], p2[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) { p1[k] = ldu(a.pose + (size_t)k * a.stride); p2[k] = ldu(a.pose + (size_t)k * a.stride + 1); }
+    V6<T> u1, u2;
+    {
+      T v1[6], v2[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) { v1[k] = ldu(a.vel + (size_t)k * a.stride); v2[k] = ldu(a.vel + (size_t)k * a.stride + 1); }
+      u1 = as_v6(v1); u2 = as_v6(v2);
+    }
+    A1 = as_se3(p1);
+    const V6<T> r = se3_log(se3_between(A1, as_se3(p2)));
+    BL6<T> Jinv;
+    Jinv.A = m3(kGpsXA); Jinv.C = m3(kGpsXC); Jinv.D = Jinv.A;
+    xi = l12 * u1 + p11 * r + p12 * (Jinv * u2);
+  }
+  pin(xi);
+  SE3<T> ex = se3_exp(xi);
+  pin(ex.R); pin(ex.t);
+  // the sensor pose and the whitened Hp = W [0 | R_sp] (Ad(S^-1)): three 6-vectors (SENS) or their translational halves
+  V6<T> Hp[SENS ? 3 : 1];
+  V3<T> hv[SENS ? 1 : 3];
+  T ew[3];
+  {
+    const SE3<T> pose = se3_compose(A1, ex);
+    SE3<T> sp = pose;
+    BL6<T> AdS;
+    bool has_sensor = false;
+    if constexpr (SENS) {
+      const double *ax = a.aux + (size_t)a.aidx[ff] * kMeasAux;
+      has_sensor = ax[17] != 0.0;
+      if (has_sensor) {
+        T sens[12];
+#pragma unroll
+        for (int k = 0; k < 12; k++) sens[k] = ax[k];
+        const SE3<T> S = as_se3(sens);
+        sp = se3_compose(pose, S);
+        AdS = se3_adjoint(se3_inverse(S));
+      }
+    }
+    T e[3] = {sp.t.x - a.meas[(size_t)ff * a.mw], sp.t.y - a.meas[(size_t)ff * a.mw + 1], sp.t.z - a.meas[(size_t)ff * a.mw + 2]};
+    // W: diag(1 / sigma), or the upper triangular square-root information of a noiseModel::Gaussian (rows <- R rows)
+    T W[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    if (a.sqi) {
+      const double *Rw = a.sqi + (size_t)ff * 9;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int q = r; q < 3; q++) W[r * 3 + q] = Rw[r * 3 + q];
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3; r++) W[r * 4] = T(1) / a.sig[(size_t)ff * 3 + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      T acc = T(0);
+      V3<T> hr = {T(0), T(0), T(0)};
+#pragma unroll
+      for (int q = r; q < 3; q++) {
+        acc += W[r * 3 + q] * e[q];
+        hr = hr + W[r * 3 + q] * V3<T>{sp.R.m[3 * q], sp.R.m[3 * q + 1], sp.R.m[3 * q + 2]};   // translation(H) = [0, R]
+      }
+      ew[r] = acc;
+      if constexpr (SENS) {
+        Hp[r] = {{T(0), T(0), T(0)}, hr};
+        if (has_sensor) Hp[r] = rowmul(Hp[r], AdS);
+        pin(Hp[r]);
+      } else {
+        hv[r] = hr;
+        pin(hv[r]);
+      }
+      pin(ew[r]);
+    }
+  }
+  T err = live ? ew[0] * ew[0] + ew[1] * ew[1] + ew[2] * ew[2] : T(0);
+  V6<T> mu[3], Lp[3];
+  {
+    // He = se3_jr(xi) = [[Jr, 0], [Q, Jr]] (rightJacobianPose3, Pose3utils.cpp:182-189), the Q block first
+    M3<T> HQ = se3_Q_seq(xi.w, xi.v);
+    pin(HQ);
+    const M3<T> Jw = so3_jr(xi.w);
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if constexpr (SENS) mu[r] = rowmul(Hp[r], BL6<T>{Jw, HQ, Jw});
+      else mu[r] = {rowmul(hv[r], HQ), rowmul(hv[r], Jw)};
+      pin(mu[r]);
+    }
+  }
+  {
+    const BL6<T> Hc21 = se3_adjoint(se3_inverse(ex));
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      if constexpr (SENS) Lp[r] = rowmul(Hp[r], Hc21);
+      else Lp[r] = {rowmul(hv[r], Hc21.C), rowmul(hv[r], Hc21.D)};
+      pin(Lp[r]);
+    }
+  }
+  pin_ptr(gp2);      // the record's J and F blocks are requested from here on, not before
+  {   // Lp += mu (p11 J + p12 F J) as (p11 mu + p12 (mu F)) J, one 3 x 3 block of the record at a time: F J is never formed and no
+      // two blocks are alive together (mu F = [mu_w FA + mu_v FC | mu_v FD], b J = [b_w JA + b_v JC | b_v JA])
+    auto n3 = [&](int off) { M3<T> m; for (int q = 0; q < 9; q++) m.m[q] = gp2[off + q]; return m; };
+    V6<T> bq[3];
+    {
+      M3<T> blk = n3(kGpsFA);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { bq[r].w = rowmul(mu[r].w, blk); pin(bq[r].w); }
+      blk = n3(kGpsFC);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { bq[r].w = p11 * mu[r].w + p12 * (bq[r].w + rowmul(mu[r].v, blk)); pin(bq[r].w); }
+      blk = n3(kGpsFD);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { bq[r].v = p11 * mu[r].v + p12 * rowmul(mu[r].v, blk); pin(bq[r].v); }
+    }
+    pin_ptr(gp2);
+    {
+      M3<T> blk = n3(kGpsJA);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { Lp[r].w = Lp[r].w + rowmul(bq[r].w, blk); Lp[r].v = Lp[r].v + rowmul(bq[r].v, blk); pin(Lp[r]); }
+      blk = n3(kGpsJC);
+#pragma unroll
+      for (int r = 0; r < 3; r++) { Lp[r].w = Lp[r].w + rowmul(bq[r].v, blk); pin(Lp[r].w); }
+    }
+  }
+  __shared__ T istage[2 * 64 * 20];
+  __shared__ int isrow[128];
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  T *st = istage + wv * 64 * 20, *mine = st + lane * 20;
+  isrow[threadIdx.x] = live ? a.row0[f] : -1;
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    put_v6(Lp[r], mine + kIRowLp); put_v6(mu[r], mine + kIRowMu);
+    mine[kIRowE] = ew[r]; mine[kIRowP11] = p11; mine[kIRowP12] = p12; mine[kIRowL12] = l12;
+    wave_store_part<T, kIRowLen, 16, 20, true>(st, isrow + wv * 64, lane, r, 0, a.rowI);
+  }
+  const T tot = block_sum(T(0.5) * err);
+  if (threadIdx.x == 0) a.partial[blockIdx.x] = tot;
+}
+
 // ------------------------------------------------------------------ landmark border (Schur complement)
 
 // TR: type of the Jacobian row tables (float on fp32 handles, whose normal equations and solver stay fp64)
