@@ -150,9 +150,9 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
                     &h->lmrow_state, &h->lmrow_ptr, &h->lm_t, &h->lm_S, &h->lm_dL, &h->lm_chunk_lm, &h->lm_chunk_j0, &h->lm_chunk_j1, &h->lm_chunk_ptr, &h->lm_part, &h->gsave, &h->dvec,
                     &h->halo_add, &h->iface_send, &h->iface_recv, &h->top_blk, &h->top_x, &h->scal, &h->flag,
                     &h->api_e, &h->api_H, &h->gps, &h->gpidx, &h->dU, &h->gsave2, &h->partial2, &h->brec, &h->btwidx,
-                    &h->rowI, &h->irowptr, &h->coll_s, &h->coll_r};
+                    &h->rowI, &h->irowptr, &h->coll_s, &h->coll_r, &h->d_clo_second, &h->clo_A, &h->clo_Y, &h->simd_cnt};
   for (DevBuf *b : bufs) b->release();
-  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri}) s->release();
+  for (SimpleSet *s : {&h->pri, &h->vpri, &h->btw, &h->lpri, &h->clo}) s->release();
   for (MeasSet &s : h->ms) s.release();
   h->fs.release();
   h->lm_gL.release();

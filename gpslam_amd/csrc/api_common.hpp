@@ -125,6 +125,7 @@ struct gpslam_hip_handle {
   bool pure6 = false;       // block size 6: nothing but d = 3 GP records in the full-width row table (fused level 0 at every size)
   bool odd_many = false;    // SE(3) records: more other full-width rows than k_fused_level0<2> fetches without a ring (-> <3>)
   DevBuf gps, gpidx, dU, gsave2;
+  DevBuf simd_cnt;          // k_fused_level0 (GPS_ROLE_SWAP): wave-0 count per SIMD of the chip, zero between launches
   // BetweenFactor<Pose3> of a chain on the structured path as 48-double records (kBtw*): at most one per left state
   bool btw_rec_ok = false;
   bool gp_rows_lead = true, btw_rows_trail = true;   // compile(): the row placement the record decoders rely on holds

@@ -2947,6 +2947,7 @@ template <typename T, typename TR = T> struct FusedArgs {
   int odd_rows;           // the structured chain has other full-width rows as well: 1 = a few (k_fused_level0<2>), 2 = many (<3>: a ring)
   int u_diag;             // Ud is diagonal (SE(3) records: k_fused_level0<1, double, 12, true>)
   const T *Ud;            // chol_upper(Qc^-1), row-major 6 x 6, in device memory: the structured velocity columns are multiples of its rows
+  int *simd_cnt = nullptr;       // round 6 (GPS_ROLE_SWAP): wave-0 count per SIMD of the chip (8192 ints, zero between launches), or null
   T *gsave, *gsave2;      // Levenberg-Marquardt: the gradient g = -J^T e per state (gsave) and, for a chunk's separator, the part of
                           // it that the PREVIOUS chunk's last rows contribute (gsave2; zero elsewhere); null: not wanted
 #ifdef GPS_TRACE_FUSED
@@ -2991,6 +2992,17 @@ template <typename T, typename TR = T> struct FusedArgs {
 #define GPS_PRIO 1
 #endif
 // c: progress in half steps (2 t at the top of block step t, 2 t + 1 in its middle)
+// Which wave of a workgroup eliminates (round 6, GPS_ROLE_SWAP).  The hardware puts wave 0 of a two-wave workgroup on SIMD a and wave 1
+// on sigma(a), sigma the 4-cycle 3 -> 0 -> 2 -> 1 -> 3 (HW_ID of 1000 workgroups, scripts/trace_fused.py); a CU's four workgroups then
+// either start on four different SIMDs -- every SIMD holds one wave 0 and one wave 1 -- or two by two on the same pair, and with
+// "wave 0 eliminates" two SIMDs of that CU hold two elimination waves (5.4 us per block step instead of 4.8) and two hold two assembly
+// waves: 27-76 of the chip's 1024 SIMDs per launch, and their workgroups are the launch's last.  With the switch on, wave 0 counts
+// itself into a per-SIMD word (one returning atomic per workgroup, undone on exit): the SECOND wave 0 of a SIMD trades roles with its
+// wave 1, which puts an elimination wave on sigma(a) -- where the first workgroup's assembly wave sits -- and every SIMD of every CU
+// holds one wave of each kind.
+#ifndef GPS_ROLE_SWAP
+#define GPS_ROLE_SWAP 1
+#endif
 __device__ __forceinline__ void fused_step_prio(int c, int role) {
 #if GPS_PRIO == 5
   const int t = c;
@@ -3034,7 +3046,24 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
   typedef double V2 __attribute__((ext_vector_type(2)));
   // (alternating which wave assembles and which eliminates between workgroups -- by bit 0, 1 or 2 of the workgroup index -- so that a
   //  SIMD gets one wave of each kind changes nothing: 0.303-0.307 ms per iteration at 1e5 states for all four assignments)
-  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6, grp = lane >> 4, r = lane & 15;
+  const int lane = threadIdx.x & 63, grp = lane >> 4, r = lane & 15;
+  int role = threadIdx.x >> 6;
+#if GPS_ROLE_SWAP
+  __shared__ int swap_s;
+  int simd_slot = -1;                             // (wave 0: the word it counted itself into)
+  if (u.simd_cnt != nullptr) {
+    if (role == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;   // HW_ID, XCC_ID
+      simd_slot = (int)((((xc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xf)) * 4 + ((hw >> 4) & 3));
+      if (lane == 0) swap_s = atomicAdd(u.simd_cnt + simd_slot, 1) > 0 ? 1 : 0;
+    }
+    __syncthreads();
+    role ^= __builtin_amdgcn_readfirstlane(swap_s);
+  }
+  auto leave = [&]() { if (simd_slot >= 0 && lane == 0) atomicSub(u.simd_cnt + simd_slot, 1); };
+#else
+  auto leave = [&]() {};
+#endif
   const int c = blockIdx.x * 4 + grp;
   const int nch = (a.n + a.m - 1) / a.m;
   const bool valid = c < nch;
@@ -3540,6 +3569,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
       if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1, t + 3); }
     }
     GPS_TR(60);
+    leave();
     return;
   }
 
@@ -3817,7 +3847,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     }
   }
   GPS_TR(59);
-  if (!tail) return;
+  if (!tail) { leave(); return; }
 
   // ================================================================== the level of groups of four, in place
   // All four chunks ended in the same block step (padding above); row grp holds what the in-loop branch above would have
@@ -3900,6 +3930,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     for (int t = lane; t < B * B / 2 + B / 2; t += 64) ua[t] = s4[t < B * B / 2 ? t : t + B * B / 2];
   }
   GPS_TR(60);
+  leave();
 }
 
 template <typename T> struct BwdArgs {

@@ -1,0 +1,70 @@
+"""Random chains with random loop closures against the oracle: every manifold, random lengths (ragged chunks, short hierarchies),
+1 .. capacity closures between random states in either order (shared states and the chain's ends included), priors every 20 states
+(the chain is well anchored: steps are comparable at 1e-9, tests/test_gpu_closure.py says why), every third chain with a velocity
+prior, two Gauss-Newton steps in lock step and then Levenberg-Marquardt in lock step.  The oracle solves these graphs by an envelope
+Cholesky in chain order, the product by the chain solver + a Woodbury correction.
+   python scripts/stress_closures.py [count] [seed]"""
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+import torch  # noqa: F401
+from oracle import oracle as O
+import test_gpu_parity as T
+import lm_lockstep as L
+import gpslam_amd
+cnt = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+for t in range(cnt):
+    kind = [O.POSE2, O.POSE3, O.ROT3, O.LINEAR3, O.POSE2, O.POSE3][t % 6]
+    N = int(rng.integers(30, 2500))
+    d = O.TANGENT_DIM[kind]
+    cap = 27 // d
+    K = int(rng.integers(1, cap + 1))
+    chart = O.CHART_FIRST_ORDER if (kind == O.POSE2 and t % 2) else O.CHART_EXPMAP
+    c = T.random_chain(kind, N, 300 + t)
+    first = rng.integers(0, N, K)
+    second = rng.integers(0, N, K)
+    for k in range(K):                                    # two different, non-adjacent states (adjacent pairs are chain factors)
+        while abs(int(second[k]) - int(first[k])) < 2:
+            second[k] = rng.integers(0, N)
+    if K >= 2:
+        first[0], second[0] = 0, N - 1                    # the chain's ends
+        first[1] = first[0]                               # two closures sharing a state
+        if abs(int(second[1]) - int(first[1])) < 2:
+            second[1] = N // 2
+    ident = {O.POSE2: np.zeros(3), O.POSE3: O.pose3((0, 0, 0), (0, 0, 0)), O.ROT3: O.rot3_ypr(0, 0, 0), O.LINEAR3: np.zeros(3)}[kind]
+    rel = lambda i, j: O.retract(kind, ident, O.local(kind, c["truth_pose"][i], c["truth_pose"][j]) + 0.01 * rng.standard_normal(d))
+    cmeas = np.stack([rel(int(first[k]), int(second[k])) for k in range(K)])
+    csig = 0.01 + 0.05 * rng.random((K, d))
+    Qc = np.diag(0.01 + 0.02 * rng.random(d))
+    solvers = []
+    for make in (lambda: O.Chain(kind, chart), lambda: gpslam_amd.ChainSolver(kind, chart)):
+        s = make()
+        s.set_qc(Qc); s.set_states(c["pose"], c["vel"])
+        s.add_gp_priors(np.arange(N - 1), c["dt"])
+        fix = np.arange(0, N, 20)
+        s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.01))
+        if t % 3 == 0:
+            s.add_vel_priors([0, N - 1], c["truth_vel"][[0, N - 1]], np.full((2, d), 0.05))
+        if kind != O.LINEAR3 and t % 2 == 0:
+            meas = np.stack([O.retract(kind, ident, O.local(kind, c["truth_pose"][i], c["truth_pose"][i + 1])) for i in range(N - 1)])
+            s.add_between(np.arange(N - 1), meas, np.full((N - 1, d), 0.02))
+        s.add_between_pairs(first, second, cmeas, csig)
+        s.compile()
+        solvers.append(s)
+    orc, dev = solvers
+    assert dev.plan_info()["R"] == 1 + K * d
+    e0, e1 = orc.error(), dev.error()
+    assert abs(e0 - e1) <= 1e-10 * max(1.0, e0), (kind, N, K, e0, e1)
+    for it in range(2):
+        (rc0, s0), (rc1, s1) = orc.iterate_gn(), dev.iterate_gn()
+        assert rc0 == 0 and rc1 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (kind, N, K, it, s0.error_after, s1.error_after)
+        (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+        T.states_close(kind, x0, v0, x1, v1, 1e-9)
+    for s_ in solvers:
+        s_.set_states(c["pose"], c["vel"])
+    lam, n_noise, slack = L.run(orc, dev, 1e-2, 5, tag=(kind, N, K))
+    (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+    T.states_close(kind, x0, v0, x1, v1, 1e-9 + 2 * slack)
+    print("ok kind %d N %d closures %d (LM: lambda %.1e, %d of 5 calls decided at rounding level)" % (kind, N, K, lam, n_noise))
+print("all %d chains with loop closures agree with the oracle" % cnt)

@@ -1,7 +1,8 @@
 """Shapes no fixed-size test names: random chain lengths of every manifold, and the BASELINE factor mixes at random small sizes,
 through the default plan against the oracle (scripts/stress_sizes.py: 3 Gauss-Newton iterations at 1e-9, then 3 Levenberg-Marquardt iterations in lock step; scripts/stress_mixes.py);
 round 6: random landmark density / window / segment length through the segmented landmark elimination (scripts/stress_segmented.py) and the retraction
-folded into the next K1, bit for bit against single iterations (scripts/stress_pending.py) -- the whole stress net runs with fixed seeds wherever the driver runs the suite."""
+folded into the next K1, bit for bit against single iterations (scripts/stress_pending.py), random loop closures on every manifold
+(scripts/stress_closures.py) -- the whole stress net runs with fixed seeds wherever the driver runs the suite."""
 import os
 import subprocess
 import sys
@@ -13,7 +14,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("script,count,seed", [("stress_sizes.py", 10, 11), ("stress_mixes.py", 8, 5), ("stress_segmented.py", 12, 3), ("stress_pending.py", 10, 7)])
+@pytest.mark.parametrize("script,count,seed", [("stress_sizes.py", 10, 11), ("stress_mixes.py", 8, 5), ("stress_segmented.py", 12, 3), ("stress_pending.py", 10, 7),
+                                               ("stress_closures.py", 12, 9)])
 def test_random_shapes_agree_with_the_oracle(script, count, seed):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", script), str(count), str(seed)], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
