@@ -3049,9 +3049,12 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
   const int lane = threadIdx.x & 63, grp = lane >> 4, r = lane & 15;
   int role = threadIdx.x >> 6;
 #if GPS_ROLE_SWAP
+  // (the variants that sit at 256 VGPRs -- a ring of full-width rows next to the records, the general-Qc line form -- keep "wave 0
+  //  eliminates": the role bookkeeping costs them 16-20 bytes of scratch, and a scratch reload drains the loads in flight)
+  constexpr bool kSwap = !(SV == 3 || (SV == 4 && !DG));
   __shared__ int swap_s;
   int simd_slot = -1;                             // (wave 0: the word it counted itself into)
-  if (u.simd_cnt != nullptr) {
+  if (kSwap && u.simd_cnt != nullptr) {
     if (role == 0) {
       const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 0xf;   // HW_ID, XCC_ID
       simd_slot = (int)((((xc * 8 + ((hw >> 13) & 7)) * 2 + ((hw >> 12) & 1)) * 16 + ((hw >> 8) & 0xf)) * 4 + ((hw >> 4) & 3));
