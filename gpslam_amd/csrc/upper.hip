@@ -27,6 +27,14 @@ template <int B, int G> struct UpDims {
 
 typedef double V2 __attribute__((ext_vector_type(2)));
 
+#ifdef GPS_TRACE_UPPER
+// debug builds only (scripts/trace_upper.py): s_memrealtime stamps of the waves of workgroup 0 of the last !TOP and TOP forward launches
+__device__ unsigned long long g_up_trace[2 * 8 * 64];
+#define UP_TR(slot) do { if (blockIdx.x == 0 && lane == 0) g_up_trace[((TOP ? 1 : 0) * 8 + wave) * 64 + (slot)] = wall_clock64(); } while (0)
+#else
+#define UP_TR(slot) do { } while (0)
+#endif
+
 template <int B, int G, bool TOP>
 __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs a) {
   typedef UpDims<B, G> DM;
@@ -37,6 +45,7 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
   const int cnt = min(G, a.n - base);
   const bool rowlane = r < B;
   const int rr = rowlane ? r : 0;            // idle lanes shadow row 0 (they never store)
+  UP_TR(0);
 
   // ---- the group's records (+ the addends the level below sent them) into LDS, as 16-byte pieces; every load of the
   // thread is issued before the first one is consumed (a load per loop iteration had exposed a memory round trip each:
@@ -72,7 +81,9 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
       reinterpret_cast<V2 *>(REC + G * BS)[t] = v;
     }
   }
+  UP_TR(1);
   __syncthreads();
+  UP_TR(2);
 
   // A sub-level costs what ONE lane's instruction stream costs (an elimination is VALU-issue bound even for a single wave), so
   // the panel of a pair is spread over as many DPP rows as the sub-level leaves free: two (CrStepWide: G / 2 pairs on NW * 4
@@ -92,14 +103,20 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
       const bool bad = st.compute(REC, act ? s : 0, act ? j : 0, r, rr, quad ? row : half);
       if (bad && act) *a.flag = 1;             // (the lane of the failed pivot reports)
     }
+    UP_TR(3 + 6 * q);
     lds_barrier();                            // every pair has read its operands
+    UP_TR(4 + 6 * q);
     if (act && rowlane) st.store_own(REC, s, j, r, quad ? row : half);
+    UP_TR(5 + 6 * q);
     lds_barrier();                            // the pairs' own blocks are in place: now the right neighbours' shares
+    UP_TR(6 + 6 * q);
     if (act && rowlane) {
       if constexpr (quad) { if (row < 2) st.add_right(REC, n, r, row); }
       else { if (half == 0) st.add_right(REC, n, r); }
     }
+    UP_TR(7 + 6 * q);
     lds_barrier();
+    UP_TR(8 + 6 * q);
   };
   if constexpr ((G >> 1) > NW) sub_level(0, std::false_type{});
   else sub_level(0, std::true_type{});
@@ -116,6 +133,7 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
       reinterpret_cast<V2 *>(a.up_blk + (size_t)g * BS)[t] = reinterpret_cast<const V2 *>(REC)[t];
     for (int t = tid; t < DP + GP; t += NT)
       reinterpret_cast<V2 *>(a.up_add + (size_t)(g + 1) * AS)[t] = reinterpret_cast<const V2 *>(REC + G * BS)[t < DP ? t : t + DP];
+    UP_TR(40);
     return;
   }
 
@@ -141,9 +159,12 @@ __global__ void __launch_bounds__((UpDims<B, G>::NT)) k_multi_forward(UpFwdArgs 
     if (row == 0 && rowlane) XS[r] = gr * invs;
   }
   if (tid < B) XS[G * B + tid] = 0.0;          // nothing beyond the top level
+  UP_TR(41);
   lds_barrier();
   cr_group_backward<B, G, Q>(REC, XS, cnt, tid, [] { lds_barrier(); });
+  UP_TR(42);
   for (int idx = tid; idx < cnt * B; idx += NT) a.x[(size_t)base * B + idx] = XS[idx];
+  UP_TR(43);
 }
 
 template <int B, int G>
@@ -221,6 +242,12 @@ template <int B, int G> int bwd_b(const UpBwdArgs &a, hipStream_t st) {
 
 }  // namespace
 
+#ifdef GPS_TRACE_UPPER
+extern "C" int gpslam_hip_debug_upper_trace(unsigned long long *out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_up_trace), sizeof(g_up_trace)) == hipSuccess ? 0 : -2;
+}
+#endif
 int upper_forward(int B, int G, bool top, const UpFwdArgs &a, hipStream_t st) {
   if (a.n <= 0 || (top && a.n > G) || (G != 32 && G != 4)) return (int)hipErrorInvalidValue;
   switch (B) {
