@@ -690,8 +690,9 @@ def main():
                                            "profiles/latest_pmc.json (bytes per launch, same workload)",
                          "algorithmic_bytes_per_launch": alg[dom],
                          "avg_launch_ms": l0_in_iter if (dom == 2 and l0_in_iter > 0) else kms[dom],
-                         "timing": ("hipEvents around the launch INSIDE 6 consecutive Gauss-Newton iterations (gpslam_hip_last_level0_ms); the "
-                                    "isolated launches of kernel_ms are faster" if (dom == 2 and l0_in_iter > 0) else "isolated launches (time_kernel)"),
+                         "timing": ("the launch's own start / stop HIP events (hipExtLaunchKernelGGL: the dispatch's time stamps, as in rocprofv3's "
+                                    "kernel trace) INSIDE 6 consecutive Gauss-Newton iterations (gpslam_hip_last_level0_ms); the "
+                                    "isolated launches of kernel_ms run on other cache contents" if (dom == 2 and l0_in_iter > 0) else "isolated launches (time_kernel)"),
                          # what actually limits the kernel the HBM fraction is quoted for: the second roof
                          "valu_fp64": ({"achieved": FUSED_FMA_FLOPS_PER_STATE * N / ((l0_in_iter if l0_in_iter > 0 else kms[dom]) * 1e-3) / 1e12,
                                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",

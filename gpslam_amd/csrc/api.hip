@@ -130,6 +130,7 @@ int gpslam_hip_create_v2(const gpslam_hip_config_v2 *in, gpslam_hip_handle **out
       hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
   for (int i = 0; i < 6; i++)
     if (hipEventCreate(&h->ev[i]) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
+  if (hipEventCreate(&h->ev_l0a) != hipSuccess || hipEventCreate(&h->ev_l0b) != hipSuccess) { delete h; return GPSLAM_E_HIP; }
   if (h->scal.reserve(16 * sizeof(double)) != hipSuccess || h->flag.reserve(sizeof(int)) != hipSuccess) {
     delete h;
     return GPSLAM_E_HIP;
@@ -158,6 +159,8 @@ int gpslam_hip_destroy(gpslam_hip_handle *h) {
   h->lm_gL.release();
   for (Level &v : h->lv) { v.blk.release(); v.add.release(); v.x.release(); }
   for (int i = 0; i < 6; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+  if (h->ev_l0a) (void)hipEventDestroy(h->ev_l0a);
+  if (h->ev_l0b) (void)hipEventDestroy(h->ev_l0b);
   if (h->aux_stream) { (void)hipStreamSynchronize(h->aux_stream); (void)hipStreamDestroy(h->aux_stream); }
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);

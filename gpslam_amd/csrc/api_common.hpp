@@ -7,6 +7,7 @@
 #include "../../include/gpslam_hip.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -70,6 +71,10 @@ struct gpslam_hip_handle {
   hipStream_t aux_stream = nullptr;   // side stream for the light factor kernels (launch_factors)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // the fused level-0 launch of a timed iteration carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's own
+  // time stamps, what rocprofv3's kernel trace reads) -- events recorded AROUND a launch add their marker packets to it (7 us of 149)
+  hipEvent_t ev_l0a = nullptr, ev_l0b = nullptr;
+  bool l0_ext = false;        // ... and this iteration's launch took them
   double Qc[36], U[36];
   std::vector<double> h_lmk;
   DevBuf pose, vel, lmk, pose_bak, vel_bak, lmk_bak;
@@ -295,8 +300,9 @@ int collect_timing(gpslam_hip_handle *h, double *acc) {
   }
   HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[4]));
   acc[4] += ms;
-  if (h->time_l0) {            // the level-0 forward launch of this iteration (ev[2] = start of the solve phase)
-    HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[5]));
+  if (h->time_l0) {            // the level-0 forward launch of this iteration: its own stamps, or (unfused) ev[2] = start of the solve phase
+    if (h->l0_ext) HIPCHK(hipEventElapsedTime(&ms, h->ev_l0a, h->ev_l0b));
+    else HIPCHK(hipEventElapsedTime(&ms, h->ev[2], h->ev[5]));
     h->l0_ms += ms;
   }
   return 0;
@@ -403,28 +409,34 @@ int backup_state(gpslam_hip_handle *h, bool restore) {
 // kernels that exist for fp64 only (hand-written 64-bit DPP row layout, v_mfma_f64): the fp32 instantiation of the
 // host code never selects them (rows_kernel_applies / compile()), these overloads only keep it compiling
 namespace {
-inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, hipStream_t st) {
+// ea / eb != null: the launch carries its own start / stop events (a timed iteration: the dispatch's own time stamps)
+#define GPS_FUSED_LAUNCH(...)                                                                                      \
+  do {                                                                                                             \
+    if (ea) hipExtLaunchKernelGGL((__VA_ARGS__), dim3(grid), dim3(128), 0, st, ea, eb, 0, u);                      \
+    else __VA_ARGS__<<<dim3(grid), dim3(128), 0, st>>>(u);                                                         \
+  } while (0)
+inline void launch_fused_k(int b, const FusedArgs<double, double> &u, int grid, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
   if (b == 6) {
-    if (u.gps) k_fused_level0<1, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);      // d = 3 records (kGp3*)
-    else k_fused_level0<0, double, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
+    if (u.gps) GPS_FUSED_LAUNCH(k_fused_level0<1, double, 6>);      // d = 3 records (kGp3*)
+    else GPS_FUSED_LAUNCH(k_fused_level0<0, double, 6>);
     return;
   }
   if (u.gps && u.rowI) {                     // records + interpolated measurement rows as 16-double lines (round 5)
-    if (u.u_diag) k_fused_level0<4, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);
-    else k_fused_level0<4><<<dim3(grid), dim3(128), 0, st>>>(u);
+    if (u.u_diag) GPS_FUSED_LAUNCH(k_fused_level0<4, double, 12, true>);
+    else GPS_FUSED_LAUNCH(k_fused_level0<4>);
   } else if (u.gps && u.odd_rows == 2) {     // records + a ring of full-width rows (measurement factors)
-    if (u.u_diag) k_fused_level0<3, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);
-    else k_fused_level0<3><<<dim3(grid), dim3(128), 0, st>>>(u);
-  } else if (u.gps && u.odd_rows) k_fused_level0<2><<<dim3(grid), dim3(128), 0, st>>>(u);
-  else if (u.gps && u.u_diag) k_fused_level0<1, double, 12, true><<<dim3(grid), dim3(128), 0, st>>>(u);   // diagonal chol(Qc^-1)
-  else if (u.gps) k_fused_level0<1><<<dim3(grid), dim3(128), 0, st>>>(u);
-  else k_fused_level0<0><<<dim3(grid), dim3(128), 0, st>>>(u);
+    if (u.u_diag) GPS_FUSED_LAUNCH(k_fused_level0<3, double, 12, true>);
+    else GPS_FUSED_LAUNCH(k_fused_level0<3>);
+  } else if (u.gps && u.odd_rows) GPS_FUSED_LAUNCH(k_fused_level0<2>);
+  else if (u.gps && u.u_diag) GPS_FUSED_LAUNCH(k_fused_level0<1, double, 12, true>);   // diagonal chol(Qc^-1)
+  else if (u.gps) GPS_FUSED_LAUNCH(k_fused_level0<1>);
+  else GPS_FUSED_LAUNCH(k_fused_level0<0>);
 }
 // fp32 handles: fp32 row tables straight into the fused kernel's fp64 accumulation (round 3: the unfused assembly had cost the
 // fp32 mode more than its halved row traffic saved)
-inline void launch_fused_k(int b, const FusedArgs<double, float> &u, int grid, hipStream_t st) {
-  if (b == 6) k_fused_level0<0, float, 6><<<dim3(grid), dim3(128), 0, st>>>(u);
-  else k_fused_level0<0, float><<<dim3(grid), dim3(128), 0, st>>>(u);
+inline void launch_fused_k(int b, const FusedArgs<double, float> &u, int grid, hipStream_t st, hipEvent_t ea = nullptr, hipEvent_t eb = nullptr) {
+  if (b == 6) GPS_FUSED_LAUNCH(k_fused_level0<0, float, 6>);
+  else GPS_FUSED_LAUNCH(k_fused_level0<0, float>);
 }
 // GPInterpolatedGPSFactorPose3 as 16-double lines: fp64 only (compile(): irow_ok)
 inline void launch_gps_lines_k(const MeasArgs<double> &a, int nb, hipStream_t st) {

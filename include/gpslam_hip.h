@@ -380,7 +380,8 @@ int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
 /* device time (ms) of the LEVEL-0 FORWARD launch -- on Pose3 chains k_fused_level0, the dominant kernel -- summed over the
  * iterations of the last timed run_gn / iterate_gn: the kernel as it runs INSIDE an iteration (behind the linearisation,
  * caches as an iteration leaves them), which is what bench.py's roofline fraction is computed from (time_kernel's isolated
- * launches are faster).  0 on the segmented landmark path. */
+ * launches are faster).  The fused launch carries its own start / stop events (the dispatch's time stamps, what a profiler's
+ * kernel trace reports); the two-launch level 0 is bracketed by events on the stream.  0 on the segmented landmark path. */
 int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms);
 /* run `iters` Gauss-Newton iterations back to back with no host synchronisation in between (the benchmark
  * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL.
