@@ -3131,6 +3131,11 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     constexpr bool FRING = !ST12 || ORING;            // a ring of full-width rows (ORING: 4 deep -- 6 in the diagonal-Qc form -- + 2 compact rows is what 256 VGPRs hold next to the records)
     double fL[FRING ? PF : 1], fR[FRING ? PF : 1], fE[FRING ? PF : 1], cL[PC], cR[PC], cE[PC];   // the two operand rings
     double fI[IROW ? PFI : 1];                           // ... and the ring of interpolated rows: element (lane & 15) of each line
+    // IROW (round 6): the compact rows (a between factor's six, a pose prior's) as ONE register per row as well -- lane c < 12 holds
+    // element c of [L (6) | R (6)], lanes 12..15 the whitened error -- so that a whole state's rows are in flight where the three
+    // registers per row of cL / cR / cE allowed two: their latency was exposed three times per block step (2.2 of its 7.1 us)
+    constexpr int PCI = 6;
+    double cV[IROW ? PCI : 1];
     const int *fptr = IROW ? u.irowptr : u.rowptr;       // the full-width table this variant walks
     int rp = 0, nf = 0, cp = 0, nc = 0;                  // rows of the state the rings belong to
     int rpn = fptr[min(s + 1, ptr_max)], cpn = u.crowptr[min(s + 1, ptr_max)];      // pointers one state ahead
@@ -3307,6 +3312,11 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
       const TR *row = u.rowC + (size_t)rho * B;
       Lv = (double)row[rc]; Rv = (double)row[Dh + rc]; ev = (double)u.rowCE[rho];
     };
+    auto ldcv = [&](int i, double &v) {      // element (lane & 15) of compact row i of the state the rings point at: [L | R | e e e e]
+      const int rho = cp + min(i, max(nc - 1, 0));
+      const TR *p = (r < B) ? u.rowC + (size_t)rho * B + r : u.rowCE + rho;
+      v = (double)*p;
+    };
     // point the rings at state s + kimg (row range known from the pointers loaded earlier) and start their first loads
     auto open_state = [&](int kimg, int p0, int p1, int q0, int q1, int g, int bqv) {
       const bool live = valid && (s + kimg) < e;
@@ -3385,7 +3395,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
         }
         open_irows(kimg + 1, rpn, rpnn);                 // the next state's lines: in flight under the rest of this state
 #pragma unroll
-        for (int q = 0; q < PC; q++) ldc(q, cL[q], cR[q], cE[q]);   // this state's compact rows: wanted behind the GP prior's twelve
+        for (int q = 0; q < PCI; q++) ldcv(q, cV[q]);    // this state's compact rows: wanted behind the GP prior's twelve
       }
       if constexpr (ST6) {                               // the d = 3 record: six rows from the lane's column of [A1 | U | A3 | U]
         const bool pc = r < 3;
@@ -3504,6 +3514,31 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
           __builtin_amdgcn_sched_barrier(0);
         }
       }
+      if constexpr (IROW) {
+        for (int i0 = 0; i0 < ncm; i0 += PCI) {          // compact rows, one register each (see cV)
+          if (i0 > 0) {                                  // more than PCI on one state (a pose prior next to a between factor): refilled in place
+#pragma unroll
+            for (int q = 0; q < PCI; q++) ldcv(i0 + q, cV[q]);
+          }
+#pragma unroll
+          for (int q = 0; q < PCI; q++) {
+            const int i = i0 + q;
+            const double V = (i < nc) ? cV[q] : 0.0;
+            // this lane's R entry sits six lanes up (row_shl:6, zero where the source lane falls off the row)
+            const int rlo = __builtin_amdgcn_update_dpp(0, __double2loint(V), 0x106, 0xf, 0xf, true);
+            const int rhi = __builtin_amdgcn_update_dpp(0, __double2hiint(V), 0x106, 0xf, 0xf, true);
+            const bool pl = r < Dh;
+            const double Lv = pl ? V : 0.0, Rv = pl ? __hiloint2double(rhi, rlo) : 0.0;
+            const double ev = row_bcast<B>(V);
+            fmac_gather<Dh>(Dacc, V, Lv);                 // D[r][k] += L[k] L[r]   (lane k < 6 of V holds L[k])
+            fmac_gather<Dh>(Oacc, V, Rv);                 // O[r][k] += L[k] R[r]
+            fmac_gather_nn<Dh, Dh>(RRacc, V, Rv);         // carry[r][k] += R[k] R[r]   (lane 6 + k holds R[k]; V was guarded above)
+            gacc = fma(-Lv, ev, gacc);
+            grr = fma(-Rv, ev, grr);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else
       for (int i0 = 0; i0 < ncm; i0 += PC) {             // compact rows (velocity-free): six columns each side
 #pragma unroll
         for (int q = 0; q < PC; q++) {

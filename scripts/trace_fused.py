@@ -1,6 +1,6 @@
 """Timeline of k_fused_level0's waves (a -DGPS_TRACE_FUSED build of the library, loaded through GPSLAM_LIB):
 when each wave starts, passes the hand-over barriers P / Q, each block step, and ends (s_memrealtime, 10 ns ticks), and
-where it ran (XCC / SE / CU / SIMD).   GPSLAM_LIB=build_ab/lib_trace.so python scripts/trace_fused.py [N] [out.npz]
+where it ran (XCC / SE / CU / SIMD).   GPSLAM_LIB=build_ab/lib_trace.so python scripts/trace_fused.py [N] [out.npz | -] [c3 | c5b]
 Build:  python -c "from gpslam_amd import build; print(build.build(extra=['-DGPS_TRACE_FUSED']))"  (copy the result to build_ab/)."""
 import ctypes as C, os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,8 +8,9 @@ import gpslam_amd as gp
 from gpslam_amd import synthetic as S
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
-out = sys.argv[2] if len(sys.argv) > 2 else None
-p = S.pose3_chain(N)
+out = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "-" else None
+mix = sys.argv[3] if len(sys.argv) > 3 else "c3"      # c3: BASELINE config 3; c5b: config 5's SE(3) mix (k_fused_level0<4>)
+p = S.pose3_gps_chain(N, keep_odometry=True) if mix == "c5b" else S.pose3_chain(N)
 s = S.apply(p, gp.ChainSolver(gp.POSE3))
 s.run_gn(3)
 s.set_states(p["pose"], p["vel"])
