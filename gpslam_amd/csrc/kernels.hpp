@@ -3051,7 +3051,8 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
 #if GPS_ROLE_SWAP
   // (the variants that sit at 256 VGPRs -- a ring of full-width rows next to the records, the general-Qc line form -- keep "wave 0
   //  eliminates": the role bookkeeping costs them 16-20 bytes of scratch, and a scratch reload drains the loads in flight)
-  constexpr bool kSwap = !(SV == 3 || (SV == 4 && !DG));
+  // (block size 6 runs three waves per SIMD, six workgroups per CU: the two-by-two argument above is about two)
+  constexpr bool kSwap = B == 12 && !(SV == 3 || (SV == 4 && !DG));
   __shared__ int swap_s;
   int simd_slot = -1;                             // (wave 0: the word it counted itself into)
   if (kSwap && u.simd_cnt != nullptr) {
