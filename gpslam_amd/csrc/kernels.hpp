@@ -3003,7 +3003,9 @@ template <typename T, typename TR = T> struct FusedArgs {
 #ifndef GPS_ROLE_SWAP
 #define GPS_ROLE_SWAP 1
 #endif
-__device__ __forceinline__ void fused_step_prio(int c, int role) {
+// (block size 12 only: the three-waves-per-SIMD kernel of the d = 3 chains gains nothing at 1e5 states and loses 2 % at 1e6)
+template <int B> __device__ __forceinline__ void fused_step_prio(int c, int role) {
+  if constexpr (B != 12) return;
 #if GPS_PRIO == 5
   const int t = c;
 #else
@@ -3450,7 +3452,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
         });
       }
       GPS_TRA(43);
-      if (kimg >= 3) fused_step_prio(2 * (kimg - 3) + 1, 1);   // (image t + 3 is assembled under block step t: its middle)
+      if (kimg >= 3) fused_step_prio<B>(2 * (kimg - 3) + 1, 1);   // (image t + 3 is assembled under block step t: its middle)
       if constexpr (ST12) {                              // the state's BetweenFactor<Pose3> record: six compact rows from its columns
         if (btw_on) {
           int rq = r;
@@ -3602,7 +3604,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     assemble(2);
     write_img(0, 2);
     for (int t = 0; t < steps; t++) {
-      fused_step_prio(2 * t, 1);
+      fused_step_prio<B>(2 * t, 1);
       GPS_TR(3 + min(t, 50));
       lds_barrier();                     // step t: image t + 2 is there; image t + 1 is dead from here on
       if (t + 1 < steps) { assemble(t + 3); write_img((t + 1) & 1, t + 3); }
@@ -3645,7 +3647,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     }
   }
   for (int t = 0; t < steps; t++) {
-    fused_step_prio(2 * t, 0);
+    fused_step_prio<B>(2 * t, 0);
     const int j = j0 + t;
     const bool live = j < e, lastb = (j == e - 1);
     const double *cur = IMG + ((t + 1) & 1) * 4 * IS, *nxt = IMG + (t & 1) * 4 * IS;   // images t + 1 and t + 2
@@ -3792,7 +3794,7 @@ __global__ void __launch_bounds__(128, GPS_FUSED_WAVES) k_fused_level0(FusedArgs
     // block step instead of one per pivot (lanes without a row keep 1)
     if (!(invs > 0.0) && live) *a.flag = 1;
     __builtin_amdgcn_sched_barrier(0);
-    fused_step_prio(2 * t + 1, 0);
+    fused_step_prio<B>(2 * t + 1, 0);
     GPS_TRE(49);
 #pragma unroll
     for (int k = 0; k < B; k++) { Or[k] *= invs; Fr[k] *= invs; }
