@@ -1377,10 +1377,6 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
 // commute by one rounding.  The interval must carry a GP prior (compile(): irow_ok), body-frame velocities (struct_ok).
 // materialise values HERE: an empty volatile asm that "modifies" them keeps the compiler from sinking their computation towards the
 // use (and, on a pointer, from hoisting the loads behind it) -- the phases of k_gps_lines below stay phases
-__device__ __forceinline__ void pin(double &x) { asm volatile("" : "+v"(x)); }
-__device__ __forceinline__ void pin(V3<double> &x) { pin(x.x); pin(x.y); pin(x.z); }
-__device__ __forceinline__ void pin(V6<double> &x) { pin(x.w); pin(x.v); }
-__device__ __forceinline__ void pin(M3<double> &x) { for (int q = 0; q < 9; q++) pin(x.m[q]); }
 template <typename P> __device__ __forceinline__ void pin_ptr(P *&p) { asm volatile("" : "+v"(p)); }
 #ifndef GPS_GPS_LINES_WAVES
 #define GPS_GPS_LINES_WAVES 2   /* 0: the general k_meas<..., IROW> kernel (round 5) */

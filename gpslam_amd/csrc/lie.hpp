@@ -212,6 +212,25 @@ template <typename T> GD BL6<T> neg(const BL6<T> &x) { return {neg(x.A), neg(x.C
 template <typename T> GD BL6<T> operator-(const BL6<T> &x, const BL6<T> &y) { return {x.A - y.A, x.C - y.C, x.D - y.D}; }
 template <typename T> GD BL6<T> operator+(const BL6<T> &x, const BL6<T> &y) { return {x.A + y.A, x.C + y.C, x.D + y.D}; }
 template <typename T> GD BL6<T> operator*(T s, const BL6<T> &x) { return {s * x.A, s * x.C, s * x.D}; }
+// materialise values HERE (device code): an empty volatile asm that "modifies" them keeps the compiler from sinking their computation
+// towards the use and from interleaving what follows with what produced them -- phases stay phases (kernels.hpp: k_gps_lines, K1)
+GD void pin(double &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#else
+  (void)x;
+#endif
+}
+GD void pin(float &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#else
+  (void)x;
+#endif
+}
+template <typename T> GD void pin(V3<T> &x) { pin(x.x); pin(x.y); pin(x.z); }
+template <typename T> GD void pin(V6<T> &x) { pin(x.w); pin(x.v); }
+template <typename T> GD void pin(M3<T> &x) { for (int q = 0; q < 9; q++) pin(x.m[q]); }
 // entry (i, j) of the 6x6
 template <typename T> GD T bl6_at(const BL6<T> &x, int i, int j) {
   if (i < 3) return j < 3 ? x.A.m[3 * i + j] : T(0);
