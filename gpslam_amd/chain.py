@@ -41,10 +41,10 @@ ABI_SYMBOLS = [
     "gpslam_hip_fs_lm_trial_phase2", "gpslam_hip_add_gp_priors_qc", "gpslam_hip_set_meas_covariance",
     "gpslam_hip_interpolate_velocities", "gpslam_hip_body_centric_velocity", "gpslam_hip_last_level0_ms",
     "gpslam_hip_lm_decide", "gpslam_hip_set_collectives", "gpslam_hip_create_v2", "gpslam_hip_abi_version", "gpslam_hip_struct_size",
-    "gpslam_hip_add_between_pairs",
+    "gpslam_hip_add_between_pairs", "gpslam_hip_set_level0_stamps",
 ]
 # the version of include/gpslam_hip.h this binding's structs mirror (GPSLAM_HIP_ABI_MAJOR / _MINOR); load_library() checks the library's
-ABI_MAJOR, ABI_MINOR = 2, 1
+ABI_MAJOR, ABI_MINOR = 2, 2
 STRUCT_CONFIG, STRUCT_CONFIG_V2, STRUCT_STATS, STRUCT_PARAMS = 0, 1, 2, 3
 
 
@@ -455,6 +455,10 @@ class ChainSolver:
         self._chk(self.lib.gpslam_hip_interpolate_poses_jac(self._h, len(left), _p(left), _p(dt), _p(tau), _p(out), _p(H)),
                   "interpolate_poses_jac")
         return out, H
+
+    def set_level0_stamps(self, on=True):
+        """timed iterations stamp the fused level-0 launch with its own dispatch events (exact duration; perturbs the other phases)"""
+        return self._chk(self.lib.gpslam_hip_set_level0_stamps(self._h, 1 if on else 0), "set_level0_stamps")
 
     def last_level0_ms(self):
         """device ms of the level-0 forward launch, summed over the iterations of the last timed run_gn / iterate_gn"""

@@ -512,6 +512,11 @@ int gpslam_hip_debug_fused_trace(gpslam_hip_handle *h, unsigned long long *out, 
   return 0;
 }
 #endif
+int gpslam_hip_set_level0_stamps(gpslam_hip_handle *h, int32_t on) {
+  if (!h) return GPSLAM_E_INVALID;
+  h->l0_stamps = on != 0;
+  return 0;
+}
 int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms) {
   if (!h || !ms) return GPSLAM_E_INVALID;
   *ms = h->l0_ms;

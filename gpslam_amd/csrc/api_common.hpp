@@ -75,6 +75,7 @@ struct gpslam_hip_handle {
   // time stamps, what rocprofv3's kernel trace reads) -- events recorded AROUND a launch add their marker packets to it (7 us of 149)
   hipEvent_t ev_l0a = nullptr, ev_l0b = nullptr;
   bool l0_ext = false;        // ... and this iteration's launch took them
+  bool l0_stamps = false;     // gpslam_hip_set_level0_stamps: timed iterations do so (off: events around the launch, as in rounds 1-5)
   double Qc[36], U[36];
   std::vector<double> h_lmk;
   DevBuf pose, vel, lmk, pose_bak, vel_bak, lmk_bak;

@@ -77,10 +77,10 @@ enum {
  * through a corrupted stack.  History: 1.0 rounds 1-4 (gpslam_hip_stats 48 bytes); 1.1 round 5 (stats 56 bytes: trials,
  * last_trial_error; GPSLAM_E_COMM; plan bits 64, 128) -- shipped without a version symbol; 2.0 this header: gpslam_hip_config_v2 +
  * gpslam_hip_create_v2 (named fields, struct_size first), gpslam_hip_abi_version, gpslam_hip_struct_size.  The v1 config and
- * gpslam_hip_create stay, bit for bit; 2.1 gpslam_hip_add_between_pairs (loop closures).  A MAJOR bump changes a struct or a
+ * gpslam_hip_create stay, bit for bit; 2.1 gpslam_hip_add_between_pairs (loop closures); 2.2 gpslam_hip_set_level0_stamps.  A MAJOR bump changes a struct or a
  * signature, a MINOR bump only adds. */
 #define GPSLAM_HIP_ABI_MAJOR 2
-#define GPSLAM_HIP_ABI_MINOR 1
+#define GPSLAM_HIP_ABI_MINOR 2
 #define GPSLAM_HIP_ABI_VERSION ((GPSLAM_HIP_ABI_MAJOR << 16) | GPSLAM_HIP_ABI_MINOR)
 uint32_t gpslam_hip_abi_version(void);
 enum { GPSLAM_STRUCT_CONFIG = 0, GPSLAM_STRUCT_CONFIG_V2 = 1, GPSLAM_STRUCT_STATS = 2, GPSLAM_STRUCT_PARAMS = 3 };
@@ -383,6 +383,11 @@ int gpslam_hip_last_timing(gpslam_hip_handle *h, double *out5);
  * launches are faster).  The fused launch carries its own start / stop events (the dispatch's time stamps, what a profiler's
  * kernel trace reports); the two-launch level 0 is bracketed by events on the stream.  0 on the segmented landmark path. */
 int gpslam_hip_last_level0_ms(gpslam_hip_handle *h, double *ms);
+/* on = 1: the fused level-0 launch of a TIMED iteration carries its own start / stop events (hipExtLaunchKernelGGL: the dispatch's
+ * time stamps -- gpslam_hip_last_level0_ms then reports what a profiler's kernel trace reports, where events recorded around the
+ * launch add their marker packets: 149 us for 142).  A stamped dispatch costs the iteration ~10 us elsewhere, so the other phase
+ * times of such a run are not to be quoted; off (the default) nothing changes.  ABI 2.2. */
+int gpslam_hip_set_level0_stamps(gpslam_hip_handle *h, int32_t on);
 /* run `iters` Gauss-Newton iterations back to back with no host synchronisation in between (the benchmark
  * loop); per-phase device time is accumulated in out5 (ms, summed over iters) when out5 != NULL.
  * The error of the state an iteration produces is the error the next iteration's linearisation evaluates, so
