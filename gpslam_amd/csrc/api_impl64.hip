@@ -16,3 +16,10 @@ typedef double RowT;
 #include "api_impl.inc"
 #undef IMPL_NS
 }  // namespace impl64
+
+#ifdef GPS_TRACE_KLIN
+extern "C" int gpslam_hip_debug_klin_trace(unsigned long long *out) {
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gps::g_klin_trace), sizeof(gps::g_klin_trace)) == hipSuccess ? 0 : -2;
+}
+#endif

@@ -147,8 +147,30 @@ template <typename T> GD BL6<T> se3_jrinv_k(const JrK<T> &k, V6<T> xi) {
   const M3<T> Q = T(-0.5) * Y + k.qa * t1 + k.qb * t2m + k.qc * t3m;
   return {Jw, neg(Jw * Q * Jw), Jw};
 }
-// central-difference derivative of Jr^-1(xi) x (see se3_jrinv_times_x_fd below); k0 = jr_coefs(xi.w) serves the six
-// evaluations that perturb only the translational half
+// e_I x b for the unit vector e_I (the products with the zeros and ones of e_I are not left to the compiler: x * 0 is not 0 in
+// IEEE arithmetic and is not folded)
+template <int I, typename T> GD V3<T> cross_unit(V3<T> b) {
+  if (I == 0) return {T(0), -b.z, b.y};
+  if (I == 1) return {b.z, T(0), -b.x};
+  return {-b.y, b.x, T(0)};
+}
+// Q(w, e_I) b of se3_Q_apply_k: rho = e_I
+template <int I, typename T> GD V3<T> se3_Q_apply_unit(const JrK<T> &k, V3<T> w, V3<T> Xb, V3<T> XXb, V3<T> b) {
+  const V3<T> Yb = cross_unit<I>(b);
+  const V3<T> XYb = cross(w, Yb), YXb = cross_unit<I>(Xb);
+  const V3<T> XYXb = cross(w, YXb);
+  const V3<T> XXYb = cross(w, XYb), YXXb = cross_unit<I>(XXb);
+  const V3<T> XYXXb = cross(w, YXXb), XXYXb = cross(w, XYXb);
+  return T(-0.5) * Yb + k.qa * (XYb + YXb - XYXb) + k.qb * (XXYb + YXXb - T(3) * XYXb) + k.qc * (XYXXb + XXYXb);
+}
+// Derivative of Jr^-1(xi) x with respect to xi as jacobianMethodNumercialDiff forms it (Pose3utils.cpp:167-200; see
+// se3_jrinv_times_x_fd below): the three ROTATIONAL columns are the reference's central difference, h = 1e-6, evaluated with the
+// reference's formulas in the reference's order -- its rounding noise (the closed-form coefficients cancel) is part of what the
+// parity tests compare.  The three TRANSLATIONAL columns are the same difference quotient in closed form (round 6): Jr^-1(xi) x
+// is affine in rho -- lower half Jw (x_v - Q(w, rho) Jw x_w), Q linear in rho -- so (f(rho + h e) - f(rho - h e)) / 2h IS
+// -Jw Q(w, e) Jw x_w; the quotient differed from it by its own rounding (1e-16 / 2h = 5e-11 of |f|, three orders below the
+// 1e-7 the rotational columns are held to) and cost six full evaluations (890 of a K1 thread's ~5000 instructions) against 250.
+// k0 = jr_coefs(xi.w).
 template <typename T> GD BL6<T> se3_jrinv_times_x_fd_k(const JrK<T> &k0, V6<T> xi, V6<T> x) {
   const T h = T(1e-6);
   const T s = T(1) / (T(2) * h);
@@ -157,24 +179,25 @@ template <typename T> GD BL6<T> se3_jrinv_times_x_fd_k(const JrK<T> &k0, V6<T> x
   D.C = M3<T>::zero();
   D.D = M3<T>::zero();
 #pragma unroll
-  for (int i = 0; i < 6; i++) {
+  for (int i = 0; i < 3; i++) {
     V6<T> xp = xi, xn = xi;
     if (i == 0) { xp.w.x += h; xn.w.x -= h; }
     if (i == 1) { xp.w.y += h; xn.w.y -= h; }
     if (i == 2) { xp.w.z += h; xn.w.z -= h; }
-    if (i == 3) { xp.v.x += h; xn.v.x -= h; }
-    if (i == 4) { xp.v.y += h; xn.v.y -= h; }
-    if (i == 5) { xp.v.z += h; xn.v.z -= h; }
-    V6<T> col;
-    if (i < 3) {
-      const JrK<T> kp = jr_coefs(xp.w), kn = jr_coefs(xn.w);
-      col = s * (se3_jrinv_apply_k(kp, xp, x) - se3_jrinv_apply_k(kn, xn, x));
-      D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
-      D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
-    } else {
-      col = s * (se3_jrinv_apply_k(k0, xp, x) - se3_jrinv_apply_k(k0, xn, x));
-      D.D.m[0 + (i - 3)] = col.v.x; D.D.m[3 + (i - 3)] = col.v.y; D.D.m[6 + (i - 3)] = col.v.z;
-    }
+    const JrK<T> kp = jr_coefs(xp.w), kn = jr_coefs(xn.w);
+    const V6<T> col = s * (se3_jrinv_apply_k(kp, xp, x) - se3_jrinv_apply_k(kn, xn, x));
+    D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
+    D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
+  }
+  {
+    const V3<T> top = so3_jrinv_apply_k(k0, xi.w, x.w);
+    const V3<T> Xb = cross(xi.w, top), XXb = cross(xi.w, Xb);
+    const V3<T> c0 = so3_jrinv_apply_k(k0, xi.w, se3_Q_apply_unit<0>(k0, xi.w, Xb, XXb, top));
+    const V3<T> c1 = so3_jrinv_apply_k(k0, xi.w, se3_Q_apply_unit<1>(k0, xi.w, Xb, XXb, top));
+    const V3<T> c2 = so3_jrinv_apply_k(k0, xi.w, se3_Q_apply_unit<2>(k0, xi.w, Xb, XXb, top));
+    D.D.m[0] = -c0.x; D.D.m[3] = -c0.y; D.D.m[6] = -c0.z;
+    D.D.m[1] = -c1.x; D.D.m[4] = -c1.y; D.D.m[7] = -c1.z;
+    D.D.m[2] = -c2.x; D.D.m[5] = -c2.y; D.D.m[8] = -c2.z;
   }
   return D;
 }
@@ -274,31 +297,8 @@ GD BL6<float> se3_jrinv_times_x_fd_k(const JrK<float> &k0, V6<float> xi, V6<floa
 // difference in the reference as well.  The result is block lower-triangular: perturbing rho leaves the rotation
 // block untouched, so the top-right 3x3 block is an exact zero in the reference too.
 template <typename T> GD BL6<T> se3_jrinv_times_x_fd(V6<T> xi, V6<T> x) {
-  const T h = T(1e-6);
-  const T s = T(1) / (T(2) * h);
-  BL6<T> D;
-  D.A = M3<T>::zero();
-  D.C = M3<T>::zero();
-  D.D = M3<T>::zero();
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    V6<T> xp = xi, xn = xi;
-    if (i == 0) { xp.w.x += h; xn.w.x -= h; }
-    if (i == 1) { xp.w.y += h; xn.w.y -= h; }
-    if (i == 2) { xp.w.z += h; xn.w.z -= h; }
-    if (i == 3) { xp.v.x += h; xn.v.x -= h; }
-    if (i == 4) { xp.v.y += h; xn.v.y -= h; }
-    if (i == 5) { xp.v.z += h; xn.v.z -= h; }
-    const V6<T> col = s * (se3_jrinv_apply(xp, x) - se3_jrinv_apply(xn, x));
-    if (i < 3) {
-      D.A.m[0 + i] = col.w.x; D.A.m[3 + i] = col.w.y; D.A.m[6 + i] = col.w.z;
-      D.C.m[0 + i] = col.v.x; D.C.m[3 + i] = col.v.y; D.C.m[6 + i] = col.v.z;
-    } else {
-      // a rho perturbation does not change Jw: the top half of the column is exactly zero
-      D.D.m[0 + (i - 3)] = col.v.x; D.D.m[3 + (i - 3)] = col.v.y; D.D.m[6 + (i - 3)] = col.v.z;
-    }
-  }
-  return D;
+  // (round 6: one function for every caller -- the rotational columns as described, the translational ones in closed form)
+  return se3_jrinv_times_x_fd_k(jr_coefs(xi.w), xi, x);
 }
 
 // ---- world-frame velocity parameterisation: the *Pose3VW factor family (GaussianProcessPriorPose3VW.h,

@@ -142,6 +142,48 @@ template <int MF> __device__ __forceinline__ void load_state_upd(const double *p
     }
   }
 }
+// states i and i + 1 of a two-state factor the same way, every request in flight before the first one is waited for (round 6): the
+// single-state form behind a branch on the solve's flag put four dependent memory round trips in front of K1's arithmetic -- state,
+// flag, update, and the same again for the right state -- 11 of a K1 wave's 33 us (scripts/trace_klin.py)
+template <int MF> __device__ __forceinline__ void load_two_states_upd(const double *pose, const double *vel, int stride, int i, const PendUpd &u,
+                                                                      bool own1, bool own2, double *p1, double *v1, double *p2, double *v2) {
+  constexpr int d = MTraits<MF>::d, pd = MTraits<MF>::pd, b = 2 * d;
+#pragma unroll
+  for (int k = 0; k < pd; k++) { p1[k] = pose[(size_t)k * stride + i]; p2[k] = pose[(size_t)k * stride + i + 1]; }
+#pragma unroll
+  for (int k = 0; k < d; k++) { v1[k] = vel[(size_t)k * stride + i]; v2[k] = vel[(size_t)k * stride + i + 1]; }
+  if (u.dx != nullptr) {
+    const int bad = *u.flag;
+    double dl1[b], dl2[b];
+#pragma unroll
+    for (int k = 0; k < b; k++) { dl1[k] = u.dx[(size_t)i * b + k]; dl2[k] = u.dx[(size_t)(i + 1) * b + k]; }
+    if (!bad) {
+      double q[pd];
+      PoseFactors<double, MF, false>::retract(p1, dl1, u.chart, q);
+#pragma unroll
+      for (int k = 0; k < pd; k++) p1[k] = q[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) v1[k] += dl1[d + k];
+      PoseFactors<double, MF, false>::retract(p2, dl2, u.chart, q);
+#pragma unroll
+      for (int k = 0; k < pd; k++) p2[k] = q[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) v2[k] += dl2[d + k];
+    }
+    if (own1) {
+#pragma unroll
+      for (int k = 0; k < pd; k++) u.pose_w[(size_t)k * stride + i] = p1[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) u.vel_w[(size_t)k * stride + i] = v1[k];
+    }
+    if (own2) {
+#pragma unroll
+      for (int k = 0; k < pd; k++) u.pose_w[(size_t)k * stride + i + 1] = p2[k];
+#pragma unroll
+      for (int k = 0; k < d; k++) u.vel_w[(size_t)k * stride + i + 1] = v2[k];
+    }
+  }
+}
 
 template <typename T> struct GpArgs {
   PendUpd pend;                // fp64 SE(3) record launches inside run_gn: the previous iteration's update, applied here
@@ -281,8 +323,16 @@ __device__ __forceinline__ void utri_times_bl6_row(const T *U, const BL6<T> &M, 
 // K1 for a chain whose GP priors reach the fused level-0 kernel as structured records (kGps* above): Log, Jr^-1, the
 // finite-difference block and J = -Jr^-1 Ad(h^-1) per factor, the whitened error -- and none of the products that turn them
 // into Jacobian columns (those moved to the consumer, where they are DPP row operations).
+#ifdef GPS_TRACE_KLIN
+// debug builds only (scripts/trace_klin.py): s_memrealtime stamps of the K1 waves -- 16 per wave, wave = f / 64
+static __device__ unsigned long long g_klin_trace[4096 * 16];
+#define KL_TR(slot) do { if (lane == 0 && (f >> 6) < 4096) g_klin_trace[(size_t)(f >> 6) * 16 + (slot)] = wall_clock64(); } while (0)
+#else
+#define KL_TR(slot) do { } while (0)
+#endif
 template <typename T>
 __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, int f, T *st, int *sr, int lane, T &err) {
+  KL_TR(0);
   T *mine = st + lane * 20;
   sr[lane] = valid ? f : -1;                 // structured records are indexed by factor, not by row
   const T *U = a.U.u;
@@ -297,8 +347,7 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
     dt = a.dt[f];
     if constexpr (std::is_same<T, double>::value) {
       // (with an update pending this thread owns state i, and the chain's last state if that is its right one)
-      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, true, p1, v1);
-      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i + 1, a.pend, i + 1 == a.pend.last, p2, v2);
+      load_two_states_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, true, i + 1 == a.pend.last, p1, v1, p2, v2);
     } else {
 #pragma unroll
       for (int k = 0; k < 12; k++) { p1[k] = T(a.pose[(size_t)k * a.stride + i]); p2[k] = T(a.pose[(size_t)k * a.stride + i + 1]); }
@@ -306,8 +355,13 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
       for (int k = 0; k < 6; k++) { v1[k] = a.vel[(size_t)k * a.stride + i]; v2[k] = a.vel[(size_t)k * a.stride + i + 1]; }
     }
   }
+  KL_TR(1);
   const SE3<T> h = se3_between(as_se3(p1), as_se3(p2));
   const V6<T> r = se3_log(h);                 // GaussianProcessPriorPose3.h:72
+#ifdef GPS_TRACE_KLIN
+  { V6<T> rr_ = r; pin(rr_); }
+  KL_TR(2);
+#endif
   const JrK<T> k0 = jr_coefs(r.w);
   const BL6<T> Jinv = se3_jrinv_k(k0, r);     // :76
   const V6<T> u1 = as_v6(v1), u2 = as_v6(v2);
@@ -333,7 +387,9 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
       mine[6 + rho] = wb;
     }
     mine[12] = -(sa * dt + sb); mine[13] = sb; mine[14] = sc; mine[15] = sa;
+    KL_TR(3);
     wave_store_part<T, kGpsLen, 16, 20, true>(st, sr, lane, 0, kGpsE, a.gps);
+    KL_TR(4);
   }
   // the matrix blocks in record order, 16 doubles (one 128-byte line) staged per lane at a time
   auto put = [&](int idx, T v) {              // (idx is a compile-time constant once the loops below are unrolled)
@@ -354,10 +410,15 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
 #pragma unroll
     for (int k = 0; k < 9; k++) put(kGpsJC + k, JC.m[k]);
   }
+  KL_TR(5);
   {   // last, with nothing but r, the coefficients and v2 alive next to it: the twelve evaluations of the difference quotient
     // (the factor's error sum waits in a spare staging slot of the lane: across this block it was what the allocator spilled)
     mine[16] = err;
-    const BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90)
+    BL6<T> FD = se3_jrinv_times_x_fd_k(k0, r, u2);   // (:81, :90)
+#ifdef GPS_TRACE_KLIN
+    pin(FD.A); pin(FD.C); pin(FD.D);
+    KL_TR(6);
+#endif
 #pragma unroll
     for (int k = 0; k < 9; k++) put(kGpsFA + k, FD.A.m[k]);
 #pragma unroll
@@ -367,6 +428,7 @@ __device__ __forceinline__ void gp_pose3_record(const GpArgs<T> &a, bool valid, 
     put(kGpsZ, T(0));
     err = mine[16];
   }
+  KL_TR(7);
 }
 
 template <typename T, bool VW>
@@ -504,8 +566,7 @@ __device__ __forceinline__ void gp_block(const GpArgs<T> &a, const int bid, T *s
       // the d = 3 record launches inside run_gn: the states as the pending update leaves them (PendUpd; nothing pending: as stored);
       // this factor owns its left state, the last factor the chain's last state as well
       double q1[pd], q2[pd], w1[d], w2[d];
-      load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, true, q1, w1);
-      load_state_upd<MF>(a.pose, a.vel, a.stride, i + 1, a.pend, i + 1 == a.pend.last, q2, w2);
+      load_two_states_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, true, i + 1 == a.pend.last, q1, w1, q2, w2);
 #pragma unroll
       for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
 #pragma unroll
@@ -713,8 +774,8 @@ __device__ __forceinline__ void between_pose3_record(const FacArgs<T> &a, const 
     const int i = a.idx[f];
     if constexpr (std::is_same<T, double>::value) {
       double vv[6];
-      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, false, x1, vv);
-      load_state_upd<POSE3>(a.pose, a.vel, a.stride, i + 1, a.pend, false, x2, vv);
+      double vv2[6];
+      load_two_states_upd<POSE3>(a.pose, a.vel, a.stride, i, a.pend, false, false, x1, vv, x2, vv2);
 #pragma unroll
       for (int k = 0; k < 12; k++) m[k] = T(a.meas[(size_t)f * 12 + k]);
     } else {
@@ -983,8 +1044,7 @@ __global__ void __launch_bounds__(128) k_meas(MeasArgs<T> a) {
       constexpr bool PEND = JAC && IsF64<T>::v && two && (MF == POSE2 || MF == ROT3 || MF == LINEAR3);
       if constexpr (PEND) {
         double q1[pd], q2[pd], w1[d], w2[d];
-        load_state_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, false, q1, w1);
-        load_state_upd<MF>(a.pose, a.vel, a.stride, i + 1, a.pend, false, q2, w2);
+        load_two_states_upd<MF>(a.pose, a.vel, a.stride, i, a.pend, false, false, q1, w1, q2, w2);
 #pragma unroll
         for (int k = 0; k < pd; k++) { p1[k] = T(q1[k]); p2[k] = T(q2[k]); }
 #pragma unroll
