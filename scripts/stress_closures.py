@@ -37,9 +37,13 @@ for t in range(cnt):
     csig = 0.01 + 0.05 * rng.random((K, d))
     Qc = np.diag(0.01 + 0.02 * rng.random(d))
     solvers = []
-    for make in (lambda: O.Chain(kind, chart), lambda: gpslam_amd.ChainSolver(kind, chart)):
+    # (the third solver is the oracle's twin, started 1e-15 away: what rounding alone does to this graph in two Gauss-Newton steps from
+    #  a start whose cost is five orders of magnitude above the optimum -- seed 205, 80 cases: an SE(3) chain of 2340 states whose first
+    #  step takes 3.8e7 to 1.7e5 and whose two ORACLES then differ by 1.4e-9 of that)
+    pose_twin = c["pose"] * (1.0 + 1e-15 * np.random.default_rng(t).standard_normal(c["pose"].shape))
+    for make, pose0 in ((lambda: O.Chain(kind, chart), c["pose"]), (lambda: gpslam_amd.ChainSolver(kind, chart), c["pose"]), (lambda: O.Chain(kind, chart), pose_twin)):
         s = make()
-        s.set_qc(Qc); s.set_states(c["pose"], c["vel"])
+        s.set_qc(Qc); s.set_states(pose0, c["vel"])
         s.add_gp_priors(np.arange(N - 1), c["dt"])
         fix = np.arange(0, N, 20)
         s.add_pose_priors(fix, c["truth_pose"][fix], np.full((len(fix), d), 0.01))
@@ -51,16 +55,18 @@ for t in range(cnt):
         s.add_between_pairs(first, second, cmeas, csig)
         s.compile()
         solvers.append(s)
-    orc, dev = solvers
+    orc, dev, twin = solvers
     assert dev.plan_info()["R"] == 1 + K * d
     e0, e1 = orc.error(), dev.error()
     assert abs(e0 - e1) <= 1e-10 * max(1.0, e0), (kind, N, K, e0, e1)
     for it in range(2):
-        (rc0, s0), (rc1, s1) = orc.iterate_gn(), dev.iterate_gn()
-        assert rc0 == 0 and rc1 == 0
-        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after), (kind, N, K, it, s0.error_after, s1.error_after)
-        (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
-        T.states_close(kind, x0, v0, x1, v1, 1e-9)
+        (rc0, s0), (rc1, s1), (rc2, s2) = orc.iterate_gn(), dev.iterate_gn(), twin.iterate_gn()
+        assert rc0 == 0 and rc1 == 0 and rc2 == 0
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after) + 10 * abs(s0.error_after - s2.error_after), (kind, N, K, it, s0.error_after, s1.error_after, s2.error_after)
+        (x0, v0), (x1, v1), (x2, v2) = orc.get_states(), dev.get_states(), twin.get_states()
+        noise = max(np.abs(x0 - x2).max() / max(1.0, np.abs(x0).max()), np.abs(v0 - v2).max() / max(1.0, np.abs(v0).max()))
+        T.states_close(kind, x0, v0, x1, v1, 1e-9 + 10 * noise)
+    solvers = [orc, dev]
     for s_ in solvers:
         s_.set_states(c["pose"], c["vel"])
     lam, n_noise, slack = L.run(orc, dev, 1e-2, 5, tag=(kind, N, K))
