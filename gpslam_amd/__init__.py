@@ -6,8 +6,8 @@ for gfx950); importing this package never falls back to a CPU implementation.
 """
 from .chain import (ChainSolver, GpslamHipError, LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS, CHART_EXPMAP,
                     CHART_FIRST_ORDER, FP32, FP64, POSE_DIM, TANGENT_DIM, Params, Stats, load_library, PLAN_UNFUSED_LEVEL0,
-                    PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS, PLAN_GENERIC_QC, PLAN_MEAS_ROWS, PLAN_SEPARATE_RETRACT, PLAN_FS_LEVEL_LAUNCHES)
+                    PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS, PLAN_GENERIC_QC, PLAN_MEAS_ROWS, PLAN_SEPARATE_RETRACT)
 
 __all__ = ["ChainSolver", "GpslamHipError", "LINEAR2", "LINEAR3", "POSE2", "POSE3", "ROT3", "ROT3_BIAS", "CHART_EXPMAP",
            "CHART_FIRST_ORDER", "FP32", "FP64", "POSE_DIM", "TANGENT_DIM", "Params", "Stats", "load_library", "PLAN_UNFUSED_LEVEL0",
-           "PLAN_COLUMN_LEVEL0", "PLAN_LEVELS_OF_FOUR", "PLAN_FS_TWO_LAUNCHES", "PLAN_GP_ROWS", "PLAN_GENERIC_QC", "PLAN_MEAS_ROWS", "PLAN_SEPARATE_RETRACT", "PLAN_FS_LEVEL_LAUNCHES"]
+           "PLAN_COLUMN_LEVEL0", "PLAN_LEVELS_OF_FOUR", "PLAN_FS_TWO_LAUNCHES", "PLAN_GP_ROWS", "PLAN_GENERIC_QC", "PLAN_MEAS_ROWS", "PLAN_SEPARATE_RETRACT"]

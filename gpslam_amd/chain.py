@@ -14,7 +14,7 @@ LINEAR2, LINEAR3, POSE2, POSE3, ROT3, ROT3_BIAS = 0, 1, 2, 3, 4, 5
 CHART_EXPMAP, CHART_FIRST_ORDER = 0, 1
 FP64, FP32 = 0, 1
 # gpslam_hip_config_v2.plan: kernel families compile() is told to use instead of its default choice (include/gpslam_hip.h)
-PLAN_UNFUSED_LEVEL0, PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS, PLAN_GENERIC_QC, PLAN_MEAS_ROWS, PLAN_SEPARATE_RETRACT, PLAN_FS_LEVEL_LAUNCHES = 1, 2, 4, 8, 16, 32, 64, 128, 256
+PLAN_UNFUSED_LEVEL0, PLAN_COLUMN_LEVEL0, PLAN_LEVELS_OF_FOUR, PLAN_FS_TWO_LAUNCHES, PLAN_GP_ROWS, PLAN_GENERIC_QC, PLAN_MEAS_ROWS, PLAN_SEPARATE_RETRACT = 1, 2, 4, 8, 16, 32, 64, 128
 # Test harness hook of this PYTHON mirror (the library itself reads no environment): plan bits OR-ed into every ChainSolver a
 # process creates, so that tests/test_gpu_switches.py can re-run whole parity suites on the fallback kernel families.
 _DEFAULT_PLAN = int(os.environ.get("GPSLAM_PY_DEFAULT_PLAN", "0"))

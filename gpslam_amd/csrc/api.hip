@@ -105,7 +105,7 @@ int gpslam_hip_create_v2(const gpslam_hip_config_v2 *in, gpslam_hip_handle **out
   if (cfg->landmark_dim != 0 && cfg->landmark_dim != 2 && cfg->landmark_dim != 3) return GPSLAM_E_INVALID;
   if (cfg->nranks < 0 || (cfg->nranks > 1 && (cfg->rank < 0 || cfg->rank >= cfg->nranks))) return GPSLAM_E_INVALID;
   if (cfg->velocity != 0 && (cfg->velocity != GPSLAM_VELOCITY_WORLD_VW || cfg->manifold != GPSLAM_POSE3)) return GPSLAM_E_INVALID;
-  constexpr int kPlanBits = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_COLUMN_LEVEL0 | GPSLAM_PLAN_LEVELS_OF_FOUR | GPSLAM_PLAN_FS_TWO_LAUNCHES | GPSLAM_PLAN_GP_ROWS | GPSLAM_PLAN_GENERIC_QC | GPSLAM_PLAN_MEAS_ROWS | GPSLAM_PLAN_SEPARATE_RETRACT | GPSLAM_PLAN_FS_LEVEL_LAUNCHES;
+  constexpr int kPlanBits = GPSLAM_PLAN_UNFUSED_LEVEL0 | GPSLAM_PLAN_COLUMN_LEVEL0 | GPSLAM_PLAN_LEVELS_OF_FOUR | GPSLAM_PLAN_FS_TWO_LAUNCHES | GPSLAM_PLAN_GP_ROWS | GPSLAM_PLAN_GENERIC_QC | GPSLAM_PLAN_MEAS_ROWS | GPSLAM_PLAN_SEPARATE_RETRACT;
   if ((cfg->plan & ~kPlanBits) != 0) return GPSLAM_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return GPSLAM_E_HIP;  // no GPU: fail loudly

@@ -23,10 +23,3 @@ extern "C" int gpslam_hip_debug_klin_trace(unsigned long long *out) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(gps::g_klin_trace), sizeof(gps::g_klin_trace)) == hipSuccess ? 0 : -2;
 }
 #endif
-
-#ifdef GPS_TRACE_TAIL
-extern "C" int gpslam_hip_debug_tail_trace(unsigned long long *out) {
-  if (hipDeviceSynchronize() != hipSuccess) return -2;
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(gps::g_tail_trace), sizeof(gps::g_tail_trace)) == hipSuccess ? 0 : -2;
-}
-#endif

@@ -1423,83 +1423,30 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
 // Every wave factors the block redundantly (they run on different SIMDs) and carries its own 64 - NBP columns of X, so the
 // waves never meet before the products.  Those -- P^T P, Q^T Q, Q^T P, P^T z, Q^T z, all of them blocks of X'^T X' with
 // X' = L^-1 X -- are 16 x 16 tiles on v_mfma_f64_16x16x4_f64 over the rows X'^T left in LDS.
-// COH (the persistent tail): every access to data another workgroup of the SAME launch writes or reads goes past the caches that
-// are not coherent across XCDs -- relaxed agent-scope atomic loads / stores (global_load / global_store ... sc1), the accesses
-// a flag is polled with.  An agent-scope release / acquire pair instead costs an L2 write-back and an L2 invalidate per task
-// (measured: the tail at 416 us where its level launches take 320).
-template <bool COH, typename T> __device__ __forceinline__ T fat_ld(const T *p) {
-  if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else return *p;
-}
-template <bool COH, typename T> __device__ __forceinline__ void fat_st(T *p, T v) {
-  if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else *p = v;
-}
-// uml / umr (the persistent tail, k_fat_tail_rows below): the blocks eliminated on the left / right of m at the PREVIOUS level whose
-// Schur complements m has not taken yet -- D_m - S2[uml] - S1[umr], g_m - sv[uml][NB ..] - sv[umr][.. NB], the very subtractions
-// of k_fat_update in its order, made on the way into the registers (-1: nothing pending).
-template <int NBP> struct FatRowsLds {
-  static constexpr int KS = NBP + 1;                         // LDS row stride of X'^T (odd: operand loads spread over the banks)
-  static constexpr int CTM = (2 * NBP + 1 + 15) / 16;        // 16-column panels of X at the largest NB this instantiation serves
-  static constexpr int N = 16 * CTM * KS;
-  static constexpr int SS = NBP + 1;                          // the persistent tail's staged matrices: row stride ...
-  static constexpr int STAGE = 4 * NBP * SS + 3 * NBP;        // ... and area: [D | H(m,l) | H(r,m)] + g + L in, [S1 | S2 | H(r,l)] + sv out
-};
-template <int NBP, typename TR, bool COH = false>
-__device__ __forceinline__ void fat_elim_rows_body(const FsArgs<double, TR> &a, double *PT, double *ST, int m, int r, int lk_lm, int lk_mr, int lk_new, int uml, int umr) {
+template <int NBP, typename TR = double>
+__global__ void __launch_bounds__(NBP <= 40 ? 256 : 512) k_fat_elim_rows(FsArgs<double, TR> a, FatLevel lv) {
   constexpr int NBL = 64 - NBP;                       // rows of X^T per wave
-  constexpr int KS = FatRowsLds<NBP>::KS, CTM = FatRowsLds<NBP>::CTM;
-  constexpr int SS = FatRowsLds<NBP>::SS, SM = NBP * SS;      // (COH) staged matrices: row stride, size
+  constexpr int KS = NBP + 1;                         // LDS row stride of X'^T (odd: operand loads spread over the banks)
+  constexpr int CTM = (2 * NBP + 1 + 15) / 16;        // 16-column panels of X at the largest NB this instantiation serves
+  __shared__ double PT[16 * CTM * KS];
   const int NB = a.NB, NB2 = NB * NB, NX = 2 * NB + 1;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, nw = blockDim.x >> 6;
   const bool isA = lane < NBP;
   const int c = wv * NBL + (lane - NBP);              // column of X of a lane behind the block rows
-  double av[NBP];
+  // ---- loads: one row per lane, element k at base[min(k, NB - 1) * stride]
+  const double *base = a.Dfat + (size_t)m * NB2;      // (a valid address for the lanes that hold padding)
+  int stride = 0;
   bool valid = false;
-  if constexpr (COH) {
-    // ---- the persistent tail: operands past the caches, so every request is a memory transaction of its own -- whole lines by
-    // consecutive threads into LDS (the pending update subtracted on the way: k_fat_update's subtractions in its order), rows from there
-    double *Ds = ST, *Hl = ST + SM, *Hr = ST + 2 * SM, *gs = ST + 3 * SM;
-    const double *Dg = a.Dfat + (size_t)m * NB2, *Hlg = a.link + (size_t)lk_lm * NB2, *Hrg = a.link + (size_t)max(lk_mr, 0) * NB2;
-    const double *S2g = a.S2 + (size_t)max(uml, 0) * NB2, *S1g = a.S1 + (size_t)max(umr, 0) * NB2;
-    for (int idx = tid; idx < NB2; idx += blockDim.x) {
-      const int i = idx / NB, j = idx - i * NB;
-      double d = fat_ld<true>(Dg + idx);
-      const double hl = fat_ld<true>(Hlg + idx), hr = (r >= 0) ? fat_ld<true>(Hrg + idx) : 0.0;
-      const double s2 = (uml >= 0) ? fat_ld<true>(S2g + idx) : 0.0, s1 = (umr >= 0) ? fat_ld<true>(S1g + idx) : 0.0;
-      d = d - s2;
-      d = d - s1;
-      Ds[i * SS + j] = d; Hl[i * SS + j] = hl; Hr[i * SS + j] = hr;
-    }
-    for (int i = tid; i < NB; i += blockDim.x) {
-      double g = fat_ld<true>(a.gfat + (size_t)m * NB + i);
-      const double s2 = (uml >= 0) ? fat_ld<true>(a.sv + (size_t)uml * 2 * NB + NB + i) : 0.0, s1 = (umr >= 0) ? fat_ld<true>(a.sv + (size_t)umr * 2 * NB + i) : 0.0;
-      g = g - s2;
-      g = g - s1;
-      gs[i] = g;
-    }
-    __syncthreads();
-    const double *bs = Ds;
-    int stride = 0;
-    if (isA) {
-      if (lane < NB) { bs = Ds + lane * SS; stride = 1; valid = true; }
-    } else if (c < NB) { bs = Hl + c; stride = SS; valid = true; }
-    else if (c < 2 * NB) { if (r >= 0) { bs = Hr + (c - NB) * SS; stride = 1; valid = true; } }
-    else if (c == 2 * NB) { bs = gs; stride = 1; valid = true; }
+  if (isA) {
+    if (lane < NB) { base = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB; stride = 1; valid = true; }
+  } else if (c < NB) { base = a.link + (size_t)lk_lm * NB2 + c; stride = NB; valid = true; }                       // H[m, l][k][c]
+  else if (c < 2 * NB) { if (r >= 0) { base = a.link + (size_t)lk_mr * NB2 + (size_t)(c - NB) * NB; stride = 1; valid = true; } }   // H[r, m][c - NB][k]
+  else if (c == 2 * NB) { base = a.gfat + (size_t)m * NB; stride = 1; valid = true; }
+  double av[NBP];
 #pragma unroll
-    for (int k = 0; k < NBP; k++) av[k] = bs[min(k, NB - 1) * stride];
-  } else {
-    // ---- loads: one row per lane, element k at base[min(k, NB - 1) * stride]
-    const double *base = a.Dfat + (size_t)m * NB2;      // (a valid address for the lanes that hold padding)
-    int stride = 0;
-    if (isA) {
-      if (lane < NB) { base = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB; stride = 1; valid = true; }
-    } else if (c < NB) { base = a.link + (size_t)lk_lm * NB2 + c; stride = NB; valid = true; }                       // H[m, l][k][c]
-    else if (c < 2 * NB) { if (r >= 0) { base = a.link + (size_t)lk_mr * NB2 + (size_t)(c - NB) * NB; stride = 1; valid = true; } }   // H[r, m][c - NB][k]
-    else if (c == 2 * NB) { base = a.gfat + (size_t)m * NB; stride = 1; valid = true; }
-#pragma unroll
-    for (int k = 0; k < NBP; k++) av[k] = base[(size_t)min(k, NB - 1) * stride];
-  }
+  for (int k = 0; k < NBP; k++) av[k] = base[(size_t)min(k, NB - 1) * stride];
 #pragma unroll
   for (int k = 0; k < NBP; k++) {
     const double pad = (isA && lane == k) ? 1.0 : 0.0;
@@ -1523,17 +1470,11 @@ __device__ __forceinline__ void fat_elim_rows_body(const FsArgs<double, TR> &a, 
   });
   if (bad && tid == 0) *a.flag = 1;
   // ---- results: L (wave 0), P / Q / z (the lanes that own the columns), X'^T rows to LDS for the products
-  double *Ls = ST + 3 * SM + NBP;                     // (COH) the factor, staged for whole-line stores
   if (isA) {
     if (wv == 0 && lane < NB) {
-      if constexpr (COH) {
+      double *dp = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB;
 #pragma unroll
-        for (int k = 0; k < NBP; k++) if (k < NB) Ls[lane * SS + k] = (k <= lane) ? av[k] : 0.0;
-      } else {
-        double *dp = a.Dfat + (size_t)m * NB2 + (size_t)lane * NB;
-#pragma unroll
-        for (int k = 0; k < NBP; k++) if (k < NB) dp[k] = (k <= lane) ? av[k] : 0.0;
-      }
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[k] = (k <= lane) ? av[k] : 0.0;
     }
   } else {
     if (c < 16 * CTM) {
@@ -1541,29 +1482,21 @@ __device__ __forceinline__ void fat_elim_rows_body(const FsArgs<double, TR> &a, 
       for (int k = 0; k < NBP; k++) PT[c * KS + k] = av[k];
     }
     if (c < NB) {
-      double *dp = a.link + (size_t)lk_lm * NB2 + c;                                  // P (consecutive lanes, consecutive addresses)
+      double *dp = a.link + (size_t)lk_lm * NB2 + c;                                  // P
 #pragma unroll
-      for (int k = 0; k < NBP; k++) if (k < NB) fat_st<COH>(dp + (size_t)k * NB, av[k]);
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[(size_t)k * NB] = av[k];
     } else if (c < 2 * NB) {
       double *dp = a.Qbuf + (size_t)m * NB2 + (c - NB);                               // Q
 #pragma unroll
-      for (int k = 0; k < NBP; k++) if (k < NB) fat_st<COH>(dp + (size_t)k * NB, av[k]);
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[(size_t)k * NB] = av[k];
     } else if (c == 2 * NB) {
       double *dp = a.gfat + (size_t)m * NB;                                           // z
 #pragma unroll
-      for (int k = 0; k < NBP; k++) if (k < NB) fat_st<COH>(dp + k, av[k]);
+      for (int k = 0; k < NBP; k++) if (k < NB) dp[k] = av[k];
     }
   }
   __syncthreads();
-  if constexpr (COH) {
-    double *Dg = a.Dfat + (size_t)m * NB2;
-    for (int idx = tid; idx < NB2; idx += blockDim.x) {
-      const int i = idx / NB, j = idx - i * NB;
-      fat_st<true>(Dg + idx, Ls[i * SS + j]);
-    }
-  }
   // ---- products: tile (ti, tj), tj <= ti, of X'^T X' (rows / columns = columns of X: P | Q | z)
-  double *S1s = ST, *S2s = ST + SM, *Lns = ST + 2 * SM, *svs = ST + 4 * SM + NBP;   // (COH: the operands' staging area is free again; sv behind L, which is still being stored)
   const int CT = (NX + 15) / 16, ntiles = CT * (CT + 1) / 2;
   const int kl = lane >> 4, cl = lane & 15;
   for (int p = wv; p < ntiles; p += nw) {
@@ -1579,74 +1512,49 @@ __device__ __forceinline__ void fat_elim_rows_body(const FsArgs<double, TR> &a, 
       const int ci = ti * 16 + kl + 4 * rg, cj = tj * 16 + cl;      // entry (ci, cj) of X'^T X'
       const double v = acc[rg];
       if (ci >= NX || cj > ci) continue;                            // padding; the upper half of a diagonal tile
-      if constexpr (COH) {
-        if (ci < NB) { S1s[ci * SS + cj] = v; S1s[cj * SS + ci] = v; }
-        else if (ci < 2 * NB) {
-          if (cj < NB) Lns[(ci - NB) * SS + cj] = -v;
-          else { S2s[(ci - NB) * SS + (cj - NB)] = v; S2s[(cj - NB) * SS + (ci - NB)] = v; }
-        } else if (cj < 2 * NB) svs[cj] = v;
-      } else {
-        if (ci < NB) {                                                // P^T P (cj < NB as well)
-          a.S1[(size_t)m * NB2 + (size_t)ci * NB + cj] = v;
-          a.S1[(size_t)m * NB2 + (size_t)cj * NB + ci] = v;
-        } else if (ci < 2 * NB) {
-          if (cj < NB) { if (r >= 0) a.link[(size_t)lk_new * NB2 + (size_t)(ci - NB) * NB + cj] = -v; }   // H[r, l] = -(Q^T P)
-          else {                                                      // Q^T Q
-            a.S2[(size_t)m * NB2 + (size_t)(ci - NB) * NB + (cj - NB)] = v;
-            a.S2[(size_t)m * NB2 + (size_t)(cj - NB) * NB + (ci - NB)] = v;
-          }
-        } else if (cj < 2 * NB) {                                     // ci == 2 NB: P^T z | Q^T z
-          a.sv[(size_t)m * 2 * NB + cj] = v;
+      if (ci < NB) {                                                // P^T P (cj < NB as well)
+        a.S1[(size_t)m * NB2 + (size_t)ci * NB + cj] = v;
+        a.S1[(size_t)m * NB2 + (size_t)cj * NB + ci] = v;
+      } else if (ci < 2 * NB) {
+        if (cj < NB) { if (r >= 0) a.link[(size_t)lk_new * NB2 + (size_t)(ci - NB) * NB + cj] = -v; }   // H[r, l] = -(Q^T P)
+        else {                                                      // Q^T Q
+          a.S2[(size_t)m * NB2 + (size_t)(ci - NB) * NB + (cj - NB)] = v;
+          a.S2[(size_t)m * NB2 + (size_t)(cj - NB) * NB + (ci - NB)] = v;
         }
+      } else if (cj < 2 * NB) {                                     // ci == 2 NB: P^T z | Q^T z
+        a.sv[(size_t)m * 2 * NB + cj] = v;
       }
     }
   }
-  if constexpr (COH) {
-    __syncthreads();
-    double *S1g = a.S1 + (size_t)m * NB2, *S2g = a.S2 + (size_t)m * NB2, *Lng = a.link + (size_t)max(lk_new, 0) * NB2;
-    for (int idx = tid; idx < NB2; idx += blockDim.x) {
-      const int i = idx / NB, j = idx - i * NB;
-      fat_st<true>(S1g + idx, S1s[i * SS + j]);
-      fat_st<true>(S2g + idx, S2s[i * SS + j]);
-      if (r >= 0) fat_st<true>(Lng + idx, Lns[i * SS + j]);
-    }
-    for (int i = tid; i < 2 * NB; i += blockDim.x) fat_st<true>(a.sv + (size_t)m * 2 * NB + i, svs[i]);
-  }
-}
-template <int NBP, typename TR = double>
-__global__ void __launch_bounds__(NBP <= 40 ? 256 : 512) k_fat_elim_rows(FsArgs<double, TR> a, FatLevel lv) {
-  __shared__ double PT[FatRowsLds<NBP>::N];
-  const int *e = lv.elim + 6 * blockIdx.x;
-  fat_elim_rows_body<NBP, TR>(a, PT, nullptr, e[0], e[2], e[3], e[4], e[5], -1, -1);
 }
 
-// blk: a survivor; ml: eliminated block whose RIGHT neighbour it is; mr: ... LEFT ...
-template <typename T, typename TR, bool COH = false> __device__ __forceinline__ void fat_update_body(const FsArgs<T, TR> &a, int blk, int ml, int mr) {
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T, TR> a, FatLevel lv) {
   const int NB = a.NB, NB2 = NB * NB;
+  const int *u = lv.upd + 3 * blockIdx.x;
+  const int blk = u[0], ml = u[1], mr = u[2];     // ml: eliminated block whose RIGHT neighbour this is; mr: ... LEFT ...
   for (int idx = threadIdx.x; idx < NB2; idx += blockDim.x) {
-    T v = fat_ld<COH>(a.Dfat + (size_t)blk * NB2 + idx);
-    if (ml >= 0) v -= fat_ld<COH>(a.S2 + (size_t)ml * NB2 + idx);
-    if (mr >= 0) v -= fat_ld<COH>(a.S1 + (size_t)mr * NB2 + idx);
-    fat_st<COH>(a.Dfat + (size_t)blk * NB2 + idx, v);
+    T v = a.Dfat[(size_t)blk * NB2 + idx];
+    if (ml >= 0) v -= a.S2[(size_t)ml * NB2 + idx];
+    if (mr >= 0) v -= a.S1[(size_t)mr * NB2 + idx];
+    a.Dfat[(size_t)blk * NB2 + idx] = v;
   }
   for (int i = threadIdx.x; i < NB; i += blockDim.x) {
-    T v = fat_ld<COH>(a.gfat + (size_t)blk * NB + i);
-    if (ml >= 0) v -= fat_ld<COH>(a.sv + (size_t)ml * 2 * NB + NB + i);
-    if (mr >= 0) v -= fat_ld<COH>(a.sv + (size_t)mr * 2 * NB + i);
-    fat_st<COH>(a.gfat + (size_t)blk * NB + i, v);
+    T v = a.gfat[(size_t)blk * NB + i];
+    if (ml >= 0) v -= a.sv[(size_t)ml * 2 * NB + NB + i];
+    if (mr >= 0) v -= a.sv[(size_t)mr * 2 * NB + i];
+    a.gfat[(size_t)blk * NB + i] = v;
   }
 }
-template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_update(FsArgs<T, TR> a, FatLevel lv) {
-  const int *u = lv.upd + 3 * blockIdx.x;
-  fat_update_body<T, TR>(a, u[0], u[1], u[2]);
-}
 
-// the last active block: dense Cholesky solve (Lm: NB (NB + 1) + NB values of LDS, Ld: (kFatMax / 4) * 10)
-template <typename T, typename TR, bool COH = false> __device__ __forceinline__ void fat_top_body(const FsArgs<T, TR> &a, int top, T *Lm, T *Ld) {
+// the last active block: dense Cholesky solve
+template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T, TR> a, int top) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
   const int NB = a.NB, LS = NB + 1;
+  T *Lm = reinterpret_cast<T *>(fat_smem);
   T *y = Lm + NB * LS;
-  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lm[(idx / NB) * LS + idx % NB] = fat_ld<COH>(a.Dfat + (size_t)top * NB * NB + idx);
-  for (int i = threadIdx.x; i < NB; i += blockDim.x) y[i] = fat_ld<COH>(a.gfat + (size_t)top * NB + i);
+  __shared__ T Ld[(kFatMax / 4) * 10];
+  for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) Lm[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)top * NB * NB + idx];
+  for (int i = threadIdx.x; i < NB; i += blockDim.x) y[i] = a.gfat[(size_t)top * NB + i];
   __syncthreads();
   fat_factor_panel4(Lm, y, Ld, NB, LS, 1, 1, a.flag);          // y <- L^-1 g
   if (threadIdx.x < 64) {                                        // x = L^-T y, right-looking, one wave
@@ -1657,13 +1565,8 @@ template <typename T, typename TR, bool COH = false> __device__ __forceinline__ 
       for (int k = lane; k < i; k += 64) y[k] -= fat_l_entry(Lm, Ld, LS, i, k) * xi;
       fs_wave_sync();
     }
-    for (int i = lane; i < NB; i += 64) fat_st<COH>(a.xfat + (size_t)top * NB + i, y[i]);
+    for (int i = lane; i < NB; i += 64) a.xfat[(size_t)top * NB + i] = y[i];
   }
-}
-template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_top(FsArgs<T, TR> a, int top) {
-  extern __shared__ __align__(16) unsigned char fat_smem[];
-  __shared__ T Ld[(kFatMax / 4) * 10];
-  fat_top_body<T, TR>(a, top, reinterpret_cast<T *>(fat_smem), Ld);
 }
 
 // x_m = L^-T (z - P x_l - Q x_r)
@@ -1701,23 +1604,25 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_f
 // (L[i][k] for all i: coalesced loads) and entry k of t = z - P x_l - Q x_r; step i broadcasts x_i = t_i / L_ii from lane i
 // (v_readlane) and every lane k < i takes L[i][k] x_i off its entry.  k_fat_back above spends 12-13 us per block (one wave,
 // 2 NB wave-level syncs around LDS round trips); this is one dependent multiply-add + broadcast per step.
-template <int NBP, typename TR, bool COH = false> __device__ __forceinline__ void fat_back_rows_body(const FsArgs<double, TR> &a, int m, int l, int r, int lk_lm) {
+template <int NBP, typename TR = double> __global__ void __launch_bounds__(64) k_fat_back_rows(FsArgs<double, TR> a, FatLevel lv) {
   const int NB = a.NB, NB2 = NB * NB, lane = threadIdx.x;
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], l = e[1], r = e[2], lk_lm = e[3];
   const int kc = min(lane, NB - 1);
   const bool on = lane < NB;
   double Lc[NBP];                                   // column `lane` of L
   const double *dp = a.Dfat + (size_t)m * NB2 + kc;
 #pragma unroll
-  for (int i = 0; i < NBP; i++) Lc[i] = fat_ld<COH>(dp + (size_t)min(i, NB - 1) * NB);
+  for (int i = 0; i < NBP; i++) Lc[i] = dp[(size_t)min(i, NB - 1) * NB];
   // t = z - P x_l - Q x_r: row `lane` of P and Q against the neighbours' solutions, broadcast entry by entry
-  const double xl = fat_ld<COH>(a.xfat + (size_t)l * NB + kc), xr = (r >= 0) ? fat_ld<COH>(a.xfat + (size_t)r * NB + kc) : 0.0;
-  double t = fat_ld<COH>(a.gfat + (size_t)m * NB + kc);
+  const double xl = a.xfat[(size_t)l * NB + kc], xr = (r >= 0) ? a.xfat[(size_t)r * NB + kc] : 0.0;
+  double t = a.gfat[(size_t)m * NB + kc];
   const double *P = a.link + (size_t)lk_lm * NB2 + (size_t)kc * NB, *Q = a.Qbuf + (size_t)m * NB2 + (size_t)kc * NB;
   static_for<0, NBP / 8>([&](auto cc) {             // eight columns at a time (all of P and Q at once would not fit the registers)
     constexpr int j0 = 8 * decltype(cc)::value;
     double pr[8], qr[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) { pr[j] = fat_ld<COH>(P + min(j0 + j, NB - 1)); qr[j] = fat_ld<COH>(Q + min(j0 + j, NB - 1)); }
+    for (int j = 0; j < 8; j++) { pr[j] = P[min(j0 + j, NB - 1)]; qr[j] = Q[min(j0 + j, NB - 1)]; }
     static_for<0, 8>([&](auto jj) {
       constexpr int j = j0 + decltype(jj)::value;
       if (j < NB) {                                 // (uniform)
@@ -1738,92 +1643,7 @@ template <int NBP, typename TR, bool COH = false> __device__ __forceinline__ voi
       t = (lane == i) ? xi : ((lane < i) ? fma(-Lc[i], xi, t) : t);
     }
   });
-  if (on) fat_st<COH>(a.xfat + (size_t)m * NB + lane, t);
-}
-template <int NBP, typename TR = double> __global__ void __launch_bounds__(64) k_fat_back_rows(FsArgs<double, TR> a, FatLevel lv) {
-  const int *e = lv.elim + 6 * blockIdx.x;
-  fat_back_rows_body<NBP, TR>(a, e[0], e[1], e[2], e[3]);
-}
-
-// ---- round 6: the levels of the cyclic reduction that are smaller than the chip, in ONE launch.
-// Config 4's 4809 fat blocks take 13 levels; from the fifth on a level is 301, 150, 75, ... 1 workgroups, and each of them cost
-// an elimination launch (16 us whatever its size), an update launch (5 us) and, on the way back, a back-substitution launch (7 us)
-// + the idle time between dependent launches: ~0.3 ms of a 3.1 ms iteration in which the chip held a handful of workgroups.
-// Here the workgroups of the first such level stay: workgroup i runs elimination i of every later level (and back-substitution i
-// on the way back), the survivors' updates go to workgroups that have no elimination at the next level, and a task starts when
-// the tasks it depends on have published their block's event count (one 64-bit word per fat block: launch number << 6 | events
-// of the block in this launch -- never reset).  Everything a task reads or writes that another workgroup of the launch wrote or
-// will read moves by relaxed agent-scope atomic loads / stores (fat_ld / fat_st<COH>: past the caches that are not coherent across
-// XCDs); a producer waits for its stores (vmcnt), meets its workgroup at a barrier and publishes with one more such store; one
-// thread of a consumer polls (bounded: 20 ms, then the launch gives up with the handle's flag set to 2).  No fence: the
-// agent-scope release / acquire pair of the first version cost an L2 write-back and an L2 invalidate per task.  A survivor that is
-// eliminated at the very next level takes its update on the way into the registers (fat_elim_rows_body: uml / umr).  The
-// arithmetic is that of the level launches, operand for operand: results are bit-identical to GPSLAM_PLAN_FS_LEVEL_LAUNCHES.
-struct FatTask {              // 16 ints
-  int type;                   // 0 eliminate, 1 update a survivor, 2 the last block (dense solve), 3 back-substitute
-  int m, l, r, lk_lm, lk_mr, lk_new;   // as FatLevel::elim (update: m = the survivor, l = ml, r = mr; top: m)
-  int uml, umr;               // eliminate: the update m takes on the way in (-1: none)
-  int wb[3], wo[3];           // start when block wb[i] has seen its wo[i]-th event of this launch (wb[i] < 0: nothing to wait for)
-  int ord;                    // this task is event `ord` of block m
-};
-struct FatTail {
-  const FatTask *tasks;
-  const int *ofs;             // tasks of workgroup b: ofs[b] .. ofs[b + 1]
-  unsigned long long *sig;    // per fat block
-  unsigned long long epoch;   // launch number (> 0)
-};
-constexpr unsigned long long kFatTailTimeout = 2000000ull;     // s_memrealtime ticks (100 MHz): 20 ms
-constexpr int kFatTailMax = 320;                               // workgroups of the tail's first level (config 4: 301)
-
-#ifdef GPS_TRACE_TAIL
-// debug builds only (scripts/trace_tail.py): s_memrealtime stamps of every task -- [workgroup][task of the workgroup][fetched, waited, done, published] + type
-static __device__ unsigned long long g_tail_trace[320 * 48 * 5];
-#define TAIL_TR(slot, val) do { if (tid == 0 && blockIdx.x < 320 && (t - tl.ofs[blockIdx.x]) < 48) g_tail_trace[((size_t)blockIdx.x * 48 + (t - tl.ofs[blockIdx.x])) * 5 + (slot)] = (val); } while (0)
-#else
-#define TAIL_TR(slot, val) do { } while (0)
-#endif
-template <int NBP, typename TR = double>
-__global__ void __launch_bounds__(256) k_fat_tail_rows(FsArgs<double, TR> a, FatTail tl) {
-  __shared__ double PT[FatRowsLds<NBP>::N];           // (>= NB (NB + 1) + NB for every NBP: the last block's factor fits)
-  __shared__ double ST[FatRowsLds<NBP>::STAGE];
-  __shared__ double Ld[(kFatMax / 4) * 10];
-  __shared__ int s_abort;
-  const int tid = threadIdx.x;
-  if (tid == 0) s_abort = 0;
-  __syncthreads();
-  const unsigned long long base = tl.epoch << 6;
-  const int t1 = tl.ofs[blockIdx.x + 1];
-  for (int t = tl.ofs[blockIdx.x]; t < t1; t++) {
-    const FatTask tk = tl.tasks[t];
-    TAIL_TR(0, wall_clock64()); TAIL_TR(4, (unsigned long long)(tk.type + 1));
-    if (tid == 0) {
-      const unsigned long long t0 = wall_clock64();
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        if (tk.wb[i] < 0) continue;
-        const unsigned long long want = base + (unsigned long long)tk.wo[i];
-        while (__hip_atomic_load(tl.sig + tk.wb[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (wall_clock64() - t0 > kFatTailTimeout) { s_abort = 1; break; }
-          __builtin_amdgcn_s_sleep(2);
-        }
-      }
-    }
-    __syncthreads();
-    if (s_abort) {
-      if (tid == 0) *a.flag = 2;
-      return;
-    }
-    TAIL_TR(1, wall_clock64());
-    if (tk.type == 0) fat_elim_rows_body<NBP, TR, true>(a, PT, ST, tk.m, tk.r, tk.lk_lm, tk.lk_mr, tk.lk_new, tk.uml, tk.umr);
-    else if (tk.type == 1) fat_update_body<double, TR, true>(a, tk.m, tk.l, tk.r);
-    else if (tk.type == 2) fat_top_body<double, TR, true>(a, tk.m, PT, Ld);
-    else if (tid < 64) fat_back_rows_body<NBP, TR, true>(a, tk.m, tk.l, tk.r, tk.lk_lm);
-    TAIL_TR(2, wall_clock64());
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // this wave's stores have left for memory (they are sc1: nothing to write back)
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(tl.sig + tk.m, base + (unsigned long long)tk.ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    TAIL_TR(3, wall_clock64());
-  }
+  if (on) a.xfat[(size_t)m * NB + lane] = t;
 }
 
 // ---- a chain split across GPUs (every piece runs from one shared cut state to the next; the shared cut and the landmarks
@@ -2112,12 +1932,6 @@ struct FatSepPlan {
   DevBuf d_fa_ptr, d_fa_it, d_fb_ptr, d_fb_it, d_fc_ptr, d_fc_it;   // rows of each landmark that touch a cut state (k_fs_fat_assemble)
   DevBuf lmMM;
   bool fused_sweep = false;                         // k_fs_sweep_syrk serves this plan (else k_fs_sweep + k_fs_syrk through Y)
-  // the persistent tail of the cyclic reduction (k_fat_tail_rows): levels tail_t0 .. in one launch of tail_G workgroups
-  // (tail_t0 < 0: every level is a launch).  Task lists: [0] forward + last block + backward (a whole chain), [1] forward only,
-  // [2] backward only (a piece of a split chain, around the exchange)
-  int tail_t0 = -1, tail_G = 0;
-  unsigned long long tail_epoch = 0;
-  DevBuf d_tail_tasks[3], d_tail_ofs[3], tail_sig;
   int ngroups = 0;
   std::vector<int> h_lmrow, h_lmstate, h_lmptr;     // compile(): rows per landmark, sorted by left state
 
@@ -2126,10 +1940,8 @@ struct FatSepPlan {
                       &fac, &Y, &Aseg, &Dfat, &link, &gfat, &Qbuf, &S1, &S2, &sv, &xfat, &gL, &rhs, &partial,
                       &send, &recv, &tD, &tlink, &tg, &tQ, &tS1, &tS2, &tsv, &tx, &d_telim, &d_tupd, &d_lm_own, &lm_tmp,
                       &d_lg_ptr, &d_lg_state, &d_lg_mptr, &d_lg_m, &Gev, &d_sc_base, &d_sc_ptr, &d_se_pk, &d_se_src,
-                      &d_fa_ptr, &d_fa_it, &d_fb_ptr, &d_fb_it, &d_fc_ptr, &d_fc_it, &lmMM,
-                      &d_tail_tasks[0], &d_tail_tasks[1], &d_tail_tasks[2], &d_tail_ofs[0], &d_tail_ofs[1], &d_tail_ofs[2], &tail_sig})
+                      &d_fa_ptr, &d_fa_it, &d_fb_ptr, &d_fb_it, &d_fc_ptr, &d_fc_it, &lmMM})
       b->release();
-    tail_t0 = -1;
     active = false;
   }
 
@@ -2173,74 +1985,6 @@ struct FatSepPlan {
     top = active[0];
     nlinks = std::max(next_link, 1);
     end_link = linkidx.empty() ? 0 : linkidx[0];
-  }
-
-  // Task lists of k_fat_tail_rows for the levels t0 .. of build_levels' sets (FatTask: 16 ints per task, grouped by workgroup).
-  // mode 0: forward, the last block, backward; 1: forward only; 2: backward only.  Elimination i of a level -> workgroup i;
-  // the update of a survivor that is eliminated at the next level rides in that elimination (uml / umr), the other updates
-  // go to the workgroups without an elimination at the next level; back-substitution i of a level -> workgroup i.
-  static void build_tail(int K, const std::vector<int> &elim, const std::vector<int> &upd, const std::vector<LevelHost> &levels, int t0, int top,
-                         int mode, std::vector<int> &tasks, std::vector<int> &ofs) {
-    const int nl = (int)levels.size(), G = levels[t0].nelim;
-    std::vector<std::vector<int>> per(G);
-    std::vector<int> cnt(K, 0), ordE(K, 0), ordX(K, 0), elim_level(K, -1), pend_l(K, -1), pend_r(K, -1);
-    for (int li = 0; li < nl; li++)
-      for (int i = 0; i < levels[li].nelim; i++) elim_level[elim[6 * (levels[li].elim_off + i)]] = li;
-    auto add = [&](int wg, int type, int m, int l, int r, int lk_lm, int lk_mr, int lk_new, int uml, int umr, const int wb[3], const int wo[3], int ord) {
-      const int t[16] = {type, m, l, r, lk_lm, lk_mr, lk_new, uml, umr, wb[0], wb[1], wb[2], wo[0], wo[1], wo[2], ord};
-      per[wg].insert(per[wg].end(), t, t + 16);
-    };
-    if (mode != 2) {
-      for (int li = t0; li < nl; li++) {
-        const LevelHost &lv = levels[li];
-        const int next_nelim = li + 1 < nl ? levels[li + 1].nelim : 0;
-        for (int i = 0; i < lv.nelim; i++) {
-          const int *e = &elim[6 * (lv.elim_off + i)];
-          const int m = e[0], uml = pend_l[m], umr = pend_r[m];
-          const int wb[3] = {uml, umr, cnt[m] > 0 ? m : -1};
-          const int wo[3] = {uml >= 0 ? ordE[uml] : 0, umr >= 0 ? ordE[umr] : 0, cnt[m]};
-          ordE[m] = ++cnt[m];
-          add(i, 0, m, e[1], e[2], e[3], e[4], e[5], uml, umr, wb, wo, ordE[m]);
-        }
-        int j = 0;
-        for (int i = 0; i < lv.nupd; i++) {
-          const int *u = &upd[3 * (lv.upd_off + i)];
-          const int blk = u[0], ml = u[1], mr = u[2];
-          if (elim_level[blk] == li + 1) { pend_l[blk] = ml; pend_r[blk] = mr; continue; }
-          const int wb[3] = {ml, mr, cnt[blk] > 0 ? blk : -1};
-          const int wo[3] = {ml >= 0 ? ordE[ml] : 0, mr >= 0 ? ordE[mr] : 0, cnt[blk]};
-          const int free_wg = G - next_nelim;
-          const int wg = free_wg > 0 ? next_nelim + (j % free_wg) : (j % G);
-          j++;
-          ++cnt[blk];
-          add(wg, 1, blk, ml, mr, -1, -1, -1, -1, -1, wb, wo, cnt[blk]);
-        }
-      }
-    }
-    if (mode == 0) {
-      const int wb[3] = {cnt[top] > 0 ? top : -1, -1, -1}, wo[3] = {cnt[top], 0, 0};
-      ordX[top] = ++cnt[top];
-      add(0, 2, top, -1, -1, -1, -1, -1, -1, -1, wb, wo, ordX[top]);
-    }
-    if (mode != 1) {
-      for (int li = nl - 1; li >= t0; li--) {
-        const LevelHost &lv = levels[li];
-        for (int i = 0; i < lv.nelim; i++) {
-          const int *e = &elim[6 * (lv.elim_off + i)];
-          const int m = e[0], l = e[1], r = e[2];
-          const int wb[3] = {ordX[l] > 0 ? l : -1, (r >= 0 && ordX[r] > 0) ? r : -1, -1};
-          const int wo[3] = {ordX[l], r >= 0 ? ordX[r] : 0, 0};
-          ordX[m] = ++cnt[m];
-          add(i, 3, m, l, r, e[3], e[4], e[5], -1, -1, wb, wo, ordX[m]);
-        }
-      }
-    }
-    tasks.clear(); ofs.assign(1, 0);
-    for (int g = 0; g < G; g++) {
-      tasks.insert(tasks.end(), per[g].begin(), per[g].end());
-      ofs.push_back((int)tasks.size() / 16);
-    }
-    if (tasks.empty()) tasks.assign(16, 0);
   }
 
   // even: segments of (nearly) equal length <= C instead of a short last one -- the pieces of a split chain, whose LAST

@@ -138,8 +138,7 @@ enum {
   GPSLAM_PLAN_GP_ROWS = 16,           /* GP priors as plain Jacobian rows instead of structured records */
   GPSLAM_PLAN_GENERIC_QC = 32,        /* SE(3) records: the general (upper-triangular) chol(Qc^-1) form even when Qc is diagonal */
   GPSLAM_PLAN_MEAS_ROWS = 64,         /* SE(3) records: interpolated GPS factors as plain 24-column rows (k_fused_level0<3>) instead of 16-double lines (<4>) */
-  GPSLAM_PLAN_SEPARATE_RETRACT = 128, /* gpslam_hip_run_gn: every iteration ends with its own k_retract launch instead of leaving the retraction to the next K1 */
-  GPSLAM_PLAN_FS_LEVEL_LAUNCHES = 256 /* segmented landmark elimination: every level of the fat blocks' cyclic reduction as launches of its own instead of one launch for the levels smaller than the chip (k_fat_tail_rows) */
+  GPSLAM_PLAN_SEPARATE_RETRACT = 128  /* gpslam_hip_run_gn: every iteration ends with its own k_retract launch instead of leaving the retraction to the next K1 */
 };
 
 /* per-call statistics; mirrors what GTSAM's optimizers expose (error(), iterations(), lambda()) */

@@ -296,31 +296,3 @@ def test_register_resident_fat_kernels_at_every_block_width():
         l0, l1 = orc.get_landmarks(), dev.get_landmarks()
         assert np.abs(l0 - l1).max() <= 1e-9 * max(1.0, np.abs(l0).max()), (div, plan)
     assert len(seen) >= 4 and min(seen) <= 24 and max(seen) >= 48, seen
-
-
-@pytest.mark.parametrize("N,L,window,seglen", [(333, 16, 100, 128), (700, 35, 100, 0), (2000, 100, 200, 0), (3000, 60, 150, 192), (9000, 450, 200, 0), (1500, 120, 100, 0),
-                                               (40000, 2000, 200, 0)])
-def test_persistent_tail_is_bit_identical_to_level_launches(N, L, window, seglen):
-    """Round 6: the levels of the fat blocks' cyclic reduction that are smaller than the chip run in ONE launch
-    (k_fat_tail_rows: workgroups that wait for each other's events through global memory; a survivor eliminated at the next level takes
-    its update on the way into the registers).  Same operands, same order of every sum: states and landmarks after three Gauss-Newton
-    iterations are BIT-IDENTICAL to GPSLAM_PLAN_FS_LEVEL_LAUNCHES (one launch per level, the path wider blocks still take), whatever
-    the number of levels -- K = 3 ... 200 fat blocks here, every tail from two levels to the whole reduction."""
-    g = gpu()
-    p = S.pose2_local_landmarks_chain(N, L=L, window=window, seed=5)
-    out = []
-    for plan in (0, g.PLAN_FS_LEVEL_LAUNCHES):
-        dev = S.apply(p, g.ChainSolver(O.POSE2, chart=g.CHART_FIRST_ORDER, landmark_dim=2, segment_length=seglen, force_segmented=True, plan=plan))
-        assert dev.segment_plan()["active"] == 1
-        errs = []
-        for it in range(3):
-            rc, st = dev.iterate_gn()
-            assert rc == 0
-            errs.append((st.error_before, st.error_after, st.delta_inf_norm))
-        out.append((dev.get_states(), dev.get_landmarks(), errs, dev.segment_plan()))
-        dev.close()
-    (xa, va), la, ea, pa = out[0]
-    (xb, vb), lb, eb, pb = out[1]
-    assert pa["NB"] <= 40, pa       # (wider blocks have no tail: nothing would be compared)
-    assert ea == eb, (ea, eb)
-    assert np.array_equal(xa, xb) and np.array_equal(va, vb) and np.array_equal(la, lb)
