@@ -13,7 +13,7 @@
 //     k_fs_syrk (the segment's Schur complement Y^T Y: a genuine dense GEMM with K = 2d * segment length, on
 //     v_mfma_f64_16x16x4_f64),  k_fs_fat_assemble (direct terms - Schur complements -> fat blocks).
 //   * the fat blocks form a block-tridiagonal system of K = N / C dense NB x NB blocks: block cyclic reduction over
-//     level sets (k_fat_elim / k_fat_update per level, k_fat_top, k_fat_back per level in reverse).
+//     level sets (k_fat_elim_* / k_fat_update per level, k_fat_top, k_fat_back per level in reverse).
 //   * k_fs_rhs / k_fs_solve1: interior states by a single-rhs forward / backward sweep with the stored factors.
 // Everything is summed in a fixed order (no atomics): results are bit-reproducible from run to run.
 #pragma once
@@ -39,7 +39,7 @@ inline int fat_wide_panel(int elem_bytes, int NB) {
   if (pw > 2 * NB + 1) pw = 2 * NB + 1;
   return (int)(pw < 4 ? 4 : pw);
 }
-constexpr int kFatLds = 80;   // round 3: 64 -> 80, what the LDS holds of all three NB x NB operands of k_fat_elim (155 KB of 160).
+constexpr int kFatLds = 80;   // round 3: 64 -> 80, what the LDS holds of all three NB x NB operands of k_fat_elim_mfma (155 KB of 160).
                               // Round 5: wider blocks keep the factor in LDS and stream [H | H | g] through it in column panels
                               // (k_fat_elim_wide).
 
@@ -1235,54 +1235,182 @@ template <typename T> __device__ __forceinline__ T fat_l_entry(const T *Lm, cons
   return Ld[(i >> 2) * 10 + a * (a + 1) / 2 + b];
 }
 
-template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_elim(FsArgs<T, TR> a, FatLevel lv) {
+// ---- one elimination of the cyclic reduction for fat blocks of 52 .. 80 columns (kFatLds): D_m and [H(m,l) | H(m,r) | g] in LDS
+// (155 KB at 80 columns, one workgroup per CU), the blocked Cholesky + L^-1 [H | H | g] of fat_factor_panel4, the five products.
+// Round 6 (VERDICT r5 "tune the wide path"): the multiply-adds are on the matrix cores and the workgroup is 16 waves.  Until then
+// (k_fat_elim: 256 threads, the panel's rank-4 updates six LDS operands per entry for four multiply-adds on one wave per SIMD, the
+// products scalar loops of four LDS reads per three multiply-adds with the symmetric ones formed twice) an 80-column block took
+// 245 us, 6.9 of the 17.9 ms per iteration of config 4's graph at three times its landmark density.  A rank-4 update of a 16 x 16
+// tile IS one v_mfma_f64_16x16x4_f64: a tile C of the trailing triangle / of the rows of X below takes -L[i, p..p+3] L[j, p..p+3]^T
+// (or ... X[p..p+3, c]), ten LDS accesses per lane per tile; the products are the tiles of k_fat_elim_rows over X where it lies; the
+// 4 x 4 diagonal factor and the row scalings are fat_factor_panel4's.  92 us per block: 13.4 ms per iteration at 3 x, 5.5 at 2 x (6.0).
+template <typename TR = double> __global__ void __launch_bounds__(1024) k_fat_elim_mfma(FsArgs<double, TR> a, FatLevel lv) {
   extern __shared__ __align__(16) unsigned char fat_smem[];
-  const int NB = a.NB, LS = NB + 1, XS = 2 * NB + 1, NB2 = NB * NB;
-  T *Lm = reinterpret_cast<T *>(fat_smem);
-  T *X = Lm + NB * LS;
-  __shared__ T Ld[(kFatMax / 4) * 10];
+  const int NB = a.NB, LS = NB + 1, XS = 2 * NB + 1, NB2 = NB * NB, NX = 2 * NB + 1;
+  double *Lm = reinterpret_cast<double *>(fat_smem);
+  double *X = Lm + NB * LS;
+  __shared__ double Ld[(kFatMax / 4) * 10];
   const int *e = lv.elim + 6 * blockIdx.x;
   const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
-  const int tid = threadIdx.x, nt = blockDim.x;
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  const int kl = lane >> 4, cl = lane & 15;
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
     Lm[i * LS + j] = a.Dfat[(size_t)m * NB2 + idx];
     X[i * XS + j] = a.link[(size_t)lk_lm * NB2 + idx];                               // H[m, l]
-    X[i * XS + NB + j] = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + j * NB + i] : T(0);    // H[m, r] = H[r, m]^T
+    X[j * XS + NB + i] = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + idx] : 0.0;           // H[m, r] = H[r, m]^T: read along H[r, m]'s rows, transposed in LDS
   }
   for (int i = tid; i < NB; i += nt) X[i * XS + 2 * NB] = a.gfat[(size_t)m * NB + i];
   __syncthreads();
-  fat_factor_panel4(Lm, X, Ld, NB, LS, XS, XS, a.flag);
+  const int CTX = (NX + 15) / 16;
+  for (int p = 0; p < NB; p += 4) {
+    // ---- 4 x 4 diagonal block: A = L L^T, W = L^-1 (both lower), every thread (fat_factor_panel4's arithmetic)
+    double A[4][4], L[4][4], W[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = Lm[(p + i) * LS + p + j];
+    bool bad = false;
+    double inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double dd = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+      if (!(dd > 0.0)) { bad = true; dd = 1.0; }
+      double y = fs_rsqrt(dd), l = dd * y;
+      l = fma(0.5 * y, fma(-l, l, dd), l);
+      y = fma(y, fma(-l, y, 1.0), y);
+      L[j][j] = l; inv[j] = y;
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) {
+        double v = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+        L[i][j] = v * y;
+      }
+    }
+    if (bad && tid == 0) *a.flag = 1;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int rr = c; rr < 4; rr++) {
+        double sacc = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = c; k < rr; k++) sacc -= L[rr][k] * W[k][c];
+        W[rr][c] = sacc * inv[rr];
+      }
+    if (tid == 0) {
+      int q = 0;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j <= i; j++) Ld[(p >> 2) * 10 + q++] = L[i][j];
+    }
+    // ---- rows below: L[i][p..p+3] = A[i][p..p+3] W^T;  the four rows of X: X[p..p+3][c] = W X[p..p+3][c]
+    const int r0 = p + 4, m2 = NB - r0;
+    for (int t = tid; t < m2 + NX; t += nt) {
+      if (t < m2) {
+        double *row = Lm + (r0 + t) * LS + p;
+        const double a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+        row[0] = a0 * W[0][0];
+        row[1] = a0 * W[1][0] + a1 * W[1][1];
+        row[2] = a0 * W[2][0] + a1 * W[2][1] + a2 * W[2][2];
+        row[3] = a0 * W[3][0] + a1 * W[3][1] + a2 * W[3][2] + a3 * W[3][3];
+      } else {
+        double *cp = X + p * XS + (t - m2);
+        const double b0 = cp[0], b1 = cp[XS], b2 = cp[2 * XS], b3 = cp[3 * XS];
+        cp[0] = W[0][0] * b0;
+        cp[XS] = W[1][0] * b0 + W[1][1] * b1;
+        cp[2 * XS] = W[2][0] * b0 + W[2][1] * b1 + W[2][2] * b2;
+        cp[3 * XS] = W[3][0] * b0 + W[3][1] * b1 + W[3][2] * b2 + W[3][3] * b3;
+      }
+    }
+    __syncthreads();
+    // ---- rank-4 update, one MFMA per 16 x 16 tile: row tile rt (rows r0 + 16 rt ..) x [triangle tiles 0 .. rt | the CTX tiles of X]
+    const int nrt = (m2 + 15) / 16;
+    const int ntile = nrt * CTX + nrt * (nrt + 1) / 2;
+    for (int t = wv; t < ntile; t += nw) {
+      int rt, ct;
+      bool tri;
+      if (t < nrt * CTX) { rt = t / CTX; ct = t - rt * CTX; tri = false; }
+      else {
+        const int u = t - nrt * CTX;
+        rt = 0;
+        while ((rt + 1) * (rt + 2) / 2 <= u) rt++;
+        ct = u - rt * (rt + 1) / 2; tri = true;
+      }
+      const int ia = r0 + 16 * rt + cl;                               // A operand: row ia, k = kl
+      const double av = (ia < NB) ? -Lm[ia * LS + p + kl] : 0.0;
+      double bv;
+      if (tri) { const int jb = r0 + 16 * ct + cl; bv = (jb < NB) ? Lm[jb * LS + p + kl] : 0.0; }
+      else { const int cb = 16 * ct + cl; bv = (cb < NX) ? X[(p + kl) * XS + cb] : 0.0; }
+      double *cbase = tri ? (Lm + r0 + 16 * ct + cl) : (X + 16 * ct + cl);
+      const int cstride = tri ? LS : XS;
+      const bool colok = tri ? (r0 + 16 * ct + cl < NB) : (16 * ct + cl < NX);
+      fs_d4 acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int ic = r0 + 16 * rt + kl + 4 * rg;
+        acc[rg] = (colok && ic < NB) ? cbase[ic * cstride] : 0.0;
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int ic = r0 + 16 * rt + kl + 4 * rg;
+        if (colok && ic < NB) cbase[ic * cstride] = acc[rg];
+      }
+    }
+    __syncthreads();
+  }
+  // ---- results: L, P, Q, z (whole lines by consecutive threads)
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
-    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);
+    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : 0.0;
     a.link[(size_t)lk_lm * NB2 + idx] = X[i * XS + j];           // P
     a.Qbuf[(size_t)m * NB2 + idx] = X[i * XS + NB + j];          // Q
-    T s1 = T(0), s2 = T(0), s3 = T(0);
-    for (int k = 0; k < NB; k++) {
-      const T pi = X[k * XS + i], pj = X[k * XS + j], qi = X[k * XS + NB + i], qj = X[k * XS + NB + j];
-      s1 += pi * pj;
-      s2 += qi * qj;
-      s3 += qi * pj;
-    }
-    a.S1[(size_t)m * NB2 + idx] = s1;
-    a.S2[(size_t)m * NB2 + idx] = s2;
-    if (r >= 0) a.link[(size_t)lk_new * NB2 + idx] = -s3;         // H[r, l] = -(Q^T P)
   }
-  for (int i = tid; i < NB; i += nt) {
-    T pz = T(0), qz = T(0);
-    for (int k = 0; k < NB; k++) { pz += X[k * XS + i] * X[k * XS + 2 * NB]; qz += X[k * XS + NB + i] * X[k * XS + 2 * NB]; }
-    a.gfat[(size_t)m * NB + i] = X[i * XS + 2 * NB];              // z
-    a.sv[(size_t)m * 2 * NB + i] = pz;
-    a.sv[(size_t)m * 2 * NB + NB + i] = qz;
+  for (int i = tid; i < NB; i += nt) a.gfat[(size_t)m * NB + i] = X[i * XS + 2 * NB];   // z
+  // ---- products: tile (ti, tj), tj <= ti, of X^T X (rows / columns = columns of X: P | Q | z), k over the NB rows
+  const int ntiles = CTX * (CTX + 1) / 2;
+  for (int t = wv; t < ntiles; t += nw) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int ca = ti * 16 + cl, cb = tj * 16 + cl;
+    const bool oka = ca < NX, okb = cb < NX;
+    const double *pa = X + kl * XS + min(ca, NX - 1), *pb = X + kl * XS + min(cb, NX - 1);
+    fs_d4 acc = fs_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k4 = 0; k4 < NB; k4 += 4) {
+      const double av = oka ? pa[k4 * XS] : 0.0, bv = okb ? pb[k4 * XS] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int ci = ti * 16 + kl + 4 * rg, cj = tj * 16 + cl;      // entry (ci, cj) of X^T X
+      const double v = acc[rg];
+      if (ci >= NX || cj > ci) continue;                            // padding; the upper half of a diagonal tile
+      if (ci < NB) {                                                // P^T P (cj < NB as well)
+        a.S1[(size_t)m * NB2 + (size_t)ci * NB + cj] = v;
+        a.S1[(size_t)m * NB2 + (size_t)cj * NB + ci] = v;
+      } else if (ci < 2 * NB) {
+        if (cj < NB) { if (r >= 0) a.link[(size_t)lk_new * NB2 + (size_t)(ci - NB) * NB + cj] = -v; }   // H[r, l] = -(Q^T P)
+        else {                                                      // Q^T Q
+          a.S2[(size_t)m * NB2 + (size_t)(ci - NB) * NB + (cj - NB)] = v;
+          a.S2[(size_t)m * NB2 + (size_t)(cj - NB) * NB + (ci - NB)] = v;
+        }
+      } else if (cj < 2 * NB) {                                     // ci == 2 NB: P^T z | Q^T z
+        a.sv[(size_t)m * 2 * NB + cj] = v;
+      }
+    }
   }
 }
 
 // ---- round 5: fat blocks wider than kFatLds.  The three NB x NB operands no longer fit the LDS together (NB = 128: 395 KB); the
 // block D_m does (132 KB).  It is factored there once (fat_factor_panel4 without a right-hand side), then the columns of
 // [H(m,l) | H(m,r) | g] pass through the rest of the LDS in panels of PW columns: X <- L^-1 X by the same four-pivot steps
-// (fat_solve_panel4: the 4 x 4 diagonal factors come back from Ld), P / Q / z go out to the places k_fat_elim writes them.  The five
-// products are then formed from P and Q where they lie (L2; 4 x 4 register tiles, the k order of k_fat_elim's sums).
+// (fat_solve_panel4: the 4 x 4 diagonal factors come back from Ld), P / Q / z go out to the places k_fat_elim_mfma writes them.  The five
+// products are then formed from P and Q where they lie (L2; 4 x 4 register tiles, the k order of a plain loop).
 template <typename T> __device__ __forceinline__ void fat_solve_panel4(const T *Lm, const T *Ld, T *X, int NB, int LS, int XS, int NX) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
@@ -1414,7 +1542,7 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
 }
 
 // ---- round 3: the same elimination with the whole factorisation in REGISTERS (fat blocks up to 48 columns, fp64).
-// k_fat_elim above takes 37-40 us for ONE 36-column block whatever the level's size (ablations: load 6, the blocked
+// k_fat_elim (the LDS kernel of rounds 2-5) took 37-40 us for ONE 36-column block whatever the level's size (ablations: load 6, the blocked
 // factorisation + L^-1 [H | H | g] through LDS 22, the five products 10) and the cyclic reduction has twelve levels of it, nine
 // of them smaller than the chip.  Here lane i < NBP of a wave holds ROW i of the block D_m (NBP = NB rounded up to 8, padded with
 // the identity) and the remaining 64 - NBP lanes hold rows of [H(m,l) | H(m,r) | g]^T: the right-looking Cholesky's row
