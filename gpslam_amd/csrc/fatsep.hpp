@@ -13,7 +13,7 @@
 //     k_fs_syrk (the segment's Schur complement Y^T Y: a genuine dense GEMM with K = 2d * segment length, on
 //     v_mfma_f64_16x16x4_f64),  k_fs_fat_assemble (direct terms - Schur complements -> fat blocks).
 //   * the fat blocks form a block-tridiagonal system of K = N / C dense NB x NB blocks: block cyclic reduction over
-//     level sets (k_fat_elim_* / k_fat_update per level, k_fat_top, k_fat_back per level in reverse).
+//     level sets (k_fat_elim_* / k_fat_update per level, k_fat_top, k_fat_back_* per level in reverse).
 //   * k_fs_rhs / k_fs_solve1: interior states by a single-rhs forward / backward sweep with the stored factors.
 // Everything is summed in a fixed order (no atomics): results are bit-reproducible from run to run.
 #pragma once
@@ -1697,40 +1697,57 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
 }
 
-// x_m = L^-T (z - P x_l - Q x_r)
-template <typename T, typename TR = T> __global__ void __launch_bounds__(64) k_fat_back(FsArgs<T, TR> a, FatLevel lv) {
-  extern __shared__ __align__(16) unsigned char fat_smem[];   // (round 5: dynamic -- NB (NB + 1) + 3 NB values, 135 KB at NB = 128)
-  const int NB = a.NB, LS = NB + 1, NB2 = NB * NB, lane = threadIdx.x;
-  T *Ls = reinterpret_cast<T *>(fat_smem), *xs = Ls + NB * LS, *ts = xs + 2 * NB;
+// ---- x_m = L^-T (z - P x_l - Q x_r) for fat blocks of 52 .. 128 columns (the factor through LDS: NB (NB + 1) + 3 NB values, 135 KB
+// at NB = 128).  Round 6: four waves.  Until then (k_fat_back) ONE wave did it: a lane walked a row of P and of Q (160 dependent
+// loads of its own line each) and the triangular solve was NB steps of two wave-level syncs: 77 us per level at 80 columns,
+// 13 levels = 1.0 ms of the 5.5 ms iteration of config 4's graph at twice its landmark density.  Now the factor arrives in whole
+// lines, a wave forms a row's two dot products with its lanes along the row, and the triangular solve takes four rows per step
+// (the 4 x 4 diagonal block solved by every lane from ten LDS broadcasts, one rank-4 update of the rest).
+template <typename TR = double> __global__ void __launch_bounds__(256) k_fat_back_w4(FsArgs<double, TR> a, FatLevel lv) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
+  const int NB = a.NB, LS = NB + 1, NB2 = NB * NB, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  double *Ls = reinterpret_cast<double *>(fat_smem), *xs = Ls + NB * LS, *ts = xs + 2 * NB;
   const int *e = lv.elim + 6 * blockIdx.x;
   const int m = e[0], l = e[1], r = e[2], lk_lm = e[3];
-  for (int idx = lane; idx < NB2; idx += 64) Ls[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)m * NB2 + idx];
-  for (int i = lane; i < NB; i += 64) {
+  for (int idx = tid; idx < NB2; idx += 256) Ls[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)m * NB2 + idx];
+  for (int i = tid; i < NB; i += 256) {
     xs[i] = a.xfat[(size_t)l * NB + i];
-    xs[NB + i] = (r >= 0) ? a.xfat[(size_t)r * NB + i] : T(0);
+    xs[NB + i] = (r >= 0) ? a.xfat[(size_t)r * NB + i] : 0.0;
   }
-  fs_wave_sync();
-  for (int i = lane; i < NB; i += 64) {
-    T t = a.gfat[(size_t)m * NB + i];
-    const T *P = a.link + (size_t)lk_lm * NB2 + (size_t)i * NB, *Q = a.Qbuf + (size_t)m * NB2 + (size_t)i * NB;
-    for (int j = 0; j < NB; j++) t -= P[j] * xs[j];
-    if (r >= 0) for (int j = 0; j < NB; j++) t -= Q[j] * xs[NB + j];
-    ts[i] = t;
+  __syncthreads();
+  const double *P = a.link + (size_t)lk_lm * NB2, *Q = a.Qbuf + (size_t)m * NB2;
+  for (int i = wv; i < NB; i += 4) {                  // t_i = z_i - P[i, :] x_l - Q[i, :] x_r
+    double sacc = 0.0;
+    for (int j = lane; j < NB; j += 64) {
+      sacc = fma(P[(size_t)i * NB + j], xs[j], sacc);
+      if (r >= 0) sacc = fma(Q[(size_t)i * NB + j], xs[NB + j], sacc);
+    }
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if (lane == 0) ts[i] = a.gfat[(size_t)m * NB + i] - sacc;
   }
-  fs_wave_sync();
-  for (int i = NB - 1; i >= 0; i--) {
-    const T xi = ts[i] / Ls[i * LS + i];
-    fs_wave_sync();
-    if (lane == 0) ts[i] = xi;
-    for (int k = lane; k < i; k += 64) ts[k] -= Ls[i * LS + k] * xi;
-    fs_wave_sync();
+  __syncthreads();
+  if (wv == 0) {                                      // L^T x = t from the last four rows up (NB is a multiple of 4)
+    for (int p = NB - 4; p >= 0; p -= 4) {
+      const double l00 = Ls[p * LS + p], l10 = Ls[(p + 1) * LS + p], l11 = Ls[(p + 1) * LS + p + 1];
+      const double l20 = Ls[(p + 2) * LS + p], l21 = Ls[(p + 2) * LS + p + 1], l22 = Ls[(p + 2) * LS + p + 2];
+      const double l30 = Ls[(p + 3) * LS + p], l31 = Ls[(p + 3) * LS + p + 1], l32 = Ls[(p + 3) * LS + p + 2], l33 = Ls[(p + 3) * LS + p + 3];
+      const double y3 = ts[p + 3] / l33;
+      const double y2 = (ts[p + 2] - l32 * y3) / l22;
+      const double y1 = (ts[p + 1] - l21 * y2 - l31 * y3) / l11;
+      const double y0 = (ts[p] - l10 * y1 - l20 * y2 - l30 * y3) / l00;
+      fs_wave_sync();                                 // (every lane has read t[p .. p + 3])
+      for (int k = lane; k < p; k += 64)
+        ts[k] -= Ls[p * LS + k] * y0 + Ls[(p + 1) * LS + k] * y1 + Ls[(p + 2) * LS + k] * y2 + Ls[(p + 3) * LS + k] * y3;
+      if (lane == 0) { ts[p] = y0; ts[p + 1] = y1; ts[p + 2] = y2; ts[p + 3] = y3; }
+      fs_wave_sync();
+    }
+    for (int i = lane; i < NB; i += 64) a.xfat[(size_t)m * NB + i] = ts[i];
   }
-  for (int i = lane; i < NB; i += 64) a.xfat[(size_t)m * NB + i] = ts[i];
 }
 
 // ---- round 3: the same back-substitution without LDS (fat blocks up to 64 columns, fp64).  Lane k holds COLUMN k of L
 // (L[i][k] for all i: coalesced loads) and entry k of t = z - P x_l - Q x_r; step i broadcasts x_i = t_i / L_ii from lane i
-// (v_readlane) and every lane k < i takes L[i][k] x_i off its entry.  k_fat_back above spends 12-13 us per block (one wave,
+// (v_readlane) and every lane k < i takes L[i][k] x_i off its entry.  The one-wave LDS kernel of round 2 spent 12-13 us per block (one wave,
 // 2 NB wave-level syncs around LDS round trips); this is one dependent multiply-add + broadcast per step.
 template <int NBP, typename TR = double> __global__ void __launch_bounds__(64) k_fat_back_rows(FsArgs<double, TR> a, FatLevel lv) {
   const int NB = a.NB, NB2 = NB * NB, lane = threadIdx.x;
