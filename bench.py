@@ -228,6 +228,30 @@ def extras(gpslam_amd, S, device):
         return res
     section("projected_sharded_1e6_pose3", projected)
 
+    # ---- config 1 (the reference's own CPU-runnable case: matlab/PlazaPose2.m on the Plaza2 log -- 4091 SE(2) states, 1816 interpolated
+    # ranges, 4 landmarks; tests/golden/plaza2.npz): wall clock per iteration of the reference's optimiser calls
+    def config1():
+        from gpslam_amd import plaza
+        data = plaza.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "plaza2.npz"))
+        p = plaza.build_problem(data)
+        s = plaza.apply(p, gpslam_amd.ChainSolver(gpslam_amd.POSE2, chart=gpslam_amd.CHART_FIRST_ORDER, landmark_dim=2, device=device))
+        s.run_gn(3)
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            s.run_gn(50)
+            dt = (time.perf_counter() - t0) / 50 * 1e3
+            best = dt if best is None else min(best, dt)
+        lam = 1e-5
+        t0 = time.perf_counter()
+        for _ in range(20):
+            _rc, _st, lam = s.iterate_lm(lam)
+        lm_ms = (time.perf_counter() - t0) / 20 * 1e3
+        s.close()
+        return {"states": int(len(p["pose"])), "ms_per_gauss_newton_iteration_wall": best, "ms_per_lm_iterate_call_wall": lm_ms,
+                "note": "run_gn(50) / 20 iterate_lm calls on the recipe's graph; accuracy against ground truth: tests/test_plaza.py"}
+    section("config1_plaza2_4091_pose2", config1)
+
     # ---- config 2 (linear GP chain) and config 4 (1e6 SE(2) poses + 5e4 locally visible range landmarks), one GPU
     def config2():
         p = S.linear_chain(100000)
