@@ -62,7 +62,11 @@ for t in range(cnt):
     for it in range(2):
         (rc0, s0), (rc1, s1), (rc2, s2) = orc.iterate_gn(), dev.iterate_gn(), twin.iterate_gn()
         assert rc0 == 0 and rc1 == 0 and rc2 == 0
-        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after) + 10 * abs(s0.error_after - s2.error_after), (kind, N, K, it, s0.error_after, s1.error_after, s2.error_after)
+        # (+ 1e-10 of the cost the step started from: two states 1e-9 apart -- the check below -- differ in cost by gradient x distance, and
+        #  two steps from the optimum the gradient is that of the cost being taken down.  Seed 405, 200 cases: an SE(3) chain with four
+        #  closures whose second step takes 1.7e5 to 2.0e3 -- costs 2.3e-9 apart, states 2.5e-10 apart, both optimisers on 614.3452962444
+        #  to sixteen digits six steps later: scripts/diag_closure_case.py)
+        assert abs(s0.error_after - s1.error_after) <= 1e-9 * max(1.0, s0.error_after) + 1e-10 * s0.error_before + 10 * abs(s0.error_after - s2.error_after), (kind, N, K, it, s0.error_after, s1.error_after, s2.error_after)
         (x0, v0), (x1, v1), (x2, v2) = orc.get_states(), dev.get_states(), twin.get_states()
         noise = max(np.abs(x0 - x2).max() / max(1.0, np.abs(x0).max()), np.abs(v0 - v2).max() / max(1.0, np.abs(v0).max()))
         T.states_close(kind, x0, v0, x1, v1, 1e-9 + 10 * noise)
