@@ -30,9 +30,9 @@
 namespace gps {
 
 constexpr int kFatMax = 128;  // largest fat block (cut state + landmark columns): what one workgroup's LDS holds of ONE NB x NB operand
-                              // (k_fat_elim_wide, k_fat_top, k_fat_back: 132 KB of 160).  Config 4's graph needs 28-36, twice its
+                              // (k_fat_elim_wide_mfma, k_fat_top, k_fat_back_w4: 132 KB of 160).  Config 4's graph needs 28-36, twice its
                               // landmark density 62, three times 96-100.
-// columns of [H | H | g] per pass of k_fat_elim_wide: what is left of 160 KB beside the block (and the 4 x 4 factors in Ld)
+// columns of [H | H | g] per pass of k_fat_elim_wide_mfma: what is left of 160 KB beside the block (and the 4 x 4 factors in Ld)
 inline int fat_wide_panel(int elem_bytes, int NB) {
   const long avail = 160L * 1024 - (long)(kFatMax / 4) * 10 * elem_bytes - (long)NB * (NB + 1) * elem_bytes - 512;
   long pw = avail / ((long)NB * elem_bytes);
@@ -41,7 +41,7 @@ inline int fat_wide_panel(int elem_bytes, int NB) {
 }
 constexpr int kFatLds = 80;   // round 3: 64 -> 80, what the LDS holds of all three NB x NB operands of k_fat_elim_mfma (155 KB of 160).
                               // Round 5: wider blocks keep the factor in LDS and stream [H | H | g] through it in column panels
-                              // (k_fat_elim_wide).
+                              // (k_fat_elim_wide_mfma).
 
 template <typename T, typename TR = T> struct FsArgs {   // TR: type of the Jacobian row tables (kernels.hpp, LmArgs)
   int N, B, ld, L, K, NB, NC, NCP;   // K cuts / fat blocks; NC = 2 NB + 1 border columns; NCP = NC rounded up to 16
@@ -1406,91 +1406,177 @@ template <typename TR = double> __global__ void __launch_bounds__(1024) k_fat_el
   }
 }
 
-// ---- round 5: fat blocks wider than kFatLds.  The three NB x NB operands no longer fit the LDS together (NB = 128: 395 KB); the
-// block D_m does (132 KB).  It is factored there once (fat_factor_panel4 without a right-hand side), then the columns of
-// [H(m,l) | H(m,r) | g] pass through the rest of the LDS in panels of PW columns: X <- L^-1 X by the same four-pivot steps
-// (fat_solve_panel4: the 4 x 4 diagonal factors come back from Ld), P / Q / z go out to the places k_fat_elim_mfma writes them.  The five
-// products are then formed from P and Q where they lie (L2; 4 x 4 register tiles, the k order of a plain loop).
-template <typename T> __device__ __forceinline__ void fat_solve_panel4(const T *Lm, const T *Ld, T *X, int NB, int LS, int XS, int NX) {
-  const int tid = threadIdx.x, nt = blockDim.x;
-  const int tx = tid & 63, ty = tid >> 6, nty = nt >> 6;
+// ---- fat blocks wider than kFatLds (84 .. 128 columns; round 5).  The three NB x NB operands no longer fit the LDS together
+// (NB = 128: 395 KB); the block D_m does (132 KB).  It is factored there once, then the columns of [H(m,l) | H(m,r) | g] pass through
+// the rest of the LDS in panels of PW columns (fat_wide_panel): X <- L^-1 X by the same four-pivot steps (the 4 x 4 diagonal factors
+// come back from Ld), P / Q / z go out to the places k_fat_elim_mfma writes them, and the five products are formed from P and Q where
+// they lie (L2).  Round 6: on the matrix cores, 16 waves -- k_fat_elim_mfma's tiles in all three phases: the factorisation's rank-4
+// updates of the trailing triangle, the panels' rank-4 updates of the rows below, the products as tiles of
+// [P | Q | z]^T [P | Q | z].  The scalar kernel (k_fat_elim_wide: 256 threads, 4 x 4 register tiles) took 1.19 ms per level launch at
+// 104 columns, 15.5 of the 33 ms per iteration of config 4's graph at four times its landmark density; this one 0.56 (25 ms).
+template <typename TR = double> __global__ void __launch_bounds__(1024) k_fat_elim_wide_mfma(FsArgs<double, TR> a, FatLevel lv, int PW) {
+  extern __shared__ __align__(16) unsigned char fat_smem[];
+  const int NB = a.NB, LS = NB + 1, XS = PW, NB2 = NB * NB, NXT = 2 * NB + 1;
+  double *Lm = reinterpret_cast<double *>(fat_smem);
+  double *X = Lm + NB * LS;
+  __shared__ double Ld[(kFatMax / 4) * 10];
+  const int *e = lv.elim + 6 * blockIdx.x;
+  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6, nw = nt >> 6;
+  const int kl = lane >> 4, cl = lane & 15;
+  for (int idx = tid; idx < NB2; idx += nt) Lm[(idx / NB) * LS + idx % NB] = a.Dfat[(size_t)m * NB2 + idx];
+  __syncthreads();
+  // ---- D_m = L L^T (fat_factor_panel4's 4 x 4 diagonal factors and row scalings, the trailing triangle by MFMA tiles)
   for (int p = 0; p < NB; p += 4) {
-    T L[4][4], W[4][4], inv[4];
-    {
+    double A[4][4], L[4][4], W[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = Lm[(p + i) * LS + p + j];
+    bool bad = false;
+    double inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      double dd = A[j][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) dd -= L[j][k] * L[j][k];
+      if (!(dd > 0.0)) { bad = true; dd = 1.0; }
+      double y = fs_rsqrt(dd), l = dd * y;
+      l = fma(0.5 * y, fma(-l, l, dd), l);
+      y = fma(y, fma(-l, y, 1.0), y);
+      L[j][j] = l; inv[j] = y;
+#pragma unroll
+      for (int i = j + 1; i < 4; i++) {
+        double v = A[i][j];
+#pragma unroll
+        for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k];
+        L[i][j] = v * y;
+      }
+    }
+    if (bad && tid == 0) *a.flag = 1;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int rr = c; rr < 4; rr++) {
+        double sacc = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = c; k < rr; k++) sacc -= L[rr][k] * W[k][c];
+        W[rr][c] = sacc * inv[rr];
+      }
+    if (tid == 0) {
       int q = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j <= i; j++) L[i][j] = Ld[(p >> 2) * 10 + q++];
+        for (int j = 0; j <= i; j++) Ld[(p >> 2) * 10 + q++] = L[i][j];
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++) inv[j] = T(1) / L[j][j];
-#pragma unroll
-    for (int c = 0; c < 4; c++)
-#pragma unroll
-      for (int r = c; r < 4; r++) {
-        T sacc = (r == c) ? T(1) : T(0);
-#pragma unroll
-        for (int k = c; k < r; k++) sacc -= L[r][k] * W[k][c];
-        W[r][c] = sacc * inv[r];
-      }
-    for (int t = tid; t < NX; t += nt) {
-      T *cp = X + p * XS + t;
-      const T b0 = cp[0], b1 = cp[XS], b2 = cp[2 * XS], b3 = cp[3 * XS];
-      cp[0] = W[0][0] * b0;
-      cp[XS] = W[1][0] * b0 + W[1][1] * b1;
-      cp[2 * XS] = W[2][0] * b0 + W[2][1] * b1 + W[2][2] * b2;
-      cp[3 * XS] = W[3][0] * b0 + W[3][1] * b1 + W[3][2] * b2 + W[3][3] * b3;
+    const int r0 = p + 4, m2 = NB - r0;
+    for (int t = tid; t < m2; t += nt) {
+      double *row = Lm + (r0 + t) * LS + p;
+      const double a0 = row[0], a1 = row[1], a2 = row[2], a3 = row[3];
+      row[0] = a0 * W[0][0];
+      row[1] = a0 * W[1][0] + a1 * W[1][1];
+      row[2] = a0 * W[2][0] + a1 * W[2][1] + a2 * W[2][2];
+      row[3] = a0 * W[3][0] + a1 * W[3][1] + a2 * W[3][2] + a3 * W[3][3];
     }
     __syncthreads();
-    for (int i = p + 4 + ty; i < NB; i += nty) {
-      const T *li = Lm + i * LS + p;
-      const T l0 = li[0], l1 = li[1], l2 = li[2], l3 = li[3];
-      for (int cc = tx; cc < NX; cc += 64) {
-        const T *xp = X + p * XS + cc;
-        X[i * XS + cc] -= l0 * xp[0] + l1 * xp[XS] + l2 * xp[2 * XS] + l3 * xp[3 * XS];
+    const int nrt = (m2 + 15) / 16, ntile = nrt * (nrt + 1) / 2;
+    for (int t = wv; t < ntile; t += nw) {
+      int rt = 0;
+      while ((rt + 1) * (rt + 2) / 2 <= t) rt++;
+      const int ct = t - rt * (rt + 1) / 2;
+      const int ia = r0 + 16 * rt + cl, jb = r0 + 16 * ct + cl;
+      const double av = (ia < NB) ? -Lm[ia * LS + p + kl] : 0.0, bv = (jb < NB) ? Lm[jb * LS + p + kl] : 0.0;
+      double *cbase = Lm + jb;
+      const bool colok = jb < NB;
+      fs_d4 acc;
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int ic = r0 + 16 * rt + kl + 4 * rg;
+        acc[rg] = (colok && ic < NB) ? cbase[ic * LS] : 0.0;
+      }
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int ic = r0 + 16 * rt + kl + 4 * rg;
+        if (colok && ic < NB) cbase[ic * LS] = acc[rg];
       }
     }
     __syncthreads();
   }
-}
-
-template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_fat_elim_wide(FsArgs<T, TR> a, FatLevel lv, int PW) {
-  extern __shared__ __align__(16) unsigned char fat_smem[];
-  const int NB = a.NB, LS = NB + 1, XS = PW, NB2 = NB * NB, NXT = 2 * NB + 1;
-  T *Lm = reinterpret_cast<T *>(fat_smem);
-  T *X = Lm + NB * LS;
-  __shared__ T Ld[(kFatMax / 4) * 10];
-  const int *e = lv.elim + 6 * blockIdx.x;
-  const int m = e[0], r = e[2], lk_lm = e[3], lk_mr = e[4], lk_new = e[5];
-  const int tid = threadIdx.x, nt = blockDim.x;
   for (int idx = tid; idx < NB2; idx += nt) {
     const int i = idx / NB, j = idx - i * NB;
-    Lm[i * LS + j] = a.Dfat[(size_t)m * NB2 + idx];
+    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : 0.0;
   }
-  __syncthreads();
-  fat_factor_panel4(Lm, X, Ld, NB, LS, XS, 0, a.flag);
-  for (int idx = tid; idx < NB2; idx += nt) {
-    const int i = idx / NB, j = idx - i * NB;
-    a.Dfat[(size_t)m * NB2 + idx] = (j <= i) ? fat_l_entry(Lm, Ld, LS, i, j) : T(0);
-  }
-  T *Pg = a.link + (size_t)lk_lm * NB2, *Qg = a.Qbuf + (size_t)m * NB2, *zg = a.gfat + (size_t)m * NB;
+  // ---- [P | Q | z] = L^-1 [H(m,l) | H(m,r) | g], PW columns at a time
+  double *Pg = a.link + (size_t)lk_lm * NB2, *Qg = a.Qbuf + (size_t)m * NB2, *zg = a.gfat + (size_t)m * NB;
   for (int c0 = 0; c0 < NXT; c0 += PW) {
     const int pw = min(PW, NXT - c0);
     __syncthreads();
     for (int idx = tid; idx < NB * pw; idx += nt) {
       const int i = idx / pw, cc = idx - i * pw, c = c0 + cc;
-      T v;
+      double v;
       if (c < NB) v = Pg[(size_t)i * NB + c];                                                             // H[m, l]
-      else if (c < 2 * NB) v = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + (size_t)(c - NB) * NB + i] : T(0);  // H[m, r] = H[r, m]^T
+      else if (c < 2 * NB) v = (r >= 0) ? a.link[(size_t)lk_mr * NB2 + (size_t)(c - NB) * NB + i] : 0.0;  // H[m, r] = H[r, m]^T
       else v = zg[i];
       X[i * XS + cc] = v;
     }
     __syncthreads();
-    fat_solve_panel4(Lm, Ld, X, NB, LS, XS, pw);
+    const int CTP = (pw + 15) / 16;
+    for (int p = 0; p < NB; p += 4) {
+      double L[4][4], W[4][4], inv[4];
+      {
+        int q = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j <= i; j++) L[i][j] = Ld[(p >> 2) * 10 + q++];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) inv[j] = 1.0 / L[j][j];
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int rr = c; rr < 4; rr++) {
+          double sacc = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+          for (int k = c; k < rr; k++) sacc -= L[rr][k] * W[k][c];
+          W[rr][c] = sacc * inv[rr];
+        }
+      for (int t = tid; t < pw; t += nt) {
+        double *cp = X + p * XS + t;
+        const double b0 = cp[0], b1 = cp[XS], b2 = cp[2 * XS], b3 = cp[3 * XS];
+        cp[0] = W[0][0] * b0;
+        cp[XS] = W[1][0] * b0 + W[1][1] * b1;
+        cp[2 * XS] = W[2][0] * b0 + W[2][1] * b1 + W[2][2] * b2;
+        cp[3 * XS] = W[3][0] * b0 + W[3][1] * b1 + W[3][2] * b2 + W[3][3] * b3;
+      }
+      __syncthreads();
+      const int r0 = p + 4, m2 = NB - r0, nrt = (m2 + 15) / 16;
+      for (int t = wv; t < nrt * CTP; t += nw) {
+        const int rt = t / CTP, ct = t - rt * CTP;
+        const int ia = r0 + 16 * rt + cl, cb = 16 * ct + cl;
+        const double av = (ia < NB) ? -Lm[ia * LS + p + kl] : 0.0, bv = (cb < pw) ? X[(p + kl) * XS + cb] : 0.0;
+        double *cbase = X + cb;
+        const bool colok = cb < pw;
+        fs_d4 acc;
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int ic = r0 + 16 * rt + kl + 4 * rg;
+          acc[rg] = (colok && ic < NB) ? cbase[ic * XS] : 0.0;
+        }
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int ic = r0 + 16 * rt + kl + 4 * rg;
+          if (colok && ic < NB) cbase[ic * XS] = acc[rg];
+        }
+      }
+      __syncthreads();
+    }
     for (int idx = tid; idx < NB * pw; idx += nt) {
       const int i = idx / pw, cc = idx - i * pw, c = c0 + cc;
-      const T v = X[i * XS + cc];
+      const double v = X[i * XS + cc];
       if (c < NB) Pg[(size_t)i * NB + c] = v;                  // P
       else if (c < 2 * NB) Qg[(size_t)i * NB + (c - NB)] = v;  // Q
       else zg[i] = v;                                          // z
@@ -1498,46 +1584,42 @@ template <typename T, typename TR = T> __global__ void __launch_bounds__(256) k_
   }
   __threadfence_block();
   __syncthreads();
-  // ---- S1 = P^T P, S2 = Q^T Q, new link = -(Q^T P), P^T z, Q^T z
-  const int n4 = NB / 4;
-  for (int tix = tid; tix < n4 * n4; tix += nt) {
-    const int i0 = (tix / n4) * 4, j0 = (tix - (tix / n4) * n4) * 4;
-    T s1[4][4], s2[4][4], s3[4][4];
-#pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-      for (int v = 0; v < 4; v++) { s1[u][v] = T(0); s2[u][v] = T(0); s3[u][v] = T(0); }
-    for (int k = 0; k < NB; k++) {
-      T pi[4], pj[4], qi[4], qj[4];
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        pi[u] = Pg[(size_t)k * NB + i0 + u]; pj[u] = Pg[(size_t)k * NB + j0 + u];
-        qi[u] = Qg[(size_t)k * NB + i0 + u]; qj[u] = Qg[(size_t)k * NB + j0 + u];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++)
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-          s1[u][v] += pi[u] * pj[v];
-          s2[u][v] += qi[u] * qj[v];
-          s3[u][v] += qi[u] * pj[v];
-        }
+  // ---- products: tile (ti, tj), tj <= ti, of [P | Q | z]^T [P | Q | z], operands from where the panels went
+  const int CT = (NXT + 15) / 16, ntiles = CT * (CT + 1) / 2;
+  auto col_ptr = [&](int c) -> const double * {        // column c of [P | Q | z]: base and row stride
+    return c < NB ? Pg + c : (c < 2 * NB ? Qg + (c - NB) : zg);
+  };
+  for (int t = wv; t < ntiles; t += nw) {
+    int ti = 0;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int ca = ti * 16 + cl, cb = tj * 16 + cl;
+    const bool oka = ca < NXT, okb = cb < NXT;
+    const double *pa = col_ptr(min(ca, NXT - 1)), *pb = col_ptr(min(cb, NXT - 1));
+    const int sa = (min(ca, NXT - 1) < 2 * NB) ? NB : 1, sb = (min(cb, NXT - 1) < 2 * NB) ? NB : 1;
+    fs_d4 acc = fs_d4{0.0, 0.0, 0.0, 0.0};
+    for (int k4 = 0; k4 < NB; k4 += 4) {
+      const double av = oka ? pa[(size_t)(k4 + kl) * sa] : 0.0, bv = okb ? pb[(size_t)(k4 + kl) * sb] : 0.0;
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++)
-#pragma unroll
-      for (int v = 0; v < 4; v++) {
-        const size_t o = (size_t)(i0 + u) * NB + j0 + v;
-        a.S1[(size_t)m * NB2 + o] = s1[u][v];
-        a.S2[(size_t)m * NB2 + o] = s2[u][v];
-        if (r >= 0) a.link[(size_t)lk_new * NB2 + o] = -s3[u][v];         // H[r, l] = -(Q^T P)
+    for (int rg = 0; rg < 4; rg++) {
+      const int ci = ti * 16 + kl + 4 * rg, cj = tj * 16 + cl;
+      const double v = acc[rg];
+      if (ci >= NXT || cj > ci) continue;
+      if (ci < NB) {
+        a.S1[(size_t)m * NB2 + (size_t)ci * NB + cj] = v;
+        a.S1[(size_t)m * NB2 + (size_t)cj * NB + ci] = v;
+      } else if (ci < 2 * NB) {
+        if (cj < NB) { if (r >= 0) a.link[(size_t)lk_new * NB2 + (size_t)(ci - NB) * NB + cj] = -v; }
+        else {
+          a.S2[(size_t)m * NB2 + (size_t)(ci - NB) * NB + (cj - NB)] = v;
+          a.S2[(size_t)m * NB2 + (size_t)(cj - NB) * NB + (ci - NB)] = v;
+        }
+      } else if (cj < 2 * NB) {
+        a.sv[(size_t)m * 2 * NB + cj] = v;
       }
-  }
-  for (int i = tid; i < NB; i += nt) {
-    T pz = T(0), qz = T(0);
-    for (int k = 0; k < NB; k++) { pz += Pg[(size_t)k * NB + i] * zg[k]; qz += Qg[(size_t)k * NB + i] * zg[k]; }
-    a.sv[(size_t)m * 2 * NB + i] = pz;
-    a.sv[(size_t)m * 2 * NB + NB + i] = qz;
+    }
   }
 }
 
