@@ -5,8 +5,9 @@ import torch  # noqa
 from oracle import oracle as O
 import test_gpu_parity as T
 import gpslam_amd
-rng = np.random.default_rng(405)
-for t in range(200):
+SEED, KIND, NN, KK, MODE = (int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]) if len(sys.argv) > 5 else (405, 3, 2156, 4, 'gn')
+rng = np.random.default_rng(SEED)
+for t in range(400):
     kind = [O.POSE2, O.POSE3, O.ROT3, O.LINEAR3, O.POSE2, O.POSE3][t % 6]
     N = int(rng.integers(30, 2500)); d = O.TANGENT_DIM[kind]; cap = 27 // d
     K = int(rng.integers(1, cap + 1))
@@ -22,7 +23,7 @@ for t in range(200):
     rel = lambda i, j: O.retract(kind, ident, O.local(kind, c["truth_pose"][i], c["truth_pose"][j]) + 0.01 * rng.standard_normal(d))
     cmeas = np.stack([rel(int(first[k]), int(second[k])) for k in range(K)])
     csig = 0.01 + 0.05 * rng.random((K, d)); Qc = np.diag(0.01 + 0.02 * rng.random(d))
-    if not (kind == 3 and N == 2156 and K == 4): continue
+    if not (kind == KIND and N == NN and K == KK): continue
     print("t", t, "first", first, "second", second)
     sol = []
     for make in (lambda: O.Chain(kind, chart), lambda: gpslam_amd.ChainSolver(kind, chart)):
@@ -34,6 +35,14 @@ for t in range(200):
             s.add_between(np.arange(N - 1), meas, np.full((N - 1, d), 0.02))
         s.add_between_pairs(first, second, cmeas, csig); s.compile(); sol.append(s)
     orc, dev = sol
+    if MODE == 'lm':
+        lam0 = lam1 = 1e-2
+        for it in range(12):
+            rc0, s0, lam0 = orc.iterate_lm(lam0); rc1, s1, lam1 = dev.iterate_lm(lam1)
+            (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
+            dx = max(float(np.abs(O.local(kind, x0[i], x1[i])).max()) for i in range(0, N, 7))
+            print("lm %d: before orc %.12e dev %.12e rel %.2e | after rel %.2e | lambda %.1e %.1e accepted %d %d | states apart %.2e vel %.2e" % (it, s0.error_before, s1.error_before, abs(s0.error_before - s1.error_before) / s0.error_before, abs(s0.error_after - s1.error_after) / s0.error_after, lam0, lam1, s0.accepted, s1.accepted, dx, np.abs(v0 - v1).max()))
+        break
     for it in range(8):
         (rc0, s0), (rc1, s1) = orc.iterate_gn(), dev.iterate_gn()
         (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()

@@ -73,7 +73,10 @@ for t in range(cnt):
     solvers = [orc, dev]
     for s_ in solvers:
         s_.set_states(c["pose"], c["vel"])
-    lam, n_noise, slack = L.run(orc, dev, 1e-2, 5, tag=(kind, N, K))
+    # (costs along the way at 3e-9: the states of the two optimisers stay 2e-10 ... 1e-9 apart from the first step on, and away from the
+    #  optimum a cost moves by gradient x distance -- seed 505, 200 cases: an SE(3) chain with three closures, costs 1.3e-9 apart at the
+    #  fourth call, lambda schedule identical, both on 1123.9938 to thirteen digits eight calls later: scripts/diag_closure_case.py ... lm)
+    lam, n_noise, slack = L.run(orc, dev, 1e-2, 5, tag=(kind, N, K), err_tol=3e-9)
     (x0, v0), (x1, v1) = orc.get_states(), dev.get_states()
     T.states_close(kind, x0, v0, x1, v1, 1e-9 + 2 * slack)
     print("ok kind %d N %d closures %d (LM: lambda %.1e, %d of 5 calls decided at rounding level)" % (kind, N, K, lam, n_noise))
